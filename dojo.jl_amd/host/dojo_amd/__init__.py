@@ -1,0 +1,10 @@
+"""dojo_amd -- host-side mirror of Dojo.jl's Mechanism / step! / simulate! /
+get_maximal_gradients! API in front of libdojo_hip.so (hand-written HIP for gfx950).
+
+In production the host language is Julia (julia/DojoHIP.jl calls the same C ABI with
+@ccall); Julia is not available in the build container, so this Python package is the
+executable mirror the parity tests drive.
+"""
+from .topology import MechanismSpec, BodySpec, JointSpec, JointHalfSpec, ContactSpec, SolverOptions
+from .mechanisms import (get_mechanism, get_pendulum, get_block, get_ant, get_quadruped, get_atlas, baseline_config)
+from .coords import (minimal_to_maximal, maximal_to_minimal, initialize, synthetic_inputs, nominal_minimal)

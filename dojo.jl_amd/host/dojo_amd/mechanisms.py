@@ -1,0 +1,280 @@
+"""Mechanism builders for the five BASELINE.json configs, restating
+DojoEnvironments/src/mechanisms/{pendulum,block,ant,quadruped,atlas}/mechanism.jl and the
+URDF -> maximal-coordinate conversion of src/mechanism/urdf.jl.
+
+These run once at set-up time on the host (they stand in for the Julia builders, which
+cannot run here); the result is a MechanismSpec = the flat topology the C ABI consumes.
+Body order is URDF document order (the reference's Dict order is not reproducible,
+SURVEY.md Appendix A-2): everything is looked up by name.
+"""
+import json
+import os
+import numpy as np
+from .quat import (qmul, qinv, vrot, rpy_to_quat, orthogonal_rows, axis_angle_to_quaternion)
+from .topology import BodySpec, JointHalfSpec, JointSpec, ContactSpec, MechanismSpec
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+X_AXIS, Y_AXIS, Z_AXIS = np.eye(3)
+
+
+# ----------------------------------------------------------------------------------
+# joint prototypes, src/joints/prototypes.jl
+# ----------------------------------------------------------------------------------
+def Floating(name, parent, child):                                   # prototypes.jl:429-447
+    return JointSpec(name, parent, child, JointHalfSpec(0, spring_offset=np.zeros(3)), JointHalfSpec(0, spring_offset=np.zeros(3)))
+
+
+def Fixed(name, parent, child, parent_vertex=np.zeros(3), child_vertex=np.zeros(3), orientation_offset=np.array([1.0, 0, 0, 0])):
+    return JointSpec(name, parent, child, JointHalfSpec(3), JointHalfSpec(3),                 # prototypes.jl:6-16
+                     np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
+
+
+def Revolute(name, parent, child, axis, parent_vertex=np.zeros(3), child_vertex=np.zeros(3),
+             orientation_offset=np.array([1.0, 0, 0, 0]), spring=0.0, damper=0.0, rot_spring_offset=np.zeros(1), rot_joint_limits=None):
+    # prototypes.jl:94-118: the same spring/damper value goes to both halves; Translational{T,3} ignores it
+    return JointSpec(name, parent, child,
+                     JointHalfSpec(3, spring=spring, damper=damper),
+                     JointHalfSpec(2, axis=np.array(axis, float), spring=spring, damper=damper,
+                                   spring_offset=np.array(rot_spring_offset, float), limits=rot_joint_limits),
+                     np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
+
+
+def Prismatic(name, parent, child, axis, parent_vertex=np.zeros(3), child_vertex=np.zeros(3),
+              orientation_offset=np.array([1.0, 0, 0, 0]), spring=0.0, damper=0.0, tra_spring_offset=np.zeros(1), tra_joint_limits=None):
+    return JointSpec(name, parent, child,                                                     # prototypes.jl:21-41
+                     JointHalfSpec(2, axis=np.array(axis, float), spring=spring, damper=damper,
+                                   spring_offset=np.array(tra_spring_offset, float), limits=tra_joint_limits),
+                     JointHalfSpec(3, spring=spring, damper=damper),
+                     np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
+
+
+def Spherical(name, parent, child, parent_vertex=np.zeros(3), child_vertex=np.zeros(3),
+              orientation_offset=np.array([1.0, 0, 0, 0]), spring=0.0, damper=0.0):
+    return JointSpec(name, parent, child, JointHalfSpec(3, spring=spring, damper=damper),       # prototypes.jl:343-362
+                     JointHalfSpec(0, spring=spring, damper=damper, spring_offset=np.zeros(3)),
+                     np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
+
+
+def box_inertia(x, y, z, m):                                          # src/bodies/shapes.jl:90
+    return m / 12.0 * np.diag([y * y + z * z, x * x + z * z, x * x + y * y])
+
+
+def contact_constraint(name, body, normal, friction_coefficient=1.0, contact_origin=np.zeros(3), contact_radius=0.0,
+                       contact_offset=np.zeros(3)):
+    """NonlinearContact(body, normal, μ; ...)  src/contacts/nonlinear.jl:24-48"""
+    V1, V2, V3 = orthogonal_rows(normal)
+    A = np.stack([V1, V2, V3], axis=1)          # orthogonal_columns
+    Ainv = np.linalg.inv(A)
+    return ContactSpec(name, body, float(friction_coefficient), Ainv[2].copy(), Ainv[0:2].copy(),
+                       np.array(contact_origin, float), float(contact_radius), np.array(contact_offset, float))
+
+
+def set_limits(spec, joint_limits):
+    """DojoEnvironments/src/utilities.jl:41-58 + src/joints/limits.jl:31-61 (one-dimensional joints only)"""
+    for jname, lim in joint_limits.items():
+        j = spec.joints[spec.joint_index(jname)]
+        if j.tra.nu == 0 and j.rot.nu == 1:
+            j.rot.limits = (np.array([lim[0]], float), np.array([lim[1]], float))
+        elif j.tra.nu == 1 and j.rot.nu == 0:
+            j.tra.limits = (np.array([lim[0]], float), np.array([lim[1]], float))
+        else:
+            raise ValueError("joint limits can only be set for one-dimensional joints")
+
+
+def set_springs_dampers(spec, springs=0.0, dampers=0.0):
+    """set_springs!/set_dampers!  DojoEnvironments/src/utilities.jl:1-39 (floating base skipped)"""
+    for j in spec.joints:
+        if j.N == 0:
+            continue
+        if springs != 0:
+            j.tra.spring = j.rot.spring = float(springs)
+        if dampers != 0:
+            j.tra.damper = j.rot.damper = float(dampers)
+
+
+# ----------------------------------------------------------------------------------
+# pendulum / block   (hand-built mechanisms)
+# ----------------------------------------------------------------------------------
+def get_pendulum(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, link_length=1.0, springs=0.0, dampers=0.0,
+                 joint_limits=None, spring_offset=np.zeros(1), orientation_offset=np.array([1.0, 0, 0, 0])):
+    """DojoEnvironments/src/mechanisms/pendulum/mechanism.jl:1-44"""
+    bodies = [BodySpec("pendulum", mass, box_inertia(0.1, 0.1, link_length, mass))]
+    joints = [Revolute("joint", -1, 0, X_AXIS, parent_vertex=(link_length + 0.1) * Z_AXIS, child_vertex=0.5 * link_length * Z_AXIS,
+                       rot_spring_offset=spring_offset, orientation_offset=orientation_offset)]
+    spec = MechanismSpec("pendulum", bodies, joints, [], timestep, input_scaling, gravity)
+    set_springs_dampers(spec, springs, dampers)
+    set_limits(spec, joint_limits or {})
+    return spec
+
+
+def get_block(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, edge_length=0.5, friction_coefficient=0.8,
+              contact=True, contact_radius=0.0, contact_corners=8):
+    """DojoEnvironments/src/mechanisms/block/mechanism.jl:1-70.  contact_corners=4 keeps the four
+    bottom corners only (BASELINE.json config 2); the reference's default is all 8."""
+    bodies = [BodySpec("block", mass, box_inertia(edge_length, edge_length, edge_length, mass))]
+    joints = [Floating("floating_base", -1, 0)]
+    h = edge_length / 2
+    origins = [[h, h, -h], [h, -h, -h], [-h, h, -h], [-h, -h, -h], [h, h, h], [h, -h, h], [-h, h, h], [-h, -h, h]]
+    contacts = []
+    if contact:
+        for i, o in enumerate(origins[:contact_corners]):
+            contacts.append(contact_constraint("contact%d" % (i + 1), 0, Z_AXIS, friction_coefficient, o, contact_radius))
+    return MechanismSpec("block", bodies, joints, contacts, timestep, input_scaling, gravity)
+
+
+# ----------------------------------------------------------------------------------
+# URDF mechanisms   src/mechanism/urdf.jl, src/mechanism/constructor.jl:89-109
+# ----------------------------------------------------------------------------------
+def mechanism_from_urdf_data(name, data, timestep, input_scaling, gravity, floating=True, parse_dampers=True, keep_fixed_joints=True):
+    links, ujoints = data["links"], data["joints"]
+    lidx = {l["name"]: i for i, l in enumerate(links)}
+    children = {j["child"] for j in ujoints}
+    roots = [l["name"] for l in links if l["name"] not in children]
+    assert len(roots) == 1, "Multiple origins"
+    assert floating, "only floating-base URDF mechanisms are built here"
+    bodies = []
+    for l in links:                                   # parse_link, urdf.jl:171-200: inertia used as given
+        ixx, ixy, ixz, iyy, iyz, izz = l["inertia"]
+        bodies.append(BodySpec(l["name"], l["mass"], np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])))
+    x_in = [np.array(l["xyz"], float) for l in links]
+    q_in = [rpy_to_quat(l["rpy"]) for l in links]
+
+    joints = [Floating("floating_base", -1, lidx[roots[0]])]            # urdf.jl:328-331
+    raw = [dict(xyz=np.zeros(3), q=np.array([1.0, 0, 0, 0]))]
+    for j in ujoints:                                                  # parse_joint / joint_selector, urdf.jl:211-268
+        p, c = lidx[j["parent"]], lidx[j["child"]]
+        damper = j["damping"] if parse_dampers else 0.0
+        if j["type"] in ("revolute", "continuous"):
+            joints.append(Revolute(j["name"], p, c, j["axis"], damper=damper))
+        elif j["type"] == "prismatic":
+            joints.append(Prismatic(j["name"], p, c, j["axis"], damper=damper))
+        elif j["type"] == "fixed":
+            joints.append(Fixed(j["name"], p, c))
+        elif j["type"] == "ball":
+            joints.append(Spherical(j["name"], p, c, damper=damper))
+        else:
+            raise NotImplementedError("URDF joint type " + j["type"])
+        raw.append(dict(xyz=np.array(j["xyz"], float), q=rpy_to_quat(j["rpy"])))
+
+    # set_parsed_values!, urdf.jl:420-507: rewrite joints/bodies into COM frames, root -> leaves
+    nb = len(bodies)
+    xb = [np.zeros(3)] * nb; qb = [np.array([1.0, 0, 0, 0])] * nb     # body world poses at zero configuration
+    xjw = {}; qjw = {}                                               # joint world poses, keyed by child body
+    parent_joint_of = {j.child: k for k, j in enumerate(joints)}
+    order, frontier = [], [0]
+    while frontier:                                                  # breadth-first from the floating base
+        k = frontier.pop(0); order.append(k)
+        frontier += [m for m, j in enumerate(joints) if j.parent == joints[k].child]
+    assert len(order) == len(joints), "kinematic loops are not supported"
+    for k in order:
+        j = joints[k]; c = j.child
+        if j.parent < 0:
+            xP, qP = np.zeros(3), np.array([1.0, 0, 0, 0]); xpj, qpj = np.zeros(3), np.array([1.0, 0, 0, 0])
+        else:
+            xP, qP = xb[j.parent], qb[j.parent]; xpj, qpj = xjw[j.parent], qjw[j.parent]
+        xjl = vrot(xpj + vrot(raw[k]["xyz"], qpj) - xP, qinv(qP))     # urdf.jl:470
+        qjl = qmul(qmul(qinv(qP), qpj), raw[k]["q"])                  # urdf.jl:471
+        xjw[c] = xP + vrot(xjl, qP); qjw[c] = qmul(qP, qjl)           # urdf.jl:474-477
+        j.orientation_offset = qmul(qjl, q_in[c])                    # urdf.jl:480
+        j.vertex_parent = xjl                                        # urdf.jl:483
+        j.vertex_child = vrot(-x_in[c], qinv(q_in[c]))               # urdf.jl:484
+        qb[c] = qmul(qP, j.orientation_offset)                       # bodies/set.jl:59-70
+        xb[c] = xP + vrot(j.vertex_parent, qP) - vrot(j.vertex_child, qb[c])
+    if not keep_fixed_joints:
+        assert all(j.N != 6 for j in joints), "reduce_fixed_joints: not needed by the BASELINE configs (A1, Atlas-simple have no fixed joints)"
+    return MechanismSpec(name, bodies, joints, [], timestep, input_scaling, gravity)
+
+
+def _load(name):
+    with open(os.path.join(_DATA, name + ".json")) as f:
+        return json.load(f)
+
+
+def get_ant(timestep=0.05, input_scaling=None, gravity=-9.81, springs=0.0, dampers=0.0, parse_springs=True, parse_dampers=True,
+            joint_limits=None, keep_fixed_joints=True, friction_coefficient=0.5, contact_feet=True, contact_body=True):
+    """DojoEnvironments/src/mechanisms/ant/mechanism.jl:1-91"""
+    data = _load("ant")
+    spec = mechanism_from_urdf_data("ant", data, timestep, input_scaling, gravity, True, parse_dampers, keep_fixed_joints)
+    set_springs_dampers(spec, 0.0 if parse_springs else springs, 0.0 if parse_dampers else dampers)
+    if joint_limits is None:
+        d = np.pi / 180
+        joint_limits = {"hip_1": [-30 * d, 30 * d], "ankle_1": [30 * d, 70 * d], "hip_2": [-30 * d, 30 * d], "ankle_2": [-70 * d, -30 * d],
+                        "hip_3": [-30 * d, 30 * d], "ankle_3": [-70 * d, -30 * d], "hip_4": [-30 * d, 30 * d], "ankle_4": [30 * d, 70 * d]}
+    set_limits(spec, joint_limits)
+    radius = {l["name"]: l["radius"] for l in data["links"]}
+    if contact_feet:
+        names = ["front_left_foot", "front_right_foot", "left_back_foot", "right_back_foot"]
+        origins = [[0.2, 0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0], [0.2, -0.2, 0]]
+        for n, o in zip(names, origins):
+            spec.contacts.append(contact_constraint(n + "_contact", spec.body_index(n), Z_AXIS, friction_coefficient, o, radius[n]))
+    if contact_body:
+        spec.contacts.append(contact_constraint("torso_contact", spec.body_index("torso"), Z_AXIS, friction_coefficient, np.zeros(3), radius["torso"]))
+        names = ["aux_1", "aux_2", "aux_3", "aux_4"]
+        origins = [[-0.1, -0.1, 0], [0.1, -0.1, 0], [0.1, 0.1, 0], [-0.1, 0.1, 0]]
+        for n, o in zip(names, origins):
+            spec.contacts.append(contact_constraint(n + "_contact", spec.body_index(n), Z_AXIS, friction_coefficient, o, radius[n]))
+    return spec
+
+
+def get_quadruped(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dampers=0.0, parse_springs=True, parse_dampers=True,
+                  spring_offset=True, joint_limits=None, keep_fixed_joints=False, friction_coefficient=0.8,
+                  contact_feet=True, contact_body=True):
+    """DojoEnvironments/src/mechanisms/quadruped/mechanism.jl:1-109"""
+    spec = mechanism_from_urdf_data("quadruped", _load("quadruped"), timestep, input_scaling, gravity, True, parse_dampers, keep_fixed_joints)
+    set_springs_dampers(spec, 0.0 if parse_springs else springs, 0.0 if parse_dampers else dampers)
+    groups = ["FR", "FL", "RR", "RL"]
+    if spring_offset:
+        for g in groups:
+            spec.joints[spec.joint_index(g + "_hip_joint")].rot.spring_offset = np.array([0.0])
+            spec.joints[spec.joint_index(g + "_thigh_joint")].rot.spring_offset = np.array([0.9])
+            spec.joints[spec.joint_index(g + "_calf_joint")].rot.spring_offset = np.array([-1.425])
+    if joint_limits is None:
+        joint_limits = {}
+        for g in groups:
+            joint_limits[g + "_hip_joint"] = [-0.5, 0.5]; joint_limits[g + "_thigh_joint"] = [-0.5, 1.5]; joint_limits[g + "_calf_joint"] = [-2.5, -1.0]
+    set_limits(spec, joint_limits)
+    if contact_feet:
+        for g in groups:
+            spec.contacts.append(contact_constraint(g + "_calf_contact", spec.body_index(g + "_calf"), Z_AXIS, friction_coefficient, [-0.006, 0, -0.092], 0.021))
+    if contact_body:
+        for g, o in zip(groups, [[-0.005, -0.023, -0.16], [-0.005, 0.023, -0.16], [-0.005, -0.023, -0.16], [-0.005, 0.023, -0.16]]):
+            spec.contacts.append(contact_constraint(g + "_thigh_contact", spec.body_index(g + "_thigh"), Z_AXIS, friction_coefficient, o, 0.023))
+        for g in groups:
+            spec.contacts.append(contact_constraint(g + "_hip_contact", spec.body_index(g + "_hip"), Z_AXIS, friction_coefficient, [0, 0.05, 0], 0.05))
+    return spec
+
+
+def get_atlas(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dampers=0.0, parse_springs=True, parse_dampers=True,
+              joint_limits=None, keep_fixed_joints=False, friction_coefficient=0.8, contact_feet=True, contact_body=True):
+    """DojoEnvironments/src/mechanisms/atlas/mechanism.jl:1-108 (urdf = :atlas_simple)"""
+    spec = mechanism_from_urdf_data("atlas", _load("atlas"), timestep, input_scaling, gravity, True, parse_dampers, keep_fixed_joints)
+    set_springs_dampers(spec, 0.0 if parse_springs else springs, 0.0 if parse_dampers else dampers)
+    set_limits(spec, joint_limits or {})
+    if contact_feet:
+        origins = [[-0.08, -0.04, 0.015], [0.12, -0.02, 0.015], [-0.08, 0.04, 0.015], [0.12, 0.02, 0.015]]
+        for side in ("l", "r"):
+            for n, o in zip(["RR", "FR", "RL", "RR"], origins):
+                spec.contacts.append(contact_constraint(side + "_" + n, spec.body_index(side + "_foot"), Z_AXIS, friction_coefficient, o, 0.025))
+    if contact_body:
+        names = ["l_hand", "r_hand", "l_lleg", "r_lleg", "l_clav", "r_clav", "pelvis", "l_uarm", "r_uarm", "head", "utorso", "utorso"]
+        origins = [[0, 0, 0], [0, 0, 0], [0.025, 0, 0.175], [0.025, 0, 0.175], [0, -0.05, -0.075], [0, -0.05, -0.075], [0, 0, 0.05],
+                   [0, -0.185, 0], [0, -0.185, 0], [0, 0, 0], [-0.095, 0, 0.25], [-0.095, 0, -0.2]]
+        radii = [0.06, 0.06, 0.075, 0.075, 0.11, 0.11, 0.19, 0.085, 0.085, 0.175, 0.15, 0.15]
+        for k, (n, o, r) in enumerate(zip(names, origins, radii)):
+            spec.contacts.append(contact_constraint("body_contact_%d" % k, spec.body_index(n), Z_AXIS, friction_coefficient, o, r))
+    return spec
+
+
+def get_mechanism(name, **kwargs):
+    """DojoEnvironments.get_mechanism(:name; kwargs...)  DojoEnvironments/src/mechanisms.jl"""
+    return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas}[name](**kwargs)
+
+
+# the five BASELINE.json configurations
+def baseline_config(i):
+    if i == 1: return get_pendulum()
+    if i == 2: return get_block(contact_corners=4)
+    if i == 3: return get_ant(contact_body=False)
+    if i == 4: return get_quadruped(contact_body=False)
+    if i == 5: return get_atlas(contact_body=False)
+    raise ValueError(i)

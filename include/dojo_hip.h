@@ -1,0 +1,196 @@
+/*
+ * dojo_hip.h -- C ABI of libdojo_hip.so: the MI355X-native batched replacement for
+ * Dojo.jl's per-timestep contact-implicit forward/backward path.
+ *
+ * The reference (Dojo.jl, 100 % Julia) has no FFI for this path; the seams this
+ * library replaces are plain Julia method calls on a mutable `Mechanism`:
+ *
+ *   dojo_create        <- Mechanism(origin, bodies, joints, contacts; timestep, input_scaling, gravity)
+ *                         src/mechanism/constructor.jl:46-82   (topology is *read*, never rebuilt)
+ *   dojo_set_options   <- SolverOptions{T}                     src/solver/options.jl:16-26
+ *   dojo_step          <- step!(mechanism, z, u; opts)         src/simulation/step.jl:11-30
+ *                         (= set_maximal_state! + set_input! + mehrotra! + update_state!)
+ *                         mehrotra!(mechanism; opts)           src/solver/mehrotra.jl:9-73
+ *   dojo_get_solution  <- get_solution(mechanism)              src/gradients/finite_difference.jl:1-18
+ *                         (what the Julia shim writes back into body.state.vsol/ωsol,
+ *                          joint.impulses[2], contact.impulses_dual[2]/impulses[2] so that
+ *                          DojoEnvironments.get_state, ant_ars.jl:72-80, keeps working)
+ *   dojo_gradients     <- get_maximal_gradients!(mechanism, z, u; opts) / get_maximal_gradients(mechanism)
+ *                         src/gradients/state.jl:69-126
+ *   dojo_rollout       <- simulate!(mechanism, steps, storage, control!)  src/simulation/simulate.jl:16-36
+ *                         with the control callback replaced by pre-sampled inputs U[k]
+ *   dojo_destroy       <- (GC of the Mechanism)
+ *
+ * All matrices at the ABI are row-major with the environment (batch) index slowest:
+ * z[B][13*Nb], u[B][nu], dz[B][12*Nb][12*Nb], du[B][12*Nb][nu].  Scalars are fp64
+ * (dtype 0) or fp32 (dtype 1) as chosen at dojo_create; topology/option structs are
+ * always fp64 and are cast on upload.  No exception crosses the boundary: every entry
+ * point returns DOJO_OK (0) or a negative error code and dojo_last_error() gives text.
+ *
+ * Pointer arguments are *host* pointers for the plain entry points and *device*
+ * pointers for the `_dev` variants (used by bench.py / torch so that inputs are
+ * resident in HBM when the timed region starts).
+ */
+#ifndef DOJO_HIP_H
+#define DOJO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOJO_OK                 0
+#define DOJO_ERR_INVALID       -1   /* bad argument / malformed topology            */
+#define DOJO_ERR_UNSUPPORTED   -2   /* e.g. kinematic loop, >1 parent joint per body */
+#define DOJO_ERR_DEVICE        -3   /* HIP runtime error (text in dojo_last_error)   */
+#define DOJO_ERR_NO_DEVICE     -4   /* no gfx950 device visible                      */
+
+/* per-environment solver status, mirrors mehrotra!'s :success / :failed and the
+ * "Excessive angular velocity" error() of src/solver/line_search.jl:18-20 */
+#define DOJO_STATUS_SUCCESS      0
+#define DOJO_STATUS_FAILED       1
+#define DOJO_STATUS_EXCESSIVE_W  2
+
+#define DOJO_DTYPE_F64 0
+#define DOJO_DTYPE_F32 1
+
+/* Body{T}: src/bodies/constructor.jl:14-27 (mass, inertia only; state is per-env) */
+typedef struct DojoBody {
+    double mass;
+    double inertia[9];            /* row-major 3x3, body (COM) frame */
+} DojoBody;
+
+/*
+ * JointConstraint{T,N,Nc,TJ,RJ} = Translational half + Rotational half
+ * (src/joints/constraints.jl:17-86, translational/constructor.jl:18-67,
+ *  rotational/constructor.jl:18-63).  Masks are exported from the live Julia object
+ * (they come from an SVD, src/joints/orthogonal.jl:1-12) as
+ *   cmask = constraint_mask(joint)  (nl   x 3, rows beyond nl   are ignored)
+ *   amask = nullspace_mask(joint)   (3-nl x 3, rows beyond 3-nl are ignored)
+ * (src/joints/joint.jl:56-64).
+ */
+typedef struct DojoJointHalf {
+    int32_t nl;                   /* N-lambda: number of constrained directions, 0..3      */
+    int32_t nlim;                 /* Nb/2: number of limited minimal coordinates (0..3-nl) */
+    double  cmask[9];
+    double  amask[9];
+    double  spring;               /* joint.spring coefficient                              */
+    double  damper;               /* joint.damper coefficient                              */
+    double  spring_offset[3];     /* length 3-nl                                           */
+    double  limit_lo[3];          /* joint_limits[1], length nlim                          */
+    double  limit_hi[3];          /* joint_limits[2], length nlim                          */
+} DojoJointHalf;
+
+typedef struct DojoJoint {
+    int32_t parent;               /* index into bodies[], -1 = origin (parent_id == 0)     */
+    int32_t child;                /* index into bodies[]                                   */
+    int32_t spring_on;            /* JointConstraint.spring flag                           */
+    int32_t damper_on;            /* JointConstraint.damper flag                           */
+    double  vertex_parent[3];     /* translational.vertices[1]                             */
+    double  vertex_child[3];      /* translational.vertices[2]                             */
+    double  orientation_offset[4];/* rotational.orientation_offset (s, v1, v2, v3)         */
+    DojoJointHalf tra;
+    DojoJointHalf rot;
+} DojoJoint;
+
+/* ContactConstraint{T,8,1,NonlinearContact,4} with SphereHalfSpaceCollision, child = origin
+ * (src/contacts/nonlinear.jl:12-48, src/contacts/collisions/sphere_halfspace.jl:11-22) */
+typedef struct DojoContact {
+    int32_t body;                 /* parent_id as index into bodies[]                      */
+    int32_t reserved;
+    double  friction_coefficient;
+    double  normal[3];            /* collision.contact_normal (1x3)                        */
+    double  tangent[6];           /* collision.contact_tangent (2x3, row-major)            */
+    double  origin[3];            /* collision.contact_origin                              */
+    double  radius;               /* collision.contact_radius                              */
+    double  offset[3];            /* collision.contact_offset                              */
+} DojoContact;
+
+typedef struct DojoTopology {
+    int32_t n_bodies, n_joints, n_contacts, reserved;
+    double  timestep;
+    double  input_scaling;
+    double  gravity[3];
+    const DojoBody*    bodies;    /* mechanism.bodies   order (defines the z layout)       */
+    const DojoJoint*   joints;    /* mechanism.joints   order (defines the u layout)       */
+    const DojoContact* contacts;  /* mechanism.contacts order                              */
+} DojoTopology;
+
+/* SolverOptions{T}: src/solver/options.jl:16-26 (ls_scale is unused by the reference,
+ * halving is hard-coded in src/solver/line_search.jl:143; verbose has no device meaning) */
+typedef struct DojoSolverOptions {
+    double  rtol;                 /* 1e-6 */
+    double  btol;                 /* 1e-4 */
+    double  undercut;             /* Inf  */
+    double  no_progress_undercut; /* 10   */
+    int32_t max_iter;             /* 50   */
+    int32_t max_ls;               /* 10   */
+    int32_t no_progress_max;      /* 3    */
+    int32_t reserved;
+} DojoSolverOptions;
+
+typedef struct DojoSim* DojoHandle;
+
+/* dimensions derived from the topology (same formulas as the reference) */
+typedef struct DojoDims {
+    int32_t n_bodies, n_joints, n_contacts;
+    int32_t nz;                   /* 13*Nb  maximal state                                  */
+    int32_t nx;                   /* 12*Nb  attitude-reduced state (gradient rows/cols)    */
+    int32_t nu;                   /* sum over joints of (3-nl_tra)+(3-nl_rot)              */
+    int32_t n_joint_impulses;     /* sum over joints of N_j = sum_halves nl + 4*nlim       */
+    int32_t n_solution;           /* n = n_joint_impulses + 6*Nb + 8*Nc                    */
+    int32_t lanes_per_env;        /* S: wavefront lanes cooperating on one environment     */
+} DojoDims;
+
+/* gradient flavour, SURVEY.md §8a note Q2 */
+#define DOJO_GRAD_REFERENCE  0    /* literal get_maximal_gradients! (data blocks on the post-update_state! state) */
+#define DOJO_GRAD_CONSISTENT 1    /* data blocks on the pre-update state (what test/data.jl checks)               */
+
+int  dojo_device_count(void);
+const char* dojo_last_error(void);
+
+int  dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t device, DojoHandle* out);
+void dojo_destroy(DojoHandle h);
+int  dojo_get_dims(DojoHandle h, DojoDims* dims);
+int  dojo_set_options(DojoHandle h, const DojoSolverOptions* opts);
+int  dojo_set_gradient_mode(DojoHandle h, int32_t mode);
+
+/* step!: z [B,13Nb], u [B,nu] (NULL = zeros) -> z_next [B,13Nb] = the mechanism's internal
+ * state after update_state! (x3,v25,q3,w25; SURVEY §8a note Q1), status [B], iters [B]
+ * (status / iters may be NULL).  with_gradient != 0 additionally leaves the IFT Jacobians
+ * of this step in the handle for dojo_gradients(). */
+int  dojo_step(DojoHandle h, const void* z, const void* u, void* z_next,
+               int32_t* status, int32_t* iters, int32_t with_gradient);
+
+/* solution of the last step in get_solution order per env:
+ * vel [B,6Nb] (v25,w25 per body), joint_imp [B,n_joint_impulses], contact_sg [B,8Nc] ([s;gamma] per contact).
+ * Any pointer may be NULL. */
+int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_sg);
+
+/* IFT Jacobians of the last dojo_step(..., with_gradient=1):
+ * dz [B,12Nb,12Nb] = jacobian_state, du [B,12Nb,nu] = jacobian_control */
+int  dojo_gradients(DojoHandle h, void* dz, void* du);
+
+/* simulate! with pre-sampled controls: z0 [B,13Nb], U [H,B,nu] (NULL = zeros) ->
+ * Z [H,B,13Nb] (state after each step; NULL = keep only the final state, readable with
+ * dojo_get_state), status [H,B] (may be NULL) */
+int  dojo_rollout(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z, int32_t* status);
+int  dojo_get_state(DojoHandle h, void* z);
+
+/* device-pointer variants: all pointers are device memory on the handle's GPU, work is
+ * enqueued on `stream` (a hipStream_t passed as void*, NULL = the null stream) and NOT
+ * synchronized; outputs are valid after the stream is synchronized. */
+int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
+                   int32_t* status, int32_t* iters, void* dz, void* du, void* stream);
+int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
+                      int32_t* status, void* stream);
+
+/* timing helper for bench.py: average duration in ms of the last `n` launches of the
+ * step kernel measured with hipEvents on the launch stream (roofline.achieved) */
+int  dojo_last_kernel_ms(DojoHandle h, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOJO_HIP_H */

@@ -1,0 +1,171 @@
+// capi.cpp -- C entry points of the CPU oracle (liboracle.so), loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.
+// All arrays at this boundary are fp64 row-major; `dtype` selects the arithmetic the
+// oracle computes in (0 = fp64, 1 = fp32).
+#include "dojo_oracle.hpp"
+#include <thread>
+#include <memory>
+#include <algorithm>
+
+using namespace orc;
+
+namespace {
+
+struct IOracle {
+    virtual ~IOracle() {}
+    virtual void set_options(const DojoSolverOptions& o) = 0;
+    virtual void dims(int* out) = 0;
+    virtual int step(const double* z, const double* u, double* z_state, double* z_return, int* iters) = 0;
+    virtual void get_solution(double* sol) = 0;
+    virtual void set_solution(const double* sol) = 0;
+    virtual void gradients(int mode, double* dz, double* du) = 0;
+    virtual void get_data(double* d) = 0;
+    virtual void set_data(const double* d) = 0;
+    virtual void evaluate_residual(const double* data, const double* sol, double* out) = 0;
+    virtual void full_matrix(double* out) = 0;
+    virtual void data_matrix(double* out) = 0;
+    virtual void data_attjac(double* out) = 0;
+    virtual void set_state(const double* z) = 0;
+    virtual void get_state(double* z) = 0;
+    virtual void set_external_force(int body, const double* force, const double* torque, const double* vertex) = 0;
+    virtual int simulate_step(const double* u, int last) = 0;
+    virtual void body_velocity_solution(double* v) = 0;
+    virtual IOracle* clone() = 0;
+};
+
+template <class T>
+struct OracleT : IOracle {
+    Mechanism<T> m;
+    std::vector<State<T>> pre;   // body states before update_state! of the last step()
+    explicit OracleT(const DojoTopology& tp) : m(tp) {}
+    std::vector<T> cast(const double* p, int n) { std::vector<T> v(n); for (int i = 0; i < n; ++i) v[i] = T(p[i]); return v; }
+    void set_options(const DojoSolverOptions& o) override {
+        m.opts.rtol = o.rtol; m.opts.btol = o.btol; m.opts.undercut = o.undercut; m.opts.no_progress_undercut = o.no_progress_undercut;
+        m.opts.max_iter = o.max_iter; m.opts.max_ls = o.max_ls; m.opts.no_progress_max = o.no_progress_max;
+    }
+    void dims(int* out) override {
+        out[0] = m.n; out[1] = m.nu(); out[2] = m.data_dim(false); out[3] = m.data_dim(true);
+        out[4] = (int)m.bodies.size(); out[5] = (int)m.joints.size(); out[6] = (int)m.contacts.size();
+    }
+    int step(const double* z, const double* u, double* z_state, double* z_return, int* iters) override {
+        int nz = 13 * (int)m.bodies.size(), nu = m.nu();
+        std::vector<T> zz = cast(z, nz), uu(nu, T(0));
+        if (u) uu = cast(u, nu);
+        m.set_maximal_state(zz.data());
+        m.set_input_all(uu.data());
+        int status = m.mehrotra();
+        pre.clear(); for (auto& B : m.bodies) pre.push_back(B.st);
+        m.update_state();
+        std::vector<T> o(nz);
+        if (z_state) { m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z_state[i] = o[i]; }
+        if (z_return) { m.get_next_state(o.data()); for (int i = 0; i < nz; ++i) z_return[i] = o[i]; }
+        if (iters) *iters = m.last_iters;
+        return status;
+    }
+    void get_solution(double* sol) override { std::vector<T> s(m.n); m.get_solution(s.data()); for (int i = 0; i < m.n; ++i) sol[i] = s[i]; }
+    void set_solution(const double* sol) override { auto s = cast(sol, m.n); m.set_solution(s.data()); }
+    void gradients(int mode, double* dz, double* du) override {
+        int nx = 12 * (int)m.bodies.size(), nu = m.nu();
+        std::vector<T> a((size_t)nx * nx), b((size_t)nx * std::max(nu, 1));
+        std::vector<T> solmat = m.A;   // un-factored matrix of the last set_entries! (mehrotra.jl:69)
+        if (mode == DOJO_GRAD_CONSISTENT && pre.size() == m.bodies.size()) {
+            std::vector<State<T>> post; for (auto& B : m.bodies) post.push_back(B.st);
+            for (size_t i = 0; i < pre.size(); ++i) m.bodies[i].st = pre[i];
+            m.get_maximal_gradients(solmat, a.data(), b.data());
+            for (size_t i = 0; i < post.size(); ++i) m.bodies[i].st = post[i];
+        } else {
+            m.get_maximal_gradients(solmat, a.data(), b.data());
+        }
+        for (size_t i = 0; i < (size_t)nx * nx; ++i) dz[i] = a[i];
+        for (size_t i = 0; i < (size_t)nx * nu; ++i) du[i] = b[i];
+    }
+    void get_data(double* d) override { int nd = m.data_dim(false); std::vector<T> v(nd); m.get_data(v.data()); for (int i = 0; i < nd; ++i) d[i] = v[i]; }
+    void set_data(const double* d) override { auto v = cast(d, m.data_dim(false)); m.set_data(v.data()); }
+    void evaluate_residual(const double* data, const double* sol, double* out) override {
+        auto d = cast(data, m.data_dim(false)); auto s = cast(sol, m.n); std::vector<T> o(m.n);
+        m.evaluate_residual(d.data(), s.data(), o.data());
+        for (int i = 0; i < m.n; ++i) out[i] = o[i];
+    }
+    void full_matrix(double* out) override { for (size_t i = 0; i < (size_t)m.n * m.n; ++i) out[i] = m.A[i]; }
+    void data_matrix(double* out) override { std::vector<T> D; int nd; m.jacobian_data(D, nd); for (size_t i = 0; i < D.size(); ++i) out[i] = D[i]; }
+    void data_attjac(double* out) override { std::vector<T> G; int nr, nc; m.data_attitude_jacobian(G, nr, nc); for (size_t i = 0; i < G.size(); ++i) out[i] = G[i]; }
+    void set_state(const double* z) override {   // state without touching inputs (for simulate!)
+        int Nb = (int)m.bodies.size();
+        for (int i = 0; i < Nb; ++i) {
+            State<T>& s = m.bodies[i].st; const double* p = z + 13 * i;
+            for (int k = 0; k < 3; ++k) { s.x2[k] = T(p[k]); s.v15[k] = T(p[3 + k]); s.w15[k] = T(p[10 + k]); }
+            s.q2 = Quat<T>(T(p[6]), T(p[7]), T(p[8]), T(p[9]));
+        }
+        m.initialize_simulation();
+    }
+    void get_state(double* z) override { int nz = 13 * (int)m.bodies.size(); std::vector<T> o(nz); m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z[i] = o[i]; }
+    void set_external_force(int body, const double* force, const double* torque, const double* vertex) override {
+        // set_external_force!(body; force, torque, vertex)  bodies/set.jl:96-101
+        State<T>& s = m.bodies[body].st;
+        SM<T> f = SM<T>::vec({T(force[0]), T(force[1]), T(force[2])}), t = SM<T>::vec({T(torque[0]), T(torque[1]), T(torque[2])}),
+              v = SM<T>::vec({T(vertex[0]), T(vertex[1]), T(vertex[2])});
+        s.Fext = vector_rotate(f, s.q2);
+        s.text = t + skew(v) * f;
+    }
+    int simulate_step(const double* u, int last) override {
+        if (u) { auto uu = cast(u, m.nu()); return m.simulate_step(uu.data(), last != 0); }
+        return m.simulate_step(nullptr, last != 0);
+    }
+    void body_velocity_solution(double* v) override {
+        for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { v[6 * i + k] = m.bodies[i].st.vsol[1][k]; v[6 * i + 3 + k] = m.bodies[i].st.wsol[1][k]; }
+    }
+    IOracle* clone() override { return new OracleT<T>(*this); }
+};
+
+} // namespace
+
+extern "C" {
+
+void* orc_create(const DojoTopology* tp, int dtype) {
+    if (dtype == DOJO_DTYPE_F32) return new OracleT<float>(*tp);
+    return new OracleT<double>(*tp);
+}
+void orc_destroy(void* h) { delete (IOracle*)h; }
+void orc_set_options(void* h, const DojoSolverOptions* o) { ((IOracle*)h)->set_options(*o); }
+void orc_dims(void* h, int* out) { ((IOracle*)h)->dims(out); }
+int  orc_step(void* h, const double* z, const double* u, double* z_state, double* z_return, int* iters) { return ((IOracle*)h)->step(z, u, z_state, z_return, iters); }
+void orc_get_solution(void* h, double* sol) { ((IOracle*)h)->get_solution(sol); }
+void orc_set_solution(void* h, const double* sol) { ((IOracle*)h)->set_solution(sol); }
+void orc_gradients(void* h, int mode, double* dz, double* du) { ((IOracle*)h)->gradients(mode, dz, du); }
+void orc_get_data(void* h, double* d) { ((IOracle*)h)->get_data(d); }
+void orc_set_data(void* h, const double* d) { ((IOracle*)h)->set_data(d); }
+void orc_evaluate_residual(void* h, const double* data, const double* sol, double* out) { ((IOracle*)h)->evaluate_residual(data, sol, out); }
+void orc_full_matrix(void* h, double* out) { ((IOracle*)h)->full_matrix(out); }
+void orc_data_matrix(void* h, double* out) { ((IOracle*)h)->data_matrix(out); }
+void orc_data_attjac(void* h, double* out) { ((IOracle*)h)->data_attjac(out); }
+void orc_set_state(void* h, const double* z) { ((IOracle*)h)->set_state(z); }
+void orc_get_state(void* h, double* z) { ((IOracle*)h)->get_state(z); }
+void orc_set_external_force(void* h, int body, const double* f, const double* t, const double* v) { ((IOracle*)h)->set_external_force(body, f, t, v); }
+int  orc_simulate_step(void* h, const double* u, int last) { return ((IOracle*)h)->simulate_step(u, last); }
+void orc_body_velocity_solution(void* h, double* v) { ((IOracle*)h)->body_velocity_solution(v); }
+
+// Batched step for the CPU baseline: one environment per thread-task over `nthreads`
+// host threads.  z [B,13Nb], u [B,nu] or NULL, outputs may be NULL.
+void orc_step_batch(void* h, int B, const double* z, const double* u, double* z_next, int* status, int* iters,
+                    int with_grad, int grad_mode, double* dz, double* du, int nthreads) {
+    IOracle* base = (IOracle*)h; int d[7]; base->dims(d);
+    int nz = 13 * d[4], nu = d[1], nx = 12 * d[4];
+    nthreads = std::max(1, std::min(nthreads, B));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+        th.emplace_back([=]() {
+            std::unique_ptr<IOracle> o(base->clone());
+            std::vector<double> zs(nz);
+            for (int e = t; e < B; e += nthreads) {
+                int it = 0;
+                int st = o->step(z + (size_t)e * nz, u ? u + (size_t)e * nu : nullptr, z_next ? z_next + (size_t)e * nz : zs.data(), nullptr, &it);
+                if (status) status[e] = st;
+                if (iters) iters[e] = it;
+                if (with_grad) o->gradients(grad_mode, dz + (size_t)e * nx * nx, du + (size_t)e * nx * nu);
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+}
+
+} // extern "C"

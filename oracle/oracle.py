@@ -1,0 +1,149 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the
+shipped product (dojo.jl_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "..", "dojo.jl_amd", "host"))
+from dojo_amd.topology import CTopology, CSolverOptions, SolverOptions  # noqa: E402
+
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "dojo_oracle.hpp", "oracle_math.hpp")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
+        if all(os.path.exists(s) for s in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_create.restype = C.c_void_p
+        _lib.orc_create.argtypes = [C.POINTER(CTopology), C.c_int]
+        for name in ("orc_destroy", "orc_set_options", "orc_dims", "orc_get_solution", "orc_set_solution", "orc_gradients",
+                     "orc_get_data", "orc_set_data", "orc_evaluate_residual", "orc_full_matrix", "orc_data_matrix",
+                     "orc_data_attjac", "orc_set_state", "orc_get_state", "orc_set_external_force",
+                     "orc_body_velocity_solution", "orc_step_batch"):
+            getattr(_lib, name).restype = None
+        _lib.orc_step.restype = C.c_int
+        _lib.orc_simulate_step.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Single-environment CPU oracle of a MechanismSpec."""
+
+    def __init__(self, spec, dtype="f64", opts=None):
+        self.spec = spec
+        self._topo, self._keep = spec.to_ctypes()
+        self.h = C.c_void_p(lib().orc_create(C.byref(self._topo), 0 if dtype == "f64" else 1))
+        d = (C.c_int * 7)()
+        lib().orc_dims(self.h, d)
+        self.n, self.nu, self.nd_full, self.nd, self.Nb, self.Ne, self.Nc = list(d)
+        assert self.n == spec.n_solution and self.nu == spec.nu
+        self.set_options(opts or SolverOptions())
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_options(self, opts):
+        self.opts = opts
+        o = opts.to_c()
+        lib().orc_set_options(self.h, C.byref(o))
+
+    # step!(mechanism, z, u)
+    def step(self, z, u=None):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        zs = np.zeros(13 * self.Nb); zr = np.zeros(13 * self.Nb); it = C.c_int(0)
+        st = lib().orc_step(self.h, _p(z), _p(u), _p(zs), _p(zr), C.byref(it))
+        return zs, dict(status=st, iters=it.value, z_return=zr)
+
+    def get_solution(self):
+        s = np.zeros(self.n); lib().orc_get_solution(self.h, _p(s)); return s
+
+    def set_solution(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64); lib().orc_set_solution(self.h, _p(s))
+
+    def gradients(self, mode=0):
+        nx = 12 * self.Nb
+        dz = np.zeros((nx, nx)); du = np.zeros((nx, max(self.nu, 1)))
+        lib().orc_gradients(self.h, mode, _p(dz), _p(du))
+        return dz, du.reshape(-1)[:nx * self.nu].reshape(nx, self.nu)
+
+    def get_data(self):
+        d = np.zeros(self.nd_full); lib().orc_get_data(self.h, _p(d)); return d
+
+    def set_data(self, d):
+        d = np.ascontiguousarray(d, dtype=np.float64); lib().orc_set_data(self.h, _p(d))
+
+    def evaluate_residual(self, data, sol):
+        out = np.zeros(self.n)
+        lib().orc_evaluate_residual(self.h, _p(np.ascontiguousarray(data, dtype=np.float64)), _p(np.ascontiguousarray(sol, dtype=np.float64)), _p(out))
+        return out
+
+    def full_matrix(self):
+        A = np.zeros((self.n, self.n)); lib().orc_full_matrix(self.h, _p(A)); return A
+
+    def data_matrix(self):
+        D = np.zeros((self.n, self.nd)); lib().orc_data_matrix(self.h, _p(D)); return D
+
+    def data_attjac(self):
+        G = np.zeros((self.nd_full, self.nd)); lib().orc_data_attjac(self.h, _p(G)); return G
+
+    # simulate! pieces
+    def set_state(self, z):
+        z = np.ascontiguousarray(z, dtype=np.float64); lib().orc_set_state(self.h, _p(z))
+
+    def get_state(self):
+        z = np.zeros(13 * self.Nb); lib().orc_get_state(self.h, _p(z)); return z
+
+    def set_external_force(self, body, force=(0, 0, 0), torque=(0, 0, 0), vertex=(0, 0, 0)):
+        f, t, v = (np.array(a, dtype=np.float64) for a in (force, torque, vertex))
+        lib().orc_set_external_force(self.h, int(body), _p(f), _p(t), _p(v))
+
+    def simulate_step(self, u=None, last=False):
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        return lib().orc_simulate_step(self.h, _p(u), int(last))
+
+    def velocity_solution(self):
+        v = np.zeros(6 * self.Nb); lib().orc_body_velocity_solution(self.h, _p(v)); return v
+
+    def simulate(self, z0, steps, control=None):
+        """simulate!(mechanism, steps, storage, control!)  -> list of maximal states after each step.
+        The last step is not followed by update_state! (simulate.jl:32), as in the reference."""
+        self.set_state(z0)
+        traj = []; status = []
+        for k in range(1, steps + 1):
+            u = control(self, k) if control else None
+            status.append(self.simulate_step(u, last=(k == steps)))
+            traj.append(self.get_state())
+        return traj, status
+
+    def step_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1):
+        Z = np.ascontiguousarray(Z, dtype=np.float64); B = Z.shape[0]
+        U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
+        Zn = np.zeros_like(Z); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+        nx = 12 * self.Nb
+        dz = np.zeros((B, nx, nx)) if with_grad else None
+        du = np.zeros((B, nx, self.nu)) if with_grad else None
+        lib().orc_step_batch(self.h, B, _p(Z), _p(U), _p(Zn), _p(st), _p(it), int(with_grad), grad_mode, _p(dz), _p(du), nthreads)
+        return Zn, st, it, dz, du

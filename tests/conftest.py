@@ -1,0 +1,31 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import dojo_amd.api as api
+        return api.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not silently pass on a fallback:
+    # gpu tests are only *skipped* when they were not explicitly selected.
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="gpu test (select with -m gpu)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

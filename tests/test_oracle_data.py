@@ -1,0 +1,58 @@
+"""Pins the oracle's data Jacobian (∂ residual / ∂ θ): restatement of test/data.jl:82-126.
+
+  simulate tsim with u = 0.2 on the actuated inputs, rtol = btol = eps, then
+  || FD(d full_vector / d data) · attjac  −  jacobian_data!(dense) ||_inf(entries) < 1e-6
+"""
+import numpy as np
+import pytest
+import dojo_amd as d
+from oracle import Oracle
+
+
+def fd_data_jacobian(o, data, sol, delta=1.0e-5):
+    n, nd = o.n, len(data)
+    J = np.zeros((n, nd))
+    for i in range(nd):
+        dp, dm = data.copy(), data.copy()
+        dp[i] += delta; dm[i] -= delta
+        J[:, i] = (o.evaluate_residual(dp, sol) - o.evaluate_residual(dm, sol)) / (2 * delta)
+    return J
+
+
+def run_data(spec, tsim=0.1, eps=1.0e-6):
+    o = Oracle(spec, opts=d.SolverOptions(rtol=eps, btol=eps))
+    z0 = d.initialize(spec)
+    steps = int(np.ceil(tsim / spec.timestep))
+    u = 0.2 * np.ones(spec.nu)
+    if spec.joints[0].nu == 6:          # ctrl!: no input on a floating base (test/data.jl:69-79)
+        u[:6] = 0.0
+    o.simulate(z0, steps, control=lambda o_, k: u)
+    data0 = o.get_data()
+    sol0 = o.get_solution()
+    fd = fd_data_jacobian(o, data0, sol0)
+    o.set_data(data0); o.set_solution(sol0)
+    fd = fd @ o.data_attjac()
+    an = o.data_matrix()
+    return np.abs(fd - an).max()
+
+
+CASES = [
+    ("pendulum", dict(), 0.1),
+    ("pendulum", dict(springs=2.0, dampers=0.3), 0.1),
+    ("pendulum", dict(springs=2.0, dampers=0.3, joint_limits={"joint": [-0.3, 0.9]}), 0.3),
+    ("block", dict(contact=False), 0.1),
+    ("block", dict(), 0.1),
+    ("block", dict(), 0.6),
+    ("ant", dict(timestep=0.01), 0.1),
+    ("ant", dict(timestep=0.01), 0.4),
+    ("quadruped", dict(), 0.1),
+    ("quadruped", dict(parse_springs=False, parse_dampers=False, springs=2.0, dampers=0.3), 0.3),
+    ("atlas", dict(), 0.1),
+    ("atlas", dict(parse_springs=False, parse_dampers=False, springs=2.0, dampers=0.3), 0.1),
+]
+
+
+@pytest.mark.parametrize("name,kw,tsim", CASES)
+def test_data_jacobian(name, kw, tsim):
+    err = run_data(d.get_mechanism(name, **kw), tsim)
+    assert err < 1.0e-6, err

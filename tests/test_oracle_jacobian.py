@@ -1,0 +1,68 @@
+"""Pins the oracle's system matrix: restatement of the reference's test/jacobian.jl:1-117.
+
+  simulate tsim with u = 0.1 on every input, rtol = btol = eps, then
+  || FD(d full_vector / d solution) + full_matrix(system) ||_inf(entries) < eps
+(full_vector = -residual, hence the '+').  "Flying" = 0.1 s, "In contact" = 0.4 s.
+"""
+import numpy as np
+import pytest
+import dojo_amd as d
+from oracle import Oracle
+
+EPS = 1.0e-7
+
+
+def fd_solution_matrix(o, data, sol, delta=1.0e-5):
+    n = len(sol)
+    J = np.zeros((n, n))
+    for i in range(n):
+        sp, sm = sol.copy(), sol.copy()
+        sp[i] += delta; sm[i] -= delta
+        J[:, i] = (o.evaluate_residual(data, sp) - o.evaluate_residual(data, sm)) / (2 * delta)
+    return J
+
+
+def run_solmat(spec, tsim, eps=EPS):
+    o = Oracle(spec, opts=d.SolverOptions(rtol=eps, btol=eps))
+    z0 = d.initialize(spec)
+    steps = int(np.ceil(tsim / spec.timestep))
+    u = 0.1 * np.ones(spec.nu)
+    traj, status = o.simulate(z0, steps, control=lambda o_, k: u)
+    # the reference test does not assert solver success either (test/jacobian.jl:19-23)
+    data = o.get_data()
+    o.set_data(data)
+    sol = o.get_solution()
+    solmat = o.full_matrix()
+    fd = fd_solution_matrix(o, data, sol)
+    err = np.abs(fd + solmat).max()
+    return err, traj
+
+
+CASES = [
+    ("pendulum", dict(springs=1.0, dampers=0.2)),
+    ("pendulum", dict()),
+    ("block", dict()),
+    ("ant", dict(timestep=0.01)),
+    ("quadruped", dict()),
+    ("quadruped", dict(parse_springs=False, parse_dampers=False, springs=1.0, dampers=0.2)),
+    ("atlas", dict(parse_dampers=False)),
+    ("atlas", dict()),
+]
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_solmat_flying(name, kw):
+    err, _ = run_solmat(d.get_mechanism(name, **kw), 0.1)
+    assert err < EPS, err
+
+
+@pytest.mark.parametrize("name,kw", [c for c in CASES if c[0] != "atlas"] + [("atlas", dict())])
+def test_solmat_in_contact(name, kw):
+    err, traj = run_solmat(d.get_mechanism(name, **kw), 0.4)
+    assert err < EPS, err
+
+
+def test_solmat_pendulum_with_limits():
+    spec = d.get_pendulum(joint_limits={"joint": [-0.3, 0.25 * np.pi]}, dampers=0.1)
+    err, _ = run_solmat(spec, 0.4)
+    assert err < EPS, err
