@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- differentiable env-steps/s of the batched contact-implicit step on MI355X.
+
+One "step" = one pass of the hot path (forward Mehrotra solve + IFT gradients) over a batch of
+B = 4096 Ant environments per GPU (BASELINE.json configs[2], the config the metric is quoted on),
+closed loop: z_{k+1} = step(z_k, u_k) with synthetic controls, all buffers resident in HBM.
+N > 1: one process per GPU (torch.distributed / RCCL), the batch is sharded (weak scaling: B per
+GPU is fixed) with no data-path collective; the final trajectories are all-gathered once per
+rollout chunk over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host"))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = Ant)")
+    ap.add_argument("--io-dtype", default="f32")
+    ap.add_argument("--no-grad", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import dojo_amd as d
+    from dojo_amd import api
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    spec = d.baseline_config(args.config)
+    B, K, W = args.batch, args.steps, args.warmup
+    tdt = torch.float32 if args.io_dtype == "f32" else torch.float64
+    w = 4 if args.io_dtype == "f32" else 8
+    # synthetic inputs: 64 seeded environments per rank tiled over the batch, distinct seeds per rank
+    Z0, U0 = d.synthetic_inputs(spec, 64, seed=20241008 + rank)
+    reps = (B + 63) // 64
+    z = torch.tensor(np.tile(Z0, (reps, 1))[:B], dtype=tdt, device=dev).contiguous()
+    rng = np.random.Generator(np.random.Philox(key=[20241008, 1000 + rank]))
+    Uall = torch.tensor(0.5 * rng.standard_normal((K + W, B, spec.nu)) * (np.abs(np.tile(U0, (reps, 1))[:B]) > 0), dtype=tdt, device=dev).contiguous()
+    zn = torch.empty_like(z)
+    status = torch.empty(B, dtype=torch.int32, device=dev); iters = torch.empty(B, dtype=torch.int32, device=dev)
+    grad = not args.no_grad
+    dz = torch.empty((B, spec.nx, spec.nx), dtype=tdt, device=dev) if grad else None
+    du = torch.empty((B, max(spec.nu, 1), spec.nx), dtype=tdt, device=dev) if grad else None
+
+    gm = api.BatchedMechanism(spec, B, dtype=args.io_dtype, device=local)
+    lib = api.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def ptr(t):
+        return C.c_void_p(0 if t is None else t.data_ptr())
+
+    kernel_ms = []
+
+    def one_step(k, timed):
+        nonlocal z, zn
+        api._chk(lib.dojo_step_dev(gm.h, ptr(z), ptr(Uall[k]), ptr(zn), ptr(status), ptr(iters), ptr(dz), ptr(du), stream))
+        if timed:
+            kernel_ms.append(gm.last_kernel_ms())      # hipEvents recorded on the launch stream
+        z, zn = zn, z
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        one_step(k, False)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        one_step(k, True)
+    if world > 1:      # all-gather of the trajectories' final states over RCCL/xGMI, once per rollout chunk
+        out = [torch.empty_like(z) for _ in range(world)]
+        dist.all_gather(out, z)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok_frac = float((status == 0).float().mean().item())
+    mean_iters = float(iters.float().mean().item())
+
+    if rank == 0:
+        nb, nu = spec.Nb, spec.nu
+        bytes_fwd = (26 * nb + nu) * w + 8
+        bytes_grad = 12 * nb * (12 * nb + nu) * w if grad else 0
+        alg_bytes = (bytes_fwd + bytes_grad) * B                      # per launch
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "differentiable env-steps/sec (fwd+grad) at batch=4096; grad inf-err vs CPU" if grad else "env-steps/sec (fwd only)",
+            "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * el / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: Ant (13 bodies as built by the reference, 8 revolute+limits, 4 fixed, 4 foot contacts), "
+                                   "batch=%d per GPU, fwd + IFT gradients, closed-loop rollout with random controls" % B,
+                       "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
+                       "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "dojo_step_kernel", "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "VALU/scratch-bound lane program, not HBM-bound (SURVEY.md §8d): frac is reported against HBM as the contract asks"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(spec, grad)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(spec, grad):
+    """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on
+    the host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import dojo_amd as d
+    from oracle import Oracle
+    cores = os.cpu_count() or 1
+    o = Oracle(spec)
+    nsample = 64 * max(1, min(cores, 16) // 4)
+    Z, U = d.synthetic_inputs(spec, nsample)
+    t0 = time.perf_counter()
+    Zn, st, it, dz, du = o.step_batch(Z, U, with_grad=grad, grad_mode=0, nthreads=cores)
+    el = time.perf_counter() - t0
+    # keep the sample within ~10-30 s of CPU work
+    rounds = 1
+    while el * cores < 10.0 and rounds < 64:
+        t1 = time.perf_counter()
+        o.step_batch(Z, U, with_grad=grad, grad_mode=0, nthreads=cores)
+        el += time.perf_counter() - t1
+        rounds += 1
+    return {"value": nsample * rounds / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d Ant env-steps (fwd%s) of the same synthetic inputs, C++ oracle (dense KKT, fp64), one env per thread" % (nsample * rounds, "+grad" if grad else "")}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1402 @@
+// dojo_device.hpp -- the per-lane algorithm of the batched contact-implicit step.
+//
+// Mapping: one wavefront lane = one (environment, supernode) pair.  A supernode
+// is a body together with its parent joint and the contacts attached to it.  S = next power
+// of two >= #bodies lanes cooperate on one environment, 64/S environments share a wavefront.
+// All per-lane data (state, KKT blocks, factors) lives in VGPRs; lanes of one environment talk
+// through wave shuffles only (ds_bpermute), along the edges of the kinematic tree:
+//   children -> parent : impulses on the parent body, Schur complements (6x6 + 6)
+//   parent -> children : configuration / velocity of the parent body, Newton step of the parent
+// HBM is touched only for the algorithmic bytes: state in, state/solution/gradient out.
+//
+// The same source runs under tests/emu (threads + barriers implement the Wave interface) so the
+// device algorithm is checked against the CPU oracle without a GPU.
+//
+// Reference functions restated here (all fused into the lane program):
+//   src/simulation/step.jl:11-30, src/mechanism/set.jl:10-53, src/bodies/set.jl:1-36
+//   src/integrators/constraint.jl:1-66          body residual d and Jacobian D
+//   src/joints/joint.jl, limits.jl, constraints.jl:114-299, translational/ & rotational/*.jl
+//   src/contacts/nonlinear.jl:50-97, contact.jl:37-138, velocity.jl, collisions/sphere_halfspace.jl
+//   src/solver/*.jl (mehrotra!, line searches, centering, correction, violations, initialization)
+//   src/gradients/state.jl:78-126, src/gradients/data.jl (data Jacobian blocks)
+#pragma once
+#include "dojo_math.hpp"
+#ifdef DJ_DEBUG
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace dj {
+
+constexpr int MAXCH = 4;          // children per body supported by the lane program
+constexpr double REG = 1e-10;     // src/Dojo.jl:4
+
+#define DJ_STATUS_SUCCESS 0
+#define DJ_STATUS_FAILED 1
+#define DJ_STATUS_EXCESSIVE_W 2
+
+template <class T>
+struct Globals {
+    T dt, input_scaling, g[3];
+    T rtol, btol, undercut, no_progress_undercut;
+    int max_iter, max_ls, no_progress_max;
+    int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
+};
+
+// per-supernode constants (body k, its parent joint, its contacts)
+template <class T>
+struct NodeP {
+    int parent, level, nchild, child[MAXCH];
+    int ncontact, contact[8];
+    int nl_t, nl_r, nlim_r, spring_on, damper_on;
+    int u_off, nu_t, nu_r, imp_off, n_imp;
+    T m, J[9];
+    T Ct[9], Cr[9], At[9], Ar[9];          // constraint / nullspace masks, zero-padded rows
+    T pa[3], pb[3], qoff[4];
+    T spring_r, damper_r, spring_off_r[3], lim_lo, lim_hi;
+};
+template <class T>
+struct ContactP { T n[3], t[6], o[3], off[3], r, mu; };
+
+// ------------------------------------------------------------------------------------------------
+// Lane-local dynamic state
+// ------------------------------------------------------------------------------------------------
+template <class T, int MAXC>
+struct Lane {
+    // configuration (constant during the solve)
+    T x2[3], q2[4], xa2[3], qa2[4];
+    T dconst[6];                 // velocity-independent part of the body residual
+    T v15[3], w15[3];            // midpoint velocities of the previous interval (data of the IFT)
+    // solution: [0] = current, [1] = candidate (vsol/ωsol, impulses, impulses_dual in the reference)
+    T v[2][3], w[2][3];
+    T lam[2][6];                 // equality multipliers: 3 translational slots, 3 rotational slots
+    T ls[2][2], lg[2][2];        // rotational joint limit: s = (s_up, s_lo), γ = (γ_up, γ_lo)
+    T cs[2][MAXC][4], cg[2][MAXC][4];
+};
+
+// factor data of one supernode, kept between the two solves of a Mehrotra iteration and
+// re-used by the IFT back-solves
+template <class T, class TL, int MAXC>
+struct Factors {
+    // linear-algebra part, in the factorization precision TL (fp32 in the mixed "f32" mode)
+    TL Sinv[144];                // inverse of the 12x12 supernode matrix [[D_b, P_b],[G_b, REG]]
+    TL W[72];                    // L S⁻¹   (6x12): rhs of the parent  -= W r_k
+    TL Z[72];                    // S⁻¹ U   (12x6): Δ_k = S⁻¹ r_k − Z Δv_parent
+    // condensation pieces, in the state precision T
+    T th_a[3], th_b[3], t_a[6], t_b[6];
+    T C134[MAXC][18], G134[MAXC][18];
+};
+
+template <class T, int MAXC>
+struct Step {                    // Newton step of this lane's unknowns
+    T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][4], dcg[MAXC][4];
+};
+
+// kinematic quantities of a body at the candidate velocity
+template <class T>
+struct Kin { T x3[3], q3[4], R3[9], Phi[9], Xi[9], c; };   // Xi = ∂φ3/∂φ2 = R(ξ)ᵀ
+
+template <class T> DJ_HD void kin_of(Kin<T>& k, const T* x2, const T* q2, const T* v, const T* w, T dt) {
+    T xi[4];
+    qstep(xi, w, dt, &k.c);
+    qmul(k.q3, q2, xi);
+    for (int i = 0; i < 3; ++i) k.x3[i] = x2[i] + dt * v[i];
+    qrot(k.R3, k.q3);
+    phi_of(k.Phi, w, k.c, dt);
+    T Rx[9];
+    qrot(Rx, xi);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k.Xi[3 * i + j] = Rx[3 * j + i];
+}
+
+// rᵀ L(q) and rᵀ R(q) for 4-vectors (rows of quaternion product Jacobians)
+template <class T> DJ_HD void rowL(T* o, const T* r, const T* q) {
+    T s = q[0], x = q[1], y = q[2], z = q[3];
+    o[0] = r[0] * s + r[1] * x + r[2] * y + r[3] * z;
+    o[1] = -r[0] * x + r[1] * s + r[2] * z - r[3] * y;
+    o[2] = -r[0] * y - r[1] * z + r[2] * s + r[3] * x;
+    o[3] = -r[0] * z + r[1] * y - r[2] * x + r[3] * s;
+}
+template <class T> DJ_HD void rowR(T* o, const T* r, const T* q) {
+    T s = q[0], x = q[1], y = q[2], z = q[3];
+    o[0] = r[0] * s + r[1] * x + r[2] * y + r[3] * z;
+    o[1] = -r[0] * x + r[1] * s - r[2] * z + r[3] * y;
+    o[2] = -r[0] * y + r[1] * z + r[2] * s - r[3] * x;
+    o[3] = -r[0] * z - r[1] * y + r[2] * x + r[3] * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// joint impulse maps at the CURRENT configuration (x2,q2): impulse_map / impulse_transform,
+// src/joints/joint.jl:67-93, src/joints/impulses.jl:4-8.  `JointCfg` caches what they need.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct JointCfg {
+    T Ra[9], Rba[9];             // R(qa2), R(qb2)ᵀ R(qa2)
+    T u2[3];                     // e2 + pa   (translational displacement at config 2, parent frame)
+    T qr[4];                     // qoff⁻¹ ⊗ qa2⁻¹ ⊗ qb2
+    T Roff[9];
+};
+template <class T> DJ_HD void joint_cfg(JointCfg<T>& c, const NodeP<T>& P, const T* xa, const T* qa, const T* xb, const T* qb) {
+    T Rb[9];
+    qrot(c.Ra, qa); qrot(Rb, qb); qrot(c.Roff, P.qoff);
+    m3tmul(c.Rba, Rb, c.Ra);
+    T t[3], wv[3];
+    m3vec(t, Rb, P.pb);
+    for (int i = 0; i < 3; ++i) wv[i] = xb[i] + t[i] - xa[i];
+    m3tvec(c.u2, c.Ra, wv);                         // = e2 + pa
+    T qab[4];
+    qcmul(qab, qa, qb);
+    qcmul(c.qr, P.qoff, qab);
+}
+// T_a p and T_b p for the translational half: 6-vectors (force in world frame, torque in body frame)
+template <class T> DJ_HD void tra_impulse(T* ia, T* ib, const JointCfg<T>& c, const NodeP<T>& P, const T* p) {
+    T F[3], t[3];
+    m3vec(F, c.Ra, p);
+    v3cross(t, c.u2, p);
+    ia[0] = -F[0]; ia[1] = -F[1]; ia[2] = -F[2]; ia[3] = -t[0]; ia[4] = -t[1]; ia[5] = -t[2];
+    T Fb[3];
+    m3vec(Fb, c.Rba, p);
+    v3cross(t, P.pb, Fb);
+    ib[0] = F[0]; ib[1] = F[1]; ib[2] = F[2]; ib[3] = t[0]; ib[4] = t[1]; ib[5] = t[2];
+}
+template <class T> DJ_HD void rot_impulse(T* ia, T* ib, const JointCfg<T>& c, const T* p) {
+    T vp[3], a[3], b[3];
+    v3cross(vp, &c.qr[1], p);
+    for (int i = 0; i < 3; ++i) { a[i] = c.qr[0] * p[i] + vp[i]; b[i] = T(0.5) * (c.qr[0] * p[i] - vp[i]); }
+    T ra[3];
+    m3vec(ra, c.Roff, a);
+    ia[0] = ia[1] = ia[2] = T(0); ia[3] = T(-0.5) * ra[0]; ia[4] = T(-0.5) * ra[1]; ia[5] = T(-0.5) * ra[2];
+    ib[0] = ib[1] = ib[2] = T(0); ib[3] = b[0]; ib[4] = b[1]; ib[5] = b[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// everything a lane computes about its parent joint at the candidate point
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct JointEval {
+    T g[6];                      // equality residual (3 tra slots, 3 rot slots; padded slots = 0)
+    T theta;                     // limited rotational coordinate
+    T imp_a[6], imp_b[6];        // joint impulse + damper on parent / child body (to be subtracted from d)
+    // Jacobian pieces (only when JAC)
+    T Ga[36], Gb[36];            // ∂g/∂(v,ω) of parent / child
+    T Pa[36], Pb[36];            // −impulse_map columns for the 6 multiplier slots
+    T Daa[36], Mab[36], Mba[36], Dbb[36];   // damper velocity Jacobians (−∂τ/∂ω)
+    T th_a[3], th_b[3];          // ∂θ/∂ω_a, ∂θ/∂ω_b
+    T GaX[18], GaP[18], GbX[18], GbP[18];   // raw rows ∂g/∂x3, ∂g/∂φ3 (6 slots x 3) of parent / child
+    T thp_a[3], thp_b[3];        // raw ∂θ/∂φ3
+    T t_a[6], t_b[6];            // impulse_transform · Arᵀ (limit impulse direction)
+};
+
+template <bool JAC, class T>
+DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg, bool has_parent,
+                      const Kin<T>& ka, const Kin<T>& kb, const T* wa, const T* wb,
+                      const T* lam, const T* lg, T dt) {
+    // ---------------- translational displacement at (x3,q3): translational/minimal.jl:4-12 ----------------
+    T t3[3], wv[3], e[3], u[3];
+    m3vec(t3, kb.R3, P.pb);
+    for (int i = 0; i < 3; ++i) wv[i] = kb.x3[i] + t3[i] - ka.x3[i];
+    m3tvec(u, ka.R3, wv);                                  // u = e + pa
+    for (int i = 0; i < 3; ++i) e[i] = u[i] - P.pa[i];
+    // ---------------- rotational displacement: rotational/minimal.jl:4-11 ----------------
+    T qab[4], qr[4];
+    qcmul(qab, ka.q3, kb.q3);
+    qcmul(qr, P.qoff, qab);
+    for (int i = 0; i < 3; ++i) {
+        E.g[i] = (i < P.nl_t) ? v3dot(&P.Ct[3 * i], e) : T(0);
+        E.g[3 + i] = (i < P.nl_r) ? v3dot(&P.Cr[3 * i], &qr[1]) : T(0);
+    }
+    T rho[4] = {0, 0, 0, 0};
+    E.theta = T(0);
+    if (P.nlim_r > 0) { T rv[3]; rotvec(rv, qr); E.theta = v3dot(P.Ar, rv); }
+    // ---------------- impulses at the current configuration ----------------
+    T pt[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        if (i < P.nl_t) for (int k = 0; k < 3; ++k) pt[k] += P.Ct[3 * i + k] * lam[i];
+        if (i < P.nl_r) for (int k = 0; k < 3; ++k) pr[k] += P.Cr[3 * i + k] * lam[3 + i];
+    }
+    if (P.nlim_r > 0) { T kk = lg[1] - lg[0]; for (int k = 0; k < 3; ++k) pr[k] += P.Ar[k] * kk; }   // projector [0; −A; A; C]ᵀ, joint.jl:92
+    T ia[6], ib[6], ja[6], jb[6];
+    tra_impulse(ia, ib, cfg, P, pt);
+    rot_impulse(ja, jb, cfg, pr);
+    for (int i = 0; i < 6; ++i) { E.imp_a[i] = ia[i] + ja[i]; E.imp_b[i] = ib[i] + jb[i]; }
+    if (JAC) {
+        for (int i = 0; i < 36; ++i) { E.Ga[i] = E.Gb[i] = E.Pa[i] = E.Pb[i] = E.Daa[i] = E.Mab[i] = E.Mba[i] = E.Dbb[i] = T(0); }
+        for (int i = 0; i < 18; ++i) { E.GaX[i] = E.GaP[i] = E.GbX[i] = E.GbP[i] = T(0); }
+        // translational rows: E_xa = −Raᵀ, E_φa = 2[u]x, E_xb = Raᵀ, E_φb = −2 RaᵀRb[pb]x
+        T RaT_Rb[9], Spb[9], Eb[9], Su[9], EaPhi[9], EbPhi[9];
+        m3tmul(RaT_Rb, ka.R3, kb.R3);
+        m3skew(Spb, P.pb);
+        m3mul(Eb, RaT_Rb, Spb);
+        for (int i = 0; i < 9; ++i) Eb[i] *= T(-2);
+        m3skew(Su, u);
+        for (int i = 0; i < 9; ++i) Su[i] *= T(2);
+        m3mul(EaPhi, Su, ka.Phi);
+        m3mul(EbPhi, Eb, kb.Phi);
+        for (int i = 0; i < 3; ++i) {
+            if (i < P.nl_t) {
+                const T* c = &P.Ct[3 * i];
+                for (int j = 0; j < 3; ++j) {
+                    T cRaT = c[0] * ka.R3[3 * j] + c[1] * ka.R3[3 * j + 1] + c[2] * ka.R3[3 * j + 2];   // (c Raᵀ)_j
+                    E.Ga[6 * i + j] = -dt * cRaT;
+                    E.Gb[6 * i + j] = dt * cRaT;
+                    E.GaX[3 * i + j] = -cRaT; E.GbX[3 * i + j] = cRaT;
+                    E.GaP[3 * i + j] = c[0] * Su[j] + c[1] * Su[3 + j] + c[2] * Su[6 + j];
+                    E.GbP[3 * i + j] = c[0] * Eb[j] + c[1] * Eb[3 + j] + c[2] * Eb[6 + j];
+                    E.Ga[6 * i + 3 + j] = c[0] * EaPhi[j] + c[1] * EaPhi[3 + j] + c[2] * EaPhi[6 + j];
+                    E.Gb[6 * i + 3 + j] = c[0] * EbPhi[j] + c[1] * EbPhi[3 + j] + c[2] * EbPhi[6 + j];
+                }
+                T a6[6], b6[6];
+                tra_impulse(a6, b6, cfg, P, c);
+                for (int r = 0; r < 6; ++r) { E.Pa[6 * r + i] = -a6[r]; E.Pb[6 * r + i] = -b6[r]; }
+            }
+        }
+        // rotational rows: E_φb = s I + [v]x ; E_φa = −(s I − [v]x) Roffᵀ
+        T Erb[9], Em[9], Era[9], EraPhi[9], ErbPhi[9];
+        m3sIpskew(Erb, qr[0], &qr[1]);
+        T nv[3] = {-qr[1], -qr[2], -qr[3]};
+        m3sIpskew(Em, qr[0], nv);
+        m3mult(Era, Em, cfg.Roff);
+        for (int i = 0; i < 9; ++i) Era[i] = -Era[i];
+        m3mul(EraPhi, Era, ka.Phi);
+        m3mul(ErbPhi, Erb, kb.Phi);
+        for (int i = 0; i < 3; ++i) {
+            if (i < P.nl_r) {
+                const T* c = &P.Cr[3 * i];
+                for (int j = 0; j < 3; ++j) {
+                    E.Ga[6 * (3 + i) + 3 + j] = c[0] * EraPhi[j] + c[1] * EraPhi[3 + j] + c[2] * EraPhi[6 + j];
+                    E.Gb[6 * (3 + i) + 3 + j] = c[0] * ErbPhi[j] + c[1] * ErbPhi[3 + j] + c[2] * ErbPhi[6 + j];
+                    E.GaP[3 * (3 + i) + j] = c[0] * Era[j] + c[1] * Era[3 + j] + c[2] * Era[6 + j];
+                    E.GbP[3 * (3 + i) + j] = c[0] * Erb[j] + c[1] * Erb[3 + j] + c[2] * Erb[6 + j];
+                }
+                T a6[6], b6[6];
+                rot_impulse(a6, b6, cfg, c);
+                for (int r = 0; r < 6; ++r) { E.Pa[6 * r + 3 + i] = -a6[r]; E.Pb[6 * r + 3 + i] = -b6[r]; }
+            }
+        }
+        if (P.nlim_r > 0) {
+            // θ = Ar·rotation_vector(qr): ∂θ/∂φb = ρ L(qr)Vᵀ, ∂θ/∂φa = −ρ R(qr)Vᵀ Roffᵀ   (rotational/minimal.jl:69-80)
+            rotvec_jac_row(rho, P.Ar, qr);
+            T rl[4], rr[4], tb[3], ta0[3], ta[3];
+            rowL(rl, rho, qr); rowR(rr, rho, qr);
+            for (int j = 0; j < 3; ++j) { tb[j] = rl[1 + j]; ta0[j] = -rr[1 + j]; }
+            m3vec(ta, cfg.Roff, ta0);               // (ta0ᵀ Roffᵀ)ᵀ = Roff ta0
+            m3tvec(E.th_b, kb.Phi, tb);             // (tbᵀ Φ)ᵀ = Φᵀ tb
+            for (int j = 0; j < 3; ++j) { E.thp_a[j] = ta[j]; E.thp_b[j] = tb[j]; }
+            m3tvec(E.th_a, ka.Phi, ta);
+            rot_impulse(E.t_a, E.t_b, cfg, P.Ar);
+        } else {
+            for (int j = 0; j < 3; ++j) E.th_a[j] = E.th_b[j] = E.thp_a[j] = E.thp_b[j] = T(0);
+            for (int j = 0; j < 6; ++j) E.t_a[j] = E.t_b[j] = T(0);
+        }
+    }
+    // ---------------- rotational damper (implicit in the candidate velocities): rotational/dampers.jl:4-30 ----------------
+    if (P.damper_on && P.nl_r < 3 && P.damper_r != T(0)) {
+        T ca = tsqrt(T(4) / (dt * dt) - v3dot(wa, wa)), cb = tsqrt(T(4) / (dt * dt) - v3dot(wb, wb));
+        T h = dt * T(0.5);
+        T wab[3];
+        m3vec(wab, cfg.Rba, wa);                     // ωa expressed in the child frame
+        T xbi[4] = {h * cb, h * wb[0], h * wb[1], h * wb[2]};
+        T roa[4] = {h * ca, -h * wab[0], -h * wab[1], -h * wab[2]};
+        T qd[4];
+        qmul(qd, xbi, roa);                          // = inv(q1) ⊗ q of rotational/minimal.jl:103-118
+        T rv[3];
+        rotvec(rv, qd);
+        T force[3] = {0, 0, 0};                      // damper · Aᵀ A rotvec / Δt   (offset frame)
+        const int nur = 3 - P.nl_r;
+        for (int i = 0; i < 3; ++i) if (i < nur) { T vel = v3dot(&P.Ar[3 * i], rv) / dt; for (int k = 0; k < 3; ++k) force[k] += P.damper_r * P.Ar[3 * i + k] * vel; }
+        T ta[3], tb[3];
+        m3vec(ta, cfg.Roff, force);                  // parent: vector_rotate(force, qoff)
+        m3vec(tb, cfg.Rba, ta);                      // child: −R(qb⁻¹ qa qoff) force
+        for (int k = 0; k < 3; ++k) { E.imp_a[3 + k] += dt * ta[k]; E.imp_b[3 + k] -= dt * tb[k]; }
+        if (JAC) {
+            // ∂vel_i/∂ωb, ∂vel_i/∂ωa  (rotational/minimal.jl:151-174 in closed form)
+            T dFa[9], dFb[9];                        // ∂force/∂ωa, ∂force/∂ωb (3x3, offset frame)
+            for (int i = 0; i < 9; ++i) dFa[i] = dFb[i] = T(0);
+            for (int i = 0; i < 3; ++i) if (i < nur) {
+                T row[4], r1[4], r2[4], gb[3], ga0[3], ga[3];
+                rotvec_jac_row(row, &P.Ar[3 * i], qd);
+                rowR(r1, row, roa);                  // row · R(ρa) : δqd = R(ρa) δξb⁻¹
+                rowL(r2, row, xbi);                  // row · L(ξb⁻¹): δqd = L(ξb⁻¹) δρa
+                for (int j = 0; j < 3; ++j) {
+                    gb[j] = (T(0.5)) * (-r1[0] * wb[j] / cb + r1[1 + j]);                 // (1/Δt)(Δt/2)[−ωbᵀ/cb; I]
+                    ga0[j] = r2[1 + j];
+                }
+                // [−ωaᵀ/ca; −Rba]: contribution −r2[0] ωa/ca − Rbaᵀ r2[1:3]
+                m3tvec(ga, cfg.Rba, ga0);
+                for (int j = 0; j < 3; ++j) ga[j] = T(0.5) * (-r2[0] * wa[j] / ca - ga[j]);
+                for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
+                    dFa[3 * k + j] += P.damper_r * P.Ar[3 * i + k] * ga[j];
+                    dFb[3 * k + j] += P.damper_r * P.Ar[3 * i + k] * gb[j];
+                }
+            }
+            T A1[9], A2[9], B1[9], B2[9];
+            m3mul(A1, cfg.Roff, dFa); m3mul(A2, cfg.Roff, dFb);       // ∂τa/∂ωa, ∂τa/∂ωb (without Δt)
+            m3mul(B1, cfg.Rba, A1);   m3mul(B2, cfg.Rba, A2);         // −∂τb/∂ωa, −∂τb/∂ωb
+            for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
+                // d_a −= Δt τa, d_b −= −Δt τb  =>  ∂d_a/∂ω = −Δt ∂τa/∂ω, ∂d_b/∂ω = +Δt Rba ∂τa/∂ω
+                E.Daa[6 * (3 + k) + 3 + j] = -dt * A1[3 * k + j];
+                E.Mab[6 * (3 + k) + 3 + j] = -dt * A2[3 * k + j];
+                E.Mba[6 * (3 + k) + 3 + j] = dt * B1[3 * k + j];
+                E.Dbb[6 * (3 + k) + 3 + j] = dt * B2[3 * k + j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ∂(joint impulse + spring + damper on parent / child body)/∂(x2, φ2 of parent / child) at the
+// configuration `c`: impulse_map_jacobian (translational/impulses.jl:9-46, rotational/impulses.jl:9-39),
+// spring_jacobian_configuration (rotational/springs.jl:46-94) and damper_jacobian_configuration
+// (rotational/dampers.jl:36-64) in closed form.  J_xy = ∂(what is subtracted from d_x)/∂z2_y, 6x6,
+// columns (x2(3), φ2(3)).
+// ------------------------------------------------------------------------------------------------
+template <class T>
+DJ_HD void joint_impulse_cfg_jac(T* Jaa, T* Jab, T* Jba, T* Jbb, const NodeP<T>& P, const JointCfg<T>& c,
+                                 const T* pt, const T* pr, const T* wa, const T* wb, T dt) {
+    for (int i = 0; i < 36; ++i) Jaa[i] = Jab[i] = Jba[i] = Jbb[i] = T(0);
+    // ---------------- translational ----------------
+    {
+        T Sp[9], RaSp[9], Su[9], SpRaT[9], SpSu[9], Spb[9], RbaT_Spb[9], SpE[9], RbaSp[9], Rp[3], SRp[9], M1[9], M2[9];
+        m3skew(Sp, pt);
+        m3mul(RaSp, c.Ra, Sp);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Jaa[6 * i + 3 + j] += T(2) * RaSp[3 * i + j]; Jba[6 * i + 3 + j] += T(-2) * RaSp[3 * i + j]; }
+        m3mult(SpRaT, Sp, c.Ra);                               // Sp Raᵀ
+        m3skew(Su, c.u2); m3mul(SpSu, Sp, Su);
+        m3skew(Spb, P.pb); m3tmul(RbaT_Spb, c.Rba, Spb); m3mul(SpE, Sp, RbaT_Spb);   // Sp Rbaᵀ[pb]x
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jaa[6 * (3 + i) + j] += -SpRaT[3 * i + j];
+            Jaa[6 * (3 + i) + 3 + j] += T(2) * SpSu[3 * i + j];
+            Jab[6 * (3 + i) + j] += SpRaT[3 * i + j];
+            Jab[6 * (3 + i) + 3 + j] += T(-2) * SpE[3 * i + j];
+        }
+        m3mul(RbaSp, c.Rba, Sp); m3mul(M1, Spb, RbaSp);         // [pb]x Rba [p]x
+        m3vec(Rp, c.Rba, pt); m3skew(SRp, Rp); m3mul(M2, Spb, SRp);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Jba[6 * (3 + i) + 3 + j] += T(-2) * M1[3 * i + j]; Jbb[6 * (3 + i) + 3 + j] += T(2) * M2[3 * i + j]; }
+    }
+    // ---------------- rotational ----------------
+    const T s = c.qr[0]; const T* v = &c.qr[1];
+    T dsa[3], dva[9], dvb[9];                                   // δs = ds·φ, δv = dv φ
+    m3vec(dsa, c.Roff, v);                                      // δs_a = (Roff v)·φa ; δs_b = −v·φb
+    {
+        T Em[9], nv[3] = {-v[0], -v[1], -v[2]};
+        m3sIpskew(Em, s, nv);                                   // s I − [v]x
+        m3mult(dva, Em, c.Roff);
+        for (int i = 0; i < 9; ++i) dva[i] = -dva[i];
+        m3sIpskew(dvb, s, v);
+    }
+    {
+        T Sp[9], SpA[9], SpB[9], Ma[9], Mb[9], RMa[9], RMb[9];
+        m3skew(Sp, pr);
+        m3mul(SpA, Sp, dva); m3mul(SpB, Sp, dvb);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Ma[3 * i + j] = pr[i] * dsa[j] - SpA[3 * i + j];        // ∂(s p + v×p)/∂φa
+            Mb[3 * i + j] = -pr[i] * v[j] - SpB[3 * i + j];         // ∂(s p + v×p)/∂φb
+        }
+        m3mul(RMa, c.Roff, Ma); m3mul(RMb, c.Roff, Mb);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jaa[6 * (3 + i) + 3 + j] += T(-0.5) * RMa[3 * i + j];
+            Jab[6 * (3 + i) + 3 + j] += T(-0.5) * RMb[3 * i + j];
+            Jba[6 * (3 + i) + 3 + j] += T(0.5) * (pr[i] * dsa[j] + SpA[3 * i + j]);   // ∂(s p − v×p)/∂φa
+            Jbb[6 * (3 + i) + 3 + j] += T(0.5) * (-pr[i] * v[j] + SpB[3 * i + j]);
+        }
+    }
+    // ---------------- rotational spring + damper: torque in the offset frame f, with ∂f/∂φa, ∂f/∂φb ----------------
+    const int nur = 3 - P.nl_r;
+    T f[3] = {0, 0, 0}, dFa[9], dFb[9];
+    for (int i = 0; i < 9; ++i) dFa[i] = dFb[i] = T(0);
+    bool any = false;
+    if (P.spring_on && P.nl_r < 3 && P.spring_r != T(0)) {
+        any = true;
+        T rv[3];
+        rotvec(rv, c.qr);
+        for (int i = 0; i < 3; ++i) if (i < nur) {
+            T dist = P.spring_off_r[i] - v3dot(&P.Ar[3 * i], rv);
+            T row[4], rl[4], rr[4], ta0[3], ta[3];
+            rotvec_jac_row(row, &P.Ar[3 * i], c.qr);
+            rowL(rl, row, c.qr); rowR(rr, row, c.qr);
+            for (int j = 0; j < 3; ++j) ta0[j] = -rr[1 + j];
+            m3vec(ta, c.Roff, ta0);
+            for (int k_ = 0; k_ < 3; ++k_) {
+                f[k_] += -P.spring_r * P.Ar[3 * i + k_] * dist;
+                for (int j = 0; j < 3; ++j) { dFb[3 * k_ + j] += P.spring_r * P.Ar[3 * i + k_] * rl[1 + j]; dFa[3 * k_ + j] += P.spring_r * P.Ar[3 * i + k_] * ta[j]; }
+            }
+        }
+    }
+    if (P.damper_on && P.nl_r < 3 && P.damper_r != T(0)) {
+        any = true;
+        T ca = tsqrt(T(4) / (dt * dt) - v3dot(wa, wa)), cb = tsqrt(T(4) / (dt * dt) - v3dot(wb, wb));
+        T h = dt * T(0.5);
+        T wab[3];
+        m3vec(wab, c.Rba, wa);
+        T xbi[4] = {h * cb, h * wb[0], h * wb[1], h * wb[2]};
+        T roa[4] = {h * ca, -h * wab[0], -h * wab[1], -h * wab[2]};
+        T qd[4], rv[3];
+        qmul(qd, xbi, roa);
+        rotvec(rv, qd);
+        T Swab[9], Swa[9], RSwa[9];
+        m3skew(Swab, wab); m3skew(Swa, wa); m3mul(RSwa, c.Rba, Swa);
+        for (int i = 0; i < 3; ++i) if (i < nur) {
+            T vel = v3dot(&P.Ar[3 * i], rv) / dt;
+            T row[4], r2[4], gb[3], ga[3];
+            rotvec_jac_row(row, &P.Ar[3 * i], qd);
+            rowL(r2, row, xbi);
+            // δvel = −(1/2) r2[1:3]·δ(wab),  δ(wab) = 2[wab]x φb − 2 Rba[ωa]x φa
+            for (int j = 0; j < 3; ++j) {
+                gb[j] = -(r2[1] * Swab[j] + r2[2] * Swab[3 + j] + r2[3] * Swab[6 + j]);
+                ga[j] = (r2[1] * RSwa[j] + r2[2] * RSwa[3 + j] + r2[3] * RSwa[6 + j]);
+            }
+            for (int k_ = 0; k_ < 3; ++k_) {
+                f[k_] += P.damper_r * P.Ar[3 * i + k_] * vel;
+                for (int j = 0; j < 3; ++j) { dFb[3 * k_ + j] += P.damper_r * P.Ar[3 * i + k_] * gb[j]; dFa[3 * k_ + j] += P.damper_r * P.Ar[3 * i + k_] * ga[j]; }
+            }
+        }
+    }
+    if (any) {
+        // τa = Δt Roff f (subtracted from d_a), τb = −Δt Rba Roff f (subtracted from d_b)
+        T w_[3], RdFa[9], RdFb[9], Sw[9], RbaSw[9], Rw[3], SRw[9], RbaRdFa[9], RbaRdFb[9];
+        m3vec(w_, c.Roff, f);
+        m3mul(RdFa, c.Roff, dFa); m3mul(RdFb, c.Roff, dFb);
+        m3skew(Sw, w_); m3mul(RbaSw, c.Rba, Sw);
+        m3vec(Rw, c.Rba, w_); m3skew(SRw, Rw);
+        m3mul(RbaRdFa, c.Rba, RdFa); m3mul(RbaRdFb, c.Rba, RdFb);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jaa[6 * (3 + i) + 3 + j] += dt * RdFa[3 * i + j];
+            Jab[6 * (3 + i) + 3 + j] += dt * RdFb[3 * i + j];
+            Jba[6 * (3 + i) + 3 + j] += -dt * (T(-2) * RbaSw[3 * i + j] + RbaRdFa[3 * i + j]);
+            Jbb[6 * (3 + i) + 3 + j] += -dt * (T(2) * SRw[3 * i + j] + RbaRdFb[3 * i + j]);
+        }
+    }
+}
+
+// rotational spring impulse (velocity independent): rotational/springs.jl:5-40; returns −(what d subtracts) pieces
+template <class T> DJ_HD void spring_impulses(T* sa, T* sb, const NodeP<T>& P, const JointCfg<T>& cfg, T dt) {
+    for (int i = 0; i < 6; ++i) sa[i] = sb[i] = T(0);
+    if (!P.spring_on || P.nl_r == 3 || P.spring_r == T(0)) return;
+    T rv[3];
+    rotvec(rv, cfg.qr);
+    T force[3] = {0, 0, 0};
+    const int nur = 3 - P.nl_r;
+    for (int i = 0; i < 3; ++i) if (i < nur) {
+        T dist = P.spring_off_r[i] - v3dot(&P.Ar[3 * i], rv);
+        for (int k = 0; k < 3; ++k) force[k] += -P.spring_r * P.Ar[3 * i + k] * dist;
+    }
+    T ta[3], tb[3];
+    m3vec(ta, cfg.Roff, force);
+    m3vec(tb, cfg.Rba, ta);
+    for (int k = 0; k < 3; ++k) { sa[3 + k] = dt * ta[k]; sb[3 + k] = -dt * tb[k]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// contact evaluation at (x3, q3) of the body: residual rows, impulse, and (JAC) C/G blocks
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct ContactEval { T c[4]; T imp[6]; T C134[18]; T G134[18]; T Dww[9]; T c1p[3], c34p[6], Qraw[9]; };   // raw = before Φ
+
+template <bool JAC, class T>
+DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& kb, const T* v, const T* w, const T* s, const T* gam, T dt) {
+    T Ro[3], l[3], Rw[3], t[3], vp[3];
+    m3vec(Ro, kb.R3, K.o);
+    for (int i = 0; i < 3; ++i) l[i] = Ro[i] - K.off[i] - K.n[i] * K.r;           // contact_point − x  (sphere_halfspace.jl:55-58)
+    T dist = T(0);
+    for (int i = 0; i < 3; ++i) dist += K.n[i] * (kb.x3[i] + Ro[i] - K.off[i]);
+    dist -= K.r;                                                                // distance (sphere_halfspace.jl:34-36)
+    m3vec(Rw, kb.R3, w);
+    v3cross(t, Rw, l);
+    for (int i = 0; i < 3; ++i) vp[i] = v[i] + t[i];                              // contact_point_velocity (velocity.jl:2-4)
+    E.c[0] = dist - s[0];
+    E.c[1] = K.mu * gam[0] - gam[1];
+    E.c[2] = v3dot(&K.t[0], vp) - s[2];
+    E.c[3] = v3dot(&K.t[3], vp) - s[3];
+    T F[3], tau[3], lxF[3];
+    for (int i = 0; i < 3; ++i) F[i] = K.n[i] * gam[0] + K.t[i] * gam[2] + K.t[3 + i] * gam[3];
+    v3cross(lxF, l, F);
+    m3tvec(tau, kb.R3, lxF);
+    for (int i = 0; i < 3; ++i) { E.imp[i] = F[i]; E.imp[3 + i] = tau[i]; }
+    if (JAC) {
+        const T* dirs[3] = {K.n, &K.t[0], &K.t[3]};
+        for (int d = 0; d < 3; ++d) {
+            T lx[3], g3[3];
+            v3cross(lx, l, dirs[d]);
+            m3tvec(g3, kb.R3, lx);
+            for (int i = 0; i < 3; ++i) { E.G134[6 * d + i] = dirs[d][i]; E.G134[6 * d + 3 + i] = g3[i]; }   // stored as 3 rows of 6 (= G134ᵀ)
+        }
+        // row 1: [Δt n | n·(−2 R[o]x) Φ]
+        T So[9], RSo[9], M1[9], A[9];
+        m3skew(So, K.o);
+        m3mul(RSo, kb.R3, So);                               // R[o]x
+        for (int i = 0; i < 9; ++i) M1[i] = T(-2) * RSo[i];
+        m3mul(A, M1, kb.Phi);                                // (−2R[o]x)Φ
+        for (int j = 0; j < 3; ++j) { E.C134[j] = dt * K.n[j]; E.C134[3 + j] = K.n[0] * A[j] + K.n[1] * A[3 + j] + K.n[2] * A[6 + j]; E.c1p[j] = K.n[0] * M1[j] + K.n[1] * M1[3 + j] + K.n[2] * M1[6 + j]; }
+        // rows 3,4: [T_i | T_i(−[l]x R + (2[l]x R [ω]x − 2[Rω]x R [o]x)Φ)]
+        T Sl[9], SlR[9], Sw[9], SRw[9], B1[9], B2[9], B[9], BPhi[9];
+        m3skew(Sl, l); m3mul(SlR, Sl, kb.R3);
+        m3skew(Sw, w); m3mul(B1, SlR, Sw);
+        m3skew(SRw, Rw); m3mul(B2, SRw, RSo);
+        for (int i = 0; i < 9; ++i) B[i] = T(2) * (B1[i] - B2[i]);
+        m3mul(BPhi, B, kb.Phi);
+        for (int r = 0; r < 2; ++r) {
+            const T* tt = &K.t[3 * r];
+            for (int j = 0; j < 3; ++j) {
+                E.C134[6 * (1 + r) + j] = tt[j];
+                T a = -(tt[0] * SlR[j] + tt[1] * SlR[3 + j] + tt[2] * SlR[6 + j]);
+                T b = tt[0] * BPhi[j] + tt[1] * BPhi[3 + j] + tt[2] * BPhi[6 + j];
+                E.C134[6 * (1 + r) + 3 + j] = a + b;
+                E.c34p[3 * r + j] = tt[0] * B[j] + tt[1] * B[3 + j] + tt[2] * B[6 + j];
+            }
+        }
+        // ∂(G γ)/∂ω (rows 3:6, cols 3:6) = 2([τ]x + [F_b]x[o]x)Φ      (contact.jl:102-138)
+        T Fb[3], St[9], SF[9], SFSo[9], Q[9];
+        m3tvec(Fb, kb.R3, F);
+        m3skew(St, tau); m3skew(SF, Fb); m3mul(SFSo, SF, So);
+        for (int i = 0; i < 9; ++i) Q[i] = T(2) * (St[i] + SFSo[i]);
+        m3mul(E.Dww, Q, kb.Phi);
+        for (int i = 0; i < 9; ++i) E.Qraw[i] = Q[i];
+    }
+}
+
+// second-order-cone helpers: src/contacts/cone.jl, src/solver/line_search.jl:98-139
+template <class T> DJ_HD T ort_step(T lam, T dl, T tau) { return dl < T(0) ? tmin(T(1), -tau * lam / dl) : T(1); }
+template <class T> DJ_HD T soc_step(const T* l, const T* d, T tau) {
+    const T eps = T(1e-14);
+    T l0 = l[0];
+    T ll = tmax(l0 * l0 - (l[1] * l[1] + l[2] * l[2]), T(1e-25));
+    ll += eps;
+    T ld = l0 * d[0] - (l[1] * d[1] + l[2] * d[2]) + eps;
+    T rs = ld / ll, sq = tsqrt(ll);
+    T f = (ld / sq + d[0]) / (l0 / sq + T(1));
+    T r1 = d[1] / sq - f * l[1] / ll, r2 = d[2] / sq - f * l[2] / ll;
+    T nr = tsqrt(r1 * r1 + r2 * r2);
+    T a = T(1);
+    if (nr - rs > T(0)) a = tmin(a, tau / (nr - rs));
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-level helpers.  `Wave` provides: lane(), shfl(v, src_lane), any(pred).
+// ------------------------------------------------------------------------------------------------
+template <class Wave, class T> DJ_HD T env_max(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmax(v, w.shfl(v, w.lane() ^ o)); return v; }
+template <class Wave, class T> DJ_HD T env_min(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmin(v, w.shfl(v, w.lane() ^ o)); return v; }
+template <class Wave, class T> DJ_HD T env_sum(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v + w.shfl(v, w.lane() ^ o); return v; }
+template <class Wave> DJ_HD int env_or(Wave& w, int v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v | w.shfl(v, w.lane() ^ o); return v; }
+
+template <int N, class Wave, class T> DJ_HD void shfl_vec(Wave& w, T* out, const T* in, int src) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = w.shfl(in[i], src);
+}
+// acc[0:N] += Σ_children in[child]
+template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave& w, T* acc, const T* in, const NP& P, int base, int maxch, bool active) {
+#pragma unroll
+    for (int ci = 0; ci < MAXCH; ++ci) {
+        if (ci < maxch) {
+            int src = (active && ci < P.nchild) ? base + P.child[ci] : w.lane();
+            bool use = active && ci < P.nchild;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { T t = w.shfl(in[i], src); if (use) acc[i] += t; }
+        }
+    }
+}
+
+// ================================================================================================
+// The lane program
+// ================================================================================================
+template <class T, class TL, int MAXC, class Wave>
+struct LaneProgram {
+    Wave& wv;
+    const Globals<T>& G;
+    const NodeP<T>& P;
+    const ContactP<T>* CP;       // contact table
+    int base;                    // first lane of this environment inside the wave
+    int k;                       // node index
+    bool active;                 // lane maps to a real (env, body)
+    bool has_parent;
+    int plane;                   // wave lane of the parent (or own lane)
+    Lane<T, MAXC> L;
+    Factors<T, TL, MAXC> F;
+    JointCfg<T> cfg;
+    T mu;                        // mechanism.μ
+#ifdef DJ_DEBUG
+    T* dbg = nullptr; bool dbg_on = false; bool trace = false;
+#endif
+    // residual pieces of the last evaluation
+    T rb[6], rj[6], theta, cres[MAXC][4];
+
+    DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, bool act)
+        : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act) {
+        has_parent = act && p.parent >= 0;
+        plane = has_parent ? base + p.parent : w.lane();
+        mu = T(0);
+    }
+
+    // ---------------------------------------------------------------- residual (+ Jacobian blocks)
+    // Evaluates at candidate index 1.  After the call: rb = full body residual d (including what the
+    // children's joints apply to this body), rj, theta, cres.  When JAC, fills S/U/Lm/Daa_up etc.
+    template <bool JAC>
+    DJ_HD void evaluate(T* Smat, T* Umat, T* Lmat, T* Dup) {
+        const T dt = G.dt;
+        // parent's candidate velocity
+        T va[3], wa[3], own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6];
+        shfl_vec<6>(wv, par6, own6, plane);
+        if (has_parent) { v3cpy(va, par6); v3cpy(wa, par6 + 3); } else { va[0] = va[1] = va[2] = wa[0] = wa[1] = wa[2] = T(0); }
+        Kin<T> kb, ka;
+        kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], dt);
+        kin_of(ka, L.xa2, L.qa2, va, wa, dt);
+        JointEval<T> E;
+        joint_eval<JAC>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt);
+        for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
+        theta = E.theta;
+        // body residual: src/integrators/constraint.jl:1-34 in closed form
+        T Jw[3], wxJw[3];
+        m3vec(Jw, P.J, L.w[1]);
+        v3cross(wxJw, L.w[1], Jw);
+        T d[6];
+        for (int i = 0; i < 3; ++i) { d[i] = P.m * L.v[1][i] + L.dconst[i]; d[3 + i] = T(0.5) * dt * (kb.c * Jw[i] + wxJw[i]) + L.dconst[3 + i]; }
+        for (int i = 0; i < 6; ++i) d[i] -= E.imp_b[i];
+        // contacts
+        ContactEval<T> CE[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < P.ncontact) {
+                contact_eval<JAC>(CE[c], CP[P.contact[c]], kb, L.v[1], L.w[1], L.cs[1][c], L.cg[1][c], dt);
+                for (int i = 0; i < 6; ++i) d[i] -= CE[c].imp[i];
+                for (int i = 0; i < 4; ++i) cres[c][i] = CE[c].c[i];
+            } else { for (int i = 0; i < 4; ++i) cres[c][i] = T(0); }
+        }
+        // what this lane's joint applies to the parent body travels up the tree
+        T up[6];
+        for (int i = 0; i < 6; ++i) up[i] = has_parent ? -E.imp_a[i] : T(0);
+        gather_children<6>(wv, d, up, P, base, G.maxch, active);
+        for (int i = 0; i < 6; ++i) rb[i] = d[i];
+        if (JAC) {
+            // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)) ----
+            for (int i = 0; i < 144; ++i) Smat[i] = T(0);
+            T Dw[9];                                          // (Δt/2)(cJ − Jω ωᵀ/c + [ω]xJ − [Jω]x)
+            {
+                T Sw[9], SJw[9], SwJ[9];
+                m3skew(Sw, L.w[1]); m3skew(SJw, Jw); m3mul(SwJ, Sw, P.J);
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+                    Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[1][j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
+            }
+            for (int i = 0; i < 3; ++i) {
+                Smat[12 * i + i] = P.m + T(REG);
+                for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] = Dw[3 * i + j];
+                Smat[12 * (3 + i) + 3 + i] += T(REG);
+            }
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                Smat[12 * i + j] += E.Dbb[6 * i + j];
+                Smat[12 * i + 6 + j] = E.Pb[6 * i + j];
+                Smat[12 * (6 + i) + j] = E.Gb[6 * i + j];
+            }
+            for (int i = 0; i < 3; ++i) {
+                Smat[12 * (6 + i) + 6 + i] = (i < P.nl_t) ? T(REG) : T(1);
+                Smat[12 * (9 + i) + 9 + i] = (i < P.nl_r) ? T(REG) : T(1);
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c < P.ncontact) {
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] -= CE[c].Dww[3 * i + j];
+                    for (int i = 0; i < 18; ++i) { F.C134[c][i] = CE[c].C134[i]; F.G134[c][i] = CE[c].G134[i]; }
+                }
+            }
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                Umat[6 * i + j] = E.Mba[6 * i + j];           // body rows wrt parent velocity
+                Umat[6 * (6 + i) + j] = E.Ga[6 * i + j];      // joint rows wrt parent velocity
+                Lmat[12 * i + j] = E.Mab[6 * i + j];          // parent rows wrt child velocity
+                Lmat[12 * i + 6 + j] = E.Pa[6 * i + j];       // parent rows wrt joint multipliers
+                Dup[6 * i + j] = E.Daa[6 * i + j];            // extra diagonal of the parent body
+            }
+            for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
+            for (int j = 0; j < 6; ++j) { F.t_a[j] = E.t_a[j]; F.t_b[j] = E.t_b[j]; }
+        }
+    }
+
+    // ---------------------------------------------------------------- violations (src/solver/violations.jl)
+    DJ_HD void violations(T& rvio, T& bvio) {
+        T r = T(0), b = T(0);
+        if (active) {
+            for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rb[i]));
+            for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rj[i]));          // only the Nλ equality rows (padded slots are 0)
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+                for (int i = 0; i < 4; ++i) r = tmax(r, tabs(cres[c][i]));
+                const T* g = L.cg[1][c]; const T* s = L.cs[1][c];
+                b = tmax(b, tabs(g[0] * s[0]));
+                b = tmax(b, tabs(g[1] * s[1] + g[2] * s[2] + g[3] * s[3]));
+                b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
+                b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
+            }
+            if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[1][0] * L.lg[1][0])); b = tmax(b, tabs(L.ls[1][1] * L.lg[1][1])); }
+        }
+        rvio = env_max(wv, r, G.S);
+        bvio = env_max(wv, b, G.S);
+    }
+
+    // ---------------------------------------------------------------- condensation of cone rows
+    // comp-row right-hand sides (r1..r4 per contact, r_cu, r_cl for the limit) -> condensed rhs
+    // additions for the parent (ra) and own (rbody) body rows; coefficients for the recovery.
+    struct ConeRhs { T cc[MAXC][4]; T lim[2]; };
+
+    DJ_HD void cone_rhs_from_state(ConeRhs& R, T mu_asm) const {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const T* g = L.cg[1][c]; const T* s = L.cs[1][c];
+            R.cc[c][0] = -(g[0] * s[0] - mu_asm);
+            R.cc[c][1] = -(g[1] * s[1] + g[2] * s[2] + g[3] * s[3] - mu_asm);
+            R.cc[c][2] = -(g[1] * s[2] + s[1] * g[2]);
+            R.cc[c][3] = -(g[1] * s[3] + s[1] * g[3]);
+        }
+        R.lim[0] = -(L.ls[1][0] * L.lg[1][0] - mu_asm);
+        R.lim[1] = -(L.ls[1][1] * L.lg[1][1] - mu_asm);
+    }
+
+    // contact condensation coefficients: Δγ_{1,3,4} = k0 + coef·(C134 Δw);  also Δs2 etc. for recovery
+    struct CCoef { T k0[3], coef[9]; T a1, b1, den, al2, al3, al4, g0, g1, g2, h0, h1, h2; };
+    DJ_HD void contact_coef(CCoef& Q, int c, const T* rc /*r1..r4*/, const T* r58 /*−constraint rows*/) const {
+        const ContactP<T>& K = CP[P.contact[c]];
+        const T* gam = L.cg[1][c]; const T* s = L.cs[1][c];
+        T g1t = gam[0] + T(REG), s1t = s[0] + T(REG);
+        Q.g0 = gam[1] + T(REG); Q.g1 = gam[2]; Q.g2 = gam[3];
+        Q.h0 = s[1] + T(REG); Q.h1 = s[2]; Q.h2 = s[3];
+        // Δγ1 = a1 + b1 (C1Δw):  γ̃1 Δs1 + s̃1 Δγ1 = r1, Δs1 = C1Δw − r5
+        Q.a1 = (rc[0] + g1t * r58[0]) / s1t; Q.b1 = -g1t / s1t;
+        T ih = T(1) / Q.h0;
+        Q.al3 = Q.g1 - Q.h1 * Q.g0 * ih; Q.al4 = Q.g2 - Q.h2 * Q.g0 * ih; Q.al2 = Q.h0 - (Q.h1 * Q.h1 + Q.h2 * Q.h2) * ih;
+        Q.den = Q.g0 - (Q.h1 * Q.g1 + Q.h2 * Q.g2) * ih;
+        // Δγ2 = μf Δγ1 − r6 = (μf a1 − r6) + μf b1 (C1Δw); Δs3 = C3Δw − r7; Δs4 = C4Δw − r8
+        T r2p = rc[1] - (Q.h1 * rc[2] + Q.h2 * rc[3]) * ih;
+        T dg2_0 = K.mu * Q.a1 - r58[1], dg2_1 = K.mu * Q.b1;
+        // Δs2 = [r2p − al3 Δs3 − al4 Δs4 − al2 Δγ2] / den
+        T id = T(1) / Q.den;
+        T s2_0 = (r2p + Q.al3 * r58[2] + Q.al4 * r58[3] - Q.al2 * dg2_0) * id;
+        T s2_c1 = -Q.al2 * dg2_1 * id, s2_c3 = -Q.al3 * id, s2_c4 = -Q.al4 * id;
+        // Δγ3 = (r3 − g1Δs2 − g0Δs3 − h1Δγ2)/h0 ; Δγ4 = (r4 − g2Δs2 − g0Δs4 − h2Δγ2)/h0
+        Q.k0[0] = Q.a1;
+        Q.coef[0] = Q.b1; Q.coef[1] = T(0); Q.coef[2] = T(0);
+        Q.k0[1] = (rc[2] - Q.g1 * s2_0 + Q.g0 * r58[2] - Q.h1 * dg2_0) * ih;
+        Q.coef[3] = (-Q.g1 * s2_c1 - Q.h1 * dg2_1) * ih; Q.coef[4] = (-Q.g1 * s2_c3 - Q.g0) * ih; Q.coef[5] = (-Q.g1 * s2_c4) * ih;
+        Q.k0[2] = (rc[3] - Q.g2 * s2_0 + Q.g0 * r58[3] - Q.h2 * dg2_0) * ih;
+        Q.coef[6] = (-Q.g2 * s2_c1 - Q.h2 * dg2_1) * ih; Q.coef[7] = (-Q.g2 * s2_c3) * ih; Q.coef[8] = (-Q.g2 * s2_c4 - Q.g0) * ih;
+    }
+
+    // ---------------------------------------------------------------- factorization sweep
+    // Condense contacts and limits, then eliminate supernodes leaves -> root.
+    DJ_HD void factorize(T* Smat, T* Umat, T* Lmat, T* Dup) {
+        // contact condensation into D_b:  D_b −= −G134·coef·C134  i.e. rows get −G Δγ  =>  S −= G134ᵀ...
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < P.ncontact) {
+                CCoef Q; T rc[4] = {0, 0, 0, 0}, r58[4] = {0, 0, 0, 0};
+                contact_coef(Q, c, rc, r58);
+                // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                    T acc = T(0);
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc += F.G134[c][6 * a + i] * Q.coef[3 * a + b] * F.C134[c][6 * b + j];
+                    Smat[12 * i + j] -= acc;
+                }
+            }
+        }
+        // limit condensation: rows x get + wκ t_x (θ_a Δω_a + θ_b Δω_b)
+        if (P.nlim_r > 0) {
+            T wk = (L.lg[1][1] + T(REG)) / (L.ls[1][1] + T(REG)) + (L.lg[1][0] + T(REG)) / (L.ls[1][0] + T(REG));
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) {
+                Smat[12 * i + 3 + j] += wk * F.t_b[i] * F.th_b[j];
+                Umat[6 * i + 3 + j] += wk * F.t_b[i] * F.th_a[j];
+                Lmat[12 * i + 3 + j] += wk * F.t_a[i] * F.th_b[j];
+                Dup[6 * i + 3 + j] += wk * F.t_a[i] * F.th_a[j];
+            }
+        }
+        // leaves -> root, in the factorization precision
+        TL Sl[144], Ul[72], Ll[72], up[36];
+        for (int i = 0; i < 144; ++i) Sl[i] = TL(Smat[i]);
+        for (int i = 0; i < 72; ++i) { Ul[i] = TL(Umat[i]); Ll[i] = TL(Lmat[i]); }
+        for (int i = 0; i < 36; ++i) up[i] = TL(0);
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            // receive the children's contributions (they were produced at lev+1)
+            TL acc[36];
+            for (int i = 0; i < 36; ++i) acc[i] = TL(0);
+            gather_children<36>(wv, acc, up, P, base, G.maxch, active && P.level == lev);
+            if (active && P.level == lev) {
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Sl[12 * i + j] += acc[6 * i + j];
+                for (int i = 0; i < 144; ++i) F.Sinv[i] = Sl[i];
+                gj_inverse<12>(F.Sinv);
+                if (has_parent) {
+                    mm<6, 12, 12>(F.W, Ll, F.Sinv);
+                    mm<12, 12, 6>(F.Z, F.Sinv, Ul);
+                    for (int i = 0; i < 36; ++i) up[i] = TL(Dup[i]);
+                    mm_sub<6, 12, 6>(up, Ll, F.Z);
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- solve with the current factors
+    // Generic right-hand side: rk0 = rhs of the body (6) and joint-equality (6) rows, R = rhs of the
+    // cone (complementarity) rows, rs = rhs of the two limit slack rows, r58 = rhs of the contact
+    // constraint rows, upx = direct rhs contribution to the parent's body rows.
+    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D) {
+        T rk[12], up[6];
+        for (int i = 0; i < 12; ++i) rk[i] = rk0[i];
+        for (int i = 0; i < 6; ++i) up[i] = upx[i];
+        CCoef Q[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < P.ncontact) {
+                contact_coef(Q[c], c, R.cc[c], r58[c]);
+                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += F.G134[c][6 * a + i] * Q[c].k0[a];
+            }
+        }
+        T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0);
+        if (P.nlim_r > 0) {
+            su = L.ls[1][0] + T(REG); sl = L.ls[1][1] + T(REG); gu = L.lg[1][0] + T(REG); gl = L.lg[1][1] + T(REG);
+            kap0 = (R.lim[1] - gl * rsl) / sl - (R.lim[0] - gu * rsu) / su;
+            for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; up[i] += F.t_a[i] * kap0; }
+        }
+        // forward: leaves -> root (factorization precision)
+        TL rl[12], y[12], send[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            TL acc[6] = {0, 0, 0, 0, 0, 0};
+            gather_children<6>(wv, acc, send, P, base, G.maxch, active && P.level == lev);
+            if (active && P.level == lev) {
+                for (int i = 0; i < 6; ++i) rl[i] += acc[i];
+                if (has_parent) { TL t[6]; mv<6, 12>(t, F.W, rl); for (int i = 0; i < 6; ++i) send[i] = TL(up[i]) - t[i]; }
+            }
+        }
+        mv<12, 12>(y, F.Sinv, rl);
+        // backward: root -> leaves
+        TL dk[12];
+        for (int i = 0; i < 12; ++i) dk[i] = y[i];
+        T dva[6] = {0, 0, 0, 0, 0, 0};
+        for (int lev = 1; lev <= G.maxlevel; ++lev) {
+            TL par[6];
+            shfl_vec<6>(wv, par, dk, plane);
+            if (active && P.level == lev && has_parent) {
+                for (int i = 0; i < 6; ++i) dva[i] = T(par[i]);
+                TL t[12]; mv<12, 6>(t, F.Z, par);
+                for (int i = 0; i < 12; ++i) dk[i] = y[i] - t[i];
+            }
+        }
+        for (int i = 0; i < 3; ++i) { D.dv[i] = T(dk[i]); D.dw[i] = T(dk[3 + i]); }
+        for (int i = 0; i < 6; ++i) D.dlam[i] = T(dk[6 + i]);
+        // recovery of the condensed variables
+        if (P.nlim_r > 0) {
+            T thd = v3dot(F.th_a, dva + 3) + v3dot(F.th_b, D.dw);
+            D.dls[0] = rsu - thd; D.dls[1] = rsl + thd;
+            D.dlg[0] = (R.lim[0] - gu * D.dls[0]) / su;
+            D.dlg[1] = (R.lim[1] - gl * D.dls[1]) / sl;
+        } else { D.dls[0] = D.dls[1] = D.dlg[0] = D.dlg[1] = T(0); }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < P.ncontact) {
+                const ContactP<T>& K = CP[P.contact[c]];
+                T cw[3];
+                for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += F.C134[c][6 * a + j] * D.dv[j] + F.C134[c][6 * a + 3 + j] * D.dw[j]; }
+                const CCoef& q = Q[c];
+                T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
+                T dg1 = q.a1 + q.b1 * cw[0];
+                T dg2 = K.mu * dg1 - r58[c][1];
+                T ih = T(1) / q.h0;
+                T r2p = R.cc[c][1] - (q.h1 * R.cc[c][2] + q.h2 * R.cc[c][3]) * ih;
+                T ds2 = (r2p - q.al3 * ds3 - q.al4 * ds4 - q.al2 * dg2) / q.den;
+                T dg3 = (R.cc[c][2] - q.g1 * ds2 - q.g0 * ds3 - q.h1 * dg2) * ih;
+                T dg4 = (R.cc[c][3] - q.g2 * ds2 - q.g0 * ds4 - q.h2 * dg2) * ih;
+                D.dcs[c][0] = ds1; D.dcs[c][1] = ds2; D.dcs[c][2] = ds3; D.dcs[c][3] = ds4;
+                D.dcg[c][0] = dg1; D.dcg[c][1] = dg2; D.dcg[c][2] = dg3; D.dcg[c][3] = dg4;
+            } else { for (int i = 0; i < 4; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
+        }
+    }
+
+    // Newton right-hand side: −residual with the given cone-row right-hand sides
+    DJ_HD void solve(const ConeRhs& R, Step<T, MAXC>& D) {
+        T rk[12], rs[2] = {0, 0}, r58[MAXC][4], upx[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i) { rk[i] = -rb[i]; rk[6 + i] = -rj[i]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r58[c][i] = -cres[c][i];
+        if (P.nlim_r > 0) {
+            rs[0] = -(L.ls[1][0] - (P.lim_hi - theta));       // limits.jl:13-14
+            rs[1] = -(L.ls[1][1] - (theta - P.lim_lo));
+        }
+        solve_rhs(rk, R, rs, r58, upx, D);
+    }
+
+    // cone_line_search!  src/solver/line_search.jl:36-96
+    DJ_HD T cone_line_search(const Step<T, MAXC>& D, T tort, T tsoc) {
+        T a = T(1);
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+                a = tmin(a, ort_step(L.cs[1][c][0], D.dcs[c][0], tort));
+                a = tmin(a, ort_step(L.cg[1][c][0], D.dcg[c][0], tort));
+                a = tmin(a, soc_step(&L.cs[1][c][1], &D.dcs[c][1], tsoc));
+                a = tmin(a, soc_step(&L.cg[1][c][1], &D.dcg[c][1], tsoc));
+            }
+            if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) {
+                a = tmin(a, ort_step(L.ls[1][i], D.dls[i], tort));
+                a = tmin(a, ort_step(L.lg[1][i], D.dlg[i], tort));
+            }
+        }
+        return env_min(wv, a, G.S);
+    }
+
+    // candidate_step!  src/solver/line_search.jl:141-163.  Returns 1 if ω had to be clipped beyond the error threshold.
+    DJ_HD int candidate_step(const Step<T, MAXC>& D, T f) {
+        int bad = 0;
+        for (int i = 0; i < 3; ++i) { L.v[1][i] = L.v[0][i] + f * D.dv[i]; L.w[1][i] = L.w[0][i] + f * D.dw[i]; }
+        T wmax = T(3.9) / (G.dt * G.dt);
+        T wd = v3dot(L.w[1], L.w[1]);
+        if (wd > wmax) { T sc = wmax / wd; for (int i = 0; i < 3; ++i) L.w[1][i] *= sc; }
+        if (v3dot(L.w[1], L.w[1]) > T(3.91) / (G.dt * G.dt)) bad = 1;
+        for (int i = 0; i < 6; ++i) L.lam[1][i] = L.lam[0][i] + f * D.dlam[i];
+        for (int i = 0; i < 2; ++i) { L.ls[1][i] = L.ls[0][i] + f * D.dls[i]; L.lg[1][i] = L.lg[0][i] + f * D.dlg[i]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[1][c][i] = L.cs[0][c][i] + f * D.dcs[c][i]; L.cg[1][c][i] = L.cg[0][c][i] + f * D.dcg[c][i]; }
+        return bad;
+    }
+    DJ_HD void accept_candidate() {     // update!  src/solver/linear_system.jl:54-69
+        for (int i = 0; i < 3; ++i) { L.v[0][i] = L.v[1][i]; L.w[0][i] = L.w[1][i]; }
+        for (int i = 0; i < 6; ++i) L.lam[0][i] = L.lam[1][i];
+        for (int i = 0; i < 2; ++i) { L.ls[0][i] = L.ls[1][i]; L.lg[0][i] = L.lg[1][i]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[0][c][i] = L.cs[1][c][i]; L.cg[0][c][i] = L.cg[1][c][i]; }
+    }
+    // ---------------------------------------------------------------- set-up of one step
+    // set_maximal_state! + set_input! (src/mechanism/set.jl:10-53): loads z, applies u, builds dconst.
+    DJ_HD void begin_step(const T* zb /*13 values of this body*/, const T* u /*this joint's inputs (<= 6) or null*/) {
+        const T dt = G.dt;
+        T v15[3] = {0, 0, 0}, w15[3] = {0, 0, 0};
+        if (active) {
+            for (int i = 0; i < 3; ++i) { L.x2[i] = zb[i]; v15[i] = zb[3 + i]; w15[i] = zb[10 + i]; }
+            for (int i = 0; i < 4; ++i) L.q2[i] = zb[6 + i];
+        } else {
+            for (int i = 0; i < 3; ++i) L.x2[i] = T(0);
+            L.q2[0] = T(1); L.q2[1] = L.q2[2] = L.q2[3] = T(0);
+        }
+        T own7[7] = {L.x2[0], L.x2[1], L.x2[2], L.q2[0], L.q2[1], L.q2[2], L.q2[3]}, par7[7];
+        shfl_vec<7>(wv, par7, own7, plane);
+        if (has_parent) { for (int i = 0; i < 3; ++i) L.xa2[i] = par7[i]; for (int i = 0; i < 4; ++i) L.qa2[i] = par7[3 + i]; }
+        else { L.xa2[0] = L.xa2[1] = L.xa2[2] = T(0); L.qa2[0] = T(1); L.qa2[1] = L.qa2[2] = L.qa2[3] = T(0); }
+        joint_cfg(cfg, P, L.xa2, L.qa2, L.x2, L.q2);
+        // warm start (set_velocity_solution!, bodies/set.jl:1-7), reset!/initialize! of the cone variables
+        for (int i = 0; i < 3; ++i) { L.v[0][i] = L.v[1][i] = v15[i]; L.w[0][i] = L.w[1][i] = w15[i]; L.v15[i] = v15[i]; L.w15[i] = w15[i]; }
+        for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < 6; ++i) L.lam[j][i] = T(0);
+            for (int i = 0; i < 2; ++i) { L.ls[j][i] = T(1); L.lg[j][i] = T(1); }            // joints/constraints.jl:440-448
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {                                                  // reset! to [1,1,0,0] then initialize! -> 1.5·[1,1,0,0]
+                L.cs[j][c][0] = L.cs[j][c][1] = T(1.5); L.cs[j][c][2] = L.cs[j][c][3] = T(0);
+                L.cg[j][c][0] = L.cg[j][c][1] = T(1.5); L.cg[j][c][2] = L.cg[j][c][3] = T(0);
+            }
+        }
+        // velocity-independent part of d: D1x + D1q (constraint.jl:15-18 in closed form) − gravity − inputs − springs
+        T J15[3], wxJ[3];
+        m3vec(J15, P.J, w15);
+        v3cross(wxJ, w15, J15);
+        T c15 = tsqrt(T(4) / (dt * dt) - v3dot(w15, w15));
+        for (int i = 0; i < 3; ++i) {
+            L.dconst[i] = -P.m * v15[i] - dt * P.m * G.g[i];
+            L.dconst[3 + i] = T(-0.5) * dt * (c15 * J15[i] - wxJ[i]);
+        }
+        // control input: set_input! + input_impulse!  (joints/joint.jl:96-99, translational/input.jl:5-27, rotational/input.jl:5-17)
+        T ina[6] = {0, 0, 0, 0, 0, 0};                          // what this joint's input applies to the parent body
+        if (active && u != nullptr) {
+            T it[3] = {0, 0, 0}, ir[3] = {0, 0, 0};
+            for (int i = 0; i < 3; ++i) {
+                if (i < P.nu_t) for (int kx = 0; kx < 3; ++kx) it[kx] += P.At[3 * i + kx] * u[i];
+                if (i < P.nu_r) for (int kx = 0; kx < 3; ++kx) ir[kx] += P.Ar[3 * i + kx] * u[P.nu_t + i];
+            }
+            for (int kx = 0; kx < 3; ++kx) { it[kx] *= G.input_scaling; ir[kx] *= G.input_scaling; }
+            T ia[6], ib[6];
+            tra_impulse(ia, ib, cfg, P, it);                    // Ta·input, Tb·input; torques get an extra 1/2 (input.jl:21-23)
+            for (int i = 0; i < 3; ++i) { ina[i] = ia[i]; ina[3 + i] = T(0.5) * ia[3 + i]; L.dconst[i] -= ib[i]; L.dconst[3 + i] -= T(0.5) * ib[3 + i]; }
+            T ta[3], tb[3];
+            m3vec(ta, cfg.Roff, ir);                            // parent: vector_rotate(−τ, qoff); child: vector_rotate(τ, qb⁻¹ qa qoff)
+            m3vec(tb, cfg.Rba, ta);
+            for (int i = 0; i < 3; ++i) { ina[3 + i] += -ta[i]; L.dconst[3 + i] -= tb[i]; }
+        }
+        // springs (velocity independent)
+        T sa[6], sb[6];
+        spring_impulses(sa, sb, P, cfg, dt);
+        for (int i = 0; i < 6; ++i) L.dconst[i] -= sb[i];
+        T up[6], acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i) up[i] = has_parent ? -(ina[i] + sa[i]) : T(0);
+        gather_children<6>(wv, acc, up, P, base, G.maxch, active);
+        for (int i = 0; i < 6; ++i) L.dconst[i] += acc[i];
+        mu = T(0);
+    }
+
+    // ---------------------------------------------------------------- mehrotra!  src/solver/mehrotra.jl:9-73
+    // returns status; iters_out = number of Newton iterations.  On return (Smat,Umat,Lmat,Dup) hold
+    // the un-factored blocks of the final linearization (mehrotra.jl:69 runs set_entries! last) and
+    // rb/rj/theta/cres the residual pieces at the solution.
+    DJ_HD int mehrotra(int& iters_out, T* Smat, T* Umat, T* Lmat, T* Dup) {
+        int status = DJ_STATUS_FAILED, excessive = 0;
+        T mutarget = T(0), undercut = G.undercut;
+        int no_progress = 0;
+        mu = T(0);
+        evaluate<true>(Smat, Umat, Lmat, Dup);
+#ifdef DJ_DEBUG
+        if (dbg_on) {   // test hook: dump the first assembly of this lane and stop (wave-uniform exit)
+          if (dbg) {
+            T* o = dbg; int q = 0;
+            for (int i = 0; i < 6; ++i) o[q++] = rb[i];
+            for (int i = 0; i < 6; ++i) o[q++] = rj[i];
+            o[q++] = theta;
+            for (int i = 0; i < 144; ++i) o[q++] = Smat[i];
+            for (int i = 0; i < 72; ++i) o[q++] = Umat[i];
+            for (int i = 0; i < 72; ++i) o[q++] = Lmat[i];
+            for (int i = 0; i < 36; ++i) o[q++] = Dup[i];
+            for (int i = 0; i < 3; ++i) o[q++] = F.th_a[i];
+            for (int i = 0; i < 3; ++i) o[q++] = F.th_b[i];
+            for (int i = 0; i < 6; ++i) o[q++] = F.t_a[i];
+            for (int i = 0; i < 6; ++i) o[q++] = F.t_b[i];
+          }
+          iters_out = 0; return 0;
+        }
+#endif
+        T rvio, bvio;
+        violations(rvio, bvio);
+        bool done = false;               // per-environment flag (identical on all lanes of an environment)
+        int iters = 0;
+        for (int n = 1; n <= G.max_iter; ++n) {
+#ifdef DJ_DEBUG
+            if (trace && wv.lane() == 0) std::printf("%3d  bvio %.3e  rvio %.3e  mu %.3e\n", n, (double)bvio, (double)rvio, (double)mu);
+#endif
+            if (!done && rvio < G.rtol && bvio < G.btol) { status = DJ_STATUS_SUCCESS; done = true; }
+            if (!wv.any(active && !done)) break;
+            // Lanes of finished environments keep executing (wave-uniform control flow, all lanes must
+            // take part in the shuffles) but never change their state: their step factor is 0.
+            if (!done) iters = n;
+            factorize(Smat, Umat, Lmat, Dup);
+            ConeRhs R;
+            cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
+            Step<T, MAXC> D;
+            solve(R, D);                                            // affine direction
+            T aaff = cone_line_search(D, T(0.95), T(0.95));
+            // centering!  src/solver/centering.jl
+            T p0 = T(0), p1 = T(0), p2 = T(0);
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+                    for (int i = 0; i < 4; ++i) { p0 += L.cs[1][c][i] * L.cg[1][c][i]; p1 += (L.cs[1][c][i] + aaff * D.dcs[c][i]) * (L.cg[1][c][i] + aaff * D.dcg[c][i]); }
+                    p2 += T(2);
+                }
+                if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[1][i] * L.lg[1][i]; p1 += (L.ls[1][i] + aaff * D.dls[i]) * (L.lg[1][i] + aaff * D.dlg[i]); p2 += T(1); }
+            }
+            p0 = env_sum(wv, p0, G.S); p1 = env_sum(wv, p1, G.S); p2 = env_sum(wv, p2, G.S);
+            T munew = G.btol / undercut;
+            if (p2 > T(0)) {
+                T nu = p0 / p2, nuaff = p1 / p2;
+                T sc = nuaff / (nu + T(1e-20));
+                sc = tmin(tmax(sc, T(0)), T(1));
+                munew = tmax(sc * sc * sc * nu, G.btol / undercut);
+            }
+            mutarget = munew;
+            // correction!: cached residual += [−Δs∘Δγ + μ]   src/solver/correction.jl
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                R.cc[c][0] += -D.dcs[c][0] * D.dcg[c][0] + mutarget;
+                R.cc[c][1] += -(D.dcs[c][1] * D.dcg[c][1] + D.dcs[c][2] * D.dcg[c][2] + D.dcs[c][3] * D.dcg[c][3]) + mutarget;
+                R.cc[c][2] += -(D.dcs[c][1] * D.dcg[c][2] + D.dcg[c][1] * D.dcs[c][2]);
+                R.cc[c][3] += -(D.dcs[c][1] * D.dcg[c][3] + D.dcg[c][1] * D.dcs[c][3]);
+            }
+            R.lim[0] += -D.dls[0] * D.dlg[0] + mutarget;
+            R.lim[1] += -D.dls[1] * D.dlg[1] + mutarget;
+            solve(R, D);                                            // corrected direction
+            T mx = tmax(rvio, bvio);
+            T tau = tmax(T(0.95), T(1) - mx * mx);
+            T alpha = cone_line_search(D, tau, tmin(tau, T(0.95)));
+            // line_search!  src/solver/line_search.jl:1-34 (halving; the last trial is taken if all are rejected)
+            T rc = rvio, bc = bvio;
+            {
+                bool searching = !done;
+                T f = done ? T(0) : alpha;
+                for (int ls = 0; ls < G.max_ls; ++ls) {
+                    if (!wv.any(active && searching)) break;
+                    int bad = candidate_step(D, f);                 // finished searches recompute the same candidate
+                    evaluate<false>(nullptr, nullptr, nullptr, nullptr);
+                    T r2, b2;
+                    violations(r2, b2);
+                    int anybad = env_or(wv, (active && searching) ? bad : 0, G.S);
+                    if (searching) {
+                        excessive |= anybad;
+                        rc = r2; bc = b2;
+                        if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
+                    }
+                }
+            }
+            if (!done) {
+                bool made = (!(rc < G.rtol) && rc < T(0.8) * rvio) || (!(bc < G.btol) && bc < T(0.8) * bvio);
+                if (made) no_progress = no_progress > 0 ? no_progress - 1 : 0; else no_progress += 1;
+                rvio = rc; bvio = bc;
+                if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
+                accept_candidate();
+                mu = mutarget;
+            }
+            evaluate<true>(Smat, Umat, Lmat, Dup);                  // set_entries! (Jacobian + residual; cone rows now carry the new μ)
+        }
+        if (excessive) status = DJ_STATUS_EXCESSIVE_W;
+        iters_out = iters;
+        return status;
+    }
+
+    // ---------------------------------------------------------------- IFT gradients
+    // get_maximal_gradients (src/gradients/state.jl:78-126): data_jacobian = solmat \ datamat for the
+    // state columns [x2 v15 φ2 ω15] of every body and the control columns of every joint, then the
+    // integrator chain to (x3, v25, φ3, ω25).  solmat is the final linearization (re-using the
+    // supernode factors instead of the reference's dense `\`); datamat = −∂residual/∂θ is assembled
+    // block-wise (src/gradients/data.jl) in closed form at the evaluation state selected by
+    // G.grad_mode: DOJO_GRAD_REFERENCE = post-update_state! states (literal
+    // reference behaviour), DOJO_GRAD_CONSISTENT = pre-update states.
+    // Output layout: column-major per environment (Julia-native): dz[env][col][row], du[env][ucol][row].
+    template <class KA>
+    DJ_HD void gradients(const KA& A, int env, T* Smat, T* Umat, T* Lmat, T* Dup) {
+        const T dt = G.dt;
+        const int nx = 12 * G.Nb;
+        factorize(Smat, Umat, Lmat, Dup);                         // factors of the final linearization
+        // ---- kinematics of the solution (chain) ----
+        T own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6], va[3], wa[3];
+        shfl_vec<6>(wv, par6, own6, plane);
+        for (int i = 0; i < 3; ++i) { va[i] = has_parent ? par6[i] : T(0); wa[i] = has_parent ? par6[3 + i] : T(0); }
+        Kin<T> kb0, ka0;
+        kin_of(kb0, L.x2, L.q2, L.v[1], L.w[1], dt);
+        kin_of(ka0, L.xa2, L.qa2, va, wa, dt);
+        // ---- evaluation state of the data blocks ----
+        T x2e[3], q2e[4], xa2e[3], qa2e[4], w15e[3];
+        if (G.grad_mode == 0) {                                   // reference: x2 <- x3, q2 <- q3, ω15 <- ω25
+            for (int i = 0; i < 3; ++i) { x2e[i] = kb0.x3[i]; xa2e[i] = ka0.x3[i]; w15e[i] = L.w[1][i]; }
+            for (int i = 0; i < 4; ++i) { q2e[i] = kb0.q3[i]; qa2e[i] = ka0.q3[i]; }
+        } else {
+            for (int i = 0; i < 3; ++i) { x2e[i] = L.x2[i]; xa2e[i] = L.xa2[i]; w15e[i] = L.w15[i]; }
+            for (int i = 0; i < 4; ++i) { q2e[i] = L.q2[i]; qa2e[i] = L.qa2[i]; }
+        }
+        JointCfg<T> ce;
+        joint_cfg(ce, P, xa2e, qa2e, x2e, q2e);
+        Kin<T> kb, ka;
+        kin_of(kb, x2e, q2e, L.v[1], L.w[1], dt);
+        kin_of(ka, xa2e, qa2e, va, wa, dt);
+        JointEval<T> E;
+        joint_eval<true>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt);
+        // ---- data blocks (datamat = −∂residual/∂θ) ----
+        T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
+        for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
+        // body rows <- own (v15, ω15): data.jl:16-55 in closed form
+        {
+            T J15[3], SwJ[9], SJw[9], Sw[9];
+            m3vec(J15, P.J, w15e);
+            T c15 = tsqrt(T(4) / (dt * dt) - v3dot(w15e, w15e));
+            m3skew(Sw, w15e); m3skew(SJw, J15); m3mul(SwJ, Sw, P.J);
+            for (int i = 0; i < 3; ++i) {
+                OwnB[i][3 + i] = P.m;
+                for (int j = 0; j < 3; ++j) OwnB[3 + i][9 + j] = T(0.5) * dt * (c15 * P.J[3 * i + j] - J15[i] * w15e[j] / c15 - SwJ[3 * i + j] + SJw[3 * i + j]);
+            }
+        }
+        // joint rows <- configuration of child / parent: −∂g/∂z3 · ∂z3/∂z2   (data.jl:4-14)
+        for (int sl = 0; sl < 6; ++sl) for (int j = 0; j < 3; ++j) {
+            OwnJ[sl][j] = -E.GbX[3 * sl + j];
+            ParJ[sl][j] = -E.GaX[3 * sl + j];
+            T pb_ = T(0), pa_ = T(0);
+            for (int m_ = 0; m_ < 3; ++m_) { pb_ += E.GbP[3 * sl + m_] * kb.Xi[3 * m_ + j]; pa_ += E.GaP[3 * sl + m_] * ka.Xi[3 * m_ + j]; }
+            OwnJ[sl][3 + j] = -pb_; ParJ[sl][3 + j] = -pa_;
+        }
+        // limit slack rows: up = −∂θ/∂φ2, lo = +∂θ/∂φ2
+        if (P.nlim_r > 0) for (int j = 0; j < 3; ++j) {
+            T pb_ = T(0), pa_ = T(0);
+            for (int m_ = 0; m_ < 3; ++m_) { pb_ += E.thp_b[m_] * kb.Xi[3 * m_ + j]; pa_ += E.thp_a[m_] * ka.Xi[3 * m_ + j]; }
+            sl_own[3 + j] = -pb_; sl_par[3 + j] = -pa_;
+        }
+        // body rows <- configurations through the joint impulse map, springs and dampers (data.jl:57-124)
+        {
+            T pt[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+            for (int i = 0; i < 3; ++i) {
+                if (i < P.nl_t) for (int q_ = 0; q_ < 3; ++q_) pt[q_] += P.Ct[3 * i + q_] * L.lam[1][i];
+                if (i < P.nl_r) for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Cr[3 * i + q_] * L.lam[1][3 + i];
+            }
+            if (P.nlim_r > 0) { T kk = L.lg[1][1] - L.lg[1][0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
+            T Jaa[36], Jab[36], Jba[36], Jbb[36];
+            joint_impulse_cfg_jac(Jaa, Jab, Jba, Jbb, P, ce, pt, pr, wa, L.w[1], dt);
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                int cj = j < 3 ? j : 3 + j;                       // x2 -> cols 0:3, φ2 -> cols 6:9 of the 12 own-data columns
+                OwnB[i][cj] += Jbb[6 * i + j];
+                ParB[i][j] = Jba[6 * i + j];
+                UpOwn[i][j] = Jab[6 * i + j];
+                UpPar[i][j] = Jaa[6 * i + j];
+            }
+        }
+        // contacts: body rows <- own φ2 (data.jl:126-135), contact rows <- own configuration (data.jl:194-205)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) Cc[c][i][j] = T(0);
+            if (c < P.ncontact) {
+                ContactEval<T> CE;
+                contact_eval<true>(CE, CP[P.contact[c]], kb, L.v[1], L.w[1], L.cs[1][c], L.cg[1][c], dt);
+                const ContactP<T>& K = CP[P.contact[c]];
+                for (int j = 0; j < 3; ++j) {
+                    Cc[c][0][j] = -K.n[j];
+                    T a0 = T(0), a2 = T(0), a3 = T(0);
+                    for (int m_ = 0; m_ < 3; ++m_) { a0 += CE.c1p[m_] * kb.Xi[3 * m_ + j]; a2 += CE.c34p[m_] * kb.Xi[3 * m_ + j]; a3 += CE.c34p[3 + m_] * kb.Xi[3 * m_ + j]; }
+                    Cc[c][0][3 + j] = -a0; Cc[c][2][3 + j] = -a2; Cc[c][3][3 + j] = -a3;
+                    for (int i = 0; i < 3; ++i) { T q_ = T(0); for (int m_ = 0; m_ < 3; ++m_) q_ += CE.Qraw[3 * i + m_] * kb.Xi[3 * m_ + j]; OwnB[3 + i][6 + j] += q_; }
+                }
+            }
+        }
+        // control columns: input_jacobian_control (translational/input.jl:33-44, rotational/input.jl:23-40)
+        for (int i = 0; i < 3; ++i) {
+            if (i < P.nu_t) {
+                T ia[6], ib[6];
+                tra_impulse(ia, ib, ce, P, &P.At[3 * i]);
+                for (int r = 0; r < 3; ++r) { UB[r][i] = G.input_scaling * ib[r]; UB[3 + r][i] = G.input_scaling * T(0.5) * ib[3 + r]; UA[r][i] = G.input_scaling * ia[r]; UA[3 + r][i] = G.input_scaling * T(0.5) * ia[3 + r]; }
+            }
+            if (i < P.nu_r) {
+                T ta[3], tb[3];
+                m3vec(ta, ce.Roff, &P.Ar[3 * i]);
+                m3vec(tb, ce.Rba, ta);
+                for (int r = 0; r < 3; ++r) { UB[3 + r][P.nu_t + i] = G.input_scaling * tb[r]; UA[3 + r][P.nu_t + i] = -G.input_scaling * ta[r]; }
+            }
+        }
+        // ---- column loop ----
+        ConeRhs R0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) R0.cc[c][i] = T(0);
+        R0.lim[0] = R0.lim[1] = T(0);
+        Step<T, MAXC> D;
+        typedef decltype(A.dz) OutPtr;
+        for (int kk = 0; kk < G.Nb; ++kk) {
+            const bool mine = active && (k == kk), child_of = active && has_parent && (P.parent == kk);
+            for (int c = 0; c < 12; ++c) {
+                const bool is_cfg = (c < 3) || (c >= 6 && c < 9);
+                const int cc = c < 3 ? c : c - 3;                  // configuration column 0..5 (valid when is_cfg)
+                T rk[12], rs[2] = {0, 0}, r58[MAXC][4], upx[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 12; ++i) rk[i] = T(0);
+#pragma unroll
+                for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
+                if (mine) {
+                    for (int i = 0; i < 6; ++i) rk[i] = OwnB[i][c];
+                    if (is_cfg) {
+                        for (int i = 0; i < 6; ++i) { rk[6 + i] = OwnJ[i][cc]; upx[i] = UpOwn[i][cc]; }
+                        rs[0] = sl_own[cc]; rs[1] = -sl_own[cc];
+#pragma unroll
+                        for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = Cc[q_][i][cc];
+                    }
+                } else if (child_of && is_cfg) {
+                    for (int i = 0; i < 6; ++i) { rk[i] = ParB[i][cc]; rk[6 + i] = ParJ[i][cc]; upx[i] = UpPar[i][cc]; }
+                    rs[0] = sl_par[cc]; rs[1] = -sl_par[cc];
+                }
+                solve_rhs(rk, R0, rs, r58, upx, D);
+                if (active && A.dz) {
+                    OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k;
+                    T pw[3];
+                    m3vec(pw, kb0.Phi, D.dw);
+                    for (int i = 0; i < 3; ++i) {
+                        T x = dt * D.dv[i], ph = pw[i];
+                        if (mine && c < 3 && c == i) x += T(1);
+                        if (mine && c >= 6 && c < 9) ph += kb0.Xi[3 * i + (c - 6)];
+                        o[i] = x; o[3 + i] = D.dv[i]; o[6 + i] = ph; o[9 + i] = D.dw[i];
+                    }
+                }
+            }
+        }
+        // control columns, joint by joint (owner lane = child body of the joint)
+        for (int kk = 0; kk < G.Nb; ++kk) {
+            const NodeP<T>& Pk = A.nodes[kk];
+            const int nuk = Pk.nu_t + Pk.nu_r;
+            const bool mine = active && (k == kk);
+            for (int c = 0; c < nuk; ++c) {
+                T rk[12], rs[2] = {0, 0}, r58[MAXC][4], upx[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 12; ++i) rk[i] = T(0);
+#pragma unroll
+                for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
+                if (mine) for (int i = 0; i < 6; ++i) { rk[i] = UB[i][c]; upx[i] = UA[i][c]; }
+                solve_rhs(rk, R0, rs, r58, upx, D);
+                if (active && A.du) {
+                    OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + c)) * nx + 12 * k;
+                    T pw[3];
+                    m3vec(pw, kb0.Phi, D.dw);
+                    for (int i = 0; i < 3; ++i) { o[i] = dt * D.dv[i]; o[3 + i] = D.dv[i]; o[6 + i] = pw[i]; o[9 + i] = D.dw[i]; }
+                }
+            }
+        }
+    }
+
+    // update_state!  src/bodies/set.jl:22-36: -> (x3, v25, q3, ω25) = the next maximal state of this body
+    DJ_HD void next_state(T* zb) const {
+        Kin<T> kb;
+        kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], G.dt);
+        for (int i = 0; i < 3; ++i) { zb[i] = kb.x3[i]; zb[3 + i] = L.v[1][i]; zb[10 + i] = L.w[1][i]; }
+        for (int i = 0; i < 4; ++i) zb[6 + i] = kb.q3[i];
+    }
+};
+
+// ================================================================================================
+// Kernel-level entry: one call per lane.  Shared by the HIP kernel (dojo_hip.hip) and the
+// thread-based SIMT emulator (tests/emu).
+// ================================================================================================
+// TIO = scalar type of the ABI buffers, T = state/residual precision (tables are stored in T)
+template <class TIO, class T>
+struct KernelArgs {
+    Globals<T> G;
+    const NodeP<T>* nodes;
+    const ContactP<T>* contacts;
+    int B;                       // number of environments
+    const TIO* z;                  // [B,13Nb]
+    const TIO* u;                  // [B,nu] or null
+    TIO* z_next;                   // [B,13Nb]
+    int* status;                 // [B] or null
+    int* iters;                  // [B] or null
+    TIO* vel;                      // [B,6Nb] or null          (v25, ω25)
+    TIO* joint_imp;                // [B,n_joint_imp] or null  (get_solution order)
+    TIO* contact_sg;               // [B,8Nc] or null          ([s; γ] per contact)
+    TIO* dz;                       // [B][12Nb cols][12Nb rows] column-major per env, or null
+    TIO* du;                       // [B][nu cols][12Nb rows] column-major per env, or null
+#ifdef DJ_DEBUG
+    T* dbg = nullptr;            // [B][Nb][512] test hook
+#endif
+};
+
+template <class TIO, class T, class TL, int MAXC, class Wave>
+DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
+    const Globals<T>& G = A.G;
+    const int S = G.S, E = wv.width() / S;
+    const int lane = wv.lane();
+    const int slot = lane / S, k = lane % S;
+    const int env = wave_index * E + slot;
+    const bool active = (env < A.B) && (k < G.Nb);
+    const int base = slot * S;
+    const NodeP<T>& P = A.nodes[k < G.Nb ? k : 0];
+    LaneProgram<T, TL, MAXC, Wave> prog(wv, G, P, A.contacts, base, k, active);
+    T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);
+    const bool has_u = A.u != nullptr;
+    if (active && has_u) for (int i = 0; i < 6; ++i) if (i < P.nu_t + P.nu_r) ue[i] = T(A.u[(size_t)env * G.nu + P.u_off + i]);
+    prog.begin_step(zb, has_u ? ue : nullptr);
+#ifdef DJ_DEBUG
+    prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
+    if (A.dbg && active) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
+#endif
+    T Smat[144], Umat[72], Lmat[72], Dup[36];
+    int iters = 0;
+    int status = prog.mehrotra(iters, Smat, Umat, Lmat, Dup);
+    if (A.dz != nullptr) prog.gradients(A, env, Smat, Umat, Lmat, Dup);
+    if (active) {
+        T zn[13];
+        prog.next_state(zn);
+        TIO* o = A.z_next + (size_t)env * 13 * G.Nb + 13 * k;
+        for (int i = 0; i < 13; ++i) o[i] = TIO(zn[i]);
+        if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; }
+        if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[1][i]); vo[3 + i] = TIO(prog.L.w[1][i]); } }
+        if (A.joint_imp && P.n_imp > 0) {
+            // get_solution order per joint: [tra: λ_t] [rot: s_up s_lo γ_up γ_lo λ_r]   (translational limits unsupported)
+            TIO* jo = A.joint_imp + (size_t)env * G.n_joint_imp + P.imp_off;
+            int o2 = 0;
+            for (int i = 0; i < 3; ++i) if (i < P.nl_t) jo[o2++] = TIO(prog.L.lam[1][i]);
+            if (P.nlim_r > 0) { jo[o2++] = TIO(prog.L.ls[1][0]); jo[o2++] = TIO(prog.L.ls[1][1]); jo[o2++] = TIO(prog.L.lg[1][0]); jo[o2++] = TIO(prog.L.lg[1][1]); }
+            for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[1][3 + i]);
+        }
+        if (A.contact_sg) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+                TIO* co = A.contact_sg + (size_t)env * 8 * G.Nc + 8 * P.contact[c];
+                for (int i = 0; i < 4; ++i) { co[i] = TIO(prog.L.cs[1][c][i]); co[4 + i] = TIO(prog.L.cg[1][c][i]); }
+            }
+        }
+    }
+}
+
+} // namespace dj

@@ -1,0 +1,299 @@
+// dojo_hip.hip -- libdojo_hip.so: HIP kernels (gfx950) + the C ABI of include/dojo_hip.h.
+//
+// One wavefront = 64/S environments x S supernodes (dojo_device.hpp).  One workgroup = one
+// wavefront (64 threads), so a batch of B environments launches ceil(B*S/64) workgroups --
+// 1024 for Ant at B = 4096, i.e. one wave per SIMD on the 256 CUs (>> 256 workgroups, and the
+// kernel needs no LDS, so placement across the 8 XCDs is irrelevant: nothing is shared).
+// There is deliberately no CPU fallback in this library: without a gfx950 device dojo_create
+// fails with DOJO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include "dojo_host.hpp"
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+
+namespace {
+
+thread_local std::string g_err;
+
+struct GpuWave {
+    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+    __device__ __forceinline__ int width() const { return 64; }
+    __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src, 64); }
+    __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src, 64); }
+    __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src, 64); }
+    __device__ __forceinline__ bool   any(bool p) const { return __any(p ? 1 : 0) != 0; }
+};
+
+// TIO = ABI scalar type, TS = state / residual precision, TL = factorization precision.
+// dtype f64: <double,double,double>.  dtype f32: fp32 buffers at the ABI with fp64 internals
+// <float,double,double>: the interior-point iteration drives s·γ to ~1e-9 and the condensed KKT
+// then has entries ~γ/s that fp32 cannot resolve (measured in tests/emu).
+template <class TIO, class TS, class TL, int MAXC>
+__global__ void __launch_bounds__(64) dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
+    GpuWave w;
+    dj::step_entry<TIO, TS, TL, MAXC, GpuWave>(w, A, (int)blockIdx.x);
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return DOJO_ERR_DEVICE; } } while (0)
+
+} // namespace
+
+struct DojoSim {
+    dj::HostModel M;
+    DojoSolverOptions opts;
+    int B = 0, dtype = 0, device = 0, grad_mode = DOJO_GRAD_REFERENCE;
+    size_t w = 8;                       // bytes per scalar
+    void* d_nodes = nullptr; void* d_contacts = nullptr;
+    // internal device buffers used by the host-pointer entry points
+    void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
+    int *d_status = nullptr, *d_iters = nullptr;
+    bool have_grad = false, have_solution = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms_sum = 0; int last_ms_n = 0;
+};
+
+namespace {
+
+template <class T>
+int upload_tables(DojoSim* s) {   // tables are stored in the state precision (fp64)
+    std::vector<dj::NodeP<T>> nodes; for (auto& n : s->M.nodes) nodes.push_back(dj::cast_node<T>(n));
+    std::vector<dj::ContactP<T>> contacts; for (auto& c : s->M.contacts) contacts.push_back(dj::cast_contact<T>(c));
+    if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
+    HIPCHK(hipMalloc(&s->d_nodes, nodes.size() * sizeof(dj::NodeP<T>)));
+    HIPCHK(hipMalloc(&s->d_contacts, contacts.size() * sizeof(dj::ContactP<T>)));
+    HIPCHK(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * sizeof(dj::NodeP<T>), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_contacts, contacts.data(), contacts.size() * sizeof(dj::ContactP<T>), hipMemcpyHostToDevice));
+    return DOJO_OK;
+}
+
+template <class TIO, class T, class TL>
+int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
+           void* dz, void* du, hipStream_t st, bool timed) {
+    dj::KernelArgs<TIO, T> A;
+    A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode);
+    A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = s->B;
+    A.z = (const TIO*)z; A.u = (const TIO*)u; A.z_next = (TIO*)zn; A.status = status; A.iters = iters;
+    A.vel = (TIO*)vel; A.joint_imp = (TIO*)jimp; A.contact_sg = (TIO*)csg; A.dz = (TIO*)dz; A.du = (TIO*)du;
+    int E = 64 / s->M.S;
+    dim3 grid((s->B + E - 1) / E), block(64);
+    if (timed) HIPCHK(hipEventRecord(s->ev0, st));
+    if (s->M.maxc <= 1)      hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 1>), grid, block, 0, st, A);
+    else if (s->M.maxc <= 4) hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 4>), grid, block, 0, st, A);
+    else                     hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 8>), grid, block, 0, st, A);
+    HIPCHK(hipGetLastError());
+    if (timed) HIPCHK(hipEventRecord(s->ev1, st));
+    return DOJO_OK;
+}
+
+int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
+               void* dz, void* du, hipStream_t st, bool timed) {
+    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed);
+    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed);
+}
+
+int ensure(void** p, size_t bytes) {
+    if (*p) return DOJO_OK;
+    HIPCHK(hipMalloc(p, bytes ? bytes : 8));
+    return DOJO_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* dojo_last_error(void) { return g_err.c_str(); }
+
+int dojo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t device, DojoHandle* out) {
+    if (!topo || !out || batch < 1 || (dtype != DOJO_DTYPE_F64 && dtype != DOJO_DTYPE_F32)) { g_err = "dojo_create: bad argument"; return DOJO_ERR_INVALID; }
+    int ndev = dojo_device_count();
+    if (ndev <= 0) { g_err = "no HIP device visible: libdojo_hip has no CPU fallback"; return DOJO_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { g_err = "dojo_create: device index out of range"; return DOJO_ERR_INVALID; }
+    DojoSim* s = new DojoSim();
+    int rc = dj::build_host_model(*topo, s->M);
+    if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
+    s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
+    s->opts = dj::default_options();
+    HIPCHK(hipSetDevice(device));
+    rc = upload_tables<double>(s);
+    if (rc != DOJO_OK) { delete s; return rc; }
+    HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
+    *out = s;
+    return DOJO_OK;
+}
+
+void dojo_destroy(DojoHandle s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters};
+    for (void* p : ps) if (p) hipFree(p);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int dojo_get_dims(DojoHandle s, DojoDims* d) {
+    if (!s || !d) { g_err = "dojo_get_dims: bad argument"; return DOJO_ERR_INVALID; }
+    d->n_bodies = s->M.Nb; d->n_joints = (int)s->M.nodes.size(); d->n_contacts = s->M.Nc;
+    d->nz = 13 * s->M.Nb; d->nx = 12 * s->M.Nb; d->nu = s->M.nu; d->n_joint_impulses = s->M.n_joint_imp;
+    d->n_solution = s->M.n_joint_imp + 6 * s->M.Nb + 8 * s->M.Nc; d->lanes_per_env = s->M.S;
+    return DOJO_OK;
+}
+
+int dojo_set_options(DojoHandle s, const DojoSolverOptions* o) {
+    if (!s || !o || o->max_iter < 1 || o->max_ls < 1) { g_err = "dojo_set_options: bad argument"; return DOJO_ERR_INVALID; }
+    s->opts = *o; return DOJO_OK;
+}
+
+int dojo_set_gradient_mode(DojoHandle s, int32_t mode) {
+    if (!s || (mode != DOJO_GRAD_REFERENCE && mode != DOJO_GRAD_CONSISTENT)) { g_err = "dojo_set_gradient_mode: bad argument"; return DOJO_ERR_INVALID; }
+    s->grad_mode = mode; return DOJO_OK;
+}
+
+int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int32_t* status, int32_t* iters, void* dz, void* du, void* stream) {
+    if (!s || !z || !z_next) { g_err = "dojo_step_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if ((dz == nullptr) != (du == nullptr) && s->M.nu > 0) { g_err = "dojo_step_dev: dz and du must both be given or both be NULL"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w;
+    int rc;
+    if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
+    if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, (hipStream_t)stream, true);
+    if (rc == DOJO_OK) { s->stream = (hipStream_t)stream; s->last_ms_n = 1; s->have_solution = true; }
+    return rc;
+}
+
+int dojo_step(DojoHandle s, const void* z, const void* u, void* z_next, int32_t* status, int32_t* iters, int32_t with_gradient) {
+    if (!s || !z || !z_next) { g_err = "dojo_step: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nx = 12 * s->M.Nb, nu = s->M.nu;
+    int rc;
+    if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_u, B * (nu + 1) * w))) return rc;
+    if ((rc = ensure((void**)&s->d_status, B * sizeof(int)))) return rc;
+    if ((rc = ensure((void**)&s->d_iters, B * sizeof(int)))) return rc;
+    if (with_gradient) {
+        if ((rc = ensure(&s->d_dz, B * nx * nx * w))) return rc;
+        if ((rc = ensure(&s->d_du, B * nx * (nu + 1) * w))) return rc;
+    }
+    HIPCHK(hipMemcpy(s->d_z, z, B * nz * w, hipMemcpyHostToDevice));
+    if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
+    rc = dojo_step_dev(s, s->d_z, (u && nu) ? s->d_u : nullptr, s->d_zn, s->d_status, s->d_iters,
+                       with_gradient ? s->d_dz : nullptr, with_gradient ? s->d_du : nullptr, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(z_next, s->d_zn, B * nz * w, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    s->have_grad = with_gradient != 0;
+    return DOJO_OK;
+}
+
+int dojo_get_solution(DojoHandle s, void* vel, void* joint_imp, void* contact_sg) {
+    if (!s || !s->have_solution) { g_err = "dojo_get_solution: no step has been taken"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    size_t B = s->B, w = s->w;
+    if (vel) HIPCHK(hipMemcpy(vel, s->d_vel, B * 6 * s->M.Nb * w, hipMemcpyDeviceToHost));
+    if (joint_imp && s->M.n_joint_imp) HIPCHK(hipMemcpy(joint_imp, s->d_jimp, B * s->M.n_joint_imp * w, hipMemcpyDeviceToHost));
+    if (contact_sg && s->M.Nc) HIPCHK(hipMemcpy(contact_sg, s->d_csg, B * 8 * s->M.Nc * w, hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
+int dojo_gradients(DojoHandle s, void* dz, void* du) {
+    if (!s || !s->have_grad) { g_err = "dojo_gradients: the last dojo_step was not run with with_gradient=1"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nx = 12 * s->M.Nb, nu = s->M.nu;
+    // device layout is column-major per environment (Julia-native); the host ABI is row-major [B,nx,nx] / [B,nx,nu]
+    std::vector<char> tmp(B * nx * std::max(nx, nu) * w);
+    auto transpose_out = [&](void* dst, const void* src, size_t ncols) -> int {
+        HIPCHK(hipMemcpy(tmp.data(), src, B * nx * ncols * w, hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b)
+            for (size_t c = 0; c < ncols; ++c)
+                for (size_t r = 0; r < nx; ++r)
+                    std::memcpy((char*)dst + ((b * nx + r) * ncols + c) * w, tmp.data() + ((b * ncols + c) * nx + r) * w, w);
+        return DOJO_OK;
+    };
+    int rc;
+    if (dz && (rc = transpose_out(dz, s->d_dz, nx))) return rc;
+    if (du && nu && (rc = transpose_out(du, s->d_du, nu))) return rc;
+    return DOJO_OK;
+}
+
+int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* stream) {
+    if (!s || !z0 || H < 1) { g_err = "dojo_rollout_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
+    int rc;
+    if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
+    if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const char* cur = (const char*)z0;
+    HIPCHK(hipEventRecord(s->ev0, st));
+    for (int k = 0; k < H; ++k) {
+        char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
+        const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
+        rc = launch_any(s, cur, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, st, false);
+        if (rc != DOJO_OK) return rc;
+        cur = nxt;
+    }
+    HIPCHK(hipEventRecord(s->ev1, st));
+    if (!Z && cur != (const char*)s->d_zn) HIPCHK(hipMemcpyAsync(s->d_zn, cur, B * nz * w, hipMemcpyDeviceToDevice, st));
+    s->stream = st; s->last_ms_n = H; s->have_solution = true; s->have_grad = false;
+    return DOJO_OK;
+}
+
+int dojo_rollout(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status) {
+    if (!s || !z0 || H < 1) { g_err = "dojo_rollout: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
+    void *dz0 = nullptr, *dU = nullptr, *dZ = nullptr; int* dS = nullptr;
+    HIPCHK(hipMalloc(&dz0, B * nz * w));
+    HIPCHK(hipMemcpy(dz0, z0, B * nz * w, hipMemcpyHostToDevice));
+    if (U && nu) { HIPCHK(hipMalloc(&dU, (size_t)H * B * nu * w)); HIPCHK(hipMemcpy(dU, U, (size_t)H * B * nu * w, hipMemcpyHostToDevice)); }
+    if (Z) HIPCHK(hipMalloc(&dZ, (size_t)H * B * nz * w));
+    if (status) HIPCHK(hipMalloc((void**)&dS, (size_t)H * B * sizeof(int)));
+    int rc = dojo_rollout_dev(s, dz0, dU, H, dZ, dS, nullptr);
+    if (rc == DOJO_OK) {
+        HIPCHK(hipDeviceSynchronize());
+        if (Z) HIPCHK(hipMemcpy(Z, dZ, (size_t)H * B * nz * w, hipMemcpyDeviceToHost));
+        if (status) HIPCHK(hipMemcpy(status, dS, (size_t)H * B * sizeof(int), hipMemcpyDeviceToHost));
+        if (Z) HIPCHK(hipMemcpy(s->d_zn, (char*)dZ + (size_t)(H - 1) * B * nz * w, B * nz * w, hipMemcpyDeviceToDevice));
+    }
+    hipFree(dz0); if (dU) hipFree(dU); if (dZ) hipFree(dZ); if (dS) hipFree(dS);
+    return rc;
+}
+
+int dojo_get_state(DojoHandle s, void* z) {
+    if (!s || !z || !s->d_zn) { g_err = "dojo_get_state: no state"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(z, s->d_zn, (size_t)s->B * 13 * s->M.Nb * s->w, hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
+int dojo_last_kernel_ms(DojoHandle s, double* ms) {
+    if (!s || !ms || s->last_ms_n < 1) { g_err = "dojo_last_kernel_ms: nothing was launched"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev1));
+    *ms = (double)t / s->last_ms_n;
+    return DOJO_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,138 @@
+// dojo_host.hpp -- host-side "symbolic phase": turns the C-POD topology of include/dojo_hip.h
+// into the per-supernode parameter tables the lane program consumes (elimination order =
+// levels of the kinematic tree, leaves first).  Plain C++ (no HIP), shared
+// by the library and by the CPU SIMT emulator used in the tests.
+#pragma once
+#include "dojo_device.hpp"
+#include "../../include/dojo_hip.h"
+#include <vector>
+#include <string>
+#include <cmath>
+
+namespace dj {
+
+struct HostModel {
+    int Nb = 0, Nc = 0, S = 1, nu = 0, n_joint_imp = 0, maxch = 0, maxlevel = 0, maxc = 0;
+    std::vector<NodeP<double>> nodes;
+    std::vector<ContactP<double>> contacts;
+    double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
+    std::string error;
+};
+
+inline int build_host_model(const DojoTopology& tp, HostModel& M) {
+    M.Nb = tp.n_bodies; M.Nc = tp.n_contacts; M.dt = tp.timestep; M.input_scaling = tp.input_scaling;
+    for (int i = 0; i < 3; ++i) M.g[i] = tp.gravity[i];
+    if (M.Nb < 1) { M.error = "mechanism has no bodies"; return DOJO_ERR_INVALID; }
+    if (M.Nb > 64) { M.error = "more than 64 bodies per environment is not supported by the lane=supernode mapping"; return DOJO_ERR_UNSUPPORTED; }
+    int S = 1; while (S < M.Nb) S <<= 1; M.S = S;
+    M.nodes.assign(M.Nb, NodeP<double>());
+    std::vector<int> pj(M.Nb, -1);
+    int uoff = 0, ioff = 0;
+    for (int j = 0; j < tp.n_joints; ++j) {
+        const DojoJoint& J = tp.joints[j];
+        if (J.child < 0 || J.child >= M.Nb || J.parent >= M.Nb) { M.error = "joint with invalid body index"; return DOJO_ERR_INVALID; }
+        if (pj[J.child] >= 0) { M.error = "body with more than one parent joint (kinematic loop) is not supported"; return DOJO_ERR_UNSUPPORTED; }
+        pj[J.child] = j;
+        NodeP<double>& P = M.nodes[J.child];
+        P.parent = J.parent;
+        P.nl_t = J.tra.nl; P.nl_r = J.rot.nl; P.nlim_r = J.rot.nlim;
+        if (J.tra.nlim != 0) { M.error = "translational joint limits are not supported yet"; return DOJO_ERR_UNSUPPORTED; }
+        if (J.rot.nlim > 1) { M.error = "joint limits on more than one rotational coordinate are not supported"; return DOJO_ERR_UNSUPPORTED; }
+        if (J.rot.nlim == 1 && J.rot.nl != 2) { M.error = "rotational limits need a one-dimensional rotational joint"; return DOJO_ERR_UNSUPPORTED; }
+        if (J.tra.nl < 3 && ((J.spring_on && J.tra.spring != 0) || (J.damper_on && J.tra.damper != 0))) {
+            M.error = "translational springs/dampers are not supported yet"; return DOJO_ERR_UNSUPPORTED;
+        }
+        P.spring_on = J.spring_on; P.damper_on = J.damper_on;
+        P.nu_t = 3 - J.tra.nl; P.nu_r = 3 - J.rot.nl;
+        P.u_off = uoff; uoff += P.nu_t + P.nu_r;
+        P.n_imp = J.tra.nl + 4 * J.tra.nlim + J.rot.nl + 4 * J.rot.nlim;
+        P.imp_off = ioff; ioff += P.n_imp;
+        for (int i = 0; i < 9; ++i) { P.Ct[i] = P.Cr[i] = P.At[i] = P.Ar[i] = 0; }
+        for (int i = 0; i < 3 * J.tra.nl; ++i) P.Ct[i] = J.tra.cmask[i];
+        for (int i = 0; i < 3 * J.rot.nl; ++i) P.Cr[i] = J.rot.cmask[i];
+        for (int i = 0; i < 3 * (3 - J.tra.nl); ++i) P.At[i] = J.tra.amask[i];
+        for (int i = 0; i < 3 * (3 - J.rot.nl); ++i) P.Ar[i] = J.rot.amask[i];
+        for (int i = 0; i < 3; ++i) { P.pa[i] = J.vertex_parent[i]; P.pb[i] = J.vertex_child[i]; P.spring_off_r[i] = J.rot.spring_offset[i]; }
+        for (int i = 0; i < 4; ++i) P.qoff[i] = J.orientation_offset[i];
+        P.spring_r = J.rot.spring; P.damper_r = J.rot.damper;
+        P.lim_lo = J.rot.limit_lo[0]; P.lim_hi = J.rot.limit_hi[0];
+    }
+    M.nu = uoff; M.n_joint_imp = ioff;
+    // NB: the u / joint-impulse offsets above follow mechanism.joints order because joints are visited in that order
+    for (int b = 0; b < M.Nb; ++b) {
+        if (pj[b] < 0) { M.error = "body without a parent joint (every body needs one; use a Floating joint to the origin)"; return DOJO_ERR_UNSUPPORTED; }
+        NodeP<double>& P = M.nodes[b];
+        P.m = tp.bodies[b].mass;
+        for (int i = 0; i < 9; ++i) P.J[i] = tp.bodies[b].inertia[i];
+        P.nchild = 0; P.ncontact = 0;
+        for (int i = 0; i < MAXCH; ++i) P.child[i] = 0;
+        for (int i = 0; i < 8; ++i) P.contact[i] = 0;
+    }
+    for (int b = 0; b < M.Nb; ++b) {
+        int p = M.nodes[b].parent;
+        if (p >= 0) {
+            if (M.nodes[p].nchild >= MAXCH) { M.error = "more than 4 child joints on one body is not supported"; return DOJO_ERR_UNSUPPORTED; }
+            M.nodes[p].child[M.nodes[p].nchild++] = b;
+        }
+    }
+    // levels (distance from the origin-connected root of each tree)
+    M.maxlevel = 0; M.maxch = 0;
+    for (int b = 0; b < M.Nb; ++b) {
+        int lev = 0, p = M.nodes[b].parent, guard = 0;
+        while (p >= 0) { ++lev; p = M.nodes[p].parent; if (++guard > M.Nb) { M.error = "cycle in the parent relation"; return DOJO_ERR_INVALID; } }
+        M.nodes[b].level = lev;
+        if (lev > M.maxlevel) M.maxlevel = lev;
+        if (M.nodes[b].nchild > M.maxch) M.maxch = M.nodes[b].nchild;
+    }
+    M.contacts.assign(M.Nc, ContactP<double>());
+    M.maxc = 0;
+    for (int c = 0; c < M.Nc; ++c) {
+        const DojoContact& K = tp.contacts[c];
+        if (K.body < 0 || K.body >= M.Nb) { M.error = "contact with invalid body index"; return DOJO_ERR_INVALID; }
+        NodeP<double>& P = M.nodes[K.body];
+        if (P.ncontact >= 8) { M.error = "more than 8 contacts on one body is not supported"; return DOJO_ERR_UNSUPPORTED; }
+        P.contact[P.ncontact++] = c;
+        if (P.ncontact > M.maxc) M.maxc = P.ncontact;
+        ContactP<double>& Q = M.contacts[c];
+        for (int i = 0; i < 3; ++i) { Q.n[i] = K.normal[i]; Q.o[i] = K.origin[i]; Q.off[i] = K.offset[i]; }
+        for (int i = 0; i < 6; ++i) Q.t[i] = K.tangent[i];
+        Q.r = K.radius; Q.mu = K.friction_coefficient;
+    }
+    return DOJO_OK;
+}
+
+template <class T> inline NodeP<T> cast_node(const NodeP<double>& a) {
+    NodeP<T> b;
+    b.parent = a.parent; b.level = a.level; b.nchild = a.nchild; for (int i = 0; i < MAXCH; ++i) b.child[i] = a.child[i];
+    b.ncontact = a.ncontact; for (int i = 0; i < 8; ++i) b.contact[i] = a.contact[i];
+    b.nl_t = a.nl_t; b.nl_r = a.nl_r; b.nlim_r = a.nlim_r; b.spring_on = a.spring_on; b.damper_on = a.damper_on;
+    b.u_off = a.u_off; b.nu_t = a.nu_t; b.nu_r = a.nu_r; b.imp_off = a.imp_off; b.n_imp = a.n_imp;
+    b.m = T(a.m);
+    for (int i = 0; i < 9; ++i) { b.J[i] = T(a.J[i]); b.Ct[i] = T(a.Ct[i]); b.Cr[i] = T(a.Cr[i]); b.At[i] = T(a.At[i]); b.Ar[i] = T(a.Ar[i]); }
+    for (int i = 0; i < 3; ++i) { b.pa[i] = T(a.pa[i]); b.pb[i] = T(a.pb[i]); b.spring_off_r[i] = T(a.spring_off_r[i]); }
+    for (int i = 0; i < 4; ++i) b.qoff[i] = T(a.qoff[i]);
+    b.spring_r = T(a.spring_r); b.damper_r = T(a.damper_r); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi);
+    return b;
+}
+template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
+    ContactP<T> b;
+    for (int i = 0; i < 3; ++i) { b.n[i] = T(a.n[i]); b.o[i] = T(a.o[i]); b.off[i] = T(a.off[i]); }
+    for (int i = 0; i < 6; ++i) b.t[i] = T(a.t[i]);
+    b.r = T(a.r); b.mu = T(a.mu);
+    return b;
+}
+template <class T> inline Globals<T> make_globals(const HostModel& M, const DojoSolverOptions& o, int grad_mode) {
+    Globals<T> G;
+    G.dt = T(M.dt); G.input_scaling = T(M.input_scaling);
+    for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
+    G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);
+    G.max_iter = o.max_iter; G.max_ls = o.max_ls; G.no_progress_max = o.no_progress_max;
+    G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode;
+    return G;
+}
+inline DojoSolverOptions default_options() {
+    DojoSolverOptions o; o.rtol = 1e-6; o.btol = 1e-4; o.undercut = INFINITY; o.no_progress_undercut = 10.0;
+    o.max_iter = 50; o.max_ls = 10; o.no_progress_max = 3; o.reserved = 0; return o;
+}
+
+} // namespace dj

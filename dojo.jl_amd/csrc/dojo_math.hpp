@@ -1,0 +1,180 @@
+// dojo_math.hpp -- tiny fixed-size linear algebra + quaternion helpers for the device code.
+// Everything is fully unrollable (compile-time extents) so per-lane data stays in VGPRs.
+// Conventions follow the reference: Hamilton quaternions q = (s, v), rotation of a body-frame
+// vector p into the world frame is R(q) p, attitude perturbation δq = q ⊗ (0, φ)
+// (src/orientation/quaternion.jl `LVᵀmat`, so the rotation angle is 2|φ|).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define DJ_HD __host__ __device__ __forceinline__
+#else
+#define DJ_HD inline
+#endif
+
+namespace dj {
+
+template <class T> DJ_HD T tmax(T a, T b) { return a > b ? a : b; }
+template <class T> DJ_HD T tmin(T a, T b) { return a < b ? a : b; }
+template <class T> DJ_HD T tabs(T a) { return a < T(0) ? -a : a; }
+DJ_HD float  tsqrt(float a)  { return sqrtf(a); }
+DJ_HD double tsqrt(double a) { return sqrt(a); }
+DJ_HD float  tatan(float a)  { return atanf(a); }
+DJ_HD double tatan(double a) { return atan(a); }
+
+// ---- 3-vectors -------------------------------------------------------------------------------
+template <class T> DJ_HD void v3set(T* a, T x, T y, T z) { a[0] = x; a[1] = y; a[2] = z; }
+template <class T> DJ_HD void v3cpy(T* a, const T* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+template <class T> DJ_HD T    v3dot(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class T> DJ_HD void v3cross(T* c, const T* a, const T* b) {
+    T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+// ---- 3x3 (row-major) -------------------------------------------------------------------------
+template <class T> DJ_HD void m3vec(T* y, const T* M, const T* x) {       // y = M x
+    T a = M[0] * x[0] + M[1] * x[1] + M[2] * x[2], b = M[3] * x[0] + M[4] * x[1] + M[5] * x[2], c = M[6] * x[0] + M[7] * x[1] + M[8] * x[2];
+    y[0] = a; y[1] = b; y[2] = c;
+}
+template <class T> DJ_HD void m3tvec(T* y, const T* M, const T* x) {      // y = Mᵀ x
+    T a = M[0] * x[0] + M[3] * x[1] + M[6] * x[2], b = M[1] * x[0] + M[4] * x[1] + M[7] * x[2], c = M[2] * x[0] + M[5] * x[1] + M[8] * x[2];
+    y[0] = a; y[1] = b; y[2] = c;
+}
+template <class T> DJ_HD void m3mul(T* C, const T* A, const T* B) {       // C = A B   (C must not alias)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+template <class T> DJ_HD void m3tmul(T* C, const T* A, const T* B) {      // C = Aᵀ B
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+template <class T> DJ_HD void m3mult(T* C, const T* A, const T* B) {      // C = A Bᵀ
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+template <class T> DJ_HD void m3skew(T* S, const T* p) {                  // [p]x
+    S[0] = 0; S[1] = -p[2]; S[2] = p[1]; S[3] = p[2]; S[4] = 0; S[5] = -p[0]; S[6] = -p[1]; S[7] = p[0]; S[8] = 0;
+}
+// s I + [v]x
+template <class T> DJ_HD void m3sIpskew(T* S, T s, const T* v) {
+    S[0] = s; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = s; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = s;
+}
+// ---- quaternions (s, v1, v2, v3) -------------------------------------------------------------
+template <class T> DJ_HD void qmul(T* c, const T* a, const T* b) {
+    T s = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    T x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    T y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    T z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    c[0] = s; c[1] = x; c[2] = y; c[3] = z;
+}
+template <class T> DJ_HD void qconj(T* c, const T* a) { c[0] = a[0]; c[1] = -a[1]; c[2] = -a[2]; c[3] = -a[3]; }
+// c = conj(a) ⊗ b
+template <class T> DJ_HD void qcmul(T* c, const T* a, const T* b) { T ac[4]; qconj(ac, a); qmul(c, ac, b); }
+// rotation_matrix(q) = VRᵀmat(q) LVᵀmat(q)  (src/orientation/rotate.jl:22); for unit q the usual rotation matrix
+template <class T> DJ_HD void qrot(T* R, const T* q) {
+    T s = q[0], x = q[1], y = q[2], z = q[3];
+    T ss = s * s, xx = x * x, yy = y * y, zz = z * z;
+    R[0] = ss + xx - yy - zz; R[1] = 2 * (x * y - s * z);  R[2] = 2 * (x * z + s * y);
+    R[3] = 2 * (x * y + s * z);  R[4] = ss - xx + yy - zz; R[5] = 2 * (y * z - s * x);
+    R[6] = 2 * (x * z - s * y);  R[7] = 2 * (y * z + s * x);  R[8] = ss - xx - yy + zz;
+}
+// quaternion_map(ω, Δt)·Δt/2 = ξ(ω): unit quaternion of the step (src/orientation/mapping.jl:1-3)
+template <class T> DJ_HD void qstep(T* xi, const T* w, T dt, T* c_out) {
+    T c = tsqrt(T(4) / (dt * dt) - v3dot(w, w));
+    T h = dt * T(0.5);
+    xi[0] = c * h; xi[1] = w[0] * h; xi[2] = w[1] * h; xi[3] = w[2] * h;
+    *c_out = c;
+}
+// Φ(ω): δφ3 = Φ δω where q3 = q2 ⊗ ξ(ω), δq3 = q3 ⊗ (0, δφ3):  Φ = Δt²/4 (c I + ω ωᵀ / c − [ω]x)
+// (= LVᵀmat(q3)ᵀ · rotational_integrator_jacobian_velocity(q2, ω, Δt), src/integrators/integrator.jl:64-66)
+template <class T> DJ_HD void phi_of(T* P, const T* w, T c, T dt) {
+    T k = dt * dt * T(0.25), ic = T(1) / c;
+    P[0] = k * (c + w[0] * w[0] * ic); P[1] = k * (w[0] * w[1] * ic + w[2]); P[2] = k * (w[0] * w[2] * ic - w[1]);
+    P[3] = k * (w[1] * w[0] * ic - w[2]); P[4] = k * (c + w[1] * w[1] * ic); P[5] = k * (w[1] * w[2] * ic + w[0]);
+    P[6] = k * (w[2] * w[0] * ic + w[1]); P[7] = k * (w[2] * w[1] * ic - w[0]); P[8] = k * (c + w[2] * w[2] * ic);
+}
+// rotation_vector(q) = 4 atan(|m|) m/|m|, m = v/(1+s)   (src/orientation/mrp.jl:61-64)
+template <class T> DJ_HD void rotvec(T* r, const T* q) {
+    T d = T(1) / (q[0] + T(1));
+    T m[3] = {q[1] * d, q[2] * d, q[3] * d};
+    T mag = tsqrt(v3dot(m, m));
+    if (mag > T(0)) { T f = T(4) * tatan(mag) / mag; r[0] = f * m[0]; r[1] = f * m[1]; r[2] = f * m[2]; }
+    else { r[0] = r[1] = r[2] = T(0); }
+}
+// aᵀ · drotation_vectordq(q): the 1x4 row  a·∂rotvec/∂q   (src/orientation/mrp.jl:66-78)
+template <class T> DJ_HD void rotvec_jac_row(T* row, const T* a, const T* q) {
+    T s1 = q[0] + T(1), di = T(1) / s1, d1 = di * di;
+    T m[3] = {q[1] * di, q[2] * di, q[3] * di};
+    T n2 = v3dot(m, m);
+    if (n2 > T(0)) {
+        T n = tsqrt(n2), th = T(4) * tatan(n);
+        // d rotvec / d m = (4/(1+n²)) m̂ m̂ᵀ + (θ/n)(I − m̂ m̂ᵀ)
+        T am = v3dot(a, m) / n2;            // (a·m̂)/n ... times m gives (a·m̂) m̂
+        T k1 = T(4) / (T(1) + n2), k2 = th / n;
+        T g[3];                              // g = aᵀ · d rotvec/d m
+        for (int i = 0; i < 3; ++i) g[i] = k2 * a[i] + (k1 - k2) * am * m[i];
+        // d m / d q = [ −v/(1+s)² | I/(1+s) ]
+        row[0] = -(g[0] * q[1] + g[1] * q[2] + g[2] * q[3]) * d1;
+        row[1] = g[0] * di; row[2] = g[1] * di; row[3] = g[2] * di;
+    } else { row[0] = T(0); row[1] = T(2) * a[0]; row[2] = T(2) * a[1]; row[3] = T(2) * a[2]; }
+}
+
+// ---- generic small dense helpers (compile-time sizes, row-major) ------------------------------
+template <int R, int K, int C, class T> DJ_HD void mm(T* O, const T* A, const T* B) {          // O(RxC) = A(RxK) B(KxC)
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) s += A[i * K + k] * B[k * C + j];
+            O[i * C + j] = s;
+        }
+}
+template <int R, int K, int C, class T> DJ_HD void mm_sub(T* O, const T* A, const T* B) {      // O -= A B
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) s += A[i * K + k] * B[k * C + j];
+            O[i * C + j] -= s;
+        }
+}
+template <int R, int C, class T> DJ_HD void mv(T* y, const T* A, const T* x) {                  // y = A x
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < C; ++j) s += A[i * C + j] * x[j];
+        y[i] = s;
+    }
+}
+// in-place inverse of an NxN matrix by Gauss-Jordan WITHOUT pivoting (pivot order is fixed by the
+// elimination order chosen on the host: body block first, then its parent joint's multipliers, so
+// every pivot is a Schur complement of a well-conditioned block -- SURVEY.md §7 H3)
+template <int N, class T> DJ_HD void gj_inverse(T* A) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        T ip = T(1) / A[k * N + k];
+        A[k * N + k] = T(1);
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[k * N + j] *= ip;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i == k) continue;
+            T f = A[i * N + k];
+            A[i * N + k] = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) A[i * N + j] -= f * A[k * N + j];
+        }
+    }
+}
+
+} // namespace dj

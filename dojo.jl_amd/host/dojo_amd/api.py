@@ -1,0 +1,169 @@
+"""ctypes binding of libdojo_hip.so + the host-side mirror of Dojo's API for the hot path.
+
+Reference surface mirrored here (argument meaning and error behaviour follow the reference):
+  step!(mechanism, z, u; opts)                 src/simulation/step.jl:11-30        -> step(mech, z, u, opts=...)
+  simulate!(mechanism, steps, storage, ctrl!)  src/simulation/simulate.jl:16-36    -> simulate(mech, z0, U)
+  get_maximal_gradients!(mechanism, z, u)      src/gradients/state.jl:69-76        -> get_maximal_gradients(mech, z, u)
+  get_solution(mechanism)                      src/gradients/finite_difference.jl  -> mech.get_solution()
+The batch axis is the leading axis of every array.  There is NO CPU fallback: if the HIP
+library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+from .topology import CTopology, CSolverOptions, CDims, SolverOptions
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc")
+_LIB_PATH = os.path.join(_CSRC, "libdojo_hip.so")
+_lib = None
+
+STATUS_SUCCESS, STATUS_FAILED, STATUS_EXCESSIVE_W = 0, 1, 2
+GRAD_REFERENCE, GRAD_CONSISTENT = 0, 1
+
+
+class DojoError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise DojoError("libdojo_hip.so not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_LIB_PATH)
+        L.dojo_last_error.restype = C.c_char_p
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_step",
+                  "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
+                  "dojo_last_kernel_ms"):
+            getattr(L, f).restype = C.c_int
+        L.dojo_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
+                    "dojo_set_gradient_mode", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
+                    "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms"]
+
+
+def device_count():
+    return lib().dojo_device_count()
+
+
+def _chk(rc):
+    if rc != 0:
+        raise DojoError("libdojo_hip error %d: %s" % (rc, lib().dojo_last_error().decode()))
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class BatchedMechanism:
+    """B independent copies of one Dojo `Mechanism` resident on one GPU."""
+
+    def __init__(self, spec, batch, dtype="f32", device=0, opts=None):
+        self.spec, self.batch = spec, int(batch)
+        self.np_dtype = np.float32 if dtype in ("f32", np.float32) else np.float64
+        self.dtype_code = 1 if self.np_dtype == np.float32 else 0
+        self._topo, self._keep = spec.to_ctypes()
+        self.h = C.c_void_p()
+        _chk(lib().dojo_create(C.byref(self._topo), self.batch, self.dtype_code, int(device), C.byref(self.h)))
+        d = CDims()
+        _chk(lib().dojo_get_dims(self.h, C.byref(d)))
+        self.dims = d
+        assert d.nu == spec.nu and d.n_solution == spec.n_solution and d.n_joint_impulses == spec.n_joint_impulses
+        self.set_options(opts or SolverOptions())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().dojo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_options(self, opts):
+        self.opts = opts
+        o = opts.to_c()
+        _chk(lib().dojo_set_options(self.h, C.byref(o)))
+
+    def set_gradient_mode(self, mode):
+        _chk(lib().dojo_set_gradient_mode(self.h, int(mode)))
+
+    def _arr(self, a, shape):
+        a = np.ascontiguousarray(a, dtype=self.np_dtype)
+        if a.shape != shape:
+            raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+        return a
+
+    def step(self, z, u=None, with_gradient=False):
+        B, s = self.batch, self.spec
+        z = self._arr(z, (B, s.nz))
+        u = None if (u is None or s.nu == 0) else self._arr(u, (B, s.nu))
+        zn = np.empty_like(z); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        _chk(lib().dojo_step(self.h, _p(z), _p(u), _p(zn), _p(st), _p(it), int(with_gradient)))
+        return zn, st, it
+
+    def get_solution(self):
+        B, s = self.batch, self.spec
+        vel = np.empty((B, 6 * s.Nb), self.np_dtype)
+        ji = np.empty((B, max(s.n_joint_impulses, 1)), self.np_dtype)
+        cs = np.empty((B, max(8 * len(s.contacts), 1)), self.np_dtype)
+        _chk(lib().dojo_get_solution(self.h, _p(vel), _p(ji), _p(cs)))
+        return vel, ji[:, :s.n_joint_impulses], cs[:, :8 * len(s.contacts)]
+
+    def gradients(self):
+        B, s = self.batch, self.spec
+        dz = np.empty((B, s.nx, s.nx), self.np_dtype)
+        du = np.empty((B, s.nx, max(s.nu, 1)), self.np_dtype)
+        _chk(lib().dojo_gradients(self.h, _p(dz), _p(du)))
+        return dz, du[:, :, :s.nu]
+
+    def rollout(self, z0, U=None, steps=None, record=True):
+        B, s = self.batch, self.spec
+        z0 = self._arr(z0, (B, s.nz))
+        if U is not None and s.nu:
+            U = np.ascontiguousarray(U, dtype=self.np_dtype); H = U.shape[0]
+            assert U.shape == (H, B, s.nu)
+        else:
+            U = None; H = int(steps)
+        Z = np.empty((H, B, s.nz), self.np_dtype) if record else None
+        st = np.empty((H, B), np.int32)
+        _chk(lib().dojo_rollout(self.h, _p(z0), _p(U), H, _p(Z), _p(st)))
+        return Z, st
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        _chk(lib().dojo_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+# ---------------------------------------------------------------------------------------
+# Dojo-style free functions
+# ---------------------------------------------------------------------------------------
+def step(mechanism, z, u=None, opts=None):
+    """step!(mechanism, z, u; opts): returns the mechanism's state after the step
+    ((x3, v25, q3, ω25) per body -- SURVEY.md §8a Q1), plus per-environment status."""
+    if opts is not None:
+        mechanism.set_options(opts)
+    zn, status, iters = mechanism.step(z, u, with_gradient=False)
+    return zn, status
+
+
+def get_maximal_gradients(mechanism, z, u=None, opts=None):
+    """get_maximal_gradients!(mechanism, z, u; opts) -> (jacobian_state [B,12Nb,12Nb], jacobian_control [B,12Nb,nu])"""
+    if opts is not None:
+        mechanism.set_options(opts)
+    mechanism.step(z, u, with_gradient=True)
+    return mechanism.gradients()
+
+
+def simulate(mechanism, z0, U=None, steps=None, opts=None, abort_upon_failure=False):
+    """simulate!(mechanism, steps, storage, control!) with pre-sampled controls U[k]."""
+    if opts is not None:
+        mechanism.set_options(opts)
+    return mechanism.rollout(z0, U, steps=steps, record=True)

@@ -30,6 +30,7 @@ struct IOracle {
     virtual void set_external_force(int body, const double* force, const double* torque, const double* vertex) = 0;
     virtual int simulate_step(const double* u, int last) = 0;
     virtual void body_velocity_solution(double* v) = 0;
+    virtual void debug_assemble(const double* z, const double* u, double* A, double* b) = 0;
     virtual IOracle* clone() = 0;
 };
 
@@ -114,6 +115,19 @@ struct OracleT : IOracle {
     void body_velocity_solution(double* v) override {
         for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { v[6 * i + k] = m.bodies[i].st.vsol[1][k]; v[6 * i + 3 + k] = m.bodies[i].st.wsol[1][k]; }
     }
+    void debug_assemble(const double* z, const double* u, double* A, double* b) override {
+        // state of mehrotra! right after its first set_entries! (mehrotra.jl:10-21)
+        int nz = 13 * (int)m.bodies.size(), nu = m.nu();
+        std::vector<T> zz = cast(z, nz), uu(nu, T(0)); if (u) uu = cast(u, nu);
+        m.set_maximal_state(zz.data()); m.set_input_all(uu.data());
+        for (auto& c : m.contacts) m.reset_contact(c);
+        for (auto& J : m.joints) m.reset_joint(J);
+        m.mu = 0;
+        for (auto& c : m.contacts) m.initialize_contact(c);
+        m.set_entries();
+        for (size_t i = 0; i < (size_t)m.n * m.n; ++i) A[i] = m.A[i];
+        for (int i = 0; i < m.n; ++i) b[i] = m.b[i];
+    }
     IOracle* clone() override { return new OracleT<T>(*this); }
 };
 
@@ -143,6 +157,8 @@ void orc_get_state(void* h, double* z) { ((IOracle*)h)->get_state(z); }
 void orc_set_external_force(void* h, int body, const double* f, const double* t, const double* v) { ((IOracle*)h)->set_external_force(body, f, t, v); }
 int  orc_simulate_step(void* h, const double* u, int last) { return ((IOracle*)h)->simulate_step(u, last); }
 void orc_body_velocity_solution(void* h, double* v) { ((IOracle*)h)->body_velocity_solution(v); }
+
+void orc_debug_assemble(void* h, const double* z, const double* u, double* A, double* b) { ((IOracle*)h)->debug_assemble(z, u, A, b); }
 
 // Batched step for the CPU baseline: one environment per thread-task over `nthreads`
 // host threads.  z [B,13Nb], u [B,nu] or NULL, outputs may be NULL.

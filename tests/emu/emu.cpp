@@ -1,0 +1,112 @@
+// emu.cpp -- thread-based SIMT emulator for the lane program (TEST INFRASTRUCTURE).
+//
+// Runs the *same* device source (dojo.jl_amd/csrc/dojo_device.hpp) on the CPU: every lane of a
+// "wave" is a std::thread and wave shuffles / votes are implemented with a barrier.  This lets
+// the CPU-only test tier (-m "not gpu") check the shipped device algorithm against the oracle.
+// It is not a product path: libdojo_hip.so has no CPU fallback.
+#define DJ_DEBUG 1
+#include "../../dojo.jl_amd/csrc/dojo_host.hpp"
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <cstring>
+#include <atomic>
+
+namespace {
+
+struct Barrier {
+    std::mutex m; std::condition_variable cv; int n, count = 0, gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        int g = gen;
+        if (++count == n) { count = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+struct Shared {
+    int W; Barrier bar; std::vector<double> slot; std::vector<int> islot;
+    explicit Shared(int w) : W(w), bar(w), slot(w), islot(w) {}
+};
+
+struct EmuWave {
+    Shared* sh; int l;
+    int lane() const { return l; }
+    int width() const { return sh->W; }
+    template <class T> T shfl(T v, int src) {
+        sh->slot[l] = (double)v;
+        sh->bar.wait();
+        T r = (T)sh->slot[src];
+        sh->bar.wait();
+        return r;
+    }
+    int shfl(int v, int src) {
+        sh->islot[l] = v;
+        sh->bar.wait();
+        int r = sh->islot[src];
+        sh->bar.wait();
+        return r;
+    }
+    bool any(bool p) {
+        sh->islot[l] = p ? 1 : 0;
+        sh->bar.wait();
+        int r = 0; for (int i = 0; i < sh->W; ++i) r |= sh->islot[i];
+        sh->bar.wait();
+        return r != 0;
+    }
+};
+
+template <class TIO, class T, class TL, int MAXC>
+void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
+         const double* z, const double* u, double* z_next, int* status, int* iters,
+         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg) {
+    std::vector<dj::NodeP<T>> nodes; for (auto& n : M.nodes) nodes.push_back(dj::cast_node<T>(n));
+    std::vector<dj::ContactP<T>> contacts; for (auto& c : M.contacts) contacts.push_back(dj::cast_contact<T>(c));
+    if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
+    int nz = 13 * M.Nb, nx = 12 * M.Nb;
+    auto castv = [](const double* p, size_t n) { std::vector<TIO> v(p ? n : 0); for (size_t i = 0; i < v.size(); ++i) v[i] = TIO(p[i]); return v; };
+    std::vector<TIO> zt = castv(z, (size_t)B * nz), ut = castv(u, (size_t)B * M.nu);
+    std::vector<TIO> zn((size_t)B * nz), velt(vel ? (size_t)B * 6 * M.Nb : 0), jt(jimp ? (size_t)B * std::max(M.n_joint_imp, 1) : 0),
+        ct(csg ? (size_t)B * 8 * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
+    dj::KernelArgs<TIO, T> A;
+    A.G = dj::make_globals<T>(M, opts, grad_mode);
+    A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
+    A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
+    A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
+    A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
+    std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
+    int E = W / M.S, nwaves = (B + E - 1) / E;
+    for (int wi = 0; wi < nwaves; ++wi) {
+        Shared sh(W);
+        std::vector<std::thread> th;
+        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC>(w, A, wi); });
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
+    for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
+    for (size_t i = 0; i < (jimp ? (size_t)B * M.n_joint_imp : 0); ++i) jimp[i] = jt[i];
+    for (size_t i = 0; i < (csg ? (size_t)B * 8 * M.Nc : 0); ++i) csg[i] = ct[i];
+    for (size_t i = 0; i < dzt.size(); ++i) dz[i] = dzt[i];
+    for (size_t i = 0; i < dbgt.size(); ++i) dbg[i] = dbgt[i];
+    for (size_t i = 0; i < (du ? (size_t)B * nx * M.nu : 0); ++i) du[i] = dut[i];
+}
+
+} // namespace
+
+extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int B, int envs_per_wave,
+                        const double* z, const double* u, double* z_next, int* status, int* iters,
+                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen) {
+    dj::HostModel M;
+    int rc = dj::build_host_model(*tp, M);
+    if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
+    int W = M.S * (envs_per_wave > 0 ? envs_per_wave : 1);
+    DojoSolverOptions o = opts ? *opts : dj::default_options();
+#define RUN(TIO, TS, TL, MC) run<TIO, TS, TL, MC>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg)
+    // dtype 0: fp64 everywhere; dtype 1: fp32 I/O + fp32 factorization/solves, fp64 state/residuals (the product's "f32" mode); dtype 2: pure fp32 (experiments only)
+    if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }
+    else if (dtype == DOJO_DTYPE_F32) { if (M.maxc <= 1) RUN(float, double, double, 1); else if (M.maxc <= 4) RUN(float, double, double, 4); else RUN(float, double, double, 8); }
+    else if (dtype == 3) { if (M.maxc <= 1) RUN(float, double, float, 1); else RUN(float, double, float, 4); }
+    else { if (M.maxc <= 1) RUN(float, float, float, 1); else RUN(float, float, float, 4); }
+    return DOJO_OK;
+}

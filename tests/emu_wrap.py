@@ -1,0 +1,53 @@
+"""ctypes wrapper of the SIMT emulator (tests/emu/libemu.so): runs the shipped device source
+(dojo.jl_amd/csrc/dojo_device.hpp) on CPU threads.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from dojo_amd.topology import CTopology, CSolverOptions, SolverOptions
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "emu", "libemu.so")
+        src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
+                                                         for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src[0]])
+        _lib = C.CDLL(so)
+        _lib.emu_step.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False):
+    Z = np.ascontiguousarray(np.atleast_2d(Z), dtype=np.float64); B = Z.shape[0]
+    U = None if U is None else np.ascontiguousarray(np.atleast_2d(U), dtype=np.float64)
+    topo, keep = spec.to_ctypes()
+    o = (opts or SolverOptions()).to_c()
+    nx, nu = 12 * spec.Nb, spec.nu
+    Zn = np.zeros_like(Z); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+    vel = np.zeros((B, 6 * spec.Nb)); jimp = np.zeros((B, max(spec.n_joint_impulses, 1))); csg = np.zeros((B, max(8 * len(spec.contacts), 1)))
+    dz = np.zeros((B, nx, nx)) if grad else None
+    du = np.zeros((B, max(nu, 1), nx)) if grad else None
+    dbg = np.zeros((B, spec.Nb, 512)) if debug else None
+    err = C.create_string_buffer(256)
+    rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32pure": 2, "f32mixed": 3}[dtype], B, envs_per_wave,
+                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256)
+    if rc != 0:
+        raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
+    out = dict(z_next=Zn, status=st, iters=it, vel=vel, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])
+    if debug:
+        out["dbg"] = dbg
+    if grad:
+        # device layout is column-major per environment: dz[b][col][row]
+        out["dz"] = dz.transpose(0, 2, 1).copy()
+        out["du"] = du.reshape(-1)[:B * nu * nx].reshape(B, nu, nx).transpose(0, 2, 1).copy() if nu else np.zeros((B, nx, 0))
+    return out
