@@ -40,10 +40,9 @@ def main():
     import dojo_amd as d
     from dojo_amd import api
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
+    from dojo_amd import distributed as D
+    import torch.distributed as dist
+    rank, world, local = D.init_from_env(backend="nccl")          # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -90,15 +89,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(W, W + K):
         one_step(k, True)
-    if world > 1:      # all-gather of the trajectories' final states over RCCL/xGMI, once per rollout chunk
-        out = [torch.empty_like(z) for _ in range(world)]
-        dist.all_gather(out, z)
+    z_all = D.all_gather_states(z, world)      # all-gather of the final states over RCCL/xGMI, once per rollout chunk
     barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev)
     ok_frac = float((status == 0).float().mean().item())
     mean_iters = float(iters.float().mean().item())
 

@@ -176,20 +176,24 @@ struct JointEval {
     T g[6];                      // equality residual (3 tra slots, 3 rot slots; padded slots = 0)
     T theta;                     // limited rotational coordinate
     T imp_a[6], imp_b[6];        // joint impulse + damper on parent / child body (to be subtracted from d)
-    // Jacobian pieces (only when JAC)
-    T Ga[36], Gb[36];            // ∂g/∂(v,ω) of parent / child
-    T Pa[36], Pb[36];            // −impulse_map columns for the 6 multiplier slots
-    T Daa[36], Mab[36], Mba[36], Dbb[36];   // damper velocity Jacobians (−∂τ/∂ω)
+    // Jacobian pieces (only when JAC).  The 6x6 blocks go straight into the supernode arrays:
+    //   S[12x12] rows 0:6 = body rows (D_b | P_b), rows 6:12 = joint rows (G_b | REG)
+    //   U[12x6]  = [M_ba; G_a]   (rows of this supernode wrt the parent's velocity)
+    //   L[6x12]  = [M_ab | P_a]  (rows of the parent body wrt this supernode's unknowns)
+    //   Dup[6x6] = contribution of this joint to the parent's diagonal block
     T th_a[3], th_b[3];          // ∂θ/∂ω_a, ∂θ/∂ω_b
     T GaX[18], GaP[18], GbX[18], GbP[18];   // raw rows ∂g/∂x3, ∂g/∂φ3 (6 slots x 3) of parent / child
     T thp_a[3], thp_b[3];        // raw ∂θ/∂φ3
     T t_a[6], t_b[6];            // impulse_transform · Arᵀ (limit impulse direction)
 };
 
-template <bool JAC, class T>
+// MODE 0: residual pieces only; 1: + Jacobian blocks into S/U/L/Dup; 2: + raw rows for the data Jacobian
+template <int MODE, class T>
 DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg, bool has_parent,
                       const Kin<T>& ka, const Kin<T>& kb, const T* wa, const T* wb,
-                      const T* lam, const T* lg, T dt) {
+                      const T* lam, const T* lg, T dt, T* S, T* U, T* L, T* Dup) {
+    constexpr bool JAC = MODE >= 1;
+    constexpr bool MAT = MODE == 1;
     // ---------------- translational displacement at (x3,q3): translational/minimal.jl:4-12 ----------------
     T t3[3], wv[3], e[3], u[3];
     m3vec(t3, kb.R3, P.pb);
@@ -219,7 +223,6 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
     rot_impulse(ja, jb, cfg, pr);
     for (int i = 0; i < 6; ++i) { E.imp_a[i] = ia[i] + ja[i]; E.imp_b[i] = ib[i] + jb[i]; }
     if (JAC) {
-        for (int i = 0; i < 36; ++i) { E.Ga[i] = E.Gb[i] = E.Pa[i] = E.Pb[i] = E.Daa[i] = E.Mab[i] = E.Mba[i] = E.Dbb[i] = T(0); }
         for (int i = 0; i < 18; ++i) { E.GaX[i] = E.GaP[i] = E.GbX[i] = E.GbP[i] = T(0); }
         // translational rows: E_xa = −Raᵀ, E_φa = 2[u]x, E_xb = Raᵀ, E_φb = −2 RaᵀRb[pb]x
         T RaT_Rb[9], Spb[9], Eb[9], Su[9], EaPhi[9], EbPhi[9];
@@ -236,17 +239,21 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
                 const T* c = &P.Ct[3 * i];
                 for (int j = 0; j < 3; ++j) {
                     T cRaT = c[0] * ka.R3[3 * j] + c[1] * ka.R3[3 * j + 1] + c[2] * ka.R3[3 * j + 2];   // (c Raᵀ)_j
-                    E.Ga[6 * i + j] = -dt * cRaT;
-                    E.Gb[6 * i + j] = dt * cRaT;
                     E.GaX[3 * i + j] = -cRaT; E.GbX[3 * i + j] = cRaT;
                     E.GaP[3 * i + j] = c[0] * Su[j] + c[1] * Su[3 + j] + c[2] * Su[6 + j];
                     E.GbP[3 * i + j] = c[0] * Eb[j] + c[1] * Eb[3 + j] + c[2] * Eb[6 + j];
-                    E.Ga[6 * i + 3 + j] = c[0] * EaPhi[j] + c[1] * EaPhi[3 + j] + c[2] * EaPhi[6 + j];
-                    E.Gb[6 * i + 3 + j] = c[0] * EbPhi[j] + c[1] * EbPhi[3 + j] + c[2] * EbPhi[6 + j];
+                    if (MAT) {
+                        U[6 * (6 + i) + j] = -dt * cRaT;
+                        S[12 * (6 + i) + j] = dt * cRaT;
+                        U[6 * (6 + i) + 3 + j] = c[0] * EaPhi[j] + c[1] * EaPhi[3 + j] + c[2] * EaPhi[6 + j];
+                        S[12 * (6 + i) + 3 + j] = c[0] * EbPhi[j] + c[1] * EbPhi[3 + j] + c[2] * EbPhi[6 + j];
+                    }
                 }
-                T a6[6], b6[6];
-                tra_impulse(a6, b6, cfg, P, c);
-                for (int r = 0; r < 6; ++r) { E.Pa[6 * r + i] = -a6[r]; E.Pb[6 * r + i] = -b6[r]; }
+                if (MAT) {
+                    T a6[6], b6[6];
+                    tra_impulse(a6, b6, cfg, P, c);
+                    for (int r = 0; r < 6; ++r) { L[12 * r + 6 + i] = -a6[r]; S[12 * r + 6 + i] = -b6[r]; }
+                }
             }
         }
         // rotational rows: E_φb = s I + [v]x ; E_φa = −(s I − [v]x) Roffᵀ
@@ -262,14 +269,18 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
             if (i < P.nl_r) {
                 const T* c = &P.Cr[3 * i];
                 for (int j = 0; j < 3; ++j) {
-                    E.Ga[6 * (3 + i) + 3 + j] = c[0] * EraPhi[j] + c[1] * EraPhi[3 + j] + c[2] * EraPhi[6 + j];
-                    E.Gb[6 * (3 + i) + 3 + j] = c[0] * ErbPhi[j] + c[1] * ErbPhi[3 + j] + c[2] * ErbPhi[6 + j];
+                    if (MAT) {
+                        U[6 * (9 + i) + 3 + j] = c[0] * EraPhi[j] + c[1] * EraPhi[3 + j] + c[2] * EraPhi[6 + j];
+                        S[12 * (9 + i) + 3 + j] = c[0] * ErbPhi[j] + c[1] * ErbPhi[3 + j] + c[2] * ErbPhi[6 + j];
+                    }
                     E.GaP[3 * (3 + i) + j] = c[0] * Era[j] + c[1] * Era[3 + j] + c[2] * Era[6 + j];
                     E.GbP[3 * (3 + i) + j] = c[0] * Erb[j] + c[1] * Erb[3 + j] + c[2] * Erb[6 + j];
                 }
-                T a6[6], b6[6];
-                rot_impulse(a6, b6, cfg, c);
-                for (int r = 0; r < 6; ++r) { E.Pa[6 * r + 3 + i] = -a6[r]; E.Pb[6 * r + 3 + i] = -b6[r]; }
+                if (MAT) {
+                    T a6[6], b6[6];
+                    rot_impulse(a6, b6, cfg, c);
+                    for (int r = 0; r < 6; ++r) { L[12 * r + 9 + i] = -a6[r]; S[12 * r + 9 + i] = -b6[r]; }
+                }
             }
         }
         if (P.nlim_r > 0) {
@@ -307,7 +318,7 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
         m3vec(ta, cfg.Roff, force);                  // parent: vector_rotate(force, qoff)
         m3vec(tb, cfg.Rba, ta);                      // child: −R(qb⁻¹ qa qoff) force
         for (int k = 0; k < 3; ++k) { E.imp_a[3 + k] += dt * ta[k]; E.imp_b[3 + k] -= dt * tb[k]; }
-        if (JAC) {
+        if (MAT) {
             // ∂vel_i/∂ωb, ∂vel_i/∂ωa  (rotational/minimal.jl:151-174 in closed form)
             T dFa[9], dFb[9];                        // ∂force/∂ωa, ∂force/∂ωb (3x3, offset frame)
             for (int i = 0; i < 9; ++i) dFa[i] = dFb[i] = T(0);
@@ -333,10 +344,10 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
             m3mul(B1, cfg.Rba, A1);   m3mul(B2, cfg.Rba, A2);         // −∂τb/∂ωa, −∂τb/∂ωb
             for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
                 // d_a −= Δt τa, d_b −= −Δt τb  =>  ∂d_a/∂ω = −Δt ∂τa/∂ω, ∂d_b/∂ω = +Δt Rba ∂τa/∂ω
-                E.Daa[6 * (3 + k) + 3 + j] = -dt * A1[3 * k + j];
-                E.Mab[6 * (3 + k) + 3 + j] = -dt * A2[3 * k + j];
-                E.Mba[6 * (3 + k) + 3 + j] = dt * B1[3 * k + j];
-                E.Dbb[6 * (3 + k) + 3 + j] = dt * B2[3 * k + j];
+                Dup[6 * (3 + k) + 3 + j] += -dt * A1[3 * k + j];
+                L[12 * (3 + k) + 3 + j] += -dt * A2[3 * k + j];
+                U[6 * (3 + k) + 3 + j] += dt * B1[3 * k + j];
+                S[12 * (3 + k) + 3 + j] += dt * B2[3 * k + j];
             }
         }
     }
@@ -640,7 +651,12 @@ struct LaneProgram {
         kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], dt);
         kin_of(ka, L.xa2, L.qa2, va, wa, dt);
         JointEval<T> E;
-        joint_eval<JAC>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt);
+        if (JAC) {
+            for (int i = 0; i < 144; ++i) Smat[i] = T(0);
+            for (int i = 0; i < 72; ++i) { Umat[i] = T(0); Lmat[i] = T(0); }
+            for (int i = 0; i < 36; ++i) Dup[i] = T(0);
+        }
+        joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, Smat, Umat, Lmat, Dup);
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
         // body residual: src/integrators/constraint.jl:1-34 in closed form
@@ -666,8 +682,7 @@ struct LaneProgram {
         gather_children<6>(wv, d, up, P, base, G.maxch, active);
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
         if (JAC) {
-            // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)) ----
-            for (int i = 0; i < 144; ++i) Smat[i] = T(0);
+            // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)); joint blocks are already in ----
             T Dw[9];                                          // (Δt/2)(cJ − Jω ωᵀ/c + [ω]xJ − [Jω]x)
             {
                 T Sw[9], SJw[9], SwJ[9];
@@ -676,14 +691,9 @@ struct LaneProgram {
                     Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[1][j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
             }
             for (int i = 0; i < 3; ++i) {
-                Smat[12 * i + i] = P.m + T(REG);
-                for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] = Dw[3 * i + j];
+                Smat[12 * i + i] += P.m + T(REG);
+                for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] += Dw[3 * i + j];
                 Smat[12 * (3 + i) + 3 + i] += T(REG);
-            }
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-                Smat[12 * i + j] += E.Dbb[6 * i + j];
-                Smat[12 * i + 6 + j] = E.Pb[6 * i + j];
-                Smat[12 * (6 + i) + j] = E.Gb[6 * i + j];
             }
             for (int i = 0; i < 3; ++i) {
                 Smat[12 * (6 + i) + 6 + i] = (i < P.nl_t) ? T(REG) : T(1);
@@ -695,13 +705,6 @@ struct LaneProgram {
                     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] -= CE[c].Dww[3 * i + j];
                     for (int i = 0; i < 18; ++i) { F.C134[c][i] = CE[c].C134[i]; F.G134[c][i] = CE[c].G134[i]; }
                 }
-            }
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-                Umat[6 * i + j] = E.Mba[6 * i + j];           // body rows wrt parent velocity
-                Umat[6 * (6 + i) + j] = E.Ga[6 * i + j];      // joint rows wrt parent velocity
-                Lmat[12 * i + j] = E.Mab[6 * i + j];          // parent rows wrt child velocity
-                Lmat[12 * i + 6 + j] = E.Pa[6 * i + j];       // parent rows wrt joint multipliers
-                Dup[6 * i + j] = E.Daa[6 * i + j];            // extra diagonal of the parent body
             }
             for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
             for (int j = 0; j < 6; ++j) { F.t_a[j] = E.t_a[j]; F.t_b[j] = E.t_b[j]; }
@@ -1023,18 +1026,16 @@ struct LaneProgram {
     }
 
     // ---------------------------------------------------------------- mehrotra!  src/solver/mehrotra.jl:9-73
-    // returns status; iters_out = number of Newton iterations.  On return (Smat,Umat,Lmat,Dup) hold
-    // the un-factored blocks of the final linearization (mehrotra.jl:69 runs set_entries! last) and
-    // rb/rj/theta/cres the residual pieces at the solution.
-    DJ_HD int mehrotra(int& iters_out, T* Smat, T* Umat, T* Lmat, T* Dup) {
-        int status = DJ_STATUS_FAILED, excessive = 0;
-        T mutarget = T(0), undercut = G.undercut;
-        int no_progress = 0;
-        mu = T(0);
+    // returns status; iters_out = number of Newton iterations.  On return F holds the factors of the
+    // final linearization (mehrotra.jl:69 runs set_entries! last) and rb/rj/theta/cres the residual
+    // pieces at the solution.
+    // set_entries! followed at once by the supernode factorization, so that the un-factored blocks
+    // (S, U, L, Dup: 324 scalars) are transient and only the factors persist through the solves.
+    DJ_HD void linearize() {
+        T Smat[144], Umat[72], Lmat[72], Dup[36];
         evaluate<true>(Smat, Umat, Lmat, Dup);
 #ifdef DJ_DEBUG
-        if (dbg_on) {   // test hook: dump the first assembly of this lane and stop (wave-uniform exit)
-          if (dbg) {
+        if (dbg_on && dbg) {   // test hook: dump the first assembly of this lane
             T* o = dbg; int q = 0;
             for (int i = 0; i < 6; ++i) o[q++] = rb[i];
             for (int i = 0; i < 6; ++i) o[q++] = rj[i];
@@ -1047,9 +1048,19 @@ struct LaneProgram {
             for (int i = 0; i < 3; ++i) o[q++] = F.th_b[i];
             for (int i = 0; i < 6; ++i) o[q++] = F.t_a[i];
             for (int i = 0; i < 6; ++i) o[q++] = F.t_b[i];
-          }
-          iters_out = 0; return 0;
         }
+#endif
+        factorize(Smat, Umat, Lmat, Dup);
+    }
+
+    DJ_HD int mehrotra(int& iters_out) {
+        int status = DJ_STATUS_FAILED, excessive = 0;
+        T mutarget = T(0), undercut = G.undercut;
+        int no_progress = 0;
+        mu = T(0);
+        linearize();
+#ifdef DJ_DEBUG
+        if (dbg_on) { iters_out = 0; return 0; }   // wave-uniform early exit of the test hook
 #endif
         T rvio, bvio;
         violations(rvio, bvio);
@@ -1064,7 +1075,6 @@ struct LaneProgram {
             // Lanes of finished environments keep executing (wave-uniform control flow, all lanes must
             // take part in the shuffles) but never change their state: their step factor is 0.
             if (!done) iters = n;
-            factorize(Smat, Umat, Lmat, Dup);
             ConeRhs R;
             cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
             Step<T, MAXC> D;
@@ -1130,7 +1140,7 @@ struct LaneProgram {
                 accept_candidate();
                 mu = mutarget;
             }
-            evaluate<true>(Smat, Umat, Lmat, Dup);                  // set_entries! (Jacobian + residual; cone rows now carry the new μ)
+            linearize();                                            // set_entries! + factorization (cone rows now carry the new μ)
         }
         if (excessive) status = DJ_STATUS_EXCESSIVE_W;
         iters_out = iters;
@@ -1147,10 +1157,9 @@ struct LaneProgram {
     // reference behaviour), DOJO_GRAD_CONSISTENT = pre-update states.
     // Output layout: column-major per environment (Julia-native): dz[env][col][row], du[env][ucol][row].
     template <class KA>
-    DJ_HD void gradients(const KA& A, int env, T* Smat, T* Umat, T* Lmat, T* Dup) {
+    DJ_HD void gradients(const KA& A, int env) {
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
-        factorize(Smat, Umat, Lmat, Dup);                         // factors of the final linearization
         // ---- kinematics of the solution (chain) ----
         T own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6], va[3], wa[3];
         shfl_vec<6>(wv, par6, own6, plane);
@@ -1173,7 +1182,7 @@ struct LaneProgram {
         kin_of(kb, x2e, q2e, L.v[1], L.w[1], dt);
         kin_of(ka, xa2e, qa2e, va, wa, dt);
         JointEval<T> E;
-        joint_eval<true>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt);
+        joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr);
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -1350,7 +1359,7 @@ struct KernelArgs {
 #endif
 };
 
-template <class TIO, class T, class TL, int MAXC, class Wave>
+template <class TIO, class T, class TL, int MAXC, bool GRAD, class Wave>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     const Globals<T>& G = A.G;
     const int S = G.S, E = wv.width() / S;
@@ -1370,10 +1379,9 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
     if (A.dbg && active) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
 #endif
-    T Smat[144], Umat[72], Lmat[72], Dup[36];
     int iters = 0;
-    int status = prog.mehrotra(iters, Smat, Umat, Lmat, Dup);
-    if (A.dz != nullptr) prog.gradients(A, env, Smat, Umat, Lmat, Dup);
+    int status = prog.mehrotra(iters);
+    if (GRAD) { if (A.dz != nullptr) prog.gradients(A, env); }
     if (active) {
         T zn[13];
         prog.next_state(zn);

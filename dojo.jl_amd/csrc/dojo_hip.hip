@@ -1,4 +1,4 @@
-// dojo_hip.hip -- libdojo_hip.so: HIP kernels (gfx950) + the C ABI of include/dojo_hip.h.
+// dojo_hip.hip -- libdojo_hip.so: host side of the C ABI of include/dojo_hip.h (kernels: dojo_kernels.hip).
 //
 // One wavefront = 64/S environments x S supernodes (dojo_device.hpp).  One workgroup = one
 // wavefront (64 threads), so a batch of B environments launches ceil(B*S/64) workgroups --
@@ -18,23 +18,10 @@ namespace {
 
 thread_local std::string g_err;
 
-struct GpuWave {
-    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
-    __device__ __forceinline__ int width() const { return 64; }
-    __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ bool   any(bool p) const { return __any(p ? 1 : 0) != 0; }
-};
-
-// TIO = ABI scalar type, TS = state / residual precision, TL = factorization precision.
-// dtype f64: <double,double,double>.  dtype f32: fp32 buffers at the ABI with fp64 internals
-// <float,double,double>: the interior-point iteration drives s·γ to ~1e-9 and the condensed KKT
-// then has entries ~γ/s that fp32 cannot resolve (measured in tests/emu).
-template <class TIO, class TS, class TL, int MAXC>
-__global__ void __launch_bounds__(64) dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
-    GpuWave w;
-    dj::step_entry<TIO, TS, TL, MAXC, GpuWave>(w, A, (int)blockIdx.x);
+// kernel launchers, one per object file of dojo_kernels.hip
+extern "C" {
+int dojo_launch_float_1(const void*, int, void*, int);  int dojo_launch_float_4(const void*, int, void*, int);  int dojo_launch_float_8(const void*, int, void*, int);
+int dojo_launch_double_1(const void*, int, void*, int); int dojo_launch_double_4(const void*, int, void*, int); int dojo_launch_double_8(const void*, int, void*, int);
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return DOJO_ERR_DEVICE; } } while (0)
@@ -79,11 +66,16 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.z = (const TIO*)z; A.u = (const TIO*)u; A.z_next = (TIO*)zn; A.status = status; A.iters = iters;
     A.vel = (TIO*)vel; A.joint_imp = (TIO*)jimp; A.contact_sg = (TIO*)csg; A.dz = (TIO*)dz; A.du = (TIO*)du;
     int E = 64 / s->M.S;
-    dim3 grid((s->B + E - 1) / E), block(64);
+    dim3 grid((s->B + E - 1) / E);
     if (timed) HIPCHK(hipEventRecord(s->ev0, st));
-    if (s->M.maxc <= 1)      hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 1>), grid, block, 0, st, A);
-    else if (s->M.maxc <= 4) hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 4>), grid, block, 0, st, A);
-    else                     hipLaunchKernelGGL((dojo_step_kernel<TIO, T, TL, 8>), grid, block, 0, st, A);
+    const int g = dz != nullptr;
+    typedef int (*launcher_t)(const void*, int, void*, int);
+    const bool f32 = sizeof(TIO) == 4;
+    launcher_t fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1 : dojo_launch_double_1)
+                  : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4 : dojo_launch_double_4)
+                                   : (f32 ? dojo_launch_float_8 : dojo_launch_double_8);
+    int lrc = fn(&A, (int)grid.x, (void*)st, g);
+    if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(s->ev1, st));
     return DOJO_OK;

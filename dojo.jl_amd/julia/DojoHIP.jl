@@ -1,0 +1,155 @@
+# DojoHIP.jl -- thin Julia shim over libdojo_hip.so (include/dojo_hip.h).
+#
+# NOT EXECUTED IN THE BUILD CONTAINER (no Julia toolchain there); kept deliberately thin: it only
+# (a) walks a live Dojo `Mechanism` and fills the C-POD topology, (b) owns a handle, (c) forwards
+# step! / simulate! / get_maximal_gradients! for a batch, and (d) offers an opt-in override of
+# Dojo.mehrotra! that round-trips one Mechanism through the library (B = 1) and writes the
+# solution back so that DojoEnvironments works unmodified.  The same calls are exercised from
+# Python by dojo.jl_amd/host/dojo_amd/api.py, which the parity tests drive.
+module DojoHIP
+
+using Dojo
+using StaticArrays
+
+const LIB = get(ENV, "DOJO_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdojo_hip.so"))
+
+# ---- C PODs (layout identical to include/dojo_hip.h) -------------------------------------------
+struct CBody;      mass::Cdouble; inertia::NTuple{9,Cdouble}; end
+struct CJointHalf
+    nl::Int32; nlim::Int32
+    cmask::NTuple{9,Cdouble}; amask::NTuple{9,Cdouble}
+    spring::Cdouble; damper::Cdouble
+    spring_offset::NTuple{3,Cdouble}; limit_lo::NTuple{3,Cdouble}; limit_hi::NTuple{3,Cdouble}
+end
+struct CJoint
+    parent::Int32; child::Int32; spring_on::Int32; damper_on::Int32
+    vertex_parent::NTuple{3,Cdouble}; vertex_child::NTuple{3,Cdouble}; orientation_offset::NTuple{4,Cdouble}
+    tra::CJointHalf; rot::CJointHalf
+end
+struct CContact
+    body::Int32; reserved::Int32; friction_coefficient::Cdouble
+    normal::NTuple{3,Cdouble}; tangent::NTuple{6,Cdouble}; origin::NTuple{3,Cdouble}; radius::Cdouble; offset::NTuple{3,Cdouble}
+end
+struct CTopology
+    n_bodies::Int32; n_joints::Int32; n_contacts::Int32; reserved::Int32
+    timestep::Cdouble; input_scaling::Cdouble; gravity::NTuple{3,Cdouble}
+    bodies::Ptr{CBody}; joints::Ptr{CJoint}; contacts::Ptr{CContact}
+end
+struct CSolverOptions
+    rtol::Cdouble; btol::Cdouble; undercut::Cdouble; no_progress_undercut::Cdouble
+    max_iter::Int32; max_ls::Int32; no_progress_max::Int32; reserved::Int32
+end
+
+pad(v, n) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, n)
+rowmajor(M) = pad(vec(permutedims(Matrix(M))), 9)          # k x 3 mask -> 9 doubles, row-major, zero padded
+
+function half(j::Dojo.Joint{T,Nλ,Nb,N,Nb½}) where {T,Nλ,Nb,N,Nb½}
+    lo = Nb½ > 0 ? j.joint_limits[1] : Float64[]
+    hi = Nb½ > 0 ? j.joint_limits[2] : Float64[]
+    CJointHalf(Nλ, Nb½, rowmajor(Dojo.constraint_mask(j)), rowmajor(Dojo.nullspace_mask(j)),
+               j.spring, j.damper, pad(j.spring_offset, 3), pad(lo, 3), pad(hi, 3))
+end
+
+"walk a Mechanism (bodies / joints / contacts in their live order) -> C arrays"
+function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
+    bidx(id) = id == 0 ? Int32(-1) : Int32(id - Ne - 1)      # node id -> 0-based index into mechanism.bodies
+    bodies = [CBody(b.mass, pad(vec(permutedims(Matrix(b.inertia))), 9)) for b in m.bodies]
+    joints = [CJoint(bidx(j.parent_id), bidx(j.child_id), Int32(j.spring), Int32(j.damper),
+                     pad(j.translational.vertices[1], 3), pad(j.translational.vertices[2], 3),
+                     pad(Dojo.vector(j.rotational.orientation_offset), 4), half(j.translational), half(j.rotational)) for j in m.joints]
+    contacts = CContact[]
+    for c in m.contacts
+        c.model isa Dojo.NonlinearContact || error("DojoHIP: only NonlinearContact is supported")
+        col = c.model.collision
+        col isa Dojo.SphereHalfSpaceCollision || error("DojoHIP: only SphereHalfSpaceCollision is supported")
+        push!(contacts, CContact(bidx(c.parent_id), 0, c.model.friction_coefficient, pad(col.contact_normal', 3),
+                                 pad(vec(permutedims(Matrix(col.contact_tangent))), 6), pad(col.contact_origin, 3),
+                                 col.contact_radius, pad(col.contact_offset, 3)))
+    end
+    return bodies, joints, contacts
+end
+
+mutable struct BatchedMechanism{T}
+    handle::Ptr{Cvoid}
+    mechanism::Dojo.Mechanism
+    batch::Int
+    nz::Int; nx::Int; nu::Int
+end
+
+check(rc) = rc == 0 || error("libdojo_hip: " * unsafe_string(@ccall LIB.dojo_last_error()::Cstring))
+
+function BatchedMechanism(m::Dojo.Mechanism, batch::Int; T=Float32, device::Int=0)
+    bodies, joints, contacts = export_topology(m)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve bodies joints contacts begin
+        topo = CTopology(length(bodies), length(joints), length(contacts), 0, m.timestep, m.input_scaling,
+                         pad(m.gravity, 3), pointer(bodies), pointer(joints), pointer(contacts))
+        check(@ccall LIB.dojo_create(Ref(topo)::Ref{CTopology}, batch::Int32, (T == Float32 ? 1 : 0)::Int32, device::Int32, h::Ref{Ptr{Cvoid}})::Cint)
+    end
+    bm = BatchedMechanism{T}(h[], m, batch, 13length(m.bodies), 12length(m.bodies), Dojo.input_dimension(m))
+    finalizer(b -> (@ccall LIB.dojo_destroy(b.handle::Ptr{Cvoid})::Cvoid), bm)
+    return bm
+end
+
+function set_options!(bm::BatchedMechanism, o::Dojo.SolverOptions)
+    c = CSolverOptions(o.rtol, o.btol, o.undercut, o.no_progress_undercut, o.max_iter, o.max_ls, o.no_progress_max, 0)
+    check(@ccall LIB.dojo_set_options(bm.handle::Ptr{Cvoid}, Ref(c)::Ref{CSolverOptions})::Cint)
+end
+
+# z: nz x B and u: nu x B column-major Julia matrices == the row-major [B, nz] / [B, nu] of the ABI
+"step!(mechanism, z, u; opts): batched, returns (z_next, status)"
+function Dojo.step!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}(), with_gradient::Bool=false) where T
+    set_options!(bm, opts)
+    zn = similar(z); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
+    check(@ccall LIB.dojo_step(bm.handle::Ptr{Cvoid}, z::Ptr{T}, u::Ptr{T}, zn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, with_gradient::Int32)::Cint)
+    return zn, status
+end
+
+"get_maximal_gradients!(mechanism, z, u; opts): batched -> (jacobian_state[12Nb,12Nb,B], jacobian_control[12Nb,nu,B])"
+function Dojo.get_maximal_gradients!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
+    Dojo.step!(bm, z, u; opts, with_gradient=true)
+    dz = Array{T}(undef, bm.nx, bm.nx, bm.batch); du = Array{T}(undef, bm.nu, bm.nx, bm.batch)      # ABI is row-major [B,nx,nx]/[B,nx,nu]
+    check(@ccall LIB.dojo_gradients(bm.handle::Ptr{Cvoid}, dz::Ptr{T}, du::Ptr{T})::Cint)
+    return permutedims(dz, (2, 1, 3)), permutedims(du, (2, 1, 3))
+end
+
+"simulate! with pre-sampled controls U[nu, B, H] -> Z[nz, B, H], status[B, H]"
+function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; opts=Dojo.SolverOptions{Float64}()) where T
+    set_options!(bm, opts)
+    H = size(U, 3)
+    Z = Array{T}(undef, bm.nz, bm.batch, H); status = Matrix{Int32}(undef, bm.batch, H)
+    check(@ccall LIB.dojo_rollout(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, status::Ptr{Int32})::Cint)
+    return Z, status
+end
+
+# ---- opt-in single-Mechanism drop-in ------------------------------------------------------------
+# DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) round-trip through the library (B = 1,
+# fp64) and write the solution back: body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual),
+# so step!/simulate!/get_state of DojoEnvironments keep working unchanged.
+const HANDLES = IdDict{Dojo.Mechanism,BatchedMechanism{Float64}}()
+enable!(m::Dojo.Mechanism) = (HANDLES[m] = BatchedMechanism(m, 1; T=Float64); m)
+
+function hip_mehrotra!(m::Dojo.Mechanism; opts=Dojo.SolverOptions{Float64}())
+    bm = HANDLES[m]
+    z = reshape(Dojo.get_maximal_state(m), :, 1)
+    u = reshape(zeros(bm.nu), :, 1)          # inputs were already applied to JF2/Jτ2 by set_input!; pass them via dojo_step's u in step! overloads
+    zn, status = Dojo.step!(bm, z, u; opts)
+    Nb = length(m.bodies)
+    vel = Vector{Float64}(undef, 6Nb); ji = Vector{Float64}(undef, max(1, sum(length.(m.joints)))); cs = Vector{Float64}(undef, max(1, 8length(m.contacts)))
+    check(@ccall LIB.dojo_get_solution(bm.handle::Ptr{Cvoid}, vel::Ptr{Float64}, ji::Ptr{Float64}, cs::Ptr{Float64})::Cint)
+    for (i, b) in enumerate(m.bodies)
+        b.state.vsol[2] = SVector{3}(vel[6i-5:6i-3]); b.state.ωsol[2] = SVector{3}(vel[6i-2:6i])
+        b.state.vsol[1] = b.state.vsol[2]; b.state.ωsol[1] = b.state.ωsol[2]
+    end
+    off = 0
+    for j in m.joints
+        n = length(j); j.impulses[2] = SVector{n}(ji[off+1:off+n]); j.impulses[1] = j.impulses[2]; off += n
+    end
+    for (i, c) in enumerate(m.contacts)
+        c.impulses_dual[2] = SVector{4}(cs[8i-7:8i-4]); c.impulses[2] = SVector{4}(cs[8i-3:8i])
+        c.impulses_dual[1] = c.impulses_dual[2]; c.impulses[1] = c.impulses[2]
+    end
+    return status[1] == 0 ? :success : :failed
+end
+
+end # module

@@ -31,6 +31,7 @@ struct IOracle {
     virtual int simulate_step(const double* u, int last) = 0;
     virtual void body_velocity_solution(double* v) = 0;
     virtual void debug_assemble(const double* z, const double* u, double* A, double* b) = 0;
+    virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
 };
 
@@ -128,6 +129,15 @@ struct OracleT : IOracle {
         for (size_t i = 0; i < (size_t)m.n * m.n; ++i) A[i] = m.A[i];
         for (int i = 0; i < m.n; ++i) b[i] = m.b[i];
     }
+    void check_solution(const double* z, const double* u, const double* sol, double* viol) override {
+        // residual_violation / bilinear_violation (src/solver/violations.jl) of a candidate solution of step!(z, u)
+        int nz = 13 * (int)m.bodies.size(), nu = m.nu();
+        std::vector<T> zz = cast(z, nz), uu(nu, T(0)); if (u) uu = cast(u, nu);
+        m.set_maximal_state(zz.data()); m.set_input_all(uu.data());
+        auto s = cast(sol, m.n); m.set_solution(s.data());
+        m.mu = 0;
+        viol[0] = (double)m.residual_violation(); viol[1] = (double)m.bilinear_violation();
+    }
     IOracle* clone() override { return new OracleT<T>(*this); }
 };
 
@@ -159,6 +169,8 @@ int  orc_simulate_step(void* h, const double* u, int last) { return ((IOracle*)h
 void orc_body_velocity_solution(void* h, double* v) { ((IOracle*)h)->body_velocity_solution(v); }
 
 void orc_debug_assemble(void* h, const double* z, const double* u, double* A, double* b) { ((IOracle*)h)->debug_assemble(z, u, A, b); }
+
+void orc_check_solution(void* h, const double* z, const double* u, const double* sol, double* viol) { ((IOracle*)h)->check_solution(z, u, sol, viol); }
 
 // Batched step for the CPU baseline: one environment per thread-task over `nthreads`
 // host threads.  z [B,13Nb], u [B,nu] or NULL, outputs may be NULL.

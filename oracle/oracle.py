@@ -34,7 +34,7 @@ def lib():
         for name in ("orc_destroy", "orc_set_options", "orc_dims", "orc_get_solution", "orc_set_solution", "orc_gradients",
                      "orc_get_data", "orc_set_data", "orc_evaluate_residual", "orc_full_matrix", "orc_data_matrix",
                      "orc_data_attjac", "orc_set_state", "orc_get_state", "orc_set_external_force",
-                     "orc_body_velocity_solution", "orc_step_batch", "orc_debug_assemble"):
+                     "orc_body_velocity_solution", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
             getattr(_lib, name).restype = None
         _lib.orc_step.restype = C.c_int
         _lib.orc_simulate_step.restype = C.c_int
@@ -113,6 +113,12 @@ class Oracle:
         A = np.zeros((self.n, self.n)); b = np.zeros(self.n)
         z = np.ascontiguousarray(z, dtype=np.float64); u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
         lib().orc_debug_assemble(self.h, _p(z), _p(u), _p(A), _p(b)); return A, b
+
+    def check_solution(self, z, u, sol):
+        """(rvio, bvio) of a candidate solution [joint impulses; body velocities; contact s,γ] of step!(z, u)"""
+        v = np.zeros(2)
+        z = np.ascontiguousarray(z, dtype=np.float64); u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        lib().orc_check_solution(self.h, _p(z), _p(u), _p(np.ascontiguousarray(sol, dtype=np.float64)), _p(v)); return v[0], v[1]
 
     # simulate! pieces
     def set_state(self, z):

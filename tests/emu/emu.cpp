@@ -80,7 +80,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     for (int wi = 0; wi < nwaves; ++wi) {
         Shared sh(W);
         std::vector<std::thread> th;
-        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC>(w, A, wi); });
+        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC, true>(w, A, wi); });
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];

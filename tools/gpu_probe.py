@@ -1,0 +1,45 @@
+"""GPU probe: timing sweeps + parity debugging dumps (writes gpurun_out/)."""
+import sys, os, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import dojo_amd as d
+from dojo_amd import api
+from oracle import Oracle
+
+out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+
+if what in ("all", "sweep"):
+    spec = d.baseline_config(3)
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    for B in (256, 1024, 4096, 16384):
+        for grad in (False, True):
+            Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+            gm = api.BatchedMechanism(spec, B, dtype="f32")
+            z = Z.astype(np.float32)
+            ms = []
+            for k in range(4):
+                zn, st, it = gm.step(z, U, with_gradient=grad); ms.append(gm.last_kernel_ms()); z = zn
+            print("sweep ant B=%d grad=%d kernel ms %s  steps/s %.0f  iters %.1f ok %.3f" % (B, grad, ["%.2f" % m for m in ms], B / (min(ms) * 1e-3), it.mean(), (st == 0).mean()), flush=True)
+            gm.close()
+
+if what in ("all", "parity"):
+    spec = d.baseline_config(3)
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
+    B = 64
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    o = Oracle(spec, opts=opts)
+    z = Z.copy(); dumps = []
+    for k in range(12):
+        zg, st, it = gm.step(z, U)
+        zo, st_o, it_o, _, _ = o.step_batch(z, U, nthreads=16)
+        err = np.abs(zg - zo).max(axis=1)
+        w = int(err.argmax())
+        print("parity step %d worst env %d err %.3e status gpu %d oracle %d iters gpu %d oracle %d; n(err>1e-6)=%d" % (k, w, err[w], st[w], st_o[w], it[w], it_o[w], (err > 1e-6).sum()), flush=True)
+        if err[w] > 1e-6:
+            dumps.append(dict(step=k, env=w, z=z[w].tolist(), u=U[w].tolist(), zg=zg[w].tolist(), zo=zo[w].tolist()))
+        z = zo
+    json.dump(dumps, open(os.path.join(out, "parity_dbg.json"), "w"))
+    gm.close()
