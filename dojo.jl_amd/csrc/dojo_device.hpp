@@ -76,20 +76,73 @@ struct Lane {
 
 // factor data of one supernode, kept between the two solves of a Mehrotra iteration and
 // re-used by the IFT back-solves
-template <class T, class TL, int MAXC>
+template <class T, class TL, int MAXC, bool QUAD>
 struct Factors {
     // linear-algebra part, in the factorization precision TL (fp32 in the mixed "f32" mode)
-    TL Sinv[144];                // inverse of the 12x12 supernode matrix [[D_b, P_b],[G_b, REG]]
-    TL W[72];                    // L S⁻¹   (6x12): rhs of the parent  -= W r_k
-    TL Z[72];                    // S⁻¹ U   (12x6): Δ_k = S⁻¹ r_k − Z Δv_parent
+    // lane = supernode mapping: the whole factor lives on one lane
+    TL Sinv[QUAD ? 1 : 144];     // inverse of the 12x12 supernode matrix [[D_b, P_b],[G_b, REG]]
+    TL W[QUAD ? 1 : 72];         // L S⁻¹   (6x12): rhs of the parent  -= W r_k
+    TL Z[QUAD ? 1 : 72];         // S⁻¹ U   (12x6): Δ_k = S⁻¹ r_k − Z Δv_parent
+    // quad mapping: lane q of a supernode keeps rows 3q..3q+2 of S⁻¹ and of U, columns 3q..3q+2 of L
+    TL Sq[QUAD ? 3 : 1][12], Uq[QUAD ? 3 : 1][6], Lq[6][QUAD ? 3 : 1];
     // condensation pieces, in the state precision T
     T th_a[3], th_b[3], t_a[6], t_b[6];
-    T C134[MAXC][18], G134[MAXC][18];
 };
+
+template <class T, int MAXC>
+struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][4], cg[MAXC][4]; };   // solution variables at the start of a line search
 
 template <class T, int MAXC>
 struct Step {                    // Newton step of this lane's unknowns
     T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][4], dcg[MAXC][4];
+};
+
+
+// ------------------------------------------------------------------------------------------------
+// Containers of the un-factored supernode blocks.  The assembly code only *adds* entries through
+// these; FullBlocks keeps everything on one lane (lane = supernode mapping), QuadBlocks keeps the
+// three rows (columns for L) that belong to the lane's role q in the 4-lanes-per-supernode mapping:
+//   q = 0: body rows of v, 1: body rows of ω, 2: translational multiplier rows, 3: rotational ones.
+// All (r, c) are compile-time constants after unrolling, so `r / 3 == q` is a predicate on a
+// register and every array element has a static index (stays in VGPRs).
+//   S[12x12] rows 0:6 = body rows (D_b | P_b), rows 6:12 = joint rows (G_b | REG)
+//   U[12x6]  = [M_ba; G_a]   rows of this supernode wrt the parent's velocity
+//   L[6x12]  = [M_ab | P_a]  rows of the parent body wrt this supernode's unknowns
+//   D[6x6]   = contribution of this joint to the parent's diagonal block
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct FullBlocks {
+    T S[144], U[72], L[72], D[36];
+    DJ_HD void zero() { for (int i = 0; i < 144; ++i) S[i] = T(0); for (int i = 0; i < 72; ++i) { U[i] = T(0); L[i] = T(0); } for (int i = 0; i < 36; ++i) D[i] = T(0); }
+    DJ_HD void addS(int r, int c, T v) { S[12 * r + c] += v; }
+    DJ_HD void addU(int r, int c, T v) { U[6 * r + c] += v; }
+    DJ_HD void addL(int r, int c, T v) { L[12 * r + c] += v; }
+    DJ_HD void addD(int r, int c, T v) { D[6 * r + c] += v; }
+};
+struct NullBlocks {
+    DJ_HD void zero() {}
+    template <class V> DJ_HD void addS(int, int, V) {}
+    template <class V> DJ_HD void addU(int, int, V) {}
+    template <class V> DJ_HD void addL(int, int, V) {}
+    template <class V> DJ_HD void addD(int, int, V) {}
+};
+template <class T>
+struct QuadBlocks {
+    T S[3][12], U[3][6], L[6][3], D[3][6];
+    int q;
+    DJ_HD void zero() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) S[i][j] = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { U[i][j] = T(0); D[i][j] = T(0); L[j][i] = T(0); }
+        }
+    }
+    DJ_HD void addS(int r, int c, T v) { if (r / 3 == q) S[r % 3][c] += v; }
+    DJ_HD void addU(int r, int c, T v) { if (r / 3 == q) U[r % 3][c] += v; }
+    DJ_HD void addL(int r, int c, T v) { if (c / 3 == q) L[r][c % 3] += v; }
+    DJ_HD void addD(int r, int c, T v) { if (r / 3 == q) D[r % 3][c] += v; }
 };
 
 // kinematic quantities of a body at the candidate velocity
@@ -147,6 +200,24 @@ template <class T> DJ_HD void joint_cfg(JointCfg<T>& c, const NodeP<T>& P, const
     qcmul(qab, qa, qb);
     qcmul(c.qr, P.qoff, qab);
 }
+// Per-lane data that is read rarely (joint frames at the current configuration, contact Jacobian
+// rows of the last linearization).  On the GPU it lives in LDS when it fits (one struct per lane,
+// stride = odd number of 8-byte words, so ds_read_b64 is bank-conflict free) to relieve VGPR pressure.
+template <class T, int MAXC>
+struct Cold {
+    JointCfg<T> cfg;
+    T C134[MAXC][18], G134[MAXC][18];
+    T pad_[((sizeof(JointCfg<T>) / sizeof(T) + 36 * MAXC) % 2 == 0) ? 1 : 2];
+};
+
+// IFT data-Jacobian blocks of one supernode (datamat = −∂residual/∂θ, src/gradients/data.jl), stored
+// once per supernode (per quad) in the precision of the ABI buffers
+template <class TB, int MAXC>
+struct GradBlocks {
+    TB OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], UB[6][6], UA[6][6];
+    TB Cc[MAXC][4][6];
+    TB pad_[1];
+};
 // T_a p and T_b p for the translational half: 6-vectors (force in world frame, torque in body frame)
 template <class T> DJ_HD void tra_impulse(T* ia, T* ib, const JointCfg<T>& c, const NodeP<T>& P, const T* p) {
     T F[3], t[3];
@@ -188,10 +259,10 @@ struct JointEval {
 };
 
 // MODE 0: residual pieces only; 1: + Jacobian blocks into S/U/L/Dup; 2: + raw rows for the data Jacobian
-template <int MODE, class T>
+template <int MODE, class T, class BK>
 DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg, bool has_parent,
                       const Kin<T>& ka, const Kin<T>& kb, const T* wa, const T* wb,
-                      const T* lam, const T* lg, T dt, T* S, T* U, T* L, T* Dup) {
+                      const T* lam, const T* lg, T dt, BK& K) {
     constexpr bool JAC = MODE >= 1;
     constexpr bool MAT = MODE == 1;
     // ---------------- translational displacement at (x3,q3): translational/minimal.jl:4-12 ----------------
@@ -234,25 +305,28 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
         for (int i = 0; i < 9; ++i) Su[i] *= T(2);
         m3mul(EaPhi, Su, ka.Phi);
         m3mul(EbPhi, Eb, kb.Phi);
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (i < P.nl_t) {
                 const T* c = &P.Ct[3 * i];
+#pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     T cRaT = c[0] * ka.R3[3 * j] + c[1] * ka.R3[3 * j + 1] + c[2] * ka.R3[3 * j + 2];   // (c Raᵀ)_j
                     E.GaX[3 * i + j] = -cRaT; E.GbX[3 * i + j] = cRaT;
                     E.GaP[3 * i + j] = c[0] * Su[j] + c[1] * Su[3 + j] + c[2] * Su[6 + j];
                     E.GbP[3 * i + j] = c[0] * Eb[j] + c[1] * Eb[3 + j] + c[2] * Eb[6 + j];
                     if (MAT) {
-                        U[6 * (6 + i) + j] = -dt * cRaT;
-                        S[12 * (6 + i) + j] = dt * cRaT;
-                        U[6 * (6 + i) + 3 + j] = c[0] * EaPhi[j] + c[1] * EaPhi[3 + j] + c[2] * EaPhi[6 + j];
-                        S[12 * (6 + i) + 3 + j] = c[0] * EbPhi[j] + c[1] * EbPhi[3 + j] + c[2] * EbPhi[6 + j];
+                        K.addU(6 + i, j, -dt * cRaT);
+                        K.addS(6 + i, j, dt * cRaT);
+                        K.addU(6 + i, 3 + j, c[0] * EaPhi[j] + c[1] * EaPhi[3 + j] + c[2] * EaPhi[6 + j]);
+                        K.addS(6 + i, 3 + j, c[0] * EbPhi[j] + c[1] * EbPhi[3 + j] + c[2] * EbPhi[6 + j]);
                     }
                 }
                 if (MAT) {
                     T a6[6], b6[6];
                     tra_impulse(a6, b6, cfg, P, c);
-                    for (int r = 0; r < 6; ++r) { L[12 * r + 6 + i] = -a6[r]; S[12 * r + 6 + i] = -b6[r]; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) { K.addL(r, 6 + i, -a6[r]); K.addS(r, 6 + i, -b6[r]); }
                 }
             }
         }
@@ -265,13 +339,15 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
         for (int i = 0; i < 9; ++i) Era[i] = -Era[i];
         m3mul(EraPhi, Era, ka.Phi);
         m3mul(ErbPhi, Erb, kb.Phi);
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (i < P.nl_r) {
                 const T* c = &P.Cr[3 * i];
+#pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (MAT) {
-                        U[6 * (9 + i) + 3 + j] = c[0] * EraPhi[j] + c[1] * EraPhi[3 + j] + c[2] * EraPhi[6 + j];
-                        S[12 * (9 + i) + 3 + j] = c[0] * ErbPhi[j] + c[1] * ErbPhi[3 + j] + c[2] * ErbPhi[6 + j];
+                        K.addU(9 + i, 3 + j, c[0] * EraPhi[j] + c[1] * EraPhi[3 + j] + c[2] * EraPhi[6 + j]);
+                        K.addS(9 + i, 3 + j, c[0] * ErbPhi[j] + c[1] * ErbPhi[3 + j] + c[2] * ErbPhi[6 + j]);
                     }
                     E.GaP[3 * (3 + i) + j] = c[0] * Era[j] + c[1] * Era[3 + j] + c[2] * Era[6 + j];
                     E.GbP[3 * (3 + i) + j] = c[0] * Erb[j] + c[1] * Erb[3 + j] + c[2] * Erb[6 + j];
@@ -279,7 +355,8 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
                 if (MAT) {
                     T a6[6], b6[6];
                     rot_impulse(a6, b6, cfg, c);
-                    for (int r = 0; r < 6; ++r) { L[12 * r + 9 + i] = -a6[r]; S[12 * r + 9 + i] = -b6[r]; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) { K.addL(r, 9 + i, -a6[r]); K.addS(r, 9 + i, -b6[r]); }
                 }
             }
         }
@@ -342,12 +419,15 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
             T A1[9], A2[9], B1[9], B2[9];
             m3mul(A1, cfg.Roff, dFa); m3mul(A2, cfg.Roff, dFb);       // ∂τa/∂ωa, ∂τa/∂ωb (without Δt)
             m3mul(B1, cfg.Rba, A1);   m3mul(B2, cfg.Rba, A2);         // −∂τb/∂ωa, −∂τb/∂ωb
-            for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
                 // d_a −= Δt τa, d_b −= −Δt τb  =>  ∂d_a/∂ω = −Δt ∂τa/∂ω, ∂d_b/∂ω = +Δt Rba ∂τa/∂ω
-                Dup[6 * (3 + k) + 3 + j] += -dt * A1[3 * k + j];
-                L[12 * (3 + k) + 3 + j] += -dt * A2[3 * k + j];
-                U[6 * (3 + k) + 3 + j] += dt * B1[3 * k + j];
-                S[12 * (3 + k) + 3 + j] += dt * B2[3 * k + j];
+                K.addD(3 + k, 3 + j, -dt * A1[3 * k + j]);
+                K.addL(3 + k, 3 + j, -dt * A2[3 * k + j]);
+                K.addU(3 + k, 3 + j, dt * B1[3 * k + j]);
+                K.addS(3 + k, 3 + j, dt * B2[3 * k + j]);
             }
         }
     }
@@ -584,21 +664,22 @@ template <class T> DJ_HD T soc_step(const T* l, const T* d, T tau) {
 // ------------------------------------------------------------------------------------------------
 // Wave-level helpers.  `Wave` provides: lane(), shfl(v, src_lane), any(pred).
 // ------------------------------------------------------------------------------------------------
-template <class Wave, class T> DJ_HD T env_max(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmax(v, w.shfl(v, w.lane() ^ o)); return v; }
-template <class Wave, class T> DJ_HD T env_min(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmin(v, w.shfl(v, w.lane() ^ o)); return v; }
-template <class Wave, class T> DJ_HD T env_sum(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v + w.shfl(v, w.lane() ^ o); return v; }
-template <class Wave> DJ_HD int env_or(Wave& w, int v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v | w.shfl(v, w.lane() ^ o); return v; }
+template <class Wave, class T> DJ_HD T lane_xor(Wave& w, T v, int o) { return o == 1 ? w.quad_xor(v, 1) : o == 2 ? w.quad_xor(v, 2) : w.shfl(v, w.lane() ^ o); }
+template <class Wave, class T> DJ_HD T env_max(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmax(v, lane_xor(w, v, o)); return v; }
+template <class Wave, class T> DJ_HD T env_min(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmin(v, lane_xor(w, v, o)); return v; }
+template <class Wave, class T> DJ_HD T env_sum(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v + lane_xor(w, v, o); return v; }
+template <class Wave> DJ_HD int env_or(Wave& w, int v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v | lane_xor(w, v, o); return v; }
 
 template <int N, class Wave, class T> DJ_HD void shfl_vec(Wave& w, T* out, const T* in, int src) {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = w.shfl(in[i], src);
 }
 // acc[0:N] += Σ_children in[child]
-template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave& w, T* acc, const T* in, const NP& P, int base, int maxch, bool active) {
+template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave& w, T* acc, const T* in, const NP& P, int base, int maxch, bool active, int stride = 1, int q = 0) {
 #pragma unroll
     for (int ci = 0; ci < MAXCH; ++ci) {
         if (ci < maxch) {
-            int src = (active && ci < P.nchild) ? base + P.child[ci] : w.lane();
+            int src = (active && ci < P.nchild) ? base + stride * P.child[ci] + q : w.lane();
             bool use = active && ci < P.nchild;
 #pragma unroll
             for (int i = 0; i < N; ++i) { T t = w.shfl(in[i], src); if (use) acc[i] += t; }
@@ -609,7 +690,9 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
 // ================================================================================================
 // The lane program
 // ================================================================================================
-template <class T, class TL, int MAXC, class Wave>
+// QUAD = false: one lane per supernode.  QUAD = true: four lanes per supernode (roles q = 0..3 own
+// rows 3q..3q+2 of the supernode system); all other per-lane state is replicated inside the quad.
+template <class T, class TL, int MAXC, bool QUAD, class Wave>
 struct LaneProgram {
     Wave& wv;
     const Globals<T>& G;
@@ -621,8 +704,10 @@ struct LaneProgram {
     bool has_parent;
     int plane;                   // wave lane of the parent (or own lane)
     Lane<T, MAXC> L;
-    Factors<T, TL, MAXC> F;
-    JointCfg<T> cfg;
+    Factors<T, TL, MAXC, QUAD> F;
+    int stride, q, envl, qb;     // lanes per supernode, role in the quad, lanes per environment, first lane of the quad
+    Cold<T, MAXC>& cold;
+    JointCfg<T>& cfg;
     T mu;                        // mechanism.μ
 #ifdef DJ_DEBUG
     T* dbg = nullptr; bool dbg_on = false; bool trace = false;
@@ -630,18 +715,19 @@ struct LaneProgram {
     // residual pieces of the last evaluation
     T rb[6], rj[6], theta, cres[MAXC][4];
 
-    DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, bool act)
-        : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act) {
+    DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, int q_, bool act, Cold<T, MAXC>& cold_)
+        : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act), cold(cold_), cfg(cold_.cfg) {
+        stride = QUAD ? 4 : 1; q = QUAD ? q_ : 0; envl = stride * g.S; qb = w.lane() - q;
         has_parent = act && p.parent >= 0;
-        plane = has_parent ? base + p.parent : w.lane();
+        plane = has_parent ? base + stride * p.parent + q : w.lane();
         mu = T(0);
     }
 
     // ---------------------------------------------------------------- residual (+ Jacobian blocks)
     // Evaluates at candidate index 1.  After the call: rb = full body residual d (including what the
     // children's joints apply to this body), rj, theta, cres.  When JAC, fills S/U/Lm/Daa_up etc.
-    template <bool JAC>
-    DJ_HD void evaluate(T* Smat, T* Umat, T* Lmat, T* Dup) {
+    template <bool JAC, class BK>
+    DJ_HD void evaluate(BK& K) {
         const T dt = G.dt;
         // parent's candidate velocity
         T va[3], wa[3], own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6];
@@ -651,12 +737,8 @@ struct LaneProgram {
         kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], dt);
         kin_of(ka, L.xa2, L.qa2, va, wa, dt);
         JointEval<T> E;
-        if (JAC) {
-            for (int i = 0; i < 144; ++i) Smat[i] = T(0);
-            for (int i = 0; i < 72; ++i) { Umat[i] = T(0); Lmat[i] = T(0); }
-            for (int i = 0; i < 36; ++i) Dup[i] = T(0);
-        }
-        joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, Smat, Umat, Lmat, Dup);
+        if (JAC) K.zero();
+        joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, K);
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
         // body residual: src/integrators/constraint.jl:1-34 in closed form
@@ -679,7 +761,7 @@ struct LaneProgram {
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -E.imp_a[i] : T(0);
-        gather_children<6>(wv, d, up, P, base, G.maxch, active);
+        gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
         if (JAC) {
             // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)); joint blocks are already in ----
@@ -690,20 +772,26 @@ struct LaneProgram {
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
                     Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[1][j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
             }
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
-                Smat[12 * i + i] += P.m + T(REG);
-                for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] += Dw[3 * i + j];
-                Smat[12 * (3 + i) + 3 + i] += T(REG);
+                K.addS(i, i, P.m + T(REG));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, Dw[3 * i + j]);
+                K.addS(3 + i, 3 + i, T(REG));
             }
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
-                Smat[12 * (6 + i) + 6 + i] = (i < P.nl_t) ? T(REG) : T(1);
-                Smat[12 * (9 + i) + 9 + i] = (i < P.nl_r) ? T(REG) : T(1);
+                K.addS(6 + i, 6 + i, (i < P.nl_t) ? T(REG) : T(1));
+                K.addS(9 + i, 9 + i, (i < P.nl_r) ? T(REG) : T(1));
             }
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 if (c < P.ncontact) {
-                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Smat[12 * (3 + i) + 3 + j] -= CE[c].Dww[3 * i + j];
-                    for (int i = 0; i < 18; ++i) { F.C134[c][i] = CE[c].C134[i]; F.G134[c][i] = CE[c].G134[i]; }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CE[c].Dww[3 * i + j]);
+                    for (int i = 0; i < 18; ++i) { cold.C134[c][i] = CE[c].C134[i]; cold.G134[c][i] = CE[c].G134[i]; }
                 }
             }
             for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
@@ -728,8 +816,8 @@ struct LaneProgram {
             }
             if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[1][0] * L.lg[1][0])); b = tmax(b, tabs(L.ls[1][1] * L.lg[1][1])); }
         }
-        rvio = env_max(wv, r, G.S);
-        bvio = env_max(wv, b, G.S);
+        rvio = env_max(wv, r, envl);
+        bvio = env_max(wv, b, envl);
     }
 
     // ---------------------------------------------------------------- condensation of cone rows
@@ -779,33 +867,48 @@ struct LaneProgram {
         Q.coef[6] = (-Q.g2 * s2_c1 - Q.h2 * dg2_1) * ih; Q.coef[7] = (-Q.g2 * s2_c3) * ih; Q.coef[8] = (-Q.g2 * s2_c4 - Q.g0) * ih;
     }
 
-    // ---------------------------------------------------------------- factorization sweep
-    // Condense contacts and limits, then eliminate supernodes leaves -> root.
-    DJ_HD void factorize(T* Smat, T* Umat, T* Lmat, T* Dup) {
-        // contact condensation into D_b:  D_b −= −G134·coef·C134  i.e. rows get −G Δγ  =>  S −= G134ᵀ...
+    // ---------------------------------------------------------------- condensation of the cone rows
+    // Contacts and joint limits are eliminated analytically onto the body rows.
+    template <class BK>
+    DJ_HD void condense(BK& K) {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
                 CCoef Q; T rc[4] = {0, 0, 0, 0}, r58[4] = {0, 0, 0, 0};
                 contact_coef(Q, c, rc, r58);
                 // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
-                for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-                    T acc = T(0);
-                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc += F.G134[c][6 * a + i] * Q.coef[3 * a + b] * F.C134[c][6 * b + j];
-                    Smat[12 * i + j] -= acc;
-                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) acc += cold.G134[c][6 * a + i] * Q.coef[3 * a + b] * cold.C134[c][6 * b + j];
+                        K.addS(i, j, -acc);
+                    }
             }
         }
         // limit condensation: rows x get + wκ t_x (θ_a Δω_a + θ_b Δω_b)
         if (P.nlim_r > 0) {
             T wk = (L.lg[1][1] + T(REG)) / (L.ls[1][1] + T(REG)) + (L.lg[1][0] + T(REG)) / (L.ls[1][0] + T(REG));
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) {
-                Smat[12 * i + 3 + j] += wk * F.t_b[i] * F.th_b[j];
-                Umat[6 * i + 3 + j] += wk * F.t_b[i] * F.th_a[j];
-                Lmat[12 * i + 3 + j] += wk * F.t_a[i] * F.th_b[j];
-                Dup[6 * i + 3 + j] += wk * F.t_a[i] * F.th_a[j];
-            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    K.addS(i, 3 + j, wk * F.t_b[i] * F.th_b[j]);
+                    K.addU(i, 3 + j, wk * F.t_b[i] * F.th_a[j]);
+                    K.addL(i, 3 + j, wk * F.t_a[i] * F.th_b[j]);
+                    K.addD(i, 3 + j, wk * F.t_a[i] * F.th_a[j]);
+                }
         }
+    }
+
+    // ---------------------------------------------------------------- factorization sweep (lane = supernode)
+    // Eliminates supernodes leaves -> root.
+    DJ_HD void factorize(FullBlocks<T>& K) {
+        T* Smat = K.S; T* Umat = K.U; T* Lmat = K.L; T* Dup = K.D;
         // leaves -> root, in the factorization precision
         TL Sl[144], Ul[72], Ll[72], up[36];
         for (int i = 0; i < 144; ++i) Sl[i] = TL(Smat[i]);
@@ -815,7 +918,7 @@ struct LaneProgram {
             // receive the children's contributions (they were produced at lev+1)
             TL acc[36];
             for (int i = 0; i < 36; ++i) acc[i] = TL(0);
-            gather_children<36>(wv, acc, up, P, base, G.maxch, active && P.level == lev);
+            gather_children<36>(wv, acc, up, P, base, G.maxch, active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Sl[12 * i + j] += acc[6 * i + j];
                 for (int i = 0; i < 144; ++i) F.Sinv[i] = Sl[i];
@@ -828,6 +931,346 @@ struct LaneProgram {
                 }
             }
         }
+    }
+
+    // ---------------------------------------------------------------- quad mapping: distributed factorization
+    // In-place Gauss-Jordan inverse of the 12x12 supernode matrix whose rows are spread over the four
+    // lanes of the quad: for every pivot the owner's (normalised) pivot row is broadcast with 12
+    // shuffles and every lane updates its three rows.  No W / Z are stored: the solves use the row
+    // block of S⁻¹ together with the lane's rows of U and columns of L.
+    DJ_HD void factorize_quad(QuadBlocks<T>& K) {
+        TL Sl[3][12], up[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) Sl[i][j] = TL(K.S[i][j]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { up[i][j] = TL(0); F.Uq[i][j] = TL(K.U[i][j]); F.Lq[j][i] = TL(K.L[j][i]); }
+        }
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            const bool at = active && P.level == lev;
+            // children's Schur complements: rows 0:3 go to role 0, rows 3:6 to role 1 (same role on the child side)
+            TL acc[18], upf[18];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
+            gather_children<18>(wv, acc, upf, P, base, G.maxch, at, stride, q);
+            if (at && q < 2) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) Sl[i][j] += acc[6 * i + j];
+            }
+            // distributed Gauss-Jordan (all lanes take part in the shuffles; only lanes at this level keep the result)
+            TL A[3][12];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 12; ++j) A[i][j] = Sl[i][j];
+#pragma unroll
+            for (int p = 0; p < 12; ++p) {
+                const int o = p / 3, ro = p % 3;
+                TL prow[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) prow[c] = wv.quad_bcast(A[ro][c], o);
+                TL ip = TL(1) / prow[p];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) prow[c] = (c == p) ? ip : prow[c] * ip;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool is_piv = (q == o) && (r == ro);
+                    TL f = A[r][p];
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) {
+                        TL upd = (c == p) ? -f * ip : A[r][c] - f * prow[c];
+                        A[r][c] = is_piv ? prow[c] : upd;
+                    }
+                }
+            }
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) F.Sq[i][j] = A[i][j];
+            }
+            // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero)
+            TL Uf[12][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { Uf[0][j] = Uf[1][j] = Uf[2][j] = TL(0); }
+#pragma unroll
+            for (int o = 1; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) Uf[3 * o + i][j] = wv.quad_bcast(F.Uq[i][j], o);
+            TL Tq[3][6], part[36];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    TL a_ = TL(0);
+#pragma unroll
+                    for (int m_ = 3; m_ < 12; ++m_) a_ += A[i][m_] * Uf[m_][j];
+                    Tq[i][j] = a_;
+                }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) part[6 * i + j] = F.Lq[i][0] * Tq[0][j] + F.Lq[i][1] * Tq[1][j] + F.Lq[i][2] * Tq[2][j];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) { part[i] += wv.quad_xor(part[i], 1); }
+#pragma unroll
+            for (int i = 0; i < 36; ++i) { part[i] += wv.quad_xor(part[i], 2); }
+            if (at && has_parent) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        TL rowv = (q == 0) ? part[6 * i + j] : part[6 * (3 + i) + j];
+                        up[i][j] = (q < 2) ? TL(K.D[i][j]) - rowv : TL(0);
+                    }
+            }
+        }
+    }
+
+    // quad mapping: NC right-hand sides at once through the tree (own rows only).  The NC chains of
+    // shuffles are independent, which hides the ds_bpermute latency in the IFT back-solves.
+    template <int NC, class TF>
+    DJ_HD void solve_quad_multi(const TF (*Sq)[12], const TF (*Uq)[6], const TF (*Lq)[3], TF (*r3)[3], const TF (*u3)[3], TF (*d3)[3]) {
+        TF y3[NC][3], send3[NC][3];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) { y3[n][0] = y3[n][1] = y3[n][2] = TF(0); send3[n][0] = send3[n][1] = send3[n][2] = TF(0); }
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            const bool at = active && P.level == lev;
+            TF acc[3 * NC], snd[3 * NC];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) { for (int i = 0; i < 3; ++i) { acc[3 * n + i] = TF(0); snd[3 * n + i] = send3[n][i]; } }
+            gather_children<3 * NC>(wv, acc, snd, P, base, G.maxch, at, stride, q);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                if (at) { r3[n][0] += acc[3 * n]; r3[n][1] += acc[3 * n + 1]; r3[n][2] += acc[3 * n + 2]; }
+                TF rf[12];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) rf[3 * o + i] = wv.quad_bcast(r3[n][i], o);
+                TF yy[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
+#pragma unroll
+                    for (int m_ = 0; m_ < 12; ++m_) a_ += Sq[i][m_] * rf[m_];
+                    yy[i] = a_; }
+                TF part[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] = Lq[i][0] * yy[0] + Lq[i][1] * yy[1] + Lq[i][2] * yy[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
+                if (at) {
+                    y3[n][0] = yy[0]; y3[n][1] = yy[1]; y3[n][2] = yy[2];
+                    if (has_parent) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) send3[n][i] = (q == 0) ? u3[n][i] - part[i] : (q == 1) ? u3[n][i] - part[3 + i] : TF(0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NC; ++n) { d3[n][0] = y3[n][0]; d3[n][1] = y3[n][1]; d3[n][2] = y3[n][2]; }
+        const int pb = has_parent ? base + stride * P.parent : qb;
+        for (int lev = 1; lev <= G.maxlevel; ++lev) {
+            const bool at = active && P.level == lev && has_parent;
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                TF pa_[6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[n][i], pb); pa_[3 + i] = wv.shfl(d3[n][i], pb + 1); }
+                TF t3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) a_ += Uq[i][j] * pa_[j];
+                    t3[i] = a_; }
+                TF tf[12];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
+                if (at) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
+#pragma unroll
+                        for (int m_ = 0; m_ < 12; ++m_) a_ += Sq[i][m_] * tf[m_];
+                        d3[n][i] = y3[n][i] - a_; }
+                }
+            }
+        }
+    }
+
+    // quad mapping: IFT column solves, six columns per sweep
+    template <class KA, class GB, class KN>
+    DJ_HD void gradient_columns_quad(const KA& A, int env, const GB& gb, const T (*GK)[6][4], T wk, const KN& kb0) {
+        const T dt = G.dt;
+        const int nx = 12 * G.Nb;
+        typedef decltype(A.dz) OutPtr;
+        const int ro = q == 1 ? 3 : 0;                         // first body row owned by roles 0 / 1
+        // the back-solves run in the precision of the ABI buffers (fp32 results do not need fp64 solves)
+        typedef typename KA::io_type TG;
+        TG Sg[3][12], Ug[3][6], Lg[6][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) Sg[i][j] = TG(F.Sq[i][j]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { Ug[i][j] = TG(F.Uq[i][j]); Lg[j][i] = TG(F.Lq[j][i]); }
+        }
+        for (int kk = 0; kk < G.Nb; ++kk) {
+            const bool mine = active && (k == kk), child_of = active && has_parent && (P.parent == kk);
+            for (int batch = 0; batch < 2; ++batch) {          // 0: configuration columns (x2, φ2), 1: velocity columns (v15, ω15)
+                TG r3[6][3], u3[6][3], d3[6][3];
+#pragma unroll
+                for (int cI = 0; cI < 6; ++cI) {
+                    const int c = batch == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
+                    T r_[3] = {0, 0, 0}, u_[3] = {0, 0, 0}, rs0 = T(0);
+                    if (mine) {
+                        if (q < 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnB[ro + i][c]); }
+                        if (batch == 0) {
+                            if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnJ[3 * (q - 2) + i][cI]); }
+                            else {
+                                for (int i = 0; i < 3; ++i) u_[i] = T(gb.UpOwn[ro + i][cI]);
+#pragma unroll
+                                for (int cn = 0; cn < MAXC; ++cn) if (cn < P.ncontact) {
+                                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) r_[i] += (q == 0 ? GK[cn][i][j] : GK[cn][3 + i][j]) * T(gb.Cc[cn][j][cI]);
+                                }
+                            }
+                            rs0 = T(gb.sl_own[cI]);
+                        }
+                    } else if (child_of && batch == 0) {
+                        if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.ParJ[3 * (q - 2) + i][cI]); }
+                        else { for (int i = 0; i < 3; ++i) { r_[i] = T(gb.ParB[ro + i][cI]); u_[i] = T(gb.UpPar[ro + i][cI]); } }
+                        rs0 = T(gb.sl_par[cI]);
+                    }
+                    if (P.nlim_r > 0 && q < 2) { T kap0 = wk * rs0; for (int i = 0; i < 3; ++i) { r_[i] += (q == 0 ? F.t_b[i] : F.t_b[3 + i]) * kap0; u_[i] += (q == 0 ? F.t_a[i] : F.t_a[3 + i]) * kap0; } }
+                    for (int i = 0; i < 3; ++i) { r3[cI][i] = TG(r_[i]); u3[cI][i] = TG(u_[i]); }
+                }
+                solve_quad_multi<6, TG>(Sg, Ug, Lg, r3, u3, d3);
+                if (active && q < 2 && A.dz) {
+#pragma unroll
+                    for (int cI = 0; cI < 6; ++cI) {
+                        const int c = batch == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
+                        OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k + 6 * q;
+                        T d_[3] = {T(d3[cI][0]), T(d3[cI][1]), T(d3[cI][2])};
+                        if (q == 0) {
+                            for (int i = 0; i < 3; ++i) { T x = dt * d_[i]; if (mine && batch == 0 && cI == i) x += T(1); o[i] = x; o[3 + i] = d_[i]; }
+                        } else {
+                            T pw[3];
+                            m3vec(pw, kb0.Phi, d_);
+                            for (int i = 0; i < 3; ++i) { T ph = pw[i]; if (mine && batch == 0 && cI >= 3) ph += kb0.Xi[3 * i + (cI - 3)]; o[i] = ph; o[3 + i] = d_[i]; }
+                        }
+                    }
+                }
+            }
+        }
+        // control columns, joint by joint (owner quad = child body of the joint); up to six inputs per joint
+        for (int kk = 0; kk < G.Nb; ++kk) {
+            const NodeP<T>& Pk = A.nodes[kk];
+            const int nuk = Pk.nu_t + Pk.nu_r;
+            if (nuk == 0) continue;
+            const bool mine = active && (k == kk);
+            TG r3[6][3], u3[6][3], d3[6][3];
+#pragma unroll
+            for (int cI = 0; cI < 6; ++cI) for (int i = 0; i < 3; ++i) {
+                r3[cI][i] = (mine && q < 2 && cI < nuk) ? TG(gb.UB[ro + i][cI]) : TG(0);
+                u3[cI][i] = (mine && q < 2 && cI < nuk) ? TG(gb.UA[ro + i][cI]) : TG(0);
+            }
+            solve_quad_multi<6, TG>(Sg, Ug, Lg, r3, u3, d3);
+            if (active && q < 2 && A.du) {
+#pragma unroll
+                for (int cI = 0; cI < 6; ++cI) if (cI < nuk) {
+                    OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + cI)) * nx + 12 * k + 6 * q;
+                    T d_[3] = {T(d3[cI][0]), T(d3[cI][1]), T(d3[cI][2])};
+                    if (q == 0) { for (int i = 0; i < 3; ++i) { o[i] = dt * d_[i]; o[3 + i] = d_[i]; } }
+                    else { T pw[3]; m3vec(pw, kb0.Phi, d_); for (int i = 0; i < 3; ++i) { o[i] = pw[i]; o[3 + i] = d_[i]; } }
+                }
+            }
+        }
+    }
+
+    // quad mapping: solve with the distributed factors
+    DJ_HD void solve_quad(const T* rk, const T* upv, T* dk_out, T* dva_out) {
+        TL r3[3], y3[3] = {0, 0, 0}, send3[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r3[i] = TL(q == 0 ? rk[i] : q == 1 ? rk[3 + i] : q == 2 ? rk[6 + i] : rk[9 + i]);
+        // forward: leaves -> root
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            const bool at = active && P.level == lev;
+            TL acc[3] = {0, 0, 0};
+            gather_children<3>(wv, acc, send3, P, base, G.maxch, at, stride, q);
+            if (at) { r3[0] += acc[0]; r3[1] += acc[1]; r3[2] += acc[2]; }
+            TL rf[12];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) rf[3 * o + i] = wv.quad_bcast(r3[i], o);
+            TL yy[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { TL a_ = TL(0);
+#pragma unroll
+                for (int m_ = 0; m_ < 12; ++m_) a_ += F.Sq[i][m_] * rf[m_];
+                yy[i] = a_; }
+            TL part[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) part[i] = F.Lq[i][0] * yy[0] + F.Lq[i][1] * yy[1] + F.Lq[i][2] * yy[2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
+            if (at) {
+                y3[0] = yy[0]; y3[1] = yy[1]; y3[2] = yy[2];
+                if (has_parent) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) send3[i] = (q == 0) ? TL(upv[i]) - part[i] : (q == 1) ? TL(upv[3 + i]) - part[3 + i] : TL(0);
+                }
+            }
+        }
+        // backward: root -> leaves
+        TL d3[3] = {y3[0], y3[1], y3[2]};
+        TL dva[6] = {0, 0, 0, 0, 0, 0};
+        const int pb = has_parent ? base + stride * P.parent : qb;
+        for (int lev = 1; lev <= G.maxlevel; ++lev) {
+            const bool at = active && P.level == lev && has_parent;
+            TL pa_[6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[i], pb); pa_[3 + i] = wv.shfl(d3[i], pb + 1); }
+            TL t3[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { TL a_ = TL(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) a_ += F.Uq[i][j] * pa_[j];
+                t3[i] = a_; }
+            TL tf[12];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dva[i] = pa_[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { TL a_ = TL(0);
+#pragma unroll
+                    for (int m_ = 0; m_ < 12; ++m_) a_ += F.Sq[i][m_] * tf[m_];
+                    d3[i] = y3[i] - a_; }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dk_out[3 * o + i] = T(wv.quad_bcast(d3[i], o));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dva_out[i] = T(dva[i]);
     }
 
     // ---------------------------------------------------------------- solve with the current factors
@@ -843,7 +1286,7 @@ struct LaneProgram {
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
                 contact_coef(Q[c], c, R.cc[c], r58[c]);
-                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += F.G134[c][6 * a + i] * Q[c].k0[a];
+                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += cold.G134[c][6 * a + i] * Q[c].k0[a];
             }
         }
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0);
@@ -852,33 +1295,10 @@ struct LaneProgram {
             kap0 = (R.lim[1] - gl * rsl) / sl - (R.lim[0] - gu * rsu) / su;
             for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; up[i] += F.t_a[i] * kap0; }
         }
-        // forward: leaves -> root (factorization precision)
-        TL rl[12], y[12], send[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
-        for (int lev = G.maxlevel; lev >= 0; --lev) {
-            TL acc[6] = {0, 0, 0, 0, 0, 0};
-            gather_children<6>(wv, acc, send, P, base, G.maxch, active && P.level == lev);
-            if (active && P.level == lev) {
-                for (int i = 0; i < 6; ++i) rl[i] += acc[i];
-                if (has_parent) { TL t[6]; mv<6, 12>(t, F.W, rl); for (int i = 0; i < 6; ++i) send[i] = TL(up[i]) - t[i]; }
-            }
-        }
-        mv<12, 12>(y, F.Sinv, rl);
-        // backward: root -> leaves
-        TL dk[12];
-        for (int i = 0; i < 12; ++i) dk[i] = y[i];
-        T dva[6] = {0, 0, 0, 0, 0, 0};
-        for (int lev = 1; lev <= G.maxlevel; ++lev) {
-            TL par[6];
-            shfl_vec<6>(wv, par, dk, plane);
-            if (active && P.level == lev && has_parent) {
-                for (int i = 0; i < 6; ++i) dva[i] = T(par[i]);
-                TL t[12]; mv<12, 6>(t, F.Z, par);
-                for (int i = 0; i < 12; ++i) dk[i] = y[i] - t[i];
-            }
-        }
-        for (int i = 0; i < 3; ++i) { D.dv[i] = T(dk[i]); D.dw[i] = T(dk[3 + i]); }
-        for (int i = 0; i < 6; ++i) D.dlam[i] = T(dk[6 + i]);
+        T dk[12], dva[6];
+        core_solve(rk, up, dk, dva);
+        for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
+        for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
         // recovery of the condensed variables
         if (P.nlim_r > 0) {
             T thd = v3dot(F.th_a, dva + 3) + v3dot(F.th_b, D.dw);
@@ -891,7 +1311,7 @@ struct LaneProgram {
             if (c < P.ncontact) {
                 const ContactP<T>& K = CP[P.contact[c]];
                 T cw[3];
-                for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += F.C134[c][6 * a + j] * D.dv[j] + F.C134[c][6 * a + 3 + j] * D.dw[j]; }
+                for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += cold.C134[c][6 * a + j] * D.dv[j] + cold.C134[c][6 * a + 3 + j] * D.dw[j]; }
                 const CCoef& q = Q[c];
                 T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
                 T dg1 = q.a1 + q.b1 * cw[0];
@@ -904,6 +1324,41 @@ struct LaneProgram {
                 D.dcs[c][0] = ds1; D.dcs[c][1] = ds2; D.dcs[c][2] = ds3; D.dcs[c][3] = ds4;
                 D.dcg[c][0] = dg1; D.dcg[c][1] = dg2; D.dcg[c][2] = dg3; D.dcg[c][3] = dg4;
             } else { for (int i = 0; i < 4; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
+        }
+    }
+
+    // forward / backward substitution through the tree with the current factors:
+    // rk = rhs of this supernode's 12 rows (cone rows already condensed), up = direct rhs for the parent's body rows
+    DJ_HD void core_solve(const T* rk, const T* up, T* dk, T* dva) {
+        for (int i = 0; i < 6; ++i) dva[i] = T(0);
+        if constexpr (QUAD) {
+            solve_quad(rk, up, dk, dva);
+        } else {
+        // forward: leaves -> root (factorization precision)
+        TL rl[12], y[12], send[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            TL acc[6] = {0, 0, 0, 0, 0, 0};
+            gather_children<6>(wv, acc, send, P, base, G.maxch, active && P.level == lev, stride, q);
+            if (active && P.level == lev) {
+                for (int i = 0; i < 6; ++i) rl[i] += acc[i];
+                if (has_parent) { TL t[6]; mv<6, 12>(t, F.W, rl); for (int i = 0; i < 6; ++i) send[i] = TL(up[i]) - t[i]; }
+            }
+        }
+        mv<12, 12>(y, F.Sinv, rl);
+        // backward: root -> leaves
+        TL dkl[12];
+        for (int i = 0; i < 12; ++i) dkl[i] = y[i];
+        for (int lev = 1; lev <= G.maxlevel; ++lev) {
+            TL par[6];
+            shfl_vec<6>(wv, par, dkl, plane);
+            if (active && P.level == lev && has_parent) {
+                for (int i = 0; i < 6; ++i) dva[i] = T(par[i]);
+                TL t[12]; mv<12, 6>(t, F.Z, par);
+                for (int i = 0; i < 12; ++i) dkl[i] = y[i] - t[i];
+            }
+        }
+        for (int i = 0; i < 12; ++i) dk[i] = T(dkl[i]);
         }
     }
 
@@ -936,30 +1391,32 @@ struct LaneProgram {
                 a = tmin(a, ort_step(L.lg[1][i], D.dlg[i], tort));
             }
         }
-        return env_min(wv, a, G.S);
+        return env_min(wv, a, envl);
     }
 
-    // candidate_step!  src/solver/line_search.jl:141-163.  Returns 1 if ω had to be clipped beyond the error threshold.
-    DJ_HD int candidate_step(const Step<T, MAXC>& D, T f) {
+    // candidate_step!  src/solver/line_search.jl:141-163: candidate = base + f Δ (base = the current iterate,
+    // live only during the line search).  Returns 1 if ω stays beyond the error threshold after clipping.
+    DJ_HD void snapshot(SolSnap<T, MAXC>& B) const {
+        for (int i = 0; i < 3; ++i) { B.v[i] = L.v[1][i]; B.w[i] = L.w[1][i]; }
+        for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[1][i];
+        for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[1][i]; B.lg[i] = L.lg[1][i]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { B.cs[c][i] = L.cs[1][c][i]; B.cg[c][i] = L.cg[1][c][i]; }
+    }
+    DJ_HD int candidate_step(const SolSnap<T, MAXC>& B, const Step<T, MAXC>& D, T f) {
         int bad = 0;
-        for (int i = 0; i < 3; ++i) { L.v[1][i] = L.v[0][i] + f * D.dv[i]; L.w[1][i] = L.w[0][i] + f * D.dw[i]; }
+        for (int i = 0; i < 3; ++i) { L.v[1][i] = B.v[i] + f * D.dv[i]; L.w[1][i] = B.w[i] + f * D.dw[i]; }
         T wmax = T(3.9) / (G.dt * G.dt);
         T wd = v3dot(L.w[1], L.w[1]);
         if (wd > wmax) { T sc = wmax / wd; for (int i = 0; i < 3; ++i) L.w[1][i] *= sc; }
         if (v3dot(L.w[1], L.w[1]) > T(3.91) / (G.dt * G.dt)) bad = 1;
-        for (int i = 0; i < 6; ++i) L.lam[1][i] = L.lam[0][i] + f * D.dlam[i];
-        for (int i = 0; i < 2; ++i) { L.ls[1][i] = L.ls[0][i] + f * D.dls[i]; L.lg[1][i] = L.lg[0][i] + f * D.dlg[i]; }
+        for (int i = 0; i < 6; ++i) L.lam[1][i] = B.lam[i] + f * D.dlam[i];
+        for (int i = 0; i < 2; ++i) { L.ls[1][i] = B.ls[i] + f * D.dls[i]; L.lg[1][i] = B.lg[i] + f * D.dlg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[1][c][i] = L.cs[0][c][i] + f * D.dcs[c][i]; L.cg[1][c][i] = L.cg[0][c][i] + f * D.dcg[c][i]; }
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[1][c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[1][c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
         return bad;
     }
-    DJ_HD void accept_candidate() {     // update!  src/solver/linear_system.jl:54-69
-        for (int i = 0; i < 3; ++i) { L.v[0][i] = L.v[1][i]; L.w[0][i] = L.w[1][i]; }
-        for (int i = 0; i < 6; ++i) L.lam[0][i] = L.lam[1][i];
-        for (int i = 0; i < 2; ++i) { L.ls[0][i] = L.ls[1][i]; L.lg[0][i] = L.lg[1][i]; }
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[0][c][i] = L.cs[1][c][i]; L.cg[0][c][i] = L.cg[1][c][i]; }
-    }
+
     // ---------------------------------------------------------------- set-up of one step
     // set_maximal_state! + set_input! (src/mechanism/set.jl:10-53): loads z, applies u, builds dconst.
     DJ_HD void begin_step(const T* zb /*13 values of this body*/, const T* u /*this joint's inputs (<= 6) or null*/) {
@@ -978,8 +1435,8 @@ struct LaneProgram {
         else { L.xa2[0] = L.xa2[1] = L.xa2[2] = T(0); L.qa2[0] = T(1); L.qa2[1] = L.qa2[2] = L.qa2[3] = T(0); }
         joint_cfg(cfg, P, L.xa2, L.qa2, L.x2, L.q2);
         // warm start (set_velocity_solution!, bodies/set.jl:1-7), reset!/initialize! of the cone variables
-        for (int i = 0; i < 3; ++i) { L.v[0][i] = L.v[1][i] = v15[i]; L.w[0][i] = L.w[1][i] = w15[i]; L.v15[i] = v15[i]; L.w15[i] = w15[i]; }
-        for (int j = 0; j < 2; ++j) {
+        for (int i = 0; i < 3; ++i) { L.v[1][i] = v15[i]; L.w[1][i] = w15[i]; L.v15[i] = v15[i]; L.w15[i] = w15[i]; }
+        for (int j = 1; j < 2; ++j) {
             for (int i = 0; i < 6; ++i) L.lam[j][i] = T(0);
             for (int i = 0; i < 2; ++i) { L.ls[j][i] = T(1); L.lg[j][i] = T(1); }            // joints/constraints.jl:440-448
 #pragma unroll
@@ -1020,7 +1477,7 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) L.dconst[i] -= sb[i];
         T up[6], acc[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -(ina[i] + sa[i]) : T(0);
-        gather_children<6>(wv, acc, up, P, base, G.maxch, active);
+        gather_children<6>(wv, acc, up, P, base, G.maxch, active, stride, q);
         for (int i = 0; i < 6; ++i) L.dconst[i] += acc[i];
         mu = T(0);
     }
@@ -1032,25 +1489,31 @@ struct LaneProgram {
     // set_entries! followed at once by the supernode factorization, so that the un-factored blocks
     // (S, U, L, Dup: 324 scalars) are transient and only the factors persist through the solves.
     DJ_HD void linearize() {
-        T Smat[144], Umat[72], Lmat[72], Dup[36];
-        evaluate<true>(Smat, Umat, Lmat, Dup);
+        if constexpr (QUAD) {
+            QuadBlocks<T> K;
+            K.q = q;
+            evaluate<true>(K);
+            condense(K);
+            factorize_quad(K);
+            return;
+        } else {
+        FullBlocks<T> K;
+        evaluate<true>(K);
+        condense(K);
 #ifdef DJ_DEBUG
-        if (dbg_on && dbg) {   // test hook: dump the first assembly of this lane
+        if (dbg_on && dbg) {   // test hook: dump the first assembly of this lane (after condensation)
             T* o = dbg; int q = 0;
             for (int i = 0; i < 6; ++i) o[q++] = rb[i];
             for (int i = 0; i < 6; ++i) o[q++] = rj[i];
             o[q++] = theta;
-            for (int i = 0; i < 144; ++i) o[q++] = Smat[i];
-            for (int i = 0; i < 72; ++i) o[q++] = Umat[i];
-            for (int i = 0; i < 72; ++i) o[q++] = Lmat[i];
-            for (int i = 0; i < 36; ++i) o[q++] = Dup[i];
-            for (int i = 0; i < 3; ++i) o[q++] = F.th_a[i];
-            for (int i = 0; i < 3; ++i) o[q++] = F.th_b[i];
-            for (int i = 0; i < 6; ++i) o[q++] = F.t_a[i];
-            for (int i = 0; i < 6; ++i) o[q++] = F.t_b[i];
+            for (int i = 0; i < 144; ++i) o[q++] = K.S[i];
+            for (int i = 0; i < 72; ++i) o[q++] = K.U[i];
+            for (int i = 0; i < 72; ++i) o[q++] = K.L[i];
+            for (int i = 0; i < 36; ++i) o[q++] = K.D[i];
         }
 #endif
-        factorize(Smat, Umat, Lmat, Dup);
+        factorize(K);
+        }
     }
 
     DJ_HD int mehrotra(int& iters_out) {
@@ -1090,7 +1553,7 @@ struct LaneProgram {
                 }
                 if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[1][i] * L.lg[1][i]; p1 += (L.ls[1][i] + aaff * D.dls[i]) * (L.lg[1][i] + aaff * D.dlg[i]); p2 += T(1); }
             }
-            p0 = env_sum(wv, p0, G.S); p1 = env_sum(wv, p1, G.S); p2 = env_sum(wv, p2, G.S);
+            p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl);
             T munew = G.btol / undercut;
             if (p2 > T(0)) {
                 T nu = p0 / p2, nuaff = p1 / p2;
@@ -1118,13 +1581,15 @@ struct LaneProgram {
             {
                 bool searching = !done;
                 T f = done ? T(0) : alpha;
+                SolSnap<T, MAXC> base_sol;
+                snapshot(base_sol);
                 for (int ls = 0; ls < G.max_ls; ++ls) {
                     if (!wv.any(active && searching)) break;
-                    int bad = candidate_step(D, f);                 // finished searches recompute the same candidate
-                    evaluate<false>(nullptr, nullptr, nullptr, nullptr);
+                    int bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
+                    { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
-                    int anybad = env_or(wv, (active && searching) ? bad : 0, G.S);
+                    int anybad = env_or(wv, (active && searching) ? bad : 0, envl);
                     if (searching) {
                         excessive |= anybad;
                         rc = r2; bc = b2;
@@ -1137,7 +1602,6 @@ struct LaneProgram {
                 if (made) no_progress = no_progress > 0 ? no_progress - 1 : 0; else no_progress += 1;
                 rvio = rc; bvio = bc;
                 if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
-                accept_candidate();
                 mu = mutarget;
             }
             linearize();                                            // set_entries! + factorization (cone rows now carry the new μ)
@@ -1182,7 +1646,7 @@ struct LaneProgram {
         kin_of(kb, x2e, q2e, L.v[1], L.w[1], dt);
         kin_of(ka, xa2e, qa2e, va, wa, dt);
         JointEval<T> E;
-        joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr);
+        { NullBlocks nk; joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, nk); }
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -1260,12 +1724,53 @@ struct LaneProgram {
                 for (int r = 0; r < 3; ++r) { UB[3 + r][P.nu_t + i] = G.input_scaling * tb[r]; UA[3 + r][P.nu_t + i] = -G.input_scaling * ta[r]; }
             }
         }
-        // ---- column loop ----
-        ConeRhs R0;
+        // ---- condensation maps for a right-hand side without cone terms (computed once) ----
+        // contact rows r58 -> body rhs:  rk[0:6] += GK r58 ;  limit slack rows (rs, −rs) -> rk += t_b wk rs, up += t_a wk rs
+        T GK[MAXC][6][4], wk = T(0);
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) R0.cc[c][i] = T(0);
-        R0.lim[0] = R0.lim[1] = T(0);
-        Step<T, MAXC> D;
+        for (int c = 0; c < MAXC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T rc0[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
+                e[j] = T(1);
+                CCoef Q;
+                if (c < P.ncontact) contact_coef(Q, c, rc0, e); else { Q.k0[0] = Q.k0[1] = Q.k0[2] = T(0); }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) GK[c][i][j] = (c < P.ncontact) ? cold.G134[c][i] * Q.k0[0] + cold.G134[c][6 + i] * Q.k0[1] + cold.G134[c][12 + i] * Q.k0[2] : T(0);
+            }
+        }
+        if (P.nlim_r > 0) wk = (L.lg[1][1] + T(REG)) / (L.ls[1][1] + T(REG)) + (L.lg[1][0] + T(REG)) / (L.ls[1][0] + T(REG));
+        // ---- stash the data blocks: one copy per supernode in LDS (quad mapping), else per-lane local memory ----
+        typedef typename KA::io_type TB;
+        GradBlocks<TB, MAXC> gb_local;
+        GradBlocks<TB, MAXC>* gbp = &gb_local;
+        if constexpr (QUAD) { wv.sync(); gbp = ((GradBlocks<TB, MAXC>*)wv.lds()) + (wv.lane() / 4); }   // aliases Cold: not needed below
+        if (!QUAD || q == 0) {
+            GradBlocks<TB, MAXC>& g_ = *gbp;
+            for (int i = 0; i < 6; ++i) {
+                for (int j = 0; j < 12; ++j) g_.OwnB[i][j] = TB(OwnB[i][j]);
+                for (int j = 0; j < 6; ++j) { g_.OwnJ[i][j] = TB(OwnJ[i][j]); g_.ParB[i][j] = TB(ParB[i][j]); g_.ParJ[i][j] = TB(ParJ[i][j]); g_.UpOwn[i][j] = TB(UpOwn[i][j]); g_.UpPar[i][j] = TB(UpPar[i][j]); g_.UB[i][j] = TB(UB[i][j]); g_.UA[i][j] = TB(UA[i][j]); }
+                g_.sl_own[i] = TB(sl_own[i]); g_.sl_par[i] = TB(sl_par[i]);
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) g_.Cc[c][i][j] = TB(Cc[c][i][j]);
+        }
+        if constexpr (QUAD) wv.sync();
+        const GradBlocks<TB, MAXC>& gb = *gbp;
+        if constexpr (QUAD) { gradient_columns_quad(A, env, gb, GK, wk, kb0); return; }
+        // ---- column loop (lane = supernode mapping) ----
+        struct { T dv[3], dw[3]; } D;
+        auto grad_solve = [&](T* rk, T rs0, const T (*r58)[4], T* upx) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rk[i] += GK[c][i][0] * r58[c][0] + GK[c][i][1] * r58[c][1] + GK[c][i][2] * r58[c][2] + GK[c][i][3] * r58[c][3];
+            }
+            if (P.nlim_r > 0) { T kap0 = wk * rs0; for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; upx[i] += F.t_a[i] * kap0; } }
+            T dk[12], dva[6];
+            core_solve(rk, upx, dk, dva);
+            for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
+        };
         typedef decltype(A.dz) OutPtr;
         for (int kk = 0; kk < G.Nb; ++kk) {
             const bool mine = active && (k == kk), child_of = active && has_parent && (P.parent == kk);
@@ -1277,19 +1782,19 @@ struct LaneProgram {
 #pragma unroll
                 for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
                 if (mine) {
-                    for (int i = 0; i < 6; ++i) rk[i] = OwnB[i][c];
+                    for (int i = 0; i < 6; ++i) rk[i] = T(gb.OwnB[i][c]);
                     if (is_cfg) {
-                        for (int i = 0; i < 6; ++i) { rk[6 + i] = OwnJ[i][cc]; upx[i] = UpOwn[i][cc]; }
-                        rs[0] = sl_own[cc]; rs[1] = -sl_own[cc];
+                        for (int i = 0; i < 6; ++i) { rk[6 + i] = T(gb.OwnJ[i][cc]); upx[i] = T(gb.UpOwn[i][cc]); }
+                        rs[0] = T(gb.sl_own[cc]); rs[1] = -rs[0];
 #pragma unroll
-                        for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = Cc[q_][i][cc];
+                        for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(gb.Cc[q_][i][cc]);
                     }
                 } else if (child_of && is_cfg) {
-                    for (int i = 0; i < 6; ++i) { rk[i] = ParB[i][cc]; rk[6 + i] = ParJ[i][cc]; upx[i] = UpPar[i][cc]; }
-                    rs[0] = sl_par[cc]; rs[1] = -sl_par[cc];
+                    for (int i = 0; i < 6; ++i) { rk[i] = T(gb.ParB[i][cc]); rk[6 + i] = T(gb.ParJ[i][cc]); upx[i] = T(gb.UpPar[i][cc]); }
+                    rs[0] = T(gb.sl_par[cc]); rs[1] = -rs[0];
                 }
-                solve_rhs(rk, R0, rs, r58, upx, D);
-                if (active && A.dz) {
+                grad_solve(rk, rs[0], r58, upx);
+                if (active && q == 0 && A.dz) {
                     OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k;
                     T pw[3];
                     m3vec(pw, kb0.Phi, D.dw);
@@ -1312,9 +1817,9 @@ struct LaneProgram {
                 for (int i = 0; i < 12; ++i) rk[i] = T(0);
 #pragma unroll
                 for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
-                if (mine) for (int i = 0; i < 6; ++i) { rk[i] = UB[i][c]; upx[i] = UA[i][c]; }
-                solve_rhs(rk, R0, rs, r58, upx, D);
-                if (active && A.du) {
+                if (mine) for (int i = 0; i < 6; ++i) { rk[i] = T(gb.UB[i][c]); upx[i] = T(gb.UA[i][c]); }
+                grad_solve(rk, rs[0], r58, upx);
+                if (active && q == 0 && A.du) {
                     OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + c)) * nx + 12 * k;
                     T pw[3];
                     m3vec(pw, kb0.Phi, D.dw);
@@ -1340,6 +1845,7 @@ struct LaneProgram {
 // TIO = scalar type of the ABI buffers, T = state/residual precision (tables are stored in T)
 template <class TIO, class T>
 struct KernelArgs {
+    typedef TIO io_type;
     Globals<T> G;
     const NodeP<T>* nodes;
     const ContactP<T>* contacts;
@@ -1359,17 +1865,30 @@ struct KernelArgs {
 #endif
 };
 
-template <class TIO, class T, class TL, int MAXC, bool GRAD, class Wave>
+// bytes of LDS one wavefront of the step kernel needs
+template <class TIO, class T, int MAXC, bool GRAD, bool QUAD>
+constexpr int step_lds_bytes() {
+    int cold = (QUAD && sizeof(Cold<T, MAXC>) * 64 <= 40 * 1024) ? (int)sizeof(Cold<T, MAXC>) * 64 : 0;
+    int gb = (QUAD && GRAD) ? (int)sizeof(GradBlocks<TIO, MAXC>) * 16 : 0;
+    return cold > gb ? cold : (gb > 16 ? gb : 16);
+}
+
+template <class TIO, class T, class TL, int MAXC, bool GRAD, bool QUAD, class Wave>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     const Globals<T>& G = A.G;
-    const int S = G.S, E = wv.width() / S;
+    const int stride = QUAD ? 4 : 1;
+    const int envl = stride * G.S, E = wv.width() / envl;        // lanes per environment, environments per wave
     const int lane = wv.lane();
-    const int slot = lane / S, k = lane % S;
+    const int slot = lane / envl, k = (lane % envl) / stride, q = lane % stride;
     const int env = wave_index * E + slot;
     const bool active = (env < A.B) && (k < G.Nb);
-    const int base = slot * S;
+    const int base = slot * envl;
     const NodeP<T>& P = A.nodes[k < G.Nb ? k : 0];
-    LaneProgram<T, TL, MAXC, Wave> prog(wv, G, P, A.contacts, base, k, active);
+    // rarely-read per-lane state goes to LDS when it fits next to three other waves of the CU
+    constexpr bool LDS_COLD = QUAD && (sizeof(Cold<T, MAXC>) * 64 <= 40 * 1024);
+    Cold<T, MAXC> cold_local;
+    Cold<T, MAXC>& cold = LDS_COLD ? ((Cold<T, MAXC>*)wv.lds())[lane] : cold_local;
+    LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, cold);
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);
     const bool has_u = A.u != nullptr;
@@ -1377,12 +1896,12 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     prog.begin_step(zb, has_u ? ue : nullptr);
 #ifdef DJ_DEBUG
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
-    if (A.dbg && active) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
+    if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
 #endif
     int iters = 0;
     int status = prog.mehrotra(iters);
     if (GRAD) { if (A.dz != nullptr) prog.gradients(A, env); }
-    if (active) {
+    if (active && q == 0) {
         T zn[13];
         prog.next_state(zn);
         TIO* o = A.z_next + (size_t)env * 13 * G.Nb + 13 * k;

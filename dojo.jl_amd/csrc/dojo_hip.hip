@@ -18,10 +18,13 @@ namespace {
 
 thread_local std::string g_err;
 
-// kernel launchers, one per object file of dojo_kernels.hip
+// kernel launchers, one per object file of dojo_kernels.hip: dojo_launch_<abi type>_<max contacts per body>_<quad>
 extern "C" {
-int dojo_launch_float_1(const void*, int, void*, int);  int dojo_launch_float_4(const void*, int, void*, int);  int dojo_launch_float_8(const void*, int, void*, int);
-int dojo_launch_double_1(const void*, int, void*, int); int dojo_launch_double_4(const void*, int, void*, int); int dojo_launch_double_8(const void*, int, void*, int);
+#define DJ_DECL(n) int n(const void*, int, void*, int);
+DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launch_float_8_1)
+DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
+DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
+#undef DJ_DECL
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return DOJO_ERR_DEVICE; } } while (0)
@@ -65,15 +68,20 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = s->B;
     A.z = (const TIO*)z; A.u = (const TIO*)u; A.z_next = (TIO*)zn; A.status = status; A.iters = iters;
     A.vel = (TIO*)vel; A.joint_imp = (TIO*)jimp; A.contact_sg = (TIO*)csg; A.dz = (TIO*)dz; A.du = (TIO*)du;
-    int E = 64 / s->M.S;
+    // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront), else one lane per supernode
+    const bool quad = s->M.S <= 16;
+    int E = 64 / (s->M.S * (quad ? 4 : 1));
     dim3 grid((s->B + E - 1) / E);
     if (timed) HIPCHK(hipEventRecord(s->ev0, st));
     const int g = dz != nullptr;
     typedef int (*launcher_t)(const void*, int, void*, int);
     const bool f32 = sizeof(TIO) == 4;
-    launcher_t fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1 : dojo_launch_double_1)
-                  : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4 : dojo_launch_double_4)
-                                   : (f32 ? dojo_launch_float_8 : dojo_launch_double_8);
+    launcher_t fn;
+    if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
+                 : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_1 : dojo_launch_double_4_1)
+                                  : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
+    else      fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_0 : dojo_launch_double_4_0)
+                                  : (f32 ? dojo_launch_float_8_0 : dojo_launch_double_8_0);
     int lrc = fn(&A, (int)grid.x, (void*)st, g);
     if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());

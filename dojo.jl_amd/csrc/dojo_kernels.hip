@@ -12,16 +12,35 @@
 #ifndef DJ_MAXC
 #define DJ_MAXC 1
 #endif
+#ifndef DJ_QUAD
+#define DJ_QUAD 1      // 1: four lanes per supernode (<= 16 bodies), 0: one lane per supernode (<= 64 bodies)
+#endif
 
 namespace {
 
 struct GpuWave {
+    void* lds_;
+    __device__ __forceinline__ void* lds() const { return lds_; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
     __device__ __forceinline__ int width() const { return 64; }
     __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ bool   any(bool p) const { return __any(p ? 1 : 0) != 0; }
+    // quad-local data movement on the DPP path (v_mov_b32 quad_perm): no LDS traffic, VALU latency
+    template <int CTRL> static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+    template <int CTRL> static __device__ __forceinline__ float dppf(float v) { return __int_as_float(dpp<CTRL>(__float_as_int(v))); }
+    template <int CTRL> static __device__ __forceinline__ double dppd(double v) { return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v))); }
+    template <int CTRL> static __device__ __forceinline__ int    dppx(int v) { return dpp<CTRL>(v); }
+    template <int CTRL> static __device__ __forceinline__ float  dppx(float v) { return dppf<CTRL>(v); }
+    template <int CTRL> static __device__ __forceinline__ double dppx(double v) { return dppd<CTRL>(v); }
+    template <class V> __device__ __forceinline__ V quad_bcast(V v, int o) const {      // value of lane o of my quad (o folds to a constant after unrolling)
+        switch (o) { case 0: return dppx<0x00>(v); case 1: return dppx<0x55>(v); case 2: return dppx<0xAA>(v); default: return dppx<0xFF>(v); }
+    }
+    template <class V> __device__ __forceinline__ V quad_xor(V v, int m) const {        // value of lane (l ^ m) inside my quad, m = 1 or 2
+        return m == 1 ? dppx<0xB1>(v) : dppx<0x4E>(v);                                  // quad_perm [1,0,3,2] / [2,3,0,1]
+    }
 };
 
 // TIO = ABI scalar type, TS = state / residual precision, TL = factorization precision.
@@ -29,21 +48,23 @@ struct GpuWave {
 // <float,double,double>: the interior-point iteration drives s·γ to ~1e-9 and the condensed KKT
 // then has entries ~γ/s that fp32 cannot resolve (measured in tests/emu).
 // GRAD = false compiles the IFT back-solves out (forward-only launches: step!, simulate!).
-template <class TIO, class TS, class TL, int MAXC, bool GRAD>
+template <class TIO, class TS, class TL, int MAXC, bool GRAD, bool QUAD>
 __global__ void __launch_bounds__(64) dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
+    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, GRAD, QUAD>() + 7) / 8];
     GpuWave w;
-    dj::step_entry<TIO, TS, TL, MAXC, GRAD, GpuWave>(w, A, (int)blockIdx.x);
+    w.lds_ = (void*)lds_buf;
+    dj::step_entry<TIO, TS, TL, MAXC, GRAD, QUAD, GpuWave>(w, A, (int)blockIdx.x);
 }
 
 } // namespace
 
-#define DJ_CAT2(a, b, c) a##b##_##c
-#define DJ_CAT(a, b, c) DJ_CAT2(a, b, c)
-#define DJ_LAUNCHER DJ_CAT(dojo_launch_, DJ_TIO, DJ_MAXC)
+#define DJ_CAT2(a, b, c, d) a##b##_##c##_##d
+#define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
+#define DJ_LAUNCHER DJ_CAT(dojo_launch_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 
 extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
-    if (grad) hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
-    else      hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    if (grad) hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, true, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    else      hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, false, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }

@@ -26,14 +26,16 @@ struct Barrier {
 };
 
 struct Shared {
-    int W; Barrier bar; std::vector<double> slot; std::vector<int> islot;
-    explicit Shared(int w) : W(w), bar(w), slot(w), islot(w) {}
+    int W; Barrier bar; std::vector<double> slot; std::vector<int> islot; std::vector<double> lds;
+    explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(160 * 1024 / 8) {}
 };
 
 struct EmuWave {
     Shared* sh; int l;
     int lane() const { return l; }
     int width() const { return sh->W; }
+    void* lds() const { return (void*)sh->lds.data(); }
+    void sync() { sh->bar.wait(); }
     template <class T> T shfl(T v, int src) {
         sh->slot[l] = (double)v;
         sh->bar.wait();
@@ -48,6 +50,8 @@ struct EmuWave {
         sh->bar.wait();
         return r;
     }
+    template <class V> V quad_bcast(V v, int o) { return shfl(v, (l & ~3) + o); }
+    template <class V> V quad_xor(V v, int m) { return shfl(v, l ^ m); }
     bool any(bool p) {
         sh->islot[l] = p ? 1 : 0;
         sh->bar.wait();
@@ -57,7 +61,7 @@ struct EmuWave {
     }
 };
 
-template <class TIO, class T, class TL, int MAXC>
+template <class TIO, class T, class TL, int MAXC, bool QUAD>
 void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
          const double* z, const double* u, double* z_next, int* status, int* iters,
          double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg) {
@@ -76,11 +80,11 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
-    int E = W / M.S, nwaves = (B + E - 1) / E;
+    int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
     for (int wi = 0; wi < nwaves; ++wi) {
         Shared sh(W);
         std::vector<std::thread> th;
-        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC, true>(w, A, wi); });
+        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC, true, QUAD>(w, A, wi); });
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
@@ -94,19 +98,20 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
 
 } // namespace
 
-extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int B, int envs_per_wave,
+extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int quad, int B, int envs_per_wave,
                         const double* z, const double* u, double* z_next, int* status, int* iters,
                         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen) {
     dj::HostModel M;
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
-    int W = M.S * (envs_per_wave > 0 ? envs_per_wave : 1);
+    if (quad && M.S > 16) { if (err) std::strncpy(err, "quad mapping needs <= 16 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
-#define RUN(TIO, TS, TL, MC) run<TIO, TS, TL, MC>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg)
-    // dtype 0: fp64 everywhere; dtype 1: fp32 I/O + fp32 factorization/solves, fp64 state/residuals (the product's "f32" mode); dtype 2: pure fp32 (experiments only)
+#define RUN(TIO, TS, TL, MC) do { if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
+                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); } while (0)
+    // dtype 0: fp64 everywhere; dtype 1: fp32 I/O with fp64 internals (the product's "f32" mode); dtype 3: fp32 factorization (experiments)
     if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }
     else if (dtype == DOJO_DTYPE_F32) { if (M.maxc <= 1) RUN(float, double, double, 1); else if (M.maxc <= 4) RUN(float, double, double, 4); else RUN(float, double, double, 8); }
-    else if (dtype == 3) { if (M.maxc <= 1) RUN(float, double, float, 1); else RUN(float, double, float, 4); }
-    else { if (M.maxc <= 1) RUN(float, float, float, 1); else RUN(float, float, float, 4); }
+    else { if (M.maxc <= 1) RUN(float, double, float, 1); else RUN(float, double, float, 4); }
     return DOJO_OK;
 }

@@ -27,7 +27,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False):
+def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False, quad=False):
     Z = np.ascontiguousarray(np.atleast_2d(Z), dtype=np.float64); B = Z.shape[0]
     U = None if U is None else np.ascontiguousarray(np.atleast_2d(U), dtype=np.float64)
     topo, keep = spec.to_ctypes()
@@ -39,7 +39,7 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     du = np.zeros((B, max(nu, 1), nx)) if grad else None
     dbg = np.zeros((B, spec.Nb, 512)) if debug else None
     err = C.create_string_buffer(256)
-    rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32pure": 2, "f32mixed": 3}[dtype], B, envs_per_wave,
+    rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256)
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))

@@ -43,3 +43,23 @@ if what in ("all", "parity"):
         z = zo
     json.dump(dumps, open(os.path.join(out, "parity_dbg.json"), "w"))
     gm.close()
+
+if what in ("all", "grad"):
+    for cfg, pre, tol in ((3, 12, 1e-7), (3, 12, 1e-8), (4, 10, 1e-7), (2, 120, 1e-7)):
+        spec = d.baseline_config(cfg)
+        opts = d.SolverOptions(rtol=tol, btol=tol)
+        B = 32
+        Z, U = d.synthetic_inputs(spec, B)
+        o = Oracle(spec, opts=opts)
+        for _ in range(pre):
+            Z, st, it, _, _ = o.step_batch(Z, U, nthreads=16)
+        gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+        zn, st, it = gm.step(Z, U, with_gradient=True)
+        dz, du = gm.gradients()
+        Zo, st_o, it_o, dz_o, du_o = o.step_batch(Z, U, with_grad=True, grad_mode=0, nthreads=16)
+        ok = np.nonzero((st == 0) & (st_o == 0))[0]
+        ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+        es = np.array([np.abs(zn[b] - Zo[b]).max() for b in ok])
+        print("grad cfg %d pre %d tol %.0e: n_ok %d/%d  state err q50 %.1e q90 %.1e max %.1e | dz rel err q50 %.1e q75 %.1e q90 %.1e max %.1e | scale max %.1e" % (
+            cfg, pre, tol, len(ok), B, *np.quantile(es, [0.5, 0.9, 1.0]), *np.quantile(ez, [0.5, 0.75, 0.9, 1.0]), max(np.abs(dz_o[b]).max() for b in ok)), flush=True)
+        gm.close()
