@@ -45,7 +45,7 @@ if what in ("all", "parity"):
     gm.close()
 
 if what in ("all", "grad"):
-    for cfg, pre, tol in ((3, 12, 1e-7), (3, 12, 1e-8), (4, 10, 1e-7), (2, 120, 1e-7)):
+    for cfg, pre, tol in ((3, 12, 1e-5), (3, 12, 1e-6), (3, 12, 1e-7), (4, 30, 1e-6), (5, 6, 1e-6), (2, 120, 1e-7)):
         spec = d.baseline_config(cfg)
         opts = d.SolverOptions(rtol=tol, btol=tol)
         B = 32
