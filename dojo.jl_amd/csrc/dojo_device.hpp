@@ -126,10 +126,14 @@ struct NullBlocks {
     template <class V> DJ_HD void addL(int, int, V) {}
     template <class V> DJ_HD void addD(int, int, V) {}
 };
+// Quad mapping: the lane's rows are assembled straight into the factor storage (Factors::Sq/Uq/Lq),
+// so the assembled blocks and the factors never coexist in registers.
 template <class T>
 struct QuadBlocks {
-    T S[3][12], U[3][6], L[6][3], D[3][6];
+    T (&S)[3][12]; T (&U)[3][6]; T (&L)[6][3];
+    T D[3][6];
     int q;
+    DJ_HD QuadBlocks(T (&s)[3][12], T (&u)[3][6], T (&l)[6][3], int q_) : S(s), U(u), L(l), q(q_) {}
     DJ_HD void zero() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -139,10 +143,10 @@ struct QuadBlocks {
             for (int j = 0; j < 6; ++j) { U[i][j] = T(0); D[i][j] = T(0); L[j][i] = T(0); }
         }
     }
-    DJ_HD void addS(int r, int c, T v) { if (r / 3 == q) S[r % 3][c] += v; }
-    DJ_HD void addU(int r, int c, T v) { if (r / 3 == q) U[r % 3][c] += v; }
-    DJ_HD void addL(int r, int c, T v) { if (c / 3 == q) L[r][c % 3] += v; }
-    DJ_HD void addD(int r, int c, T v) { if (r / 3 == q) D[r % 3][c] += v; }
+    template <class V> DJ_HD void addS(int r, int c, V v) { if (r / 3 == q) S[r % 3][c] += T(v); }
+    template <class V> DJ_HD void addU(int r, int c, V v) { if (r / 3 == q) U[r % 3][c] += T(v); }
+    template <class V> DJ_HD void addL(int r, int c, V v) { if (c / 3 == q) L[r][c % 3] += T(v); }
+    template <class V> DJ_HD void addD(int r, int c, V v) { if (r / 3 == q) D[r % 3][c] += T(v); }
 };
 
 // kinematic quantities of a body at the candidate velocity
@@ -703,8 +707,9 @@ struct LaneProgram {
     bool active;                 // lane maps to a real (env, body)
     bool has_parent;
     int plane;                   // wave lane of the parent (or own lane)
-    Lane<T, MAXC> L;
+    Lane<T, MAXC>& L;            // per lane, or one copy per supernode in LDS (lock-step quad mapping)
     Factors<T, TL, MAXC, QUAD> F;
+    void* gb_lds = nullptr;      // LDS home of this supernode's GradBlocks (quad mapping)
     int stride, q, envl, qb;     // lanes per supernode, role in the quad, lanes per environment, first lane of the quad
     Cold<T, MAXC>& cold;
     JointCfg<T>& cfg;
@@ -715,8 +720,8 @@ struct LaneProgram {
     // residual pieces of the last evaluation
     T rb[6], rj[6], theta, cres[MAXC][4];
 
-    DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, int q_, bool act, Cold<T, MAXC>& cold_)
-        : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act), cold(cold_), cfg(cold_.cfg) {
+    DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, int q_, bool act, Lane<T, MAXC>& lane_, Cold<T, MAXC>& cold_)
+        : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act), L(lane_), cold(cold_), cfg(cold_.cfg) {
         stride = QUAD ? 4 : 1; q = QUAD ? q_ : 0; envl = stride * g.S; qb = w.lane() - q;
         has_parent = act && p.parent >= 0;
         plane = has_parent ? base + stride * p.parent + q : w.lane();
@@ -938,15 +943,15 @@ struct LaneProgram {
     // lanes of the quad: for every pivot the owner's (normalised) pivot row is broadcast with 12
     // shuffles and every lane updates its three rows.  No W / Z are stored: the solves use the row
     // block of S⁻¹ together with the lane's rows of U and columns of L.
-    DJ_HD void factorize_quad(QuadBlocks<T>& K) {
-        TL Sl[3][12], up[3][6];
+    DJ_HD void factorize_quad(QuadBlocks<TL>& K) {
+        // F.Sq holds the raw rows until the lane's level is reached and the inverse rows afterwards:
+        // the elimination runs in place and is a no-op (fe = 0) on lanes that are not at the level.
+        TL up[3][6];
+        TL (&A)[3][12] = F.Sq;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 12; ++j) Sl[i][j] = TL(K.S[i][j]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { up[i][j] = TL(0); F.Uq[i][j] = TL(K.U[i][j]); F.Lq[j][i] = TL(K.L[j][i]); }
-        }
+            for (int j = 0; j < 6; ++j) up[i][j] = TL(0);
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             const bool at = active && P.level == lev;
             // children's Schur complements: rows 0:3 go to role 0, rows 3:6 to role 1 (same role on the child side)
@@ -960,39 +965,27 @@ struct LaneProgram {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) Sl[i][j] += acc[6 * i + j];
+                    for (int j = 0; j < 6; ++j) A[i][j] += acc[6 * i + j];
             }
-            // distributed Gauss-Jordan (all lanes take part in the shuffles; only lanes at this level keep the result)
-            TL A[3][12];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 12; ++j) A[i][j] = Sl[i][j];
+            // distributed Gauss-Jordan (all lanes take part in the shuffles; only lanes at this level change)
 #pragma unroll
             for (int p = 0; p < 12; ++p) {
                 const int o = p / 3, ro = p % 3;
                 TL prow[12];
 #pragma unroll
                 for (int c = 0; c < 12; ++c) prow[c] = wv.quad_bcast(A[ro][c], o);
-                TL ip = TL(1) / prow[p];
+                TL ip = TL(1) / (at ? prow[p] : TL(1));
 #pragma unroll
                 for (int c = 0; c < 12; ++c) prow[c] = (c == p) ? ip : prow[c] * ip;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const bool is_piv = (q == o) && (r == ro);
-                    TL f = A[r][p];
+                    const TL f = A[r][p];
+                    const TL fe = at ? f : TL(0);          // lanes not at this level keep their rows (ip = 1, prow = own row)
 #pragma unroll
-                    for (int c = 0; c < 12; ++c) {
-                        TL upd = (c == p) ? -f * ip : A[r][c] - f * prow[c];
-                        A[r][c] = is_piv ? prow[c] : upd;
-                    }
+                    for (int c = 0; c < 12; ++c) if (c != p) A[r][c] = is_piv ? prow[c] : A[r][c] - fe * prow[c];
+                    A[r][p] = at ? (is_piv ? ip : -f * ip) : f;
                 }
-            }
-            if (at) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) F.Sq[i][j] = A[i][j];
             }
             // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero)
             TL Uf[12][6];
@@ -1034,109 +1027,61 @@ struct LaneProgram {
         }
     }
 
-    // quad mapping: NC right-hand sides at once through the tree (own rows only).  The NC chains of
-    // shuffles are independent, which hides the ds_bpermute latency in the IFT back-solves.
-    template <int NC, class TF>
-    DJ_HD void solve_quad_multi(const TF (*Sq)[12], const TF (*Uq)[6], const TF (*Lq)[3], TF (*r3)[3], const TF (*u3)[3], TF (*d3)[3]) {
-        TF y3[NC][3], send3[NC][3];
-#pragma unroll
-        for (int n = 0; n < NC; ++n) { y3[n][0] = y3[n][1] = y3[n][2] = TF(0); send3[n][0] = send3[n][1] = send3[n][2] = TF(0); }
-        for (int lev = G.maxlevel; lev >= 0; --lev) {
-            const bool at = active && P.level == lev;
-            TF acc[3 * NC], snd[3 * NC];
-#pragma unroll
-            for (int n = 0; n < NC; ++n) { for (int i = 0; i < 3; ++i) { acc[3 * n + i] = TF(0); snd[3 * n + i] = send3[n][i]; } }
-            gather_children<3 * NC>(wv, acc, snd, P, base, G.maxch, at, stride, q);
-#pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                if (at) { r3[n][0] += acc[3 * n]; r3[n][1] += acc[3 * n + 1]; r3[n][2] += acc[3 * n + 2]; }
-                TF rf[12];
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) rf[3 * o + i] = wv.quad_bcast(r3[n][i], o);
-                TF yy[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
-#pragma unroll
-                    for (int m_ = 0; m_ < 12; ++m_) a_ += Sq[i][m_] * rf[m_];
-                    yy[i] = a_; }
-                TF part[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) part[i] = Lq[i][0] * yy[0] + Lq[i][1] * yy[1] + Lq[i][2] * yy[2];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
-                if (at) {
-                    y3[n][0] = yy[0]; y3[n][1] = yy[1]; y3[n][2] = yy[2];
-                    if (has_parent) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) send3[n][i] = (q == 0) ? u3[n][i] - part[i] : (q == 1) ? u3[n][i] - part[3 + i] : TF(0);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NC; ++n) { d3[n][0] = y3[n][0]; d3[n][1] = y3[n][1]; d3[n][2] = y3[n][2]; }
-        const int pb = has_parent ? base + stride * P.parent : qb;
-        for (int lev = 1; lev <= G.maxlevel; ++lev) {
-            const bool at = active && P.level == lev && has_parent;
-#pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                TF pa_[6];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[n][i], pb); pa_[3 + i] = wv.shfl(d3[n][i], pb + 1); }
-                TF t3[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) a_ += Uq[i][j] * pa_[j];
-                    t3[i] = a_; }
-                TF tf[12];
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
-                if (at) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { TF a_ = TF(0);
-#pragma unroll
-                        for (int m_ = 0; m_ < 12; ++m_) a_ += Sq[i][m_] * tf[m_];
-                        d3[n][i] = y3[n][i] - a_; }
-                }
-            }
-        }
-    }
-
-    // quad mapping: IFT column solves, six columns per sweep
+    // quad mapping: IFT column solves  X = solmat⁻¹ · datamat  (DESIGN.md §5).
+    // Columns travel through the tree six at a time ("batches") and the two sweeps are software-
+    // pipelined over the batches: in step t of the up-sweep a supernode at level l works on batch
+    // t − (maxlevel − l), in step t of the down-sweep on batch t − l.  Every lane therefore does one
+    // useful block product per step instead of idling at the other levels' turns, and the whole
+    // IFT costs (batches + depth) steps per sweep instead of batches × depth.  The forward-substituted
+    // right-hand sides y wait between the two sweeps in the output buffer itself (the v / ω slots of
+    // the column, which the down-sweep then overwrites with the final values).
     template <class KA, class GB, class KN>
     DJ_HD void gradient_columns_quad(const KA& A, int env, const GB& gb, const T (*GK)[6][4], T wk, const KN& kb0) {
+        typedef typename KA::io_type TIO;
+        typedef TL TG;
+        constexpr int NC = 6;
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
-        typedef decltype(A.dz) OutPtr;
         const int ro = q == 1 ? 3 : 0;                         // first body row owned by roles 0 / 1
-        // the back-solves run in the precision of the ABI buffers (fp32 results do not need fp64 solves)
-        typedef typename KA::io_type TG;
-        TG Sg[3][12], Ug[3][6], Lg[6][3];
+        const TG (&Sg)[3][12] = F.Sq; const TG (&Ug)[3][6] = F.Uq; const TG (&Lg)[6][3] = F.Lq;
+        const int nbs = 2 * G.Nb;                              // state batches: (body kk, configuration | velocity columns)
+        const int nbu = (A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0;   // control batches: six input columns each
+        const int NB = nbs + nbu;
+        const int myu = P.nu_t + P.nu_r;
+        const int lvl = P.level;
+        const int pb = has_parent ? base + stride * P.parent : qb;
+        // this lane's six rows of column cI of batch b in the output buffers (null: padding column)
+        auto colptr = [&](int b, int cI) -> TIO* {
+            if (b < nbs) {
+                const int c = (b & 1) == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
+                return A.dz + ((size_t)env * nx + (size_t)(12 * (b >> 1) + c)) * nx + 12 * k + 6 * q;
+            }
+            const int ui = NC * (b - nbs) + cI;
+            return ui < G.nu ? A.du + ((size_t)env * G.nu + (size_t)ui) * nx + 12 * k + 6 * q : (TIO*)nullptr;
+        };
+        // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
+        TG send3[NC][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int n = 0; n < NC; ++n) send3[n][0] = send3[n][1] = send3[n][2] = TG(0);
+        for (int t = 0; t < NB + G.maxlevel; ++t) {
+            const int b = t - (G.maxlevel - lvl);
+            const bool valid = active && b >= 0 && b < NB;
+            // the children finished this batch in the previous step
+            TG acc[3 * NC], snd[3 * NC];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) Sg[i][j] = TG(F.Sq[i][j]);
+            for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { acc[3 * n + i] = TG(0); snd[3 * n + i] = send3[n][i]; }
+            gather_children<3 * NC>(wv, acc, snd, P, base, G.maxch, valid, stride, q);
+            const bool isS = b < nbs;
+            const int kk = b >> 1, typ = b & 1;
+            const bool mine = valid && isS && (k == kk), child_of = valid && isS && has_parent && (P.parent == kk);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { Ug[i][j] = TG(F.Uq[i][j]); Lg[j][i] = TG(F.Lq[j][i]); }
-        }
-        for (int kk = 0; kk < G.Nb; ++kk) {
-            const bool mine = active && (k == kk), child_of = active && has_parent && (P.parent == kk);
-            for (int batch = 0; batch < 2; ++batch) {          // 0: configuration columns (x2, φ2), 1: velocity columns (v15, ω15)
-                TG r3[6][3], u3[6][3], d3[6][3];
-#pragma unroll
-                for (int cI = 0; cI < 6; ++cI) {
-                    const int c = batch == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
-                    T r_[3] = {0, 0, 0}, u_[3] = {0, 0, 0}, rs0 = T(0);
+            for (int cI = 0; cI < NC; ++cI) {
+                T r_[3] = {0, 0, 0}, u_[3] = {0, 0, 0}, rs0 = T(0);
+                if (isS) {
+                    const int c = typ == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
                     if (mine) {
                         if (q < 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnB[ro + i][c]); }
-                        if (batch == 0) {
+                        if (typ == 0) {
                             if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnJ[3 * (q - 2) + i][cI]); }
                             else {
                                 for (int i = 0; i < 3; ++i) u_[i] = T(gb.UpOwn[ro + i][cI]);
@@ -1147,52 +1092,89 @@ struct LaneProgram {
                             }
                             rs0 = T(gb.sl_own[cI]);
                         }
-                    } else if (child_of && batch == 0) {
+                    } else if (child_of && typ == 0) {
                         if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.ParJ[3 * (q - 2) + i][cI]); }
                         else { for (int i = 0; i < 3; ++i) { r_[i] = T(gb.ParB[ro + i][cI]); u_[i] = T(gb.UpPar[ro + i][cI]); } }
                         rs0 = T(gb.sl_par[cI]);
                     }
                     if (P.nlim_r > 0 && q < 2) { T kap0 = wk * rs0; for (int i = 0; i < 3; ++i) { r_[i] += (q == 0 ? F.t_b[i] : F.t_b[3 + i]) * kap0; u_[i] += (q == 0 ? F.t_a[i] : F.t_a[3 + i]) * kap0; } }
-                    for (int i = 0; i < 3; ++i) { r3[cI][i] = TG(r_[i]); u3[cI][i] = TG(u_[i]); }
+                } else {
+                    const int cu = NC * (b - nbs) + cI - P.u_off;      // control column: owner = child body of the joint
+                    if (valid && q < 2 && cu >= 0 && cu < myu) { for (int i = 0; i < 3; ++i) { r_[i] = T(gb.UB[ro + i][cu]); u_[i] = T(gb.UA[ro + i][cu]); } }
                 }
-                solve_quad_multi<6, TG>(Sg, Ug, Lg, r3, u3, d3);
-                if (active && q < 2 && A.dz) {
+                TG r3[3];
 #pragma unroll
-                    for (int cI = 0; cI < 6; ++cI) {
-                        const int c = batch == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
-                        OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k + 6 * q;
-                        T d_[3] = {T(d3[cI][0]), T(d3[cI][1]), T(d3[cI][2])};
-                        if (q == 0) {
-                            for (int i = 0; i < 3; ++i) { T x = dt * d_[i]; if (mine && batch == 0 && cI == i) x += T(1); o[i] = x; o[3 + i] = d_[i]; }
-                        } else {
-                            T pw[3];
-                            m3vec(pw, kb0.Phi, d_);
-                            for (int i = 0; i < 3; ++i) { T ph = pw[i]; if (mine && batch == 0 && cI >= 3) ph += kb0.Xi[3 * i + (cI - 3)]; o[i] = ph; o[3 + i] = d_[i]; }
-                        }
-                    }
+                for (int i = 0; i < 3; ++i) r3[i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0);
+                TG rf[12];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) rf[3 * o + i] = wv.quad_bcast(r3[i], o);
+                TG yy[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
+#pragma unroll
+                    for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * rf[m_];
+                    yy[i] = a_; }
+                TG part[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] = Lg[i][0] * yy[0] + Lg[i][1] * yy[1] + Lg[i][2] * yy[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? part[i] : part[3 + i]) : TG(0);
+                    if (q < 2) { TIO* o = colptr(b, cI); if (o) { o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); } }
                 }
             }
         }
-        // control columns, joint by joint (owner quad = child body of the joint); up to six inputs per joint
-        for (int kk = 0; kk < G.Nb; ++kk) {
-            const NodeP<T>& Pk = A.nodes[kk];
-            const int nuk = Pk.nu_t + Pk.nu_r;
-            if (nuk == 0) continue;
-            const bool mine = active && (k == kk);
-            TG r3[6][3], u3[6][3], d3[6][3];
+        // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
+        TG d3[NC][3];
 #pragma unroll
-            for (int cI = 0; cI < 6; ++cI) for (int i = 0; i < 3; ++i) {
-                r3[cI][i] = (mine && q < 2 && cI < nuk) ? TG(gb.UB[ro + i][cI]) : TG(0);
-                u3[cI][i] = (mine && q < 2 && cI < nuk) ? TG(gb.UA[ro + i][cI]) : TG(0);
-            }
-            solve_quad_multi<6, TG>(Sg, Ug, Lg, r3, u3, d3);
-            if (active && q < 2 && A.du) {
+        for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
+        for (int t = 0; t < NB + G.maxlevel; ++t) {
+            const int b = t - lvl;
+            const bool valid = active && b >= 0 && b < NB;
+            const bool isS = b < nbs;
+            const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
 #pragma unroll
-                for (int cI = 0; cI < 6; ++cI) if (cI < nuk) {
-                    OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + cI)) * nx + 12 * k + 6 * q;
-                    T d_[3] = {T(d3[cI][0]), T(d3[cI][1]), T(d3[cI][2])};
-                    if (q == 0) { for (int i = 0; i < 3; ++i) { o[i] = dt * d_[i]; o[3 + i] = d_[i]; } }
-                    else { T pw[3]; m3vec(pw, kb0.Phi, d_); for (int i = 0; i < 3; ++i) { o[i] = pw[i]; o[3 + i] = d_[i]; } }
+            for (int n = 0; n < NC; ++n) {
+                TG pa_[6];                                     // the parent finished this batch in the previous step
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[n][i], pb); pa_[3 + i] = wv.shfl(d3[n][i], pb + 1); }
+                TG t3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) a_ += Ug[i][j] * pa_[j];
+                    t3[i] = a_; }
+                TG tf[12];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
+                TIO* o = (valid && q < 2) ? colptr(b, n) : (TIO*)nullptr;
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        TG a_ = TG(0);
+#pragma unroll
+                        for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * tf[m_];
+                        TG y = o ? TG(o[3 + i]) : TG(0);
+                        d3[n][i] = has_parent ? y - a_ : y;
+                    }
+                }
+                if (o) {
+                    T d_[3] = {T(d3[n][0]), T(d3[n][1]), T(d3[n][2])};
+                    if (q == 0) {
+                        for (int i = 0; i < 3; ++i) { T x = dt * d_[i]; if (mine && n == i) x += T(1); o[i] = TIO(x); o[3 + i] = TIO(d_[i]); }
+                    } else {
+                        T pw[3];
+                        m3vec(pw, kb0.Phi, d_);
+                        for (int i = 0; i < 3; ++i) { T ph = pw[i]; if (mine && n >= 3) ph += kb0.Xi[3 * i + (n - 3)]; o[i] = TIO(ph); o[3 + i] = TIO(d_[i]); }
+                    }
                 }
             }
         }
@@ -1490,8 +1472,7 @@ struct LaneProgram {
     // (S, U, L, Dup: 324 scalars) are transient and only the factors persist through the solves.
     DJ_HD void linearize() {
         if constexpr (QUAD) {
-            QuadBlocks<T> K;
-            K.q = q;
+            QuadBlocks<TL> K(F.Sq, F.Uq, F.Lq, q);
             evaluate<true>(K);
             condense(K);
             factorize_quad(K);
@@ -1744,7 +1725,7 @@ struct LaneProgram {
         typedef typename KA::io_type TB;
         GradBlocks<TB, MAXC> gb_local;
         GradBlocks<TB, MAXC>* gbp = &gb_local;
-        if constexpr (QUAD) { wv.sync(); gbp = ((GradBlocks<TB, MAXC>*)wv.lds()) + (wv.lane() / 4); }   // aliases Cold: not needed below
+        if constexpr (QUAD) { wv.sync(); gbp = (GradBlocks<TB, MAXC>*)gb_lds; }   // aliases Cold: not needed below
         if (!QUAD || q == 0) {
             GradBlocks<TB, MAXC>& g_ = *gbp;
             for (int i = 0; i < 6; ++i) {
@@ -1865,13 +1846,26 @@ struct KernelArgs {
 #endif
 };
 
-// bytes of LDS one wavefront of the step kernel needs
-template <class TIO, class T, int MAXC, bool GRAD, bool QUAD>
-constexpr int step_lds_bytes() {
-    int cold = (QUAD && sizeof(Cold<T, MAXC>) * 64 <= 40 * 1024) ? (int)sizeof(Cold<T, MAXC>) * 64 : 0;
-    int gb = (QUAD && GRAD) ? (int)sizeof(GradBlocks<TIO, MAXC>) * 16 : 0;
-    return cold > gb ? cold : (gb > 16 ? gb : 16);
-}
+// LDS layout of one wavefront of the step kernel (quad mapping).
+// LOCKSTEP (the GPU): everything the four lanes of a supernode hold identically — the solver state
+// (Lane) and the cold linearization data (Cold) — exists once per supernode in LDS; the four lanes
+// read it with broadcast ds_reads and write identical values in the same instruction.  The SIMT
+// emulator's threads are not in lock step, so there Lane stays per-lane and Cold is per-lane in "LDS".
+//   [0, lane_bytes)            : Lane  x 16 supernodes            (LOCKSTEP only)
+//   [lane_bytes, +max(cold,gb)): Cold x 16 (or x 64), overlaid by GradBlocks x 16 in the IFT phase
+template <class T, int MAXC>
+struct LaneSlot { Lane<T, MAXC> L; T pad_[(sizeof(Lane<T, MAXC>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };   // odd stride in 8-byte words
+template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP>
+struct StepLds {
+    static constexpr int lane_bytes = (QUAD && LOCKSTEP) ? (int)sizeof(LaneSlot<T, MAXC>) * 16 : 0;
+    static constexpr int cold_n = LOCKSTEP ? 16 : 64;
+    static constexpr bool cold_in_lds = QUAD && ((int)sizeof(Cold<T, MAXC>) * cold_n + lane_bytes <= 40 * 1024);
+    static constexpr int cold_bytes = cold_in_lds ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
+    static constexpr int gb_bytes = (QUAD && GRAD) ? (int)sizeof(GradBlocks<TIO, MAXC>) * 16 : 0;
+    static constexpr int bytes = lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16;
+};
+template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true>
+constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP>::bytes; }
 
 template <class TIO, class T, class TL, int MAXC, bool GRAD, bool QUAD, class Wave>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
@@ -1884,11 +1878,15 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     const bool active = (env < A.B) && (k < G.Nb);
     const int base = slot * envl;
     const NodeP<T>& P = A.nodes[k < G.Nb ? k : 0];
-    // rarely-read per-lane state goes to LDS when it fits next to three other waves of the CU
-    constexpr bool LDS_COLD = QUAD && (sizeof(Cold<T, MAXC>) * 64 <= 40 * 1024);
+    typedef StepLds<TIO, T, MAXC, GRAD, QUAD, Wave::kLockstep> LY;
+    constexpr bool SHARE = QUAD && Wave::kLockstep;
+    char* lds = (char*)wv.lds();
+    Lane<T, MAXC> lane_local;
     Cold<T, MAXC> cold_local;
-    Cold<T, MAXC>& cold = LDS_COLD ? ((Cold<T, MAXC>*)wv.lds())[lane] : cold_local;
-    LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, cold);
+    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)lds)[lane / 4].L : lane_local;
+    Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local;
+    LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);
+    if (QUAD) prog.gb_lds = (void*)(((GradBlocks<TIO, MAXC>*)(lds + LY::lane_bytes)) + lane / 4);
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);
     const bool has_u = A.u != nullptr;

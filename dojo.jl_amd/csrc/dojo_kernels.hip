@@ -19,6 +19,7 @@
 namespace {
 
 struct GpuWave {
+    static constexpr bool kLockstep = true;     // the 64 lanes execute every instruction together
     void* lds_;
     __device__ __forceinline__ void* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }

@@ -31,6 +31,7 @@ struct Shared {
 };
 
 struct EmuWave {
+    static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
     Shared* sh; int l;
     int lane() const { return l; }
     int width() const { return sh->W; }
