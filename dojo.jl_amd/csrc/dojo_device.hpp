@@ -67,11 +67,12 @@ struct Lane {
     T x2[3], q2[4], xa2[3], qa2[4];
     T dconst[6];                 // velocity-independent part of the body residual
     T v15[3], w15[3];            // midpoint velocities of the previous interval (data of the IFT)
-    // solution: [0] = current, [1] = candidate (vsol/ωsol, impulses, impulses_dual in the reference)
-    T v[2][3], w[2][3];
-    T lam[2][6];                 // equality multipliers: 3 translational slots, 3 rotational slots
-    T ls[2][2], lg[2][2];        // rotational joint limit: s = (s_up, s_lo), γ = (γ_up, γ_lo)
-    T cs[2][MAXC][4], cg[2][MAXC][4];
+    // candidate solution (vsol[2]/ωsol[2], impulses[2], impulses_dual[2] in the reference); the accepted
+    // iterate lives in a SolSnap during the line search
+    T v[3], w[3];
+    T lam[6];                    // equality multipliers: 3 translational slots, 3 rotational slots
+    T ls[2], lg[2];              // rotational joint limit: s = (s_up, s_lo), γ = (γ_up, γ_lo)
+    T cs[MAXC][4], cg[MAXC][4];
 };
 
 // factor data of one supernode, kept between the two solves of a Mehrotra iteration and
@@ -717,6 +718,14 @@ struct LaneProgram {
 #ifdef DJ_DEBUG
     T* dbg = nullptr; bool dbg_on = false; bool trace = false;
 #endif
+#ifdef DJ_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;    // cycle counters per phase (profiling builds only)
+#define DJ_PB() (pt0 = wv.clock())
+#define DJ_PE(i) (pc[i] += wv.clock() - pt0)
+#else
+#define DJ_PB() ((void)0)
+#define DJ_PE(i) ((void)0)
+#endif
     // residual pieces of the last evaluation
     T rb[6], rj[6], theta, cres[MAXC][4];
 
@@ -735,30 +744,30 @@ struct LaneProgram {
     DJ_HD void evaluate(BK& K) {
         const T dt = G.dt;
         // parent's candidate velocity
-        T va[3], wa[3], own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6];
+        T va[3], wa[3], own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6];
         shfl_vec<6>(wv, par6, own6, plane);
         if (has_parent) { v3cpy(va, par6); v3cpy(wa, par6 + 3); } else { va[0] = va[1] = va[2] = wa[0] = wa[1] = wa[2] = T(0); }
         Kin<T> kb, ka;
-        kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], dt);
+        kin_of(kb, L.x2, L.q2, L.v, L.w, dt);
         kin_of(ka, L.xa2, L.qa2, va, wa, dt);
         JointEval<T> E;
         if (JAC) K.zero();
-        joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, K);
+        joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, K);
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
         // body residual: src/integrators/constraint.jl:1-34 in closed form
         T Jw[3], wxJw[3];
-        m3vec(Jw, P.J, L.w[1]);
-        v3cross(wxJw, L.w[1], Jw);
+        m3vec(Jw, P.J, L.w);
+        v3cross(wxJw, L.w, Jw);
         T d[6];
-        for (int i = 0; i < 3; ++i) { d[i] = P.m * L.v[1][i] + L.dconst[i]; d[3 + i] = T(0.5) * dt * (kb.c * Jw[i] + wxJw[i]) + L.dconst[3 + i]; }
+        for (int i = 0; i < 3; ++i) { d[i] = P.m * L.v[i] + L.dconst[i]; d[3 + i] = T(0.5) * dt * (kb.c * Jw[i] + wxJw[i]) + L.dconst[3 + i]; }
         for (int i = 0; i < 6; ++i) d[i] -= E.imp_b[i];
         // contacts
         ContactEval<T> CE[MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
-                contact_eval<JAC>(CE[c], CP[P.contact[c]], kb, L.v[1], L.w[1], L.cs[1][c], L.cg[1][c], dt);
+                contact_eval<JAC>(CE[c], CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
                 for (int i = 0; i < 6; ++i) d[i] -= CE[c].imp[i];
                 for (int i = 0; i < 4; ++i) cres[c][i] = CE[c].c[i];
             } else { for (int i = 0; i < 4; ++i) cres[c][i] = T(0); }
@@ -773,9 +782,9 @@ struct LaneProgram {
             T Dw[9];                                          // (Δt/2)(cJ − Jω ωᵀ/c + [ω]xJ − [Jω]x)
             {
                 T Sw[9], SJw[9], SwJ[9];
-                m3skew(Sw, L.w[1]); m3skew(SJw, Jw); m3mul(SwJ, Sw, P.J);
+                m3skew(Sw, L.w); m3skew(SJw, Jw); m3mul(SwJ, Sw, P.J);
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
-                    Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[1][j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
+                    Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -813,13 +822,13 @@ struct LaneProgram {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
                 for (int i = 0; i < 4; ++i) r = tmax(r, tabs(cres[c][i]));
-                const T* g = L.cg[1][c]; const T* s = L.cs[1][c];
+                const T* g = L.cg[c]; const T* s = L.cs[c];
                 b = tmax(b, tabs(g[0] * s[0]));
                 b = tmax(b, tabs(g[1] * s[1] + g[2] * s[2] + g[3] * s[3]));
                 b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
                 b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
             }
-            if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[1][0] * L.lg[1][0])); b = tmax(b, tabs(L.ls[1][1] * L.lg[1][1])); }
+            if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
         }
         rvio = env_max(wv, r, envl);
         bvio = env_max(wv, b, envl);
@@ -833,21 +842,21 @@ struct LaneProgram {
     DJ_HD void cone_rhs_from_state(ConeRhs& R, T mu_asm) const {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            const T* g = L.cg[1][c]; const T* s = L.cs[1][c];
+            const T* g = L.cg[c]; const T* s = L.cs[c];
             R.cc[c][0] = -(g[0] * s[0] - mu_asm);
             R.cc[c][1] = -(g[1] * s[1] + g[2] * s[2] + g[3] * s[3] - mu_asm);
             R.cc[c][2] = -(g[1] * s[2] + s[1] * g[2]);
             R.cc[c][3] = -(g[1] * s[3] + s[1] * g[3]);
         }
-        R.lim[0] = -(L.ls[1][0] * L.lg[1][0] - mu_asm);
-        R.lim[1] = -(L.ls[1][1] * L.lg[1][1] - mu_asm);
+        R.lim[0] = -(L.ls[0] * L.lg[0] - mu_asm);
+        R.lim[1] = -(L.ls[1] * L.lg[1] - mu_asm);
     }
 
     // contact condensation coefficients: Δγ_{1,3,4} = k0 + coef·(C134 Δw);  also Δs2 etc. for recovery
     struct CCoef { T k0[3], coef[9]; T a1, b1, den, al2, al3, al4, g0, g1, g2, h0, h1, h2; };
     DJ_HD void contact_coef(CCoef& Q, int c, const T* rc /*r1..r4*/, const T* r58 /*−constraint rows*/) const {
         const ContactP<T>& K = CP[P.contact[c]];
-        const T* gam = L.cg[1][c]; const T* s = L.cs[1][c];
+        const T* gam = L.cg[c]; const T* s = L.cs[c];
         T g1t = gam[0] + T(REG), s1t = s[0] + T(REG);
         Q.g0 = gam[1] + T(REG); Q.g1 = gam[2]; Q.g2 = gam[3];
         Q.h0 = s[1] + T(REG); Q.h1 = s[2]; Q.h2 = s[3];
@@ -897,7 +906,7 @@ struct LaneProgram {
         }
         // limit condensation: rows x get + wκ t_x (θ_a Δω_a + θ_b Δω_b)
         if (P.nlim_r > 0) {
-            T wk = (L.lg[1][1] + T(REG)) / (L.ls[1][1] + T(REG)) + (L.lg[1][0] + T(REG)) / (L.ls[1][0] + T(REG));
+            T wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1273,7 +1282,7 @@ struct LaneProgram {
         }
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0);
         if (P.nlim_r > 0) {
-            su = L.ls[1][0] + T(REG); sl = L.ls[1][1] + T(REG); gu = L.lg[1][0] + T(REG); gl = L.lg[1][1] + T(REG);
+            su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
             kap0 = (R.lim[1] - gl * rsl) / sl - (R.lim[0] - gu * rsu) / su;
             for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; up[i] += F.t_a[i] * kap0; }
         }
@@ -1351,8 +1360,8 @@ struct LaneProgram {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r58[c][i] = -cres[c][i];
         if (P.nlim_r > 0) {
-            rs[0] = -(L.ls[1][0] - (P.lim_hi - theta));       // limits.jl:13-14
-            rs[1] = -(L.ls[1][1] - (theta - P.lim_lo));
+            rs[0] = -(L.ls[0] - (P.lim_hi - theta));       // limits.jl:13-14
+            rs[1] = -(L.ls[1] - (theta - P.lim_lo));
         }
         solve_rhs(rk, R, rs, r58, upx, D);
     }
@@ -1363,14 +1372,14 @@ struct LaneProgram {
         if (active) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                a = tmin(a, ort_step(L.cs[1][c][0], D.dcs[c][0], tort));
-                a = tmin(a, ort_step(L.cg[1][c][0], D.dcg[c][0], tort));
-                a = tmin(a, soc_step(&L.cs[1][c][1], &D.dcs[c][1], tsoc));
-                a = tmin(a, soc_step(&L.cg[1][c][1], &D.dcg[c][1], tsoc));
+                a = tmin(a, ort_step(L.cs[c][0], D.dcs[c][0], tort));
+                a = tmin(a, ort_step(L.cg[c][0], D.dcg[c][0], tort));
+                a = tmin(a, soc_step(&L.cs[c][1], &D.dcs[c][1], tsoc));
+                a = tmin(a, soc_step(&L.cg[c][1], &D.dcg[c][1], tsoc));
             }
             if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) {
-                a = tmin(a, ort_step(L.ls[1][i], D.dls[i], tort));
-                a = tmin(a, ort_step(L.lg[1][i], D.dlg[i], tort));
+                a = tmin(a, ort_step(L.ls[i], D.dls[i], tort));
+                a = tmin(a, ort_step(L.lg[i], D.dlg[i], tort));
             }
         }
         return env_min(wv, a, envl);
@@ -1379,23 +1388,23 @@ struct LaneProgram {
     // candidate_step!  src/solver/line_search.jl:141-163: candidate = base + f Δ (base = the current iterate,
     // live only during the line search).  Returns 1 if ω stays beyond the error threshold after clipping.
     DJ_HD void snapshot(SolSnap<T, MAXC>& B) const {
-        for (int i = 0; i < 3; ++i) { B.v[i] = L.v[1][i]; B.w[i] = L.w[1][i]; }
-        for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[1][i];
-        for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[1][i]; B.lg[i] = L.lg[1][i]; }
+        for (int i = 0; i < 3; ++i) { B.v[i] = L.v[i]; B.w[i] = L.w[i]; }
+        for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[i];
+        for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[i]; B.lg[i] = L.lg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { B.cs[c][i] = L.cs[1][c][i]; B.cg[c][i] = L.cg[1][c][i]; }
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { B.cs[c][i] = L.cs[c][i]; B.cg[c][i] = L.cg[c][i]; }
     }
     DJ_HD int candidate_step(const SolSnap<T, MAXC>& B, const Step<T, MAXC>& D, T f) {
         int bad = 0;
-        for (int i = 0; i < 3; ++i) { L.v[1][i] = B.v[i] + f * D.dv[i]; L.w[1][i] = B.w[i] + f * D.dw[i]; }
+        for (int i = 0; i < 3; ++i) { L.v[i] = B.v[i] + f * D.dv[i]; L.w[i] = B.w[i] + f * D.dw[i]; }
         T wmax = T(3.9) / (G.dt * G.dt);
-        T wd = v3dot(L.w[1], L.w[1]);
-        if (wd > wmax) { T sc = wmax / wd; for (int i = 0; i < 3; ++i) L.w[1][i] *= sc; }
-        if (v3dot(L.w[1], L.w[1]) > T(3.91) / (G.dt * G.dt)) bad = 1;
-        for (int i = 0; i < 6; ++i) L.lam[1][i] = B.lam[i] + f * D.dlam[i];
-        for (int i = 0; i < 2; ++i) { L.ls[1][i] = B.ls[i] + f * D.dls[i]; L.lg[1][i] = B.lg[i] + f * D.dlg[i]; }
+        T wd = v3dot(L.w, L.w);
+        if (wd > wmax) { T sc = wmax / wd; for (int i = 0; i < 3; ++i) L.w[i] *= sc; }
+        if (v3dot(L.w, L.w) > T(3.91) / (G.dt * G.dt)) bad = 1;
+        for (int i = 0; i < 6; ++i) L.lam[i] = B.lam[i] + f * D.dlam[i];
+        for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[1][c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[1][c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
         return bad;
     }
 
@@ -1417,14 +1426,14 @@ struct LaneProgram {
         else { L.xa2[0] = L.xa2[1] = L.xa2[2] = T(0); L.qa2[0] = T(1); L.qa2[1] = L.qa2[2] = L.qa2[3] = T(0); }
         joint_cfg(cfg, P, L.xa2, L.qa2, L.x2, L.q2);
         // warm start (set_velocity_solution!, bodies/set.jl:1-7), reset!/initialize! of the cone variables
-        for (int i = 0; i < 3; ++i) { L.v[1][i] = v15[i]; L.w[1][i] = w15[i]; L.v15[i] = v15[i]; L.w15[i] = w15[i]; }
-        for (int j = 1; j < 2; ++j) {
-            for (int i = 0; i < 6; ++i) L.lam[j][i] = T(0);
-            for (int i = 0; i < 2; ++i) { L.ls[j][i] = T(1); L.lg[j][i] = T(1); }            // joints/constraints.jl:440-448
+        for (int i = 0; i < 3; ++i) { L.v[i] = v15[i]; L.w[i] = w15[i]; L.v15[i] = v15[i]; L.w15[i] = w15[i]; }
+        {
+            for (int i = 0; i < 6; ++i) L.lam[i] = T(0);
+            for (int i = 0; i < 2; ++i) { L.ls[i] = T(1); L.lg[i] = T(1); }            // joints/constraints.jl:440-448
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {                                                  // reset! to [1,1,0,0] then initialize! -> 1.5·[1,1,0,0]
-                L.cs[j][c][0] = L.cs[j][c][1] = T(1.5); L.cs[j][c][2] = L.cs[j][c][3] = T(0);
-                L.cg[j][c][0] = L.cg[j][c][1] = T(1.5); L.cg[j][c][2] = L.cg[j][c][3] = T(0);
+                L.cs[c][0] = L.cs[c][1] = T(1.5); L.cs[c][2] = L.cs[c][3] = T(0);
+                L.cg[c][0] = L.cg[c][1] = T(1.5); L.cg[c][2] = L.cg[c][3] = T(0);
             }
         }
         // velocity-independent part of d: D1x + D1q (constraint.jl:15-18 in closed form) − gravity − inputs − springs
@@ -1473,9 +1482,12 @@ struct LaneProgram {
     DJ_HD void linearize() {
         if constexpr (QUAD) {
             QuadBlocks<TL> K(F.Sq, F.Uq, F.Lq, q);
+            DJ_PB();
             evaluate<true>(K);
             condense(K);
+            DJ_PE(0); DJ_PB();
             factorize_quad(K);
+            DJ_PE(1);
             return;
         } else {
         FullBlocks<T> K;
@@ -1522,17 +1534,19 @@ struct LaneProgram {
             ConeRhs R;
             cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
             Step<T, MAXC> D;
+            DJ_PB();
             solve(R, D);                                            // affine direction
+            DJ_PE(4);
             T aaff = cone_line_search(D, T(0.95), T(0.95));
             // centering!  src/solver/centering.jl
             T p0 = T(0), p1 = T(0), p2 = T(0);
             if (active) {
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                    for (int i = 0; i < 4; ++i) { p0 += L.cs[1][c][i] * L.cg[1][c][i]; p1 += (L.cs[1][c][i] + aaff * D.dcs[c][i]) * (L.cg[1][c][i] + aaff * D.dcg[c][i]); }
+                    for (int i = 0; i < 4; ++i) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
                     p2 += T(2);
                 }
-                if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[1][i] * L.lg[1][i]; p1 += (L.ls[1][i] + aaff * D.dls[i]) * (L.lg[1][i] + aaff * D.dlg[i]); p2 += T(1); }
+                if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
             }
             p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl);
             T munew = G.btol / undercut;
@@ -1553,7 +1567,9 @@ struct LaneProgram {
             }
             R.lim[0] += -D.dls[0] * D.dlg[0] + mutarget;
             R.lim[1] += -D.dls[1] * D.dlg[1] + mutarget;
+            DJ_PB();
             solve(R, D);                                            // corrected direction
+            DJ_PE(2);
             T mx = tmax(rvio, bvio);
             T tau = tmax(T(0.95), T(1) - mx * mx);
             T alpha = cone_line_search(D, tau, tmin(tau, T(0.95)));
@@ -1564,6 +1580,7 @@ struct LaneProgram {
                 T f = done ? T(0) : alpha;
                 SolSnap<T, MAXC> base_sol;
                 snapshot(base_sol);
+                DJ_PB();
                 for (int ls = 0; ls < G.max_ls; ++ls) {
                     if (!wv.any(active && searching)) break;
                     int bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
@@ -1577,6 +1594,7 @@ struct LaneProgram {
                         if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
                     }
                 }
+                DJ_PE(3);
             }
             if (!done) {
                 bool made = (!(rc < G.rtol) && rc < T(0.8) * rvio) || (!(bc < G.btol) && bc < T(0.8) * bvio);
@@ -1605,17 +1623,18 @@ struct LaneProgram {
     DJ_HD void gradients(const KA& A, int env) {
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
+        DJ_PB();
         // ---- kinematics of the solution (chain) ----
-        T own6[6] = {L.v[1][0], L.v[1][1], L.v[1][2], L.w[1][0], L.w[1][1], L.w[1][2]}, par6[6], va[3], wa[3];
+        T own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6], va[3], wa[3];
         shfl_vec<6>(wv, par6, own6, plane);
         for (int i = 0; i < 3; ++i) { va[i] = has_parent ? par6[i] : T(0); wa[i] = has_parent ? par6[3 + i] : T(0); }
         Kin<T> kb0, ka0;
-        kin_of(kb0, L.x2, L.q2, L.v[1], L.w[1], dt);
+        kin_of(kb0, L.x2, L.q2, L.v, L.w, dt);
         kin_of(ka0, L.xa2, L.qa2, va, wa, dt);
         // ---- evaluation state of the data blocks ----
         T x2e[3], q2e[4], xa2e[3], qa2e[4], w15e[3];
         if (G.grad_mode == 0) {                                   // reference: x2 <- x3, q2 <- q3, ω15 <- ω25
-            for (int i = 0; i < 3; ++i) { x2e[i] = kb0.x3[i]; xa2e[i] = ka0.x3[i]; w15e[i] = L.w[1][i]; }
+            for (int i = 0; i < 3; ++i) { x2e[i] = kb0.x3[i]; xa2e[i] = ka0.x3[i]; w15e[i] = L.w[i]; }
             for (int i = 0; i < 4; ++i) { q2e[i] = kb0.q3[i]; qa2e[i] = ka0.q3[i]; }
         } else {
             for (int i = 0; i < 3; ++i) { x2e[i] = L.x2[i]; xa2e[i] = L.xa2[i]; w15e[i] = L.w15[i]; }
@@ -1624,10 +1643,10 @@ struct LaneProgram {
         JointCfg<T> ce;
         joint_cfg(ce, P, xa2e, qa2e, x2e, q2e);
         Kin<T> kb, ka;
-        kin_of(kb, x2e, q2e, L.v[1], L.w[1], dt);
+        kin_of(kb, x2e, q2e, L.v, L.w, dt);
         kin_of(ka, xa2e, qa2e, va, wa, dt);
         JointEval<T> E;
-        { NullBlocks nk; joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w[1], L.lam[1], L.lg[1], dt, nk); }
+        { NullBlocks nk; joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, nk); }
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -1660,12 +1679,12 @@ struct LaneProgram {
         {
             T pt[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
             for (int i = 0; i < 3; ++i) {
-                if (i < P.nl_t) for (int q_ = 0; q_ < 3; ++q_) pt[q_] += P.Ct[3 * i + q_] * L.lam[1][i];
-                if (i < P.nl_r) for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Cr[3 * i + q_] * L.lam[1][3 + i];
+                if (i < P.nl_t) for (int q_ = 0; q_ < 3; ++q_) pt[q_] += P.Ct[3 * i + q_] * L.lam[i];
+                if (i < P.nl_r) for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Cr[3 * i + q_] * L.lam[3 + i];
             }
-            if (P.nlim_r > 0) { T kk = L.lg[1][1] - L.lg[1][0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
+            if (P.nlim_r > 0) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
             T Jaa[36], Jab[36], Jba[36], Jbb[36];
-            joint_impulse_cfg_jac(Jaa, Jab, Jba, Jbb, P, ce, pt, pr, wa, L.w[1], dt);
+            joint_impulse_cfg_jac(Jaa, Jab, Jba, Jbb, P, ce, pt, pr, wa, L.w, dt);
             for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
                 int cj = j < 3 ? j : 3 + j;                       // x2 -> cols 0:3, φ2 -> cols 6:9 of the 12 own-data columns
                 OwnB[i][cj] += Jbb[6 * i + j];
@@ -1680,7 +1699,7 @@ struct LaneProgram {
             for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) Cc[c][i][j] = T(0);
             if (c < P.ncontact) {
                 ContactEval<T> CE;
-                contact_eval<true>(CE, CP[P.contact[c]], kb, L.v[1], L.w[1], L.cs[1][c], L.cg[1][c], dt);
+                contact_eval<true>(CE, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
                 const ContactP<T>& K = CP[P.contact[c]];
                 for (int j = 0; j < 3; ++j) {
                     Cc[c][0][j] = -K.n[j];
@@ -1720,7 +1739,7 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) GK[c][i][j] = (c < P.ncontact) ? cold.G134[c][i] * Q.k0[0] + cold.G134[c][6 + i] * Q.k0[1] + cold.G134[c][12 + i] * Q.k0[2] : T(0);
             }
         }
-        if (P.nlim_r > 0) wk = (L.lg[1][1] + T(REG)) / (L.ls[1][1] + T(REG)) + (L.lg[1][0] + T(REG)) / (L.ls[1][0] + T(REG));
+        if (P.nlim_r > 0) wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
         // ---- stash the data blocks: one copy per supernode in LDS (quad mapping), else per-lane local memory ----
         typedef typename KA::io_type TB;
         GradBlocks<TB, MAXC> gb_local;
@@ -1738,7 +1757,7 @@ struct LaneProgram {
         }
         if constexpr (QUAD) wv.sync();
         const GradBlocks<TB, MAXC>& gb = *gbp;
-        if constexpr (QUAD) { gradient_columns_quad(A, env, gb, GK, wk, kb0); return; }
+        if constexpr (QUAD) { DJ_PE(5); DJ_PB(); gradient_columns_quad(A, env, gb, GK, wk, kb0); DJ_PE(6); return; }
         // ---- column loop (lane = supernode mapping) ----
         struct { T dv[3], dw[3]; } D;
         auto grad_solve = [&](T* rk, T rs0, const T (*r58)[4], T* upx) {
@@ -1813,8 +1832,8 @@ struct LaneProgram {
     // update_state!  src/bodies/set.jl:22-36: -> (x3, v25, q3, ω25) = the next maximal state of this body
     DJ_HD void next_state(T* zb) const {
         Kin<T> kb;
-        kin_of(kb, L.x2, L.q2, L.v[1], L.w[1], G.dt);
-        for (int i = 0; i < 3; ++i) { zb[i] = kb.x3[i]; zb[3 + i] = L.v[1][i]; zb[10 + i] = L.w[1][i]; }
+        kin_of(kb, L.x2, L.q2, L.v, L.w, G.dt);
+        for (int i = 0; i < 3; ++i) { zb[i] = kb.x3[i]; zb[3 + i] = L.v[i]; zb[10 + i] = L.w[i]; }
         for (int i = 0; i < 4; ++i) zb[6 + i] = kb.q3[i];
     }
 };
@@ -1851,13 +1870,17 @@ struct KernelArgs {
 // (Lane) and the cold linearization data (Cold) — exists once per supernode in LDS; the four lanes
 // read it with broadcast ds_reads and write identical values in the same instruction.  The SIMT
 // emulator's threads are not in lock step, so there Lane stays per-lane and Cold is per-lane in "LDS".
-//   [0, lane_bytes)            : Lane  x 16 supernodes            (LOCKSTEP only)
+//   [0, node_bytes)            : NodeP x 16 supernodes (copied once from the table in global memory; LOCKSTEP only)
+//   [node_bytes, lane_bytes)   : Lane  x 16 supernodes            (LOCKSTEP only)
 //   [lane_bytes, +max(cold,gb)): Cold x 16 (or x 64), overlaid by GradBlocks x 16 in the IFT phase
 template <class T, int MAXC>
 struct LaneSlot { Lane<T, MAXC> L; T pad_[(sizeof(Lane<T, MAXC>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };   // odd stride in 8-byte words
+template <class T>
+struct NodeSlot { NodeP<T> P; char pad_[(sizeof(NodeP<T>) / 8) % 2 == 0 ? 8 : 16]; };                    // odd stride in 8-byte words
 template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP>
 struct StepLds {
-    static constexpr int lane_bytes = (QUAD && LOCKSTEP) ? (int)sizeof(LaneSlot<T, MAXC>) * 16 : 0;
+    static constexpr int node_bytes = (QUAD && LOCKSTEP) ? (int)sizeof(NodeSlot<T>) * 16 : 0;      // the supernode's constants
+    static constexpr int lane_bytes = node_bytes + ((QUAD && LOCKSTEP) ? (int)sizeof(LaneSlot<T, MAXC>) * 16 : 0);
     static constexpr int cold_n = LOCKSTEP ? 16 : 64;
     static constexpr bool cold_in_lds = QUAD && ((int)sizeof(Cold<T, MAXC>) * cold_n + lane_bytes <= 40 * 1024);
     static constexpr int cold_bytes = cold_in_lds ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
@@ -1877,13 +1900,15 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     const int env = wave_index * E + slot;
     const bool active = (env < A.B) && (k < G.Nb);
     const int base = slot * envl;
-    const NodeP<T>& P = A.nodes[k < G.Nb ? k : 0];
     typedef StepLds<TIO, T, MAXC, GRAD, QUAD, Wave::kLockstep> LY;
     constexpr bool SHARE = QUAD && Wave::kLockstep;
     char* lds = (char*)wv.lds();
+    const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];
+    if (SHARE) ((NodeSlot<T>*)lds)[lane / 4].P = Pg;           // the four lanes store identical values
+    const NodeP<T>& P = SHARE ? ((NodeSlot<T>*)lds)[lane / 4].P : Pg;
     Lane<T, MAXC> lane_local;
     Cold<T, MAXC> cold_local;
-    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)lds)[lane / 4].L : lane_local;
+    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)(lds + LY::node_bytes))[lane / 4].L : lane_local;
     Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local;
     LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);
     if (QUAD) prog.gb_lds = (void*)(((GradBlocks<TIO, MAXC>*)(lds + LY::lane_bytes)) + lane / 4);
@@ -1897,28 +1922,38 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
 #endif
     int iters = 0;
+#ifdef DJ_PROF
+    unsigned long long t_all = wv.clock();
+#endif
     int status = prog.mehrotra(iters);
     if (GRAD) { if (A.dz != nullptr) prog.gradients(A, env); }
+#ifdef DJ_PROF
+    prog.pc[7] = wv.clock() - t_all;
+#endif
     if (active && q == 0) {
         T zn[13];
         prog.next_state(zn);
         TIO* o = A.z_next + (size_t)env * 13 * G.Nb + 13 * k;
         for (int i = 0; i < 13; ++i) o[i] = TIO(zn[i]);
         if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; }
-        if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[1][i]); vo[3 + i] = TIO(prog.L.w[1][i]); } }
+        if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[i]); vo[3 + i] = TIO(prog.L.w[i]); } }
+#ifdef DJ_PROF
+        if (A.vel && k == 0) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb; for (int i = 0; i < 6; ++i) vo[i] = TIO((double)prog.pc[i]); }   // phases 0-5 (cycles)
+        if (A.vel && k == 1) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6; vo[0] = TIO((double)prog.pc[7]); vo[1] = TIO((double)iters); vo[2] = TIO((double)prog.pc[6]); }
+#endif
         if (A.joint_imp && P.n_imp > 0) {
             // get_solution order per joint: [tra: λ_t] [rot: s_up s_lo γ_up γ_lo λ_r]   (translational limits unsupported)
             TIO* jo = A.joint_imp + (size_t)env * G.n_joint_imp + P.imp_off;
             int o2 = 0;
-            for (int i = 0; i < 3; ++i) if (i < P.nl_t) jo[o2++] = TIO(prog.L.lam[1][i]);
-            if (P.nlim_r > 0) { jo[o2++] = TIO(prog.L.ls[1][0]); jo[o2++] = TIO(prog.L.ls[1][1]); jo[o2++] = TIO(prog.L.lg[1][0]); jo[o2++] = TIO(prog.L.lg[1][1]); }
-            for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[1][3 + i]);
+            for (int i = 0; i < 3; ++i) if (i < P.nl_t) jo[o2++] = TIO(prog.L.lam[i]);
+            if (P.nlim_r > 0) { jo[o2++] = TIO(prog.L.ls[0]); jo[o2++] = TIO(prog.L.ls[1]); jo[o2++] = TIO(prog.L.lg[0]); jo[o2++] = TIO(prog.L.lg[1]); }
+            for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[3 + i]);
         }
         if (A.contact_sg) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
                 TIO* co = A.contact_sg + (size_t)env * 8 * G.Nc + 8 * P.contact[c];
-                for (int i = 0; i < 4; ++i) { co[i] = TIO(prog.L.cs[1][c][i]); co[4 + i] = TIO(prog.L.cg[1][c][i]); }
+                for (int i = 0; i < 4; ++i) { co[i] = TIO(prog.L.cs[c][i]); co[4 + i] = TIO(prog.L.cg[c][i]); }
             }
         }
     }

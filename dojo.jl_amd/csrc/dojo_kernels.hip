@@ -25,6 +25,7 @@ struct GpuWave {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
     __device__ __forceinline__ int width() const { return 64; }
+    __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
     __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src, 64); }
@@ -49,12 +50,29 @@ struct GpuWave {
 // <float,double,double>: the interior-point iteration drives s·γ to ~1e-9 and the condensed KKT
 // then has entries ~γ/s that fp32 cannot resolve (measured in tests/emu).
 // GRAD = false compiles the IFT back-solves out (forward-only launches: step!, simulate!).
-template <class TIO, class TS, class TL, int MAXC, bool GRAD, bool QUAD>
-__global__ void __launch_bounds__(64) dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
-    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, GRAD, QUAD>() + 7) / 8];
+// Two entry points so that the register budget can differ: DJ_FWD_WAVES / DJ_GRAD_WAVES = resident
+// waves per SIMD the compiler must allow for (512 unified VGPRs / waves; LDS must fit as well).
+#ifndef DJ_FWD_WAVES
+#define DJ_FWD_WAVES 1
+#endif
+#ifndef DJ_GRAD_WAVES
+#define DJ_GRAD_WAVES 1
+#endif
+template <class TIO, class TS, class TL, int MAXC, bool QUAD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DJ_FWD_WAVES, DJ_FWD_WAVES)))
+dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
+    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, false, QUAD>() + 7) / 8];
     GpuWave w;
     w.lds_ = (void*)lds_buf;
-    dj::step_entry<TIO, TS, TL, MAXC, GRAD, QUAD, GpuWave>(w, A, (int)blockIdx.x);
+    dj::step_entry<TIO, TS, TL, MAXC, false, QUAD, GpuWave>(w, A, (int)blockIdx.x);
+}
+template <class TIO, class TS, class TL, int MAXC, bool QUAD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
+dojo_step_grad_kernel(dj::KernelArgs<TIO, TS> A) {
+    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, true, QUAD>() + 7) / 8];
+    GpuWave w;
+    w.lds_ = (void*)lds_buf;
+    dj::step_entry<TIO, TS, TL, MAXC, true, QUAD, GpuWave>(w, A, (int)blockIdx.x);
 }
 
 } // namespace
@@ -65,7 +83,7 @@ __global__ void __launch_bounds__(64) dojo_step_kernel(dj::KernelArgs<TIO, TS> A
 
 extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
-    if (grad) hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, true, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
-    else      hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, false, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    if (grad) hipLaunchKernelGGL((dojo_step_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    else      hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }

@@ -14,7 +14,7 @@ import numpy as np
 from .topology import CTopology, CSolverOptions, CDims, SolverOptions
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libdojo_hip.so")
+_LIB_PATH = os.environ.get("DOJO_HIP_LIB") or os.path.join(_CSRC, "libdojo_hip.so")   # override: instrumented builds (tools/build_variant.sh prof -DDJ_PROF)
 _lib = None
 
 STATUS_SUCCESS, STATUS_FAILED, STATUS_EXCESSIVE_W = 0, 1, 2

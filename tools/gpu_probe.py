@@ -63,3 +63,25 @@ if what in ("all", "grad"):
         print("grad cfg %d pre %d tol %.0e: n_ok %d/%d  state err q50 %.1e q90 %.1e max %.1e | dz rel err q50 %.1e q75 %.1e q90 %.1e max %.1e | scale max %.1e" % (
             cfg, pre, tol, len(ok), B, *np.quantile(es, [0.5, 0.9, 1.0]), *np.quantile(ez, [0.5, 0.75, 0.9, 1.0]), max(np.abs(dz_o[b]).max() for b in ok)), flush=True)
         gm.close()
+
+if what == "phases":
+    # needs the instrumented library: DOJO_HIP_LIB=dojo.jl_amd/csrc/libdojo_hip_prof.so (tools/build_variant.sh prof -DDJ_PROF);
+    # the step kernel then reports per-phase cycle counts of every wave through the `vel` export
+    spec = d.baseline_config(3)
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    B = 4096
+    Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f32")
+    z = Z.astype(np.float32)
+    for grad in (False, True):
+        for k in range(3):
+            zn, st, it = gm.step(z, U, with_gradient=grad); z = zn
+        vel, ji, cs = gm.get_solution()
+        ph = np.concatenate([vel[:, :6], vel[:, 8:9]], axis=1).astype(np.float64); tot = vel[:, 6].astype(np.float64); iters = vel[:, 7]
+        names = ["assemble+condense", "factorize", "solve(corrector)", "line search", "solve(affine)", "grad data", "grad sweeps"]
+        print("phases grad=%d kernel %.2f ms; mean cycles/wave %.0f, iters %.2f (max %d)" % (grad, gm.last_kernel_ms(), tot.mean(), iters.mean(), iters.max()))
+        for n, v in zip(names, ph.mean(axis=0)):
+            print("   %-20s %10.0f cycles  %5.1f%%" % (n, v, 100 * v / tot.mean()))
+        print("   %-20s %10.0f cycles  %5.1f%%" % ("other", tot.mean() - ph.mean(axis=0).sum(), 100 * (1 - ph.mean(axis=0).sum() / tot.mean())))
+        json.dump(dict(total=tot.tolist(), iters=iters.tolist()), open(os.path.join(out, "phase_hist_grad%d.json" % grad), "w"))
+    gm.close()
