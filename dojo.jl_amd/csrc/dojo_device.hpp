@@ -41,6 +41,7 @@ struct Globals {
     T rtol, btol, undercut, no_progress_undercut;
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
+    unsigned char maxch_lev[64]; // largest number of children among the supernodes of each level (bounds the level sweeps' gathers)
 };
 
 // per-supernode constants (body k, its parent joint, its contacts)
@@ -686,8 +687,9 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
         if (ci < maxch) {
             int src = (active && ci < P.nchild) ? base + stride * P.child[ci] + q : w.lane();
             bool use = active && ci < P.nchild;
+            const T usef = use ? T(1) : T(0);                  // unused slots read the lane's own (finite) value and add 0·t
 #pragma unroll
-            for (int i = 0; i < N; ++i) { T t = w.shfl(in[i], src); if (use) acc[i] += t; }
+            for (int i = 0; i < N; ++i) { T t = w.shfl(in[i], src); acc[i] += usef * t; }
         }
     }
 }
@@ -932,7 +934,7 @@ struct LaneProgram {
             // receive the children's contributions (they were produced at lev+1)
             TL acc[36];
             for (int i = 0; i < 36; ++i) acc[i] = TL(0);
-            gather_children<36>(wv, acc, up, P, base, G.maxch, active && P.level == lev, stride, q);
+            gather_children<36>(wv, acc, up, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Sl[12 * i + j] += acc[6 * i + j];
                 for (int i = 0; i < 144; ++i) F.Sinv[i] = Sl[i];
@@ -969,32 +971,45 @@ struct LaneProgram {
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
-            gather_children<18>(wv, acc, upf, P, base, G.maxch, at, stride, q);
+            gather_children<18>(wv, acc, upf, P, base, G.maxch_lev[lev], at, stride, q);
             if (at && q < 2) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) A[i][j] += acc[6 * i + j];
             }
-            // distributed Gauss-Jordan (all lanes take part in the shuffles; only lanes at this level change)
+            // distributed Gauss-Jordan (all lanes take part in the shuffles; only lanes at this level change).
+            // The owner keeps its pivot row UNSCALED until all twelve pivots are done (a row that has been a
+            // pivot only ever receives row operations afterwards, so the factor 1/pivot commutes to the end):
+            // every row then takes the same update A −= fe·prow with fe = 0 on the pivot row itself.
+            const TL atf = at ? TL(1) : TL(0);
+            TL ipown[3] = {TL(1), TL(1), TL(1)};
 #pragma unroll
             for (int p = 0; p < 12; ++p) {
                 const int o = p / 3, ro = p % 3;
+                const bool own = (q == o);
                 TL prow[12];
 #pragma unroll
                 for (int c = 0; c < 12; ++c) prow[c] = wv.quad_bcast(A[ro][c], o);
-                TL ip = TL(1) / (at ? prow[p] : TL(1));
+                const TL ip = TL(1) / (at ? prow[p] : TL(1));
+                if (own) ipown[ro] = ip;
 #pragma unroll
-                for (int c = 0; c < 12; ++c) prow[c] = (c == p) ? ip : prow[c] * ip;
+                for (int c = 0; c < 12; ++c) if (c != p) prow[c] *= ip;
+                const TL ipc = at ? ip : TL(-1);               // lanes elsewhere: −f·(−1) = f, column p unchanged
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const bool is_piv = (q == o) && (r == ro);
                     const TL f = A[r][p];
-                    const TL fe = at ? f : TL(0);          // lanes not at this level keep their rows (ip = 1, prow = own row)
+                    const TL fe = (r == ro) ? (own ? TL(0) : f * atf) : f * atf;
 #pragma unroll
-                    for (int c = 0; c < 12; ++c) if (c != p) A[r][c] = is_piv ? prow[c] : A[r][c] - fe * prow[c];
-                    A[r][p] = at ? (is_piv ? ip : -f * ip) : f;
+                    for (int c = 0; c < 12; ++c) if (c != p) A[r][c] -= fe * prow[c];
+                    A[r][p] = (r == ro) ? (own ? (at ? TL(1) : f) : -f * ipc) : -f * ipc;
                 }
+            }
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) A[i][c] *= ipown[i];
             }
             // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero)
             TL Uf[12][6];
@@ -1198,7 +1213,7 @@ struct LaneProgram {
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             const bool at = active && P.level == lev;
             TL acc[3] = {0, 0, 0};
-            gather_children<3>(wv, acc, send3, P, base, G.maxch, at, stride, q);
+            gather_children<3>(wv, acc, send3, P, base, G.maxch_lev[lev], at, stride, q);
             if (at) { r3[0] += acc[0]; r3[1] += acc[1]; r3[2] += acc[2]; }
             TL rf[12];
 #pragma unroll
@@ -1330,7 +1345,7 @@ struct LaneProgram {
         for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             TL acc[6] = {0, 0, 0, 0, 0, 0};
-            gather_children<6>(wv, acc, send, P, base, G.maxch, active && P.level == lev, stride, q);
+            gather_children<6>(wv, acc, send, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) rl[i] += acc[i];
                 if (has_parent) { TL t[6]; mv<6, 12>(t, F.W, rl); for (int i = 0; i < 6; ++i) send[i] = TL(up[i]) - t[i]; }
