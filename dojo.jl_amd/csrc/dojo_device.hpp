@@ -224,6 +224,27 @@ struct GradBlocks {
     TB Cc[MAXC][4][6];
     TB pad_[1];
 };
+// Quad mapping: the IFT right-hand sides of one supernode, laid out per role (lane q owns rows
+// 3q..3q+2) with the cone condensation already folded in, so that the column sweeps load their
+// rows with one address computation and no divergence.  Flat array, offsets below; odd word count.
+template <class TB>
+struct alignas(8) QuadRhs {
+    enum { ROWNV = 0,     // [2 roles][3 rows][6]  owner body rows, velocity columns (v15 ω15)
+           ROWNJ = 36,    // [2][3][6]  owner joint rows (roles 2, 3), configuration columns (x2 φ2)
+           RPAR = 72,     // [4][3][6]  rows of this supernode for the PARENT's configuration columns
+           UOWN = 144,    // [2][3][6]  what the owner's configuration columns put on the parent's body rows
+           UPAR = 180,    // [2][3][6]  the same for the parent's own configuration columns
+           UB = 216,      // [2][3][6]  control columns: child body rows
+           UA = 252,      // [2][3][6]  control columns: parent body rows
+           SLO = 288,     // [6]  joint-limit slack rows, owner's configuration columns  (applied as t·wκ·sl in the sweep:
+           SLP = 294,     // [6]  ... parent's configuration columns                       rounding must stay along t)
+           SIZE = 300 };
+    TB a[SIZE];
+    // owner body rows of the configuration columns, cone condensation folded in: kept in double even with
+    // fp32 ABI buffers (the folded terms ~γ/s cancel against the stiff rows of S⁻¹)      [2 roles][3][6]
+    double own_cfg[36];
+    double pad_[(SIZE * sizeof(TB) / 8 + 36) % 2 == 0 ? 1 : 2];     // odd stride in 8-byte words
+};
 // T_a p and T_b p for the translational half: 6-vectors (force in world frame, torque in body frame)
 template <class T> DJ_HD void tra_impulse(T* ia, T* ib, const JointCfg<T>& c, const NodeP<T>& P, const T* p) {
     T F[3], t[3];
@@ -1059,8 +1080,8 @@ struct LaneProgram {
     // IFT costs (batches + depth) steps per sweep instead of batches × depth.  The forward-substituted
     // right-hand sides y wait between the two sweeps in the output buffer itself (the v / ω slots of
     // the column, which the down-sweep then overwrites with the final values).
-    template <class KA, class GB, class KN>
-    DJ_HD void gradient_columns_quad(const KA& A, int env, const GB& gb, const T (*GK)[6][4], T wk, const KN& kb0) {
+    template <class KA, class RH, class KN>
+    DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
         constexpr int NC = 6;
@@ -1074,14 +1095,13 @@ struct LaneProgram {
         const int myu = P.nu_t + P.nu_r;
         const int lvl = P.level;
         const int pb = has_parent ? base + stride * P.parent : qb;
-        // this lane's six rows of column cI of batch b in the output buffers (null: padding column)
-        auto colptr = [&](int b, int cI) -> TIO* {
-            if (b < nbs) {
-                const int c = (b & 1) == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
-                return A.dz + ((size_t)env * nx + (size_t)(12 * (b >> 1) + c)) * nx + 12 * k + 6 * q;
-            }
-            const int ui = NC * (b - nbs) + cI;
-            return ui < G.nu ? A.du + ((size_t)env * G.nu + (size_t)ui) * nx + 12 * k + 6 * q : (TIO*)nullptr;
+        const int qh = q & 1;
+        const TG tb3[3] = {TG(F.t_b[3 * qh]), TG(F.t_b[3 * qh + 1]), TG(F.t_b[3 * qh + 2])}, ta3[3] = {TG(F.t_a[3 * qh]), TG(F.t_a[3 * qh + 1]), TG(F.t_a[3 * qh + 2])};
+        // this lane's six rows of the first column of batch b in the output buffers, element stride between columns = nx;
+        // state batches: column cI sits at index cI (+3 for cI >= 3: the batch holds x2|φ2 or v15|ω15)
+        auto colbase = [&](int b) -> TIO* {
+            if (b < nbs) return A.dz + ((size_t)env * nx + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nx + 12 * k + 6 * q;
+            return A.du + ((size_t)env * G.nu + (size_t)(NC * (b - nbs))) * nx + 12 * k + 6 * q;
         };
         // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
         TG send3[NC][3];
@@ -1097,34 +1117,37 @@ struct LaneProgram {
             gather_children<3 * NC>(wv, acc, snd, P, base, G.maxch, valid, stride, q);
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
-            const bool mine = valid && isS && (k == kk), child_of = valid && isS && has_parent && (P.parent == kk);
+            const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (P.parent == kk);
+            // where this lane's rows of the batch's right-hand sides live in the supernode's QuadRhs (all blocks are [.][3][6]):
+            //   own batch: body roles: own_cfg (configuration columns, double) | ROWNV (velocity columns); joint roles: ROWNJ | 0
+            //   parent's configuration batch: RPAR[q] ;  control batch: UB on the owner (child body of the joint)
+            //   parent-row parts (roles 0, 1): UOWN / UPAR / UA
+            const int cu0 = NC * (b - nbs) - P.u_off;             // control batch: local input index of column 0
+            const int r_off = isS ? (mine ? (q < 2 ? RH::ROWNV : RH::ROWNJ) + qh * 18 : RH::RPAR + q * 18) : RH::UB + qh * 18 + cu0;
+            const int u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
+            const bool od = mine && typ == 0 && q < 2;              // the folded owner rows come from the double block
+            const TG rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0), um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
+            TIO* const cb = valid ? colbase(b) : (TIO*)nullptr;
+            // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
+            const TG wkm = (P.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
+            const int sl_off = mine ? RH::SLO : RH::SLP;
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
-                T r_[3] = {0, 0, 0}, u_[3] = {0, 0, 0}, rs0 = T(0);
-                if (isS) {
-                    const int c = typ == 0 ? (cI < 3 ? cI : cI + 3) : (cI < 3 ? 3 + cI : 6 + cI);
-                    if (mine) {
-                        if (q < 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnB[ro + i][c]); }
-                        if (typ == 0) {
-                            if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.OwnJ[3 * (q - 2) + i][cI]); }
-                            else {
-                                for (int i = 0; i < 3; ++i) u_[i] = T(gb.UpOwn[ro + i][cI]);
+                const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
+                const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
+                const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
+                const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
+                TG r_[3], u_[3];
 #pragma unroll
-                                for (int cn = 0; cn < MAXC; ++cn) if (cn < P.ncontact) {
-                                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) r_[i] += (q == 0 ? GK[cn][i][j] : GK[cn][3 + i][j]) * T(gb.Cc[cn][j][cI]);
-                                }
-                            }
-                            rs0 = T(gb.sl_own[cI]);
-                        }
-                    } else if (child_of && typ == 0) {
-                        if (q >= 2) { for (int i = 0; i < 3; ++i) r_[i] = T(gb.ParJ[3 * (q - 2) + i][cI]); }
-                        else { for (int i = 0; i < 3; ++i) { r_[i] = T(gb.ParB[ro + i][cI]); u_[i] = T(gb.UpPar[ro + i][cI]); } }
-                        rs0 = T(gb.sl_par[cI]);
-                    }
-                    if (P.nlim_r > 0 && q < 2) { T kap0 = wk * rs0; for (int i = 0; i < 3; ++i) { r_[i] += (q == 0 ? F.t_b[i] : F.t_b[3 + i]) * kap0; u_[i] += (q == 0 ? F.t_a[i] : F.t_a[3 + i]) * kap0; } }
-                } else {
-                    const int cu = NC * (b - nbs) + cI - P.u_off;      // control column: owner = child body of the joint
-                    if (valid && q < 2 && cu >= 0 && cu < myu) { for (int i = 0; i < 3; ++i) { r_[i] = T(gb.UB[ro + i][cu]); u_[i] = T(gb.UA[ro + i][cu]); } }
+                for (int i = 0; i < 3; ++i) {
+                    const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
+                    r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
+                    u_[i] = um * TG(R.a[iu + i * 6]);
+                }
+                {
+                    const TG kap0 = wkm * TG(R.a[sl_off + cI]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { r_[i] += tb3[i] * kap0; u_[i] += ta3[i] * kap0; }
                 }
                 TG r3[3];
 #pragma unroll
@@ -1150,7 +1173,7 @@ struct LaneProgram {
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? part[i] : part[3 + i]) : TG(0);
-                    if (q < 2) { TIO* o = colptr(b, cI); if (o) { o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); } }
+                    if (q < 2 && (isS || NC * (b - nbs) + cI < G.nu)) { TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
                 }
             }
         }
@@ -1163,6 +1186,7 @@ struct LaneProgram {
             const bool valid = active && b >= 0 && b < NB;
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
+            TIO* const cb = valid ? colbase(b) : (TIO*)nullptr;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
                 TG pa_[6];                                     // the parent finished this batch in the previous step
@@ -1179,7 +1203,7 @@ struct LaneProgram {
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
-                TIO* o = (valid && q < 2) ? colptr(b, n) : (TIO*)nullptr;
+                TIO* o = (valid && q < 2 && (isS || NC * (b - nbs) + n < G.nu)) ? cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx : (TIO*)nullptr;
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -1755,13 +1779,49 @@ struct LaneProgram {
             }
         }
         if (P.nlim_r > 0) wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
-        // ---- stash the data blocks: one copy per supernode in LDS (quad mapping), else per-lane local memory ----
         typedef typename KA::io_type TB;
+        if constexpr (QUAD) {
+            // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
+            wv.sync();                                              // aliases Cold: not needed below
+            QuadRhs<TB>& R = *(QuadRhs<TB>*)gb_lds;
+            const bool lim = P.nlim_r > 0;
+            if (q == 0) {
+#pragma unroll
+                for (int cI = 0; cI < 6; ++cI) { R.a[QuadRhs<TB>::SLO + cI] = TB(lim ? sl_own[cI] : T(0)); R.a[QuadRhs<TB>::SLP + cI] = TB(lim ? sl_par[cI] : T(0)); }
+#pragma unroll
+                for (int row = 0; row < 12; ++row) {
+                    const int qh_ = (row / 3) & 1, i = row % 3, o_ = qh_ * 18 + i * 6;
+#pragma unroll
+                    for (int cI = 0; cI < 6; ++cI) {
+                        const int cc = cI < 3 ? cI : cI + 3;        // configuration column (x2 | φ2) of the 12 own-data columns
+                        if (row < 6) {
+                            T v = OwnB[row][cc];
+#pragma unroll
+                            for (int cn = 0; cn < MAXC; ++cn) if (cn < P.ncontact) for (int j = 0; j < 4; ++j) v += GK[cn][row][j] * Cc[cn][j][cI];
+                            R.own_cfg[o_ + cI] = (double)v;
+                            R.a[QuadRhs<TB>::ROWNV + o_ + cI] = TB(OwnB[row][cc + 3]);
+                            R.a[QuadRhs<TB>::UOWN + o_ + cI] = TB(UpOwn[row][cI]);
+                            R.a[QuadRhs<TB>::UPAR + o_ + cI] = TB(UpPar[row][cI]);
+                            R.a[QuadRhs<TB>::UB + o_ + cI] = TB(UB[row][cI]);
+                            R.a[QuadRhs<TB>::UA + o_ + cI] = TB(UA[row][cI]);
+                            R.a[QuadRhs<TB>::RPAR + (row / 3) * 18 + i * 6 + cI] = TB(ParB[row][cI]);
+                        } else {
+                            R.a[QuadRhs<TB>::ROWNJ + o_ + cI] = TB(OwnJ[row - 6][cI]);
+                            R.a[QuadRhs<TB>::RPAR + (row / 3) * 18 + i * 6 + cI] = TB(ParJ[row - 6][cI]);
+                        }
+                    }
+                }
+            }
+            wv.sync();
+            DJ_PE(5); DJ_PB();
+            gradient_columns_quad(A, env, R, wk, kb0);
+            DJ_PE(6);
+            return;
+        }
+        // ---- lane = supernode mapping: data blocks in per-lane local memory ----
         GradBlocks<TB, MAXC> gb_local;
-        GradBlocks<TB, MAXC>* gbp = &gb_local;
-        if constexpr (QUAD) { wv.sync(); gbp = (GradBlocks<TB, MAXC>*)gb_lds; }   // aliases Cold: not needed below
-        if (!QUAD || q == 0) {
-            GradBlocks<TB, MAXC>& g_ = *gbp;
+        {
+            GradBlocks<TB, MAXC>& g_ = gb_local;
             for (int i = 0; i < 6; ++i) {
                 for (int j = 0; j < 12; ++j) g_.OwnB[i][j] = TB(OwnB[i][j]);
                 for (int j = 0; j < 6; ++j) { g_.OwnJ[i][j] = TB(OwnJ[i][j]); g_.ParB[i][j] = TB(ParB[i][j]); g_.ParJ[i][j] = TB(ParJ[i][j]); g_.UpOwn[i][j] = TB(UpOwn[i][j]); g_.UpPar[i][j] = TB(UpPar[i][j]); g_.UB[i][j] = TB(UB[i][j]); g_.UA[i][j] = TB(UA[i][j]); }
@@ -1770,9 +1830,7 @@ struct LaneProgram {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) g_.Cc[c][i][j] = TB(Cc[c][i][j]);
         }
-        if constexpr (QUAD) wv.sync();
-        const GradBlocks<TB, MAXC>& gb = *gbp;
-        if constexpr (QUAD) { DJ_PE(5); DJ_PB(); gradient_columns_quad(A, env, gb, GK, wk, kb0); DJ_PE(6); return; }
+        const GradBlocks<TB, MAXC>& gb = gb_local;
         // ---- column loop (lane = supernode mapping) ----
         struct { T dv[3], dw[3]; } D;
         auto grad_solve = [&](T* rk, T rs0, const T (*r58)[4], T* upx) {
@@ -1875,6 +1933,8 @@ struct KernelArgs {
     TIO* contact_sg;               // [B,8Nc] or null          ([s; γ] per contact)
     TIO* dz;                       // [B][12Nb cols][12Nb rows] column-major per env, or null
     TIO* du;                       // [B][nu cols][12Nb rows] column-major per env, or null
+    T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
+    T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
 #endif
@@ -1899,39 +1959,95 @@ struct StepLds {
     static constexpr int cold_n = LOCKSTEP ? 16 : 64;
     static constexpr bool cold_in_lds = QUAD && ((int)sizeof(Cold<T, MAXC>) * cold_n + lane_bytes <= 40 * 1024);
     static constexpr int cold_bytes = cold_in_lds ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
-    static constexpr int gb_bytes = (QUAD && GRAD) ? (int)sizeof(GradBlocks<TIO, MAXC>) * 16 : 0;
+    static constexpr int gb_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * 16 : 0;
     static constexpr int bytes = lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16;
 };
 template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP>::bytes; }
 
-template <class TIO, class T, class TL, int MAXC, bool GRAD, bool QUAD, class Wave>
-DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
-    const Globals<T>& G = A.G;
-    const int stride = QUAD ? 4 : 1;
-    const int envl = stride * G.S, E = wv.width() / envl;        // lanes per environment, environments per wave
-    const int lane = wv.lane();
-    const int slot = lane / envl, k = (lane % envl) / stride, q = lane % stride;
-    const int env = wave_index * E + slot;
-    const bool active = (env < A.B) && (k < G.Nb);
-    const int base = slot * envl;
-    typedef StepLds<TIO, T, MAXC, GRAD, QUAD, Wave::kLockstep> LY;
-    constexpr bool SHARE = QUAD && Wave::kLockstep;
-    char* lds = (char*)wv.lds();
-    const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];
-    if (SHARE) ((NodeSlot<T>*)lds)[lane / 4].P = Pg;           // the four lanes store identical values
-    const NodeP<T>& P = SHARE ? ((NodeSlot<T>*)lds)[lane / 4].P : Pg;
-    Lane<T, MAXC> lane_local;
-    Cold<T, MAXC> cold_local;
-    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)(lds + LY::node_bytes))[lane / 4].L : lane_local;
-    Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local;
-    LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);
-    if (QUAD) prog.gb_lds = (void*)(((GradBlocks<TIO, MAXC>*)(lds + LY::lane_bytes)) + lane / 4);
-    T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);
-    const bool has_u = A.u != nullptr;
-    if (active && has_u) for (int i = 0; i < 6; ++i) if (i < P.nu_t + P.nu_r) ue[i] = T(A.u[(size_t)env * G.nu + P.u_off + i]);
+// doubles per supernode in the step -> IFT hand-off record: v ω λ(6), s,γ of the joint limit, s,γ of the contacts, μ,
+// and the pieces of the final linearization the IFT needs besides the factors: t_a, t_b (limit condensation), G134
+template <int MAXC> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC; }
+// quad mapping: the factors themselves travel too (72 values per lane, stored [wave][72][64 lanes]: coalesced)
+constexpr int FAC_PER_LANE = 72;
+
+// The forward step and the IFT gradients are separate kernels (separate register allocations: the
+// gradient sweeps must not cost the Newton loop its registers).  The IFT kernel rebuilds the lane
+// program from (z, u), restores the converged solution from the hand-off record and re-linearizes
+// there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
+#define DJ_LANE_SETUP(GRAD_LAYOUT)                                                                                        \
+    const Globals<T>& G = A.G;                                                                                            \
+    const int stride = QUAD ? 4 : 1;                                                                                      \
+    const int envl = stride * G.S, E = wv.width() / envl;        /* lanes per environment, environments per wave */       \
+    const int lane = wv.lane();                                                                                           \
+    const int slot = lane / envl, k = (lane % envl) / stride, q = lane % stride;                                          \
+    const int env = wave_index * E + slot;                                                                                \
+    const bool active = (env < A.B) && (k < G.Nb);                                                                        \
+    const int base = slot * envl;                                                                                         \
+    typedef StepLds<TIO, T, MAXC, GRAD_LAYOUT, QUAD, Wave::kLockstep> LY;                                                 \
+    constexpr bool SHARE = QUAD && Wave::kLockstep;                                                                       \
+    char* lds = (char*)wv.lds();                                                                                          \
+    const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];                                                                       \
+    if (SHARE) ((NodeSlot<T>*)lds)[lane / 4].P = Pg;           /* the four lanes store identical values */                \
+    const NodeP<T>& P = SHARE ? ((NodeSlot<T>*)lds)[lane / 4].P : Pg;                                                     \
+    Lane<T, MAXC> lane_local;                                                                                             \
+    Cold<T, MAXC> cold_local;                                                                                             \
+    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)(lds + LY::node_bytes))[lane / 4].L : lane_local;           \
+    Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local; \
+    LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);                \
+    if (QUAD) prog.gb_lds = (void*)(((QuadRhs<TIO>*)(lds + LY::lane_bytes)) + lane / 4);                                  \
+    T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
+    for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
+    const bool has_u = A.u != nullptr;                                                                                    \
+    if (active && has_u) for (int i = 0; i < 6; ++i) if (i < P.nu_t + P.nu_r) ue[i] = T(A.u[(size_t)env * G.nu + P.u_off + i]); \
     prog.begin_step(zb, has_u ? ue : nullptr);
+
+// IFT kernel entry: one call per lane
+template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
+DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
+    DJ_LANE_SETUP(true)
+    {   // restore the converged solution (identical on the four lanes of a quad)
+        const T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
+        if (active) {
+            for (int i = 0; i < 3; ++i) { prog.L.v[i] = r[i]; prog.L.w[i] = r[3 + i]; }
+            for (int i = 0; i < 6; ++i) prog.L.lam[i] = r[6 + i];
+            prog.L.ls[0] = r[12]; prog.L.ls[1] = r[13]; prog.L.lg[0] = r[14]; prog.L.lg[1] = r[15];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { prog.L.cs[c][i] = r[16 + 8 * c + i]; prog.L.cg[c][i] = r[20 + 8 * c + i]; }
+            prog.mu = r[16 + 8 * MAXC];
+            if (QUAD) {
+                const T* r2 = r + 17 + 8 * MAXC;
+                for (int i = 0; i < 6; ++i) { prog.F.t_a[i] = r2[i]; prog.F.t_b[i] = r2[6 + i]; }
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 18; ++i) cold.G134[c][i] = r2[12 + 18 * c + i];
+            }
+        }
+    }
+#ifdef DJ_PROF
+    unsigned long long t_all = wv.clock();
+#endif
+    if constexpr (QUAD) {                                     // the final factors of the Newton loop, as the step kernel left them
+        const T* f = A.fac + (size_t)wave_index * FAC_PER_LANE * wv.width() + lane;
+        const int W = wv.width();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) prog.F.Sq[i][j] = TL(f[(size_t)(12 * i + j) * W]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { prog.F.Uq[i][j] = TL(f[(size_t)(36 + 6 * i + j) * W]); prog.F.Lq[j][i] = TL(f[(size_t)(54 + 6 * i + j) * W]); }
+        }
+    } else {
+        prog.linearize();                                     // lane mapping: rebuild the final linearization instead
+    }
+    prog.gradients(A, env);
+#ifdef DJ_PROF
+    if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); }
+#endif
+}
+
+template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
+DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
+    DJ_LANE_SETUP(false)
 #ifdef DJ_DEBUG
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
     if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
@@ -1941,10 +2057,35 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     unsigned long long t_all = wv.clock();
 #endif
     int status = prog.mehrotra(iters);
-    if (GRAD) { if (A.dz != nullptr) prog.gradients(A, env); }
 #ifdef DJ_PROF
     prog.pc[7] = wv.clock() - t_all;
 #endif
+    if (active && q == 0 && A.sol) {                          // hand-off to the IFT kernel, in the state precision
+        T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
+        for (int i = 0; i < 3; ++i) { r[i] = prog.L.v[i]; r[3 + i] = prog.L.w[i]; }
+        for (int i = 0; i < 6; ++i) r[6 + i] = prog.L.lam[i];
+        r[12] = prog.L.ls[0]; r[13] = prog.L.ls[1]; r[14] = prog.L.lg[0]; r[15] = prog.L.lg[1];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { r[16 + 8 * c + i] = prog.L.cs[c][i]; r[20 + 8 * c + i] = prog.L.cg[c][i]; }
+        r[16 + 8 * MAXC] = prog.mu;
+        if (QUAD) {
+            T* r2 = r + 17 + 8 * MAXC;
+            for (int i = 0; i < 6; ++i) { r2[i] = prog.F.t_a[i]; r2[6 + i] = prog.F.t_b[i]; }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 18; ++i) r2[12 + 18 * c + i] = cold.G134[c][i];
+        }
+    }
+    if (QUAD && A.fac) {
+        T* f = A.fac + (size_t)wave_index * FAC_PER_LANE * wv.width() + lane;
+        const int W = wv.width();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) f[(size_t)(12 * i + j) * W] = T(prog.F.Sq[i][j]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { f[(size_t)(36 + 6 * i + j) * W] = T(prog.F.Uq[i][j]); f[(size_t)(54 + 6 * i + j) * W] = T(prog.F.Lq[j][i]); }
+        }
+    }
     if (active && q == 0) {
         T zn[13];
         prog.next_state(zn);

@@ -39,6 +39,8 @@ struct DojoSim {
     void* d_nodes = nullptr; void* d_contacts = nullptr;
     // internal device buffers used by the host-pointer entry points
     void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
+    void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
+    void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false;
     hipStream_t stream = nullptr;
@@ -74,6 +76,13 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     dim3 grid((s->B + E - 1) / E);
     if (timed) HIPCHK(hipEventRecord(s->ev0, st));
     const int g = dz != nullptr;
+    A.sol = nullptr;
+    if (g) {
+        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
+        A.sol = (T*)s->d_sol;
+        if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, (size_t)grid.x * dj::FAC_PER_LANE * 64 * sizeof(T)));
+    }
+    A.fac = g ? (T*)s->d_fac : nullptr;
     typedef int (*launcher_t)(const void*, int, void*, int);
     const bool f32 = sizeof(TIO) == 4;
     launcher_t fn;
@@ -134,7 +143,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     hipSetDevice(s->device);
-    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters};
+    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac};
     for (void* p : ps) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);

@@ -8,8 +8,10 @@
 
 #if defined(__HIPCC__)
 #define DJ_HD __host__ __device__ __forceinline__
+#define DJ_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define DJ_HD inline
+#define DJ_HD_NOINLINE inline
 #endif
 
 namespace dj {

@@ -81,11 +81,18 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
+    std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
+    std::vector<T> facbuf((dz && QUAD) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
+    // the same two launches as the product: step kernel, then (when gradients are wanted) the IFT kernel
+    for (int pass = 0; pass < ((dz && !dbg) ? 2 : 1); ++pass)
     for (int wi = 0; wi < nwaves; ++wi) {
         Shared sh(W);
         std::vector<std::thread> th;
-        for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWave w{&sh, l}; dj::step_entry<TIO, T, TL, MAXC, true, QUAD>(w, A, wi); });
+        for (int l = 0; l < W; ++l) th.emplace_back([&, l, pass]() {
+            EmuWave w{&sh, l};
+            if (pass == 0) dj::step_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi); else dj::grad_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi);
+        });
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
