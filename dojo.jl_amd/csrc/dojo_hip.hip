@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 // kernel launchers, one per object file of dojo_kernels.hip: dojo_launch_<abi type>_<max contacts per body>_<quad>
 extern "C" {
-#define DJ_DECL(n) int n(const void*, int, void*, int);
+#define DJ_DECL(n) int n(const void*, int, void*, int, void*);
 DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launch_float_8_1)
 DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
 DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
@@ -44,8 +44,8 @@ struct DojoSim {
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_ms_sum = 0; int last_ms_n = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;   // launch begin / end / between the step and the IFT kernel
+    double last_ms_sum = 0; int last_ms_n = 0; bool last_has_mid = false;
 };
 
 namespace {
@@ -83,7 +83,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, (size_t)grid.x * dj::FAC_PER_LANE * 64 * sizeof(T)));
     }
     A.fac = g ? (T*)s->d_fac : nullptr;
-    typedef int (*launcher_t)(const void*, int, void*, int);
+    typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
     launcher_t fn;
     if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
@@ -91,7 +91,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
     else      fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_0 : dojo_launch_double_4_0)
                                   : (f32 ? dojo_launch_float_8_0 : dojo_launch_double_8_0);
-    int lrc = fn(&A, (int)grid.x, (void*)st, g);
+    int lrc = fn(&A, (int)grid.x, (void*)st, g, (timed && g) ? (void*)s->evm : nullptr);
+    if (timed) s->last_has_mid = g != 0;
     if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(s->ev1, st));
@@ -135,7 +136,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     HIPCHK(hipSetDevice(device));
     rc = upload_tables<double>(s);
     if (rc != DOJO_OK) { delete s; return rc; }
-    HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); HIPCHK(hipEventCreate(&s->evm));
     *out = s;
     return DOJO_OK;
 }
@@ -147,6 +148,7 @@ void dojo_destroy(DojoHandle s) {
     for (void* p : ps) if (p) hipFree(p);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->evm) hipEventDestroy(s->evm);
     delete s;
 }
 
@@ -262,7 +264,7 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     }
     HIPCHK(hipEventRecord(s->ev1, st));
     if (!Z && cur != (const char*)s->d_zn) HIPCHK(hipMemcpyAsync(s->d_zn, cur, B * nz * w, hipMemcpyDeviceToDevice, st));
-    s->stream = st; s->last_ms_n = H; s->have_solution = true; s->have_grad = false;
+    s->stream = st; s->last_ms_n = H; s->last_has_mid = false; s->have_solution = true; s->have_grad = false;
     return DOJO_OK;
 }
 
@@ -302,6 +304,19 @@ int dojo_last_kernel_ms(DojoHandle s, double* ms) {
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev1));
     *ms = (double)t / s->last_ms_n;
+    return DOJO_OK;
+}
+
+int dojo_last_kernel_times(DojoHandle s, double* step_ms, double* ift_ms) {
+    if (!s || !step_ms || !ift_ms || s->last_ms_n < 1) { g_err = "dojo_last_kernel_times: nothing was launched"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    float t = 0, t1 = 0;
+    HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev1));
+    if (s->last_has_mid) {
+        HIPCHK(hipEventElapsedTime(&t1, s->ev0, s->evm));
+        *step_ms = (double)t1; *ift_ms = (double)t - (double)t1;
+    } else { *step_ms = (double)t / s->last_ms_n; *ift_ms = 0.0; }
     return DOJO_OK;
 }
 

@@ -83,9 +83,11 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 
-extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad) {
+// mid_event (may be null) is recorded between the two kernels so that each can be timed on its own
+extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, void* mid_event) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
     hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
     if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }

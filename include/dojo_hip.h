@@ -189,6 +189,9 @@ int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, vo
 /* timing helper for bench.py: average duration in ms of the last `n` launches of the
  * step kernel measured with hipEvents on the launch stream (roofline.achieved) */
 int  dojo_last_kernel_ms(DojoHandle h, double* ms);
+/* the same, split by kernel: the step kernel (Newton loop: step!/mehrotra!) and the IFT kernel (the
+ * back-solves of get_maximal_gradients!, src/gradients/state.jl:78-126; 0 when not requested) */
+int  dojo_last_kernel_times(DojoHandle h, double* step_ms, double* ift_ms);
 
 #ifdef __cplusplus
 }

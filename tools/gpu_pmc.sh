@@ -1,23 +1,42 @@
 #!/bin/bash
-# PMC passes (separate from --kernel-trace/--stats as the guide prescribes): instruction mix + HBM traffic of the step kernel
+# PMC passes (separate from --kernel-trace/--stats, as the MI355X guide prescribes): instruction mix, stall
+# breakdown and HBM traffic of the two kernels of the step.  Output: gpurun_out/pmc/*.csv, pmc_summary.txt and
+# pmc_traffic.json (copy to profiles/<round>_pmc_traffic.json: bench.py reports it as roofline.traffic).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}"
 cd /tmp
+: > $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 600 rocprofv3 --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc/$name.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -name "*counter_collection.csv" | head -1)
-  echo "== $set -> $f"
-  python3 - "$f" <<'PY'
+  echo "== $set" | tee -a $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
+  python3 - "$f" <<'PY' | tee -a $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows:
-    if 'dojo_step' not in r['Kernel_Name']: continue
-    acc[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
-for c, d in acc.items():
-    v = list(d.values()); print("  %-24s per-dispatch mean %.4g  (n=%d)" % (c, sum(v)/len(v), len(v)))
+    kn = 'dojo_step_kernel' if 'dojo_step_kernel' in r['Kernel_Name'] else 'dojo_grad_kernel' if 'dojo_grad_kernel' in r['Kernel_Name'] else None
+    if kn is None: continue
+    acc[(kn, r['Counter_Name'])][r['Dispatch_Id']] += float(r['Counter_Value'])
+for (kn, c), d in sorted(acc.items()):
+    v = list(d.values()); print("  %-18s %-24s per-dispatch mean %.6g  (n=%d)" % (kn, c, sum(v)/len(v), len(v)))
 PY
 done
+python3 - <<'PY'
+import re, json, os
+root = os.environ['GRAFT_REPO_ROOT']
+txt = open(os.path.join(root, 'gpurun_out/pmc/pmc_summary.txt')).read()
+out = {}
+for kn in ('dojo_step_kernel', 'dojo_grad_kernel'):
+    f = re.search(kn + r'\s+FETCH_SIZE\s+per-dispatch mean ([0-9.e+-]+)', txt); w = re.search(kn + r'\s+WRITE_SIZE\s+per-dispatch mean ([0-9.e+-]+)', txt)
+    if f and w:
+        fk, wk = float(f.group(1)), float(w.group(1))
+        # rocprofv3 reports KB; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is
+        out[kn] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024.0,
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB, per launch, mean over the dispatches of bench.py " + os.environ.get('BENCH_ARGS', '--steps 3 --warmup 1')}
+json.dump(out, open(os.path.join(root, 'gpurun_out/pmc/pmc_traffic.json'), 'w'), indent=1)
+print(json.dumps(out))
+PY
