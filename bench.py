@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = Ant)")
     ap.add_argument("--io-dtype", default="f32")
     ap.add_argument("--no-grad", action="store_true")
+    ap.add_argument("--chunks", type=int, default=2, help="the per-GPU batch is stepped as this many independent groups of environments, "
+                    "each on its own HIP stream, so that the few environments that run into max_iter do not idle the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -62,20 +64,27 @@ def main():
     dz = torch.empty((B, spec.nx, spec.nx), dtype=tdt, device=dev) if grad else None
     du = torch.empty((B, max(spec.nu, 1), spec.nx), dtype=tdt, device=dev) if grad else None
 
-    gm = api.BatchedMechanism(spec, B, dtype=args.io_dtype, device=local)
+    # The batch is stepped as `chunks` independent groups of environments, one handle + one HIP stream each.  Environments
+    # are independent, so no group ever waits for another: while the rare environment that runs into
+    # max_iter = 50 (5x the mean iteration count, one wavefront) finishes in one group, the other groups' kernels fill the GPU.
+    NCH = max(1, min(args.chunks, B // 64))
+    bounds = [(c * B) // NCH for c in range(NCH + 1)]
     lib = api.lib()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    groups = []
+    for c in range(NCH):
+        lo, hi = bounds[c], bounds[c + 1]
+        groups.append({"lo": lo, "hi": hi, "gm": api.BatchedMechanism(spec, hi - lo, dtype=args.io_dtype, device=local),
+                       "stream": torch.cuda.Stream(device=dev)})
 
     def ptr(t):
         return C.c_void_p(0 if t is None else t.data_ptr())
 
-    kernel_ms = []
-
-    def one_step(k, timed):
+    def one_step(k):
         nonlocal z, zn
-        api._chk(lib.dojo_step_dev(gm.h, ptr(z), ptr(Uall[k]), ptr(zn), ptr(status), ptr(iters), ptr(dz), ptr(du), stream))
-        if timed:
-            kernel_ms.append(gm.last_kernel_times())   # (step kernel, IFT kernel) ms: hipEvents recorded on the launch stream
+        for g in groups:
+            lo, hi = g["lo"], g["hi"]
+            api._chk(lib.dojo_step_dev(g["gm"].h, ptr(z[lo:hi]), ptr(Uall[k][lo:hi]), ptr(zn[lo:hi]), ptr(status[lo:hi]), ptr(iters[lo:hi]),
+                                       ptr(dz[lo:hi]) if grad else None, ptr(du[lo:hi]) if grad else None, C.c_void_p(g["stream"].cuda_stream)))
         z, zn = zn, z
 
     def barrier():
@@ -83,15 +92,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()                     # inputs were produced on the default stream
     for k in range(W):
-        one_step(k, False)
+        one_step(k)
     barrier()
+    for g in groups:
+        g["gm"].kernel_time_totals(reset=True)   # kernel timing: hipEvents on each launch stream, accumulated without host waits
     t0 = time.perf_counter()
     for k in range(W, W + K):
-        one_step(k, True)
+        one_step(k)
+    for g in groups:
+        torch.cuda.current_stream().wait_stream(g["stream"])
     z_all = D.all_gather_states(z, world)      # all-gather of the final states over RCCL/xGMI, once per rollout chunk
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev)
+    tot = [g["gm"].kernel_time_totals() for g in groups]
+    kernel_ms = [(a / n, b / n) for a, b, n in tot if n > 0]
     ok_frac = float((status == 0).float().mean().item())
     mean_iters = float(iters.float().mean().item())
 
@@ -109,10 +125,12 @@ def main():
             ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             t = traffic.get(kernel)
             return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": t["bytes_per_launch"] if t else None, "traffic_source": t["source"] if t else None,
+                    "traffic": t["bytes_per_launch"] * (B // NCH) / t["envs_per_launch"] if t else None,     # scaled to this launch size
+                    "traffic_source": t["source"] if t else None,
                     "kernel": kernel, "avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes}
-        r_step = roof("dojo_step_kernel", step_ms, bytes_fwd * B)
-        r_ift = roof("dojo_grad_kernel", ift_ms, bytes_grad * B) if grad else None
+        Bl = B // NCH                                                 # environments per launch
+        r_step = roof("dojo_step_kernel", step_ms, bytes_fwd * Bl)
+        r_ift = roof("dojo_grad_kernel", ift_ms, bytes_grad * Bl) if grad else None
         dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
         dominant["note"] = ("VALU-issue-bound fp64 lane program (DESIGN.md §8; tools/ubench): the KKT systems never leave registers/LDS, "
                             "so the algorithmic HBM bytes are tiny and frac against HBM is reported only because the contract asks for it")
@@ -125,7 +143,7 @@ def main():
                                    "batch=%d per GPU, fwd + IFT gradients, closed-loop rollout with random controls" % B,
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "parallelism": "batch-sharded x%d, no data-path collective; per GPU %d independent environment groups of %d on their own HIP streams" % (world, NCH, B // NCH),
                        "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters},
             "roofline": dominant,
         }
@@ -146,7 +164,7 @@ def measured_traffic():
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             for k, v in json.load(open(f)).items():
-                out[k] = {"bytes_per_launch": v["bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+                out[k] = {"bytes_per_launch": v["bytes_per_launch"], "envs_per_launch": v.get("envs_per_launch", 4096), "source": os.path.relpath(f, ROOT)}
         except Exception:
             pass
     return out

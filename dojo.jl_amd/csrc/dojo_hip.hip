@@ -44,8 +44,11 @@ struct DojoSim {
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;   // launch begin / end / between the step and the IFT kernel
-    double last_ms_sum = 0; int last_ms_n = 0; bool last_has_mid = false;
+    // kernel timing: a ring of event triples (launch begin / between the step and the IFT kernel / end), so that
+    // timed launches never make the host wait; totals are accumulated when a slot is reused or queried
+    struct Ev3 { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool has_mid = false, used = false; int n = 1; };
+    std::vector<Ev3> ring; size_t ring_next = 0; int last_slot = -1;
+    double acc_step_ms = 0, acc_ift_ms = 0; long long acc_n = 0;
 };
 
 namespace {
@@ -62,6 +65,26 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     return DOJO_OK;
 }
 
+int drain_slot(DojoSim* s, DojoSim::Ev3& e) {
+    if (!e.used) return DOJO_OK;
+    HIPCHK(hipEventSynchronize(e.b));
+    float t = 0, t1 = 0;
+    HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+    if (e.has_mid) { HIPCHK(hipEventElapsedTime(&t1, e.a, e.m)); s->acc_step_ms += t1; s->acc_ift_ms += (double)t - t1; }
+    else s->acc_step_ms += t;
+    s->acc_n += e.n;
+    e.used = false;
+    return DOJO_OK;
+}
+int acquire_slot(DojoSim* s, int* idx) {
+    if (s->ring.empty()) {
+        s->ring.resize(64);
+        for (auto& e : s->ring) { HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.m)); HIPCHK(hipEventCreate(&e.b)); }
+    }
+    *idx = (int)(s->ring_next++ % s->ring.size());
+    return drain_slot(s, s->ring[*idx]);
+}
+
 template <class TIO, class T, class TL>
 int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
            void* dz, void* du, hipStream_t st, bool timed) {
@@ -74,7 +97,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     const bool quad = s->M.S <= 16;
     int E = 64 / (s->M.S * (quad ? 4 : 1));
     dim3 grid((s->B + E - 1) / E);
-    if (timed) HIPCHK(hipEventRecord(s->ev0, st));
+    int slot = -1;
+    if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = dz != nullptr;
     A.sol = nullptr;
     if (g) {
@@ -91,11 +115,10 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
     else      fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_0 : dojo_launch_double_4_0)
                                   : (f32 ? dojo_launch_float_8_0 : dojo_launch_double_8_0);
-    int lrc = fn(&A, (int)grid.x, (void*)st, g, (timed && g) ? (void*)s->evm : nullptr);
-    if (timed) s->last_has_mid = g != 0;
+    int lrc = fn(&A, (int)grid.x, (void*)st, g, (timed && g) ? (void*)s->ring[slot].m : nullptr);
     if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
-    if (timed) HIPCHK(hipEventRecord(s->ev1, st));
+    if (timed) { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = g != 0; e.n = 1; e.used = true; s->last_slot = slot; }
     return DOJO_OK;
 }
 
@@ -136,7 +159,6 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     HIPCHK(hipSetDevice(device));
     rc = upload_tables<double>(s);
     if (rc != DOJO_OK) { delete s; return rc; }
-    HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); HIPCHK(hipEventCreate(&s->evm));
     *out = s;
     return DOJO_OK;
 }
@@ -146,9 +168,7 @@ void dojo_destroy(DojoHandle s) {
     hipSetDevice(s->device);
     void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac};
     for (void* p : ps) if (p) hipFree(p);
-    if (s->ev0) hipEventDestroy(s->ev0);
-    if (s->ev1) hipEventDestroy(s->ev1);
-    if (s->evm) hipEventDestroy(s->evm);
+    for (auto& e : s->ring) { if (e.a) hipEventDestroy(e.a); if (e.m) hipEventDestroy(e.m); if (e.b) hipEventDestroy(e.b); }
     delete s;
 }
 
@@ -180,7 +200,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
     if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
     rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, (hipStream_t)stream, true);
-    if (rc == DOJO_OK) { s->stream = (hipStream_t)stream; s->last_ms_n = 1; s->have_solution = true; }
+    if (rc == DOJO_OK) { s->stream = (hipStream_t)stream; s->have_solution = true; }
     return rc;
 }
 
@@ -254,7 +274,9 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const char* cur = (const char*)z0;
-    HIPCHK(hipEventRecord(s->ev0, st));
+    int slot = -1;
+    { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; }
+    HIPCHK(hipEventRecord(s->ring[slot].a, st));
     for (int k = 0; k < H; ++k) {
         char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
         const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
@@ -262,9 +284,9 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
         if (rc != DOJO_OK) return rc;
         cur = nxt;
     }
-    HIPCHK(hipEventRecord(s->ev1, st));
+    { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = false; e.n = H; e.used = true; s->last_slot = slot; }
     if (!Z && cur != (const char*)s->d_zn) HIPCHK(hipMemcpyAsync(s->d_zn, cur, B * nz * w, hipMemcpyDeviceToDevice, st));
-    s->stream = st; s->last_ms_n = H; s->last_has_mid = false; s->have_solution = true; s->have_grad = false;
+    s->stream = st; s->have_solution = true; s->have_grad = false;
     return DOJO_OK;
 }
 
@@ -298,25 +320,32 @@ int dojo_get_state(DojoHandle s, void* z) {
 }
 
 int dojo_last_kernel_ms(DojoHandle s, double* ms) {
-    if (!s || !ms || s->last_ms_n < 1) { g_err = "dojo_last_kernel_ms: nothing was launched"; return DOJO_ERR_INVALID; }
-    HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipEventSynchronize(s->ev1));
-    float t = 0;
-    HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev1));
-    *ms = (double)t / s->last_ms_n;
-    return DOJO_OK;
+    double a = 0, b = 0;
+    int rc = dojo_last_kernel_times(s, &a, &b);
+    if (rc == DOJO_OK && ms) *ms = a + b;
+    return rc;
 }
 
 int dojo_last_kernel_times(DojoHandle s, double* step_ms, double* ift_ms) {
-    if (!s || !step_ms || !ift_ms || s->last_ms_n < 1) { g_err = "dojo_last_kernel_times: nothing was launched"; return DOJO_ERR_INVALID; }
+    if (!s || !step_ms || !ift_ms || s->last_slot < 0) { g_err = "dojo_last_kernel_times: nothing was launched"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipEventSynchronize(s->ev1));
+    DojoSim::Ev3& e = s->ring[s->last_slot];
+    HIPCHK(hipEventSynchronize(e.b));
     float t = 0, t1 = 0;
-    HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev1));
-    if (s->last_has_mid) {
-        HIPCHK(hipEventElapsedTime(&t1, s->ev0, s->evm));
-        *step_ms = (double)t1; *ift_ms = (double)t - (double)t1;
-    } else { *step_ms = (double)t / s->last_ms_n; *ift_ms = 0.0; }
+    HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+    if (e.has_mid) { HIPCHK(hipEventElapsedTime(&t1, e.a, e.m)); *step_ms = (double)t1; *ift_ms = (double)t - (double)t1; }
+    else { *step_ms = (double)t / e.n; *ift_ms = 0.0; }
+    return DOJO_OK;
+}
+
+int dojo_kernel_time_totals(DojoHandle s, double* step_ms, double* ift_ms, int64_t* launches, int32_t reset) {
+    if (!s) { g_err = "dojo_kernel_time_totals: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    for (auto& e : s->ring) { int rc = drain_slot(s, e); if (rc != DOJO_OK) return rc; }
+    if (step_ms) *step_ms = s->acc_step_ms;
+    if (ift_ms) *ift_ms = s->acc_ift_ms;
+    if (launches) *launches = (int64_t)s->acc_n;
+    if (reset) { s->acc_step_ms = s->acc_ift_ms = 0; s->acc_n = 0; }
     return DOJO_OK;
 }
 

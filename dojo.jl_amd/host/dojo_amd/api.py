@@ -34,7 +34,7 @@ def lib():
         L.dojo_last_error.restype = C.c_char_p
         for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_step",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
-                  "dojo_last_kernel_ms", "dojo_last_kernel_times"):
+                  "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals"):
             getattr(L, f).restype = C.c_int
         L.dojo_destroy.restype = None
         _lib = L
@@ -43,7 +43,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
                     "dojo_set_gradient_mode", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
-                    "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times"]
+                    "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals"]
 
 
 def device_count():
@@ -140,6 +140,12 @@ class BatchedMechanism:
         ms = C.c_double(0)
         _chk(lib().dojo_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def kernel_time_totals(self, reset=False):
+        """(sum of step-kernel ms, sum of IFT-kernel ms, launches) over the timed launches since the last reset."""
+        a = C.c_double(0); b = C.c_double(0); n = C.c_int64(0)
+        _chk(lib().dojo_kernel_time_totals(self.h, C.byref(a), C.byref(b), C.byref(n), 1 if reset else 0))
+        return a.value, b.value, n.value
 
     def last_kernel_times(self):
         """(step kernel ms, IFT kernel ms) of the last launch, from hipEvents on the launch stream."""

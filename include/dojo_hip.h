@@ -169,7 +169,8 @@ int  dojo_step(DojoHandle h, const void* z, const void* u, void* z_next,
 int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_sg);
 
 /* IFT Jacobians of the last dojo_step(..., with_gradient=1):
- * dz [B,12Nb,12Nb] = jacobian_state, du [B,12Nb,nu] = jacobian_control */
+ * dz [B,12Nb,12Nb] = jacobian_state, du [B,12Nb,nu] = jacobian_control, row-major per environment
+ * (transposed on the device from the kernels' column-major layout) */
 int  dojo_gradients(DojoHandle h, void* dz, void* du);
 
 /* simulate! with pre-sampled controls: z0 [B,13Nb], U [H,B,nu] (NULL = zeros) ->
@@ -192,6 +193,9 @@ int  dojo_last_kernel_ms(DojoHandle h, double* ms);
 /* the same, split by kernel: the step kernel (Newton loop: step!/mehrotra!) and the IFT kernel (the
  * back-solves of get_maximal_gradients!, src/gradients/state.jl:78-126; 0 when not requested) */
 int  dojo_last_kernel_times(DojoHandle h, double* step_ms, double* ift_ms);
+/* totals over all timed launches since the last reset (the events are kept in a ring, so timing never makes the
+ * host wait inside a rollout loop): summed kernel durations in ms and the number of step launches */
+int  dojo_kernel_time_totals(DojoHandle h, double* step_ms, double* ift_ms, int64_t* launches, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}"
+ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --chunks 1}"   # one launch = the whole batch of 4096 environments
 cd /tmp
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -35,8 +35,8 @@ for kn in ('dojo_step_kernel', 'dojo_grad_kernel'):
     if f and w:
         fk, wk = float(f.group(1)), float(w.group(1))
         # rocprofv3 reports KB; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is
-        out[kn] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024.0,
-                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB, per launch, mean over the dispatches of bench.py " + os.environ.get('BENCH_ARGS', '--steps 3 --warmup 1')}
+        out[kn] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024.0, "envs_per_launch": 4096,
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB, per launch, mean over the dispatches of bench.py " + os.environ.get('BENCH_ARGS', '--steps 3 --warmup 1 --chunks 1')}
 json.dump(out, open(os.path.join(root, 'gpurun_out/pmc/pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out))
 PY

@@ -88,3 +88,26 @@ if what == "phases":
             print("   IFT kernel: total %.0f cycles/wave = linearize %.0f + %.0f, data blocks %.0f, sweeps %.0f" % (g[4], g[0], g[1], g[2], g[3]))
         json.dump(dict(total=tot.tolist(), iters=iters.tolist()), open(os.path.join(out, "phase_hist_grad%d.json" % grad), "w"))
     gm.close()
+
+if what == "stragglers":
+    # closed-loop rollout like bench.py (fp64 ABI so the inputs are exact): dump the (z, u) of every environment-step that
+    # did not converge, with the iteration histogram, for a CPU-side comparison with the oracle
+    spec = d.baseline_config(3)
+    B = 4096
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (B // 64, 1)); mask = (np.abs(np.tile(U0, (B // 64, 1))) > 0)
+    rng = np.random.Generator(np.random.Philox(key=[20241008, 1000]))
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    z = Z.copy(); dumps = []; hist = np.zeros(52, int)
+    for k in range(23):
+        U = 0.5 * rng.standard_normal((B, spec.nu)) * mask
+        zn, st, it = gm.step(z, U)
+        hist += np.bincount(np.clip(it, 0, 51), minlength=52)
+        bad = np.nonzero(st != 0)[0]
+        for b in bad[:8]:
+            dumps.append(dict(step=k, env=int(b), status=int(st[b]), iters=int(it[b]), z=z[b].tolist(), u=U[b].tolist()))
+        print("step %d: failed %d, iters mean %.2f max %d, kernel %.2f ms" % (k, len(bad), it.mean(), it.max(), gm.last_kernel_ms()), flush=True)
+        z = zn
+    print("iteration histogram:", {i: int(h) for i, h in enumerate(hist) if h})
+    json.dump(dumps, open(os.path.join(out, "stragglers.json"), "w"))
+    gm.close()
