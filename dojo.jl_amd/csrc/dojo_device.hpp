@@ -734,6 +734,11 @@ struct LaneProgram {
     Lane<T, MAXC>& L;            // per lane, or one copy per supernode in LDS (lock-step quad mapping)
     Factors<T, TL, MAXC, QUAD> F;
     void* gb_lds = nullptr;      // LDS home of this supernode's GradBlocks (quad mapping)
+    // LDS mailbox (quad mapping): one slot of MAIL_N doubles per (supernode, body-row role).  Tree neighbours exchange
+    // their 3-row pieces through it with wide ds_read/ds_write instead of one ds_bpermute per dword.
+    enum { MAIL_N = 18, MAIL_STRIDE = 20 };
+    double* mail = nullptr;
+    DJ_HD double* mail_slot(int supernode_lane0, int role) const { return mail + (size_t)((supernode_lane0 >> 2) * 2 + role) * MAIL_STRIDE; }
     int stride, q, envl, qb;     // lanes per supernode, role in the quad, lanes per environment, first lane of the quad
     Cold<T, MAXC>& cold;
     JointCfg<T>& cfg;
@@ -1096,12 +1101,18 @@ struct LaneProgram {
         const int lvl = P.level;
         const int pb = has_parent ? base + stride * P.parent : qb;
         const int qh = q & 1;
-        const TG tb3[3] = {TG(F.t_b[3 * qh]), TG(F.t_b[3 * qh + 1]), TG(F.t_b[3 * qh + 2])}, ta3[3] = {TG(F.t_a[3 * qh]), TG(F.t_a[3 * qh + 1]), TG(F.t_a[3 * qh + 2])};
+        // (selects, not F.t_b[3 * qh + i]: ONE dynamically indexed member keeps the whole LaneProgram object in scratch)
+        const TG tb3[3] = {TG(qh ? F.t_b[3] : F.t_b[0]), TG(qh ? F.t_b[4] : F.t_b[1]), TG(qh ? F.t_b[5] : F.t_b[2])},
+                 ta3[3] = {TG(qh ? F.t_a[3] : F.t_a[0]), TG(qh ? F.t_a[4] : F.t_a[1]), TG(qh ? F.t_a[5] : F.t_a[2])};
         // this lane's six rows of the first column of batch b in the output buffers, element stride between columns = nx;
         // state batches: column cI sits at index cI (+3 for cI >= 3: the batch holds x2|φ2 or v15|ω15)
-        auto colbase = [&](int b) -> TIO* {
-            if (b < nbs) return A.dz + ((size_t)env * nx + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nx + 12 * k + 6 * q;
-            return A.du + ((size_t)env * G.nu + (size_t)(NC * (b - nbs))) * nx + 12 * k + 6 * q;
+        TIO* const dz_p = DJ_GLOBAL_PTR(TIO, A.dz);
+        TIO* const du_p = DJ_GLOBAL_PTR(TIO, nbu > 0 ? A.du : A.dz);
+        const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * G.nu, row0 = (size_t)(12 * k + 6 * q), nxs = (size_t)nx;
+        auto colbase = [=](int b) -> TIO* {
+            TIO* pz = dz_p + (env_dz + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nxs + row0;
+            TIO* pu = du_p + (env_du + (size_t)(NC * (b - nbs))) * nxs + row0;
+            return b < nbs ? pz : pu;
         };
         // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
         TG send3[NC][3];
@@ -1114,7 +1125,26 @@ struct LaneProgram {
             TG acc[3 * NC], snd[3 * NC];
 #pragma unroll
             for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { acc[3 * n + i] = TG(0); snd[3 * n + i] = send3[n][i]; }
-            gather_children<3 * NC>(wv, acc, snd, P, base, G.maxch, valid, stride, q);
+#ifdef DJ_PROF
+            unsigned long long tg0 = wv.clock();
+#endif
+            {   // children -> parent through the mailbox (only the body-row roles carry anything)
+                wv.sync();
+                if (q < 2) { double* ms_ = mail_slot(qb, q);
+#pragma unroll
+                    for (int i = 0; i < 3 * NC; ++i) ms_[i] = (double)snd[i]; }
+                wv.sync();
+                for (int ci = 0; ci < G.maxch; ++ci) {
+                    if (valid && q < 2 && ci < P.nchild) {
+                        const double* cs_ = mail_slot(base + stride * P.child[ci], q);
+#pragma unroll
+                        for (int i = 0; i < 3 * NC; ++i) acc[i] += TG(cs_[i]);
+                    }
+                }
+            }
+#ifdef DJ_PROF
+            pc[2] += wv.clock() - tg0;
+#endif
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
             const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (P.parent == kk);
@@ -1127,7 +1157,7 @@ struct LaneProgram {
             const int u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
             const bool od = mine && typ == 0 && q < 2;              // the folded owner rows come from the double block
             const TG rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0), um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
-            TIO* const cb = valid ? colbase(b) : (TIO*)nullptr;
+            TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
             const TG wkm = (P.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
             const int sl_off = mine ? RH::SLO : RH::SLP;
@@ -1177,6 +1207,9 @@ struct LaneProgram {
                 }
             }
         }
+#ifdef DJ_PROF
+        unsigned long long td0 = wv.clock();
+#endif
         // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
         TG d3[NC][3];
 #pragma unroll
@@ -1186,12 +1219,22 @@ struct LaneProgram {
             const bool valid = active && b >= 0 && b < NB;
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
-            TIO* const cb = valid ? colbase(b) : (TIO*)nullptr;
+            TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            // the parent finished this batch in the previous step: its two body-row roles posted Δv, Δω of the six columns
+            wv.sync();
+            if (q < 2) { double* ms_ = mail_slot(qb, q);
+#pragma unroll
+                for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)d3[n][i]; }
+            wv.sync();
+            TG pall[NC][6];
+            {
+                const double* p0 = mail_slot(pb, 0); const double* p1 = mail_slot(pb, 1);
+#pragma unroll
+                for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { pall[n][i] = TG(p0[3 * n + i]); pall[n][3 + i] = TG(p1[3 * n + i]); }
+            }
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
-                TG pa_[6];                                     // the parent finished this batch in the previous step
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[n][i], pb); pa_[3 + i] = wv.shfl(d3[n][i], pb + 1); }
+                const TG (&pa_)[6] = pall[n];
                 TG t3[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
@@ -1203,18 +1246,19 @@ struct LaneProgram {
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
-                TIO* o = (valid && q < 2 && (isS || NC * (b - nbs) + n < G.nu)) ? cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx : (TIO*)nullptr;
+                const bool o_ok = valid && q < 2 && (isS || NC * (b - nbs) + n < G.nu);
+                TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         TG a_ = TG(0);
 #pragma unroll
                         for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * tf[m_];
-                        TG y = o ? TG(o[3 + i]) : TG(0);
+                        TG y = o_ok ? TG(o[3 + i]) : TG(0);
                         d3[n][i] = has_parent ? y - a_ : y;
                     }
                 }
-                if (o) {
+                if (o_ok) {
                     T d_[3] = {T(d3[n][0]), T(d3[n][1]), T(d3[n][2])};
                     if (q == 0) {
                         for (int i = 0; i < 3; ++i) { T x = dt * d_[i]; if (mine && n == i) x += T(1); o[i] = TIO(x); o[3 + i] = TIO(d_[i]); }
@@ -1226,6 +1270,9 @@ struct LaneProgram {
                 }
             }
         }
+#ifdef DJ_PROF
+        pc[4] += wv.clock() - td0;
+#endif
     }
 
     // quad mapping: solve with the distributed factors
@@ -1760,7 +1807,12 @@ struct LaneProgram {
                 T ta[3], tb[3];
                 m3vec(ta, ce.Roff, &P.Ar[3 * i]);
                 m3vec(tb, ce.Rba, ta);
-                for (int r = 0; r < 3; ++r) { UB[3 + r][P.nu_t + i] = G.input_scaling * tb[r]; UA[3 + r][P.nu_t + i] = -G.input_scaling * ta[r]; }
+                // column P.nu_t + i, written with selects (a dynamic index would put UB / UA into scratch)
+#pragma unroll
+                for (int c_ = 0; c_ < 6; ++c_) if (c_ >= i) {
+                    const bool hit = (c_ == P.nu_t + i);
+                    for (int r = 0; r < 3; ++r) { UB[3 + r][c_] = hit ? G.input_scaling * tb[r] : UB[3 + r][c_]; UA[3 + r][c_] = hit ? -G.input_scaling * ta[r] : UA[3 + r][c_]; }
+                }
             }
         }
         // ---- condensation maps for a right-hand side without cone terms (computed once) ----
@@ -1960,7 +2012,13 @@ struct StepLds {
     static constexpr bool cold_in_lds = QUAD && ((int)sizeof(Cold<T, MAXC>) * cold_n + lane_bytes <= 40 * 1024);
     static constexpr int cold_bytes = cold_in_lds ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
     static constexpr int gb_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * 16 : 0;
-    static constexpr int bytes = lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16;
+    // mailbox of the tree exchanges: 32 slots (16 supernodes x 2 body-row roles) x 20 doubles.  In the IFT kernel it
+    // overlays the Lane block (the solver state is dead once the column sweeps start); elsewhere it has its own room.
+    static constexpr int mail_need = QUAD ? 32 * 20 * 8 : 0;
+    static constexpr bool mail_on_lane = QUAD && LOCKSTEP && GRAD && (lane_bytes - node_bytes >= mail_need);
+    static constexpr int mail_off = mail_on_lane ? node_bytes : lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes);
+    static constexpr int bytes = (mail_on_lane ? mail_off : mail_off + mail_need) + 16 > lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16
+                               ? (mail_on_lane ? mail_off : mail_off + mail_need) + 16 : lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16;
 };
 template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP>::bytes; }
@@ -1996,6 +2054,7 @@ constexpr int FAC_PER_LANE = 72;
     Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local; \
     LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);                \
     if (QUAD) prog.gb_lds = (void*)(((QuadRhs<TIO>*)(lds + LY::lane_bytes)) + lane / 4);                                  \
+    if (QUAD) prog.mail = (double*)(lds + LY::mail_off);                                                                  \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
     const bool has_u = A.u != nullptr;                                                                                    \
@@ -2041,7 +2100,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     }
     prog.gradients(A, env);
 #ifdef DJ_PROF
-    if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); }
+    if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); }
 #endif
 }
 

@@ -22,7 +22,10 @@ struct GpuWave {
     static constexpr bool kLockstep = true;     // the 64 lanes execute every instruction together
     void* lds_;
     __device__ __forceinline__ void* lds() const { return lds_; }
-    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // The workgroup IS one wavefront and LDS instructions of a wave execute in issue order, so lanes only need the
+    // compiler to keep LDS accesses in program order.  (__syncthreads() would also drain the outstanding global
+    // stores -- vmcnt(0) -- which costs the IFT sweeps a memory round trip per pipeline step.)
+    __device__ __forceinline__ void sync() const { __asm__ volatile("" ::: "memory"); }
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
     __device__ __forceinline__ int width() const { return 64; }
     __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }

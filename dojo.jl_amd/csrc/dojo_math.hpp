@@ -14,6 +14,20 @@
 #define DJ_HD_NOINLINE inline
 #endif
 
+// Tell the compiler that a pointer taken from the kernel arguments points to GLOBAL memory: otherwise selects between
+// such pointers decay to generic pointers and the accesses become FLAT instructions, which count on lgkmcnt as well
+// as vmcnt and make every later LDS wait sit behind the HBM round trip.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class X> __device__ __forceinline__ X* dj_assume_global(X* p) {
+    __builtin_assume(!__builtin_amdgcn_is_shared((const void*)p));
+    __builtin_assume(!__builtin_amdgcn_is_private((const void*)p));
+    return p;
+}
+#define DJ_GLOBAL_PTR(T, p) dj_assume_global<T>(p)
+#else
+#define DJ_GLOBAL_PTR(T, p) (p)
+#endif
+
 namespace dj {
 
 template <class T> DJ_HD T tmax(T a, T b) { return a > b ? a : b; }
