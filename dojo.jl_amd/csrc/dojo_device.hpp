@@ -1070,7 +1070,8 @@ struct LaneProgram {
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
-                        TL rowv = (q == 0) ? part[6 * i + j] : part[6 * (3 + i) + j];
+                        const TL pa0_ = part[6 * i + j], pa1_ = part[6 * (3 + i) + j];
+                        TL rowv = (q == 0) ? pa0_ : pa1_;
                         up[i][j] = (q < 2) ? TL(K.D[i][j]) - rowv : TL(0);
                     }
             }
@@ -1202,7 +1203,7 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
                 if (valid) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? part[i] : part[3 + i]) : TG(0);
+                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? p0_ : p1_) : TG(0); }
                     if (q < 2 && (isS || NC * (b - nbs) + cI < G.nu)) { TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
                 }
             }
@@ -1279,7 +1280,10 @@ struct LaneProgram {
     DJ_HD void solve_quad(const T* rk, const T* upv, T* dk_out, T* dva_out) {
         TL r3[3], y3[3] = {0, 0, 0}, send3[3] = {0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) r3[i] = TL(q == 0 ? rk[i] : q == 1 ? rk[3 + i] : q == 2 ? rk[6 + i] : rk[9 + i]);
+        for (int i = 0; i < 3; ++i) {   // values first, then the select: `q == 0 ? rk[i] : ...` on lvalues becomes a select of POINTERS and keeps rk[] in scratch
+            const T a_ = rk[i], b_ = rk[3 + i], c_ = rk[6 + i], d_ = rk[9 + i];
+            r3[i] = TL(q == 0 ? a_ : q == 1 ? b_ : q == 2 ? c_ : d_);
+        }
         // forward: leaves -> root
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             const bool at = active && P.level == lev;
@@ -1308,7 +1312,10 @@ struct LaneProgram {
                 y3[0] = yy[0]; y3[1] = yy[1]; y3[2] = yy[2];
                 if (has_parent) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) send3[i] = (q == 0) ? TL(upv[i]) - part[i] : (q == 1) ? TL(upv[3 + i]) - part[3 + i] : TL(0);
+                    for (int i = 0; i < 3; ++i) {
+                        const TL s0_ = TL(upv[i]) - part[i], s1_ = TL(upv[3 + i]) - part[3 + i];
+                        send3[i] = (q == 0) ? s0_ : (q == 1) ? s1_ : TL(0);
+                    }
                 }
             }
         }
