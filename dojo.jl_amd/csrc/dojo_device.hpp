@@ -739,6 +739,41 @@ struct LaneProgram {
     enum { MAIL_N = 18, MAIL_STRIDE = 20 };
     double* mail = nullptr;
     DJ_HD double* mail_slot(int supernode_lane0, int role) const { return mail + (size_t)((supernode_lane0 >> 2) * 2 + role) * MAIL_STRIDE; }
+    // the two body-row roles of every supernode post N values ...
+    template <int N, class TV> DJ_HD void mail_post_roles(const TV* v) {
+        wv.sync();
+        if (q < 2) { double* ms_ = mail_slot(qb, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i) ms_[i] = (double)v[i]; }
+        wv.sync();
+    }
+    // ... and a parent adds up what the same role of each of its children posted
+    template <int N, class TV> DJ_HD void mail_add_children(TV* acc, bool act, int maxch) {
+        for (int ci = 0; ci < maxch; ++ci) {
+            if (act && q < 2 && ci < P.nchild) {
+                const double* cs_ = mail_slot(base + stride * P.child[ci], q);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[i] += TV(cs_[i]);
+            }
+        }
+    }
+    template <int N, class TV> DJ_HD void mail_add_children_node(TV* acc, bool act, int maxch) {   // all four lanes read the children's node posts
+        for (int ci = 0; ci < maxch; ++ci) {
+            if (act && ci < P.nchild) {
+                const double* cs_ = mail_slot(base + stride * P.child[ci], 0);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[i] += TV(cs_[i]);
+            }
+        }
+    }
+    // role 0 of every supernode posts N values that all four lanes hold identically; any lane can read a neighbour's post
+    template <int N, class TV> DJ_HD void mail_post_node(const TV* v) {
+        wv.sync();
+        if (q == 0) { double* ms_ = mail_slot(qb, 0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) ms_[i] = (double)v[i]; }
+        wv.sync();
+    }
     int stride, q, envl, qb;     // lanes per supernode, role in the quad, lanes per environment, first lane of the quad
     Cold<T, MAXC>& cold;
     JointCfg<T>& cfg;
@@ -773,7 +808,12 @@ struct LaneProgram {
         const T dt = G.dt;
         // parent's candidate velocity
         T va[3], wa[3], own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6];
-        shfl_vec<6>(wv, par6, own6, plane);
+        if constexpr (QUAD) {
+            mail_post_node<6>(own6);
+            const double* pp_ = mail_slot(has_parent ? base + stride * P.parent : qb, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) par6[i] = T(pp_[i]);
+        } else shfl_vec<6>(wv, par6, own6, plane);
         if (has_parent) { v3cpy(va, par6); v3cpy(wa, par6 + 3); } else { va[0] = va[1] = va[2] = wa[0] = wa[1] = wa[2] = T(0); }
         Kin<T> kb, ka;
         kin_of(kb, L.x2, L.q2, L.v, L.w, dt);
@@ -803,7 +843,8 @@ struct LaneProgram {
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -E.imp_a[i] : T(0);
-        gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
+        if constexpr (QUAD) { mail_post_node<6>(up); mail_add_children_node<6>(d, active, G.maxch); }
+        else gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
         if (JAC) {
             // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)); joint blocks are already in ----
@@ -997,7 +1038,8 @@ struct LaneProgram {
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
-            gather_children<18>(wv, acc, upf, P, base, G.maxch_lev[lev], at, stride, q);
+            mail_post_roles<18>(upf);
+            mail_add_children<18>(acc, at, G.maxch_lev[lev]);
             if (at && q < 2) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -1288,7 +1330,8 @@ struct LaneProgram {
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             const bool at = active && P.level == lev;
             TL acc[3] = {0, 0, 0};
-            gather_children<3>(wv, acc, send3, P, base, G.maxch_lev[lev], at, stride, q);
+            mail_post_roles<3>(send3);
+            mail_add_children<3>(acc, at, G.maxch_lev[lev]);
             if (at) { r3[0] += acc[0]; r3[1] += acc[1]; r3[2] += acc[2]; }
             TL rf[12];
 #pragma unroll
@@ -1326,8 +1369,10 @@ struct LaneProgram {
         for (int lev = 1; lev <= G.maxlevel; ++lev) {
             const bool at = active && P.level == lev && has_parent;
             TL pa_[6];
+            mail_post_roles<3>(d3);
+            { const double* p0 = mail_slot(pb, 0); const double* p1 = mail_slot(pb, 1);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { pa_[i] = wv.shfl(d3[i], pb); pa_[3 + i] = wv.shfl(d3[i], pb + 1); }
+              for (int i = 0; i < 3; ++i) { pa_[i] = TL(p0[i]); pa_[3 + i] = TL(p1[i]); } }
             TL t3[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { TL a_ = TL(0);
