@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = Ant)")
     ap.add_argument("--io-dtype", default="f32")
     ap.add_argument("--no-grad", action="store_true")
-    ap.add_argument("--chunks", type=int, default=2, help="the per-GPU batch is stepped as this many independent groups of environments, "
+    ap.add_argument("--chunks", type=int, default=3, help="the per-GPU batch is stepped as this many independent groups of environments, "
                     "each on its own HIP stream, so that the few environments that run into max_iter do not idle the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

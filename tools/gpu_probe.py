@@ -111,3 +111,19 @@ if what == "stragglers":
     print("iteration histogram:", {i: int(h) for i, h in enumerate(hist) if h})
     json.dump(dumps, open(os.path.join(out, "stragglers.json"), "w"))
     gm.close()
+
+if what == "configs":
+    # the five BASELINE.json configurations at their own batch sizes (per GPU), kernel time of one step
+    for cfg, B, dt_, grad in ((1, 1024, "f64", True), (2, 1024, "f64", False), (3, 4096, "f32", True), (4, 1024, "f32", False), (5, 256, "f32", True)):
+        spec = d.baseline_config(cfg)
+        Z0, U0 = d.synthetic_inputs(spec, min(B, 64))
+        reps = (B + len(Z0) - 1) // len(Z0)
+        Z = np.tile(Z0, (reps, 1))[:B]; U = np.tile(U0, (reps, 1))[:B]
+        gm = api.BatchedMechanism(spec, B, dtype=dt_)
+        z = Z.astype(gm.np_dtype); ms = []
+        for k in range(4):
+            zn, st, it = gm.step(z, U, with_gradient=grad); ms.append(gm.last_kernel_times()); z = zn
+        a, b = min(m[0] for m in ms), min(m[1] for m in ms)
+        print("config %d %-10s B=%d %s grad=%d: step kernel %.3f ms, IFT kernel %.3f ms -> %.0f env-steps/s; iters %.1f ok %.3f" % (
+            cfg, spec.name, B, dt_, grad, a, b, B / ((a + b) * 1e-3), it.mean(), (st == 0).mean()), flush=True)
+        gm.close()
