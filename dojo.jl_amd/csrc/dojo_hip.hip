@@ -9,9 +9,11 @@
 #include <hip/hip_runtime.h>
 #include "dojo_host.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <mutex>
 
 namespace {
@@ -39,6 +41,7 @@ struct DojoSim {
     void* d_nodes = nullptr; void* d_contacts = nullptr;
     // internal device buffers used by the host-pointer entry points
     void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
+    std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
     int *d_status = nullptr, *d_iters = nullptr;
@@ -85,28 +88,36 @@ int acquire_slot(DojoSim* s, int* idx) {
     return drain_slot(s, s->ring[*idx]);
 }
 
+// Launches the step (and IFT) kernels for the environments [env0, env0 + nenv) of the batch; all pointers are the
+// batch-level buffers.  env0 must be a multiple of the environments per wavefront.
 template <class TIO, class T, class TL>
 int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-           void* dz, void* du, hipStream_t st, bool timed) {
+           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1) {
+    if (nenv < 0) nenv = s->B;
+    const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
+    auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
     dj::KernelArgs<TIO, T> A;
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode);
-    A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = s->B;
-    A.z = (const TIO*)z; A.u = (const TIO*)u; A.z_next = (TIO*)zn; A.status = status; A.iters = iters;
-    A.vel = (TIO*)vel; A.joint_imp = (TIO*)jimp; A.contact_sg = (TIO*)csg; A.dz = (TIO*)dz; A.du = (TIO*)du;
+    A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
+    A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb);
+    A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
+    A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
+    A.dz = off(dz, nx * nx); A.du = off(du, nx * nu);
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront), else one lane per supernode
     const bool quad = s->M.S <= 16;
     int E = 64 / (s->M.S * (quad ? 4 : 1));
-    dim3 grid((s->B + E - 1) / E);
+    dim3 grid((nenv + E - 1) / E);
+    const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = dz != nullptr;
     A.sol = nullptr;
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
-        A.sol = (T*)s->d_sol;
-        if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, (size_t)grid.x * dj::FAC_PER_LANE * 64 * sizeof(T)));
+        A.sol = (T*)s->d_sol + env0 * s->M.S * dj::sol_record<8>();          // any record size <= sol_record<8> fits this spacing
+        if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * sizeof(T)));
     }
-    A.fac = g ? (T*)s->d_fac : nullptr;
+    A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 : nullptr;
     typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
     launcher_t fn;
@@ -123,9 +134,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
 }
 
 int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-               void* dz, void* du, hipStream_t st, bool timed) {
-    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed);
-    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed);
+               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1) {
+    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv);
+    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv);
 }
 
 int ensure(void** p, size_t bytes) {
@@ -168,6 +179,9 @@ void dojo_destroy(DojoHandle s) {
     hipSetDevice(s->device);
     void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac};
     for (void* p : ps) if (p) hipFree(p);
+    for (auto g_ : s->gstreams) hipStreamDestroy(g_);
+    for (auto gev_ : s->gevents) hipEventDestroy(gev_);
+    if (s->fork_event) hipEventDestroy(s->fork_event);
     for (auto& e : s->ring) { if (e.a) hipEventDestroy(e.a); if (e.m) hipEventDestroy(e.m); if (e.b) hipEventDestroy(e.b); }
     delete s;
 }
@@ -277,13 +291,43 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     int slot = -1;
     { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; }
     HIPCHK(hipEventRecord(s->ring[slot].a, st));
-    for (int k = 0; k < H; ++k) {
-        char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
-        const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
-        rc = launch_any(s, cur, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, st, false);
-        if (rc != DOJO_OK) return rc;
-        cur = nxt;
+    // Environments are independent, so the batch is rolled out as NG groups on internal streams: a group whose step
+    // contains an environment that runs into max_iter (one wavefront, ~5x the mean step time) delays only itself while
+    // the other groups' launches keep the GPU busy.  (ROCm runs at most GPU_MAX_HW_QUEUES streams concurrently.)
+    const bool quad_ = s->M.S <= 16;
+    const size_t E_ = 64 / (s->M.S * (quad_ ? 4 : 1));
+    size_t NG = (H >= 2 && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
+    {   // streams beyond the hardware queues serialize behind each other: stay below GPU_MAX_HW_QUEUES (ROCm default 4)
+        const char* hq = getenv("GPU_MAX_HW_QUEUES");
+        int nq = hq ? atoi(hq) : 4;
+        NG = std::min<size_t>(NG, (size_t)std::max(1, nq - 1));
     }
+    size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;            // group size: multiple of 64 (and so of the environments per wave)
+    (void)E_;
+    if (NG > 1) {
+        while (s->gstreams.size() < NG) { hipStream_t g_; HIPCHK(hipStreamCreateWithFlags(&g_, hipStreamNonBlocking)); s->gstreams.push_back(g_); hipEvent_t gev_; HIPCHK(hipEventCreateWithFlags(&gev_, hipEventDisableTiming)); s->gevents.push_back(gev_); }
+        if (!s->fork_event) HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(s->fork_event, st));
+    }
+    const char* last = cur;
+    for (size_t gi = 0; gi < NG; ++gi) {
+        const size_t env0 = gi * per;
+        if (env0 >= B) break;
+        const int nenv = (int)std::min(per, B - env0);
+        hipStream_t gs = NG > 1 ? s->gstreams[gi] : st;
+        if (NG > 1) HIPCHK(hipStreamWaitEvent(gs, s->fork_event, 0));
+        const char* c = (const char*)z0;
+        for (int k = 0; k < H; ++k) {
+            char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
+            const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
+            rc = launch_any(s, c, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, gs, false, env0, nenv);
+            if (rc != DOJO_OK) return rc;
+            c = nxt;
+        }
+        last = c;
+        if (NG > 1) { HIPCHK(hipEventRecord(s->gevents[gi], gs)); HIPCHK(hipStreamWaitEvent(st, s->gevents[gi], 0)); }
+    }
+    cur = last;
     { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = false; e.n = H; e.used = true; s->last_slot = slot; }
     if (!Z && cur != (const char*)s->d_zn) HIPCHK(hipMemcpyAsync(s->d_zn, cur, B * nz * w, hipMemcpyDeviceToDevice, st));
     s->stream = st; s->have_solution = true; s->have_grad = false;

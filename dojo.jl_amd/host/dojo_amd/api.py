@@ -10,6 +10,8 @@ library or a GPU is missing, construction raises.
 """
 import ctypes as C
 import os
+# one hardware queue per environment group of dojo_rollout (must be set before the HIP runtime starts; ROCm default is 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 from .topology import CTopology, CSolverOptions, CDims, SolverOptions
 

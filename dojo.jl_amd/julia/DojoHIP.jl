@@ -11,6 +11,10 @@ module DojoHIP
 using Dojo
 using StaticArrays
 
+# one hardware queue per environment group of dojo_rollout (INTEGRATION.md "Streams and hardware queues");
+# has to be in the environment before the HIP runtime starts
+get!(ENV, "GPU_MAX_HW_QUEUES", "24")
+
 const LIB = get(ENV, "DOJO_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdojo_hip.so"))
 
 # ---- C PODs (layout identical to include/dojo_hip.h) -------------------------------------------

@@ -127,3 +127,20 @@ if what == "configs":
         print("config %d %-10s B=%d %s grad=%d: step kernel %.3f ms, IFT kernel %.3f ms -> %.0f env-steps/s; iters %.1f ok %.3f" % (
             cfg, spec.name, B, dt_, grad, a, b, B / ((a + b) * 1e-3), it.mean(), (st == 0).mean()), flush=True)
         gm.close()
+
+if what == "rollout":
+    # simulate!-style forward rollout (dojo_rollout): the library steps the batch as environment groups on internal streams
+    spec = d.baseline_config(3)
+    B, H = 4096, 40
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (B // 64, 1)); mask = (np.abs(np.tile(U0, (B // 64, 1))) > 0)
+    rng = np.random.Generator(np.random.Philox(key=[20241008, 1000]))
+    Uh = 0.5 * rng.standard_normal((H, B, spec.nu)) * mask
+    gm = api.BatchedMechanism(spec, B, dtype="f32")
+    for rep in range(3):
+        t0 = time.perf_counter()
+        traj, st = gm.rollout(Z.astype(np.float32), Uh.astype(np.float32), record=False)
+        el = time.perf_counter() - t0
+        print("rollout ant B=%d H=%d: kernel time per step %.2f ms -> %.0f env-steps/s (host wall incl. copies %.1f ms/step); converged %.4f" % (
+            B, H, gm.last_kernel_ms(), B / (gm.last_kernel_ms() * 1e-3), 1e3 * el / H, (st == 0).mean()), flush=True)
+    gm.close()
