@@ -206,15 +206,15 @@ template <class T> DJ_HD void joint_cfg(JointCfg<T>& c, const NodeP<T>& P, const
     qcmul(qab, qa, qb);
     qcmul(c.qr, P.qoff, qab);
 }
-// Per-lane data that is read rarely (joint frames at the current configuration, contact Jacobian
-// rows of the last linearization).  On the GPU it lives in LDS when it fits (one struct per lane,
-// stride = odd number of 8-byte words, so ds_read_b64 is bank-conflict free) to relieve VGPR pressure.
+// Data that is read rarely: the joint frames at the current configuration (Cold) and the contact Jacobian rows of the
+// last linearization (ContactCold).  Quad mapping on the GPU: once per supernode / per contact in LDS.
 template <class T, int MAXC>
 struct Cold {
     JointCfg<T> cfg;
-    T C134[MAXC][18], G134[MAXC][18];
-    T pad_[((sizeof(JointCfg<T>) / sizeof(T) + 36 * MAXC) % 2 == 0) ? 1 : 2];
+    T pad_[((sizeof(JointCfg<T>) / sizeof(T)) % 2 == 0) ? 1 : 2];       // odd stride in 8-byte words
 };
+template <class T>
+struct ContactCold { T C134[18], G134[18]; };
 
 // IFT data-Jacobian blocks of one supernode (datamat = −∂residual/∂θ, src/gradients/data.jl), stored
 // once per supernode (per quad) in the precision of the ABI buffers
@@ -715,6 +715,9 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
     }
 }
 
+// the NodeP fields the IFT column sweeps need, cached in registers (the sweeps' right-hand sides overlay NodeP in LDS)
+struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH]; };
+
 // ================================================================================================
 // The lane program
 // ================================================================================================
@@ -776,6 +779,11 @@ struct LaneProgram {
     }
     int stride, q, envl, qb;     // lanes per supernode, role in the quad, lanes per environment, first lane of the quad
     Cold<T, MAXC>& cold;
+    ContactCold<T>* cpool = nullptr;   // contact rows: slot (supernode, c) [pool_by_id = false] or slot = contact index of the environment
+    bool pool_by_id = false; int pool_base = 0;
+    char* lane_slots = nullptr; int lane_slot_stride = 0;   // lock-step quad mapping: the Lane blocks of all supernodes of the workgroup (parents are read in place)
+    DJ_HD const Lane<T, MAXC>& parent_state() const { return *(const Lane<T, MAXC>*)(lane_slots + (size_t)((has_parent ? base + stride * P.parent : qb) >> 2) * lane_slot_stride); }
+    DJ_HD ContactCold<T>& ccold(int c) const { return cpool[pool_by_id ? P.contact[c] : pool_base + c]; }
     JointCfg<T>& cfg;
     T mu;                        // mechanism.μ
 #ifdef DJ_DEBUG
@@ -809,10 +817,16 @@ struct LaneProgram {
         // parent's candidate velocity
         T va[3], wa[3], own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6];
         if constexpr (QUAD) {
-            mail_post_node<6>(own6);
-            const double* pp_ = mail_slot(has_parent ? base + stride * P.parent : qb, 0);
+            if (lane_slots) {                                    // the parent's candidate velocity, read in place
+                wv.sync();
+                const Lane<T, MAXC>& Lp = parent_state();
+                for (int i = 0; i < 3; ++i) { par6[i] = Lp.v[i]; par6[3 + i] = Lp.w[i]; }
+            } else {
+                mail_post_node<6>(own6);
+                const double* pp_ = mail_slot(has_parent ? base + stride * P.parent : qb, 0);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) par6[i] = T(pp_[i]);
+                for (int i = 0; i < 6; ++i) par6[i] = T(pp_[i]);
+            }
         } else shfl_vec<6>(wv, par6, own6, plane);
         if (has_parent) { v3cpy(va, par6); v3cpy(wa, par6 + 3); } else { va[0] = va[1] = va[2] = wa[0] = wa[1] = wa[2] = T(0); }
         Kin<T> kb, ka;
@@ -874,7 +888,7 @@ struct LaneProgram {
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CE[c].Dww[3 * i + j]);
-                    for (int i = 0; i < 18; ++i) { cold.C134[c][i] = CE[c].C134[i]; cold.G134[c][i] = CE[c].G134[i]; }
+                    { ContactCold<T>& cc_ = ccold(c); for (int i = 0; i < 18; ++i) { cc_.C134[i] = CE[c].C134[i]; cc_.G134[i] = CE[c].G134[i]; } }
                 }
             }
             for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
@@ -959,6 +973,7 @@ struct LaneProgram {
             if (c < P.ncontact) {
                 CCoef Q; T rc[4] = {0, 0, 0, 0}, r58[4] = {0, 0, 0, 0};
                 contact_coef(Q, c, rc, r58);
+                const ContactCold<T>& cc_ = ccold(c);
                 // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
@@ -968,7 +983,7 @@ struct LaneProgram {
 #pragma unroll
                         for (int a = 0; a < 3; ++a)
 #pragma unroll
-                            for (int b = 0; b < 3; ++b) acc += cold.G134[c][6 * a + i] * Q.coef[3 * a + b] * cold.C134[c][6 * b + j];
+                            for (int b = 0; b < 3; ++b) acc += cc_.G134[6 * a + i] * Q.coef[3 * a + b] * cc_.C134[6 * b + j];
                         K.addS(i, j, -acc);
                     }
             }
@@ -1129,7 +1144,7 @@ struct LaneProgram {
     // right-hand sides y wait between the two sweeps in the output buffer itself (the v / ω slots of
     // the column, which the down-sweep then overwrites with the final values).
     template <class KA, class RH, class KN>
-    DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0) {
+    DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0, const SweepP& sp) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
         constexpr int NC = 6;
@@ -1140,9 +1155,9 @@ struct LaneProgram {
         const int nbs = 2 * G.Nb;                              // state batches: (body kk, configuration | velocity columns)
         const int nbu = (A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0;   // control batches: six input columns each
         const int NB = nbs + nbu;
-        const int myu = P.nu_t + P.nu_r;
-        const int lvl = P.level;
-        const int pb = has_parent ? base + stride * P.parent : qb;
+        const int myu = sp.myu;
+        const int lvl = sp.level;
+        const int pb = sp.pb;
         const int qh = q & 1;
         // (selects, not F.t_b[3 * qh + i]: ONE dynamically indexed member keeps the whole LaneProgram object in scratch)
         const TG tb3[3] = {TG(qh ? F.t_b[3] : F.t_b[0]), TG(qh ? F.t_b[4] : F.t_b[1]), TG(qh ? F.t_b[5] : F.t_b[2])},
@@ -1177,9 +1192,10 @@ struct LaneProgram {
 #pragma unroll
                     for (int i = 0; i < 3 * NC; ++i) ms_[i] = (double)snd[i]; }
                 wv.sync();
-                for (int ci = 0; ci < G.maxch; ++ci) {
-                    if (valid && q < 2 && ci < P.nchild) {
-                        const double* cs_ = mail_slot(base + stride * P.child[ci], q);
+#pragma unroll
+                for (int ci = 0; ci < MAXCH; ++ci) {
+                    if (valid && q < 2 && ci < sp.nchild) {
+                        const double* cs_ = mail_slot(sp.child_lane0[ci], q);
 #pragma unroll
                         for (int i = 0; i < 3 * NC; ++i) acc[i] += TG(cs_[i]);
                     }
@@ -1190,19 +1206,19 @@ struct LaneProgram {
 #endif
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
-            const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (P.parent == kk);
+            const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (sp.parent == kk);
             // where this lane's rows of the batch's right-hand sides live in the supernode's QuadRhs (all blocks are [.][3][6]):
             //   own batch: body roles: own_cfg (configuration columns, double) | ROWNV (velocity columns); joint roles: ROWNJ | 0
             //   parent's configuration batch: RPAR[q] ;  control batch: UB on the owner (child body of the joint)
             //   parent-row parts (roles 0, 1): UOWN / UPAR / UA
-            const int cu0 = NC * (b - nbs) - P.u_off;             // control batch: local input index of column 0
+            const int cu0 = NC * (b - nbs) - sp.u_off;            // control batch: local input index of column 0
             const int r_off = isS ? (mine ? (q < 2 ? RH::ROWNV : RH::ROWNJ) + qh * 18 : RH::RPAR + q * 18) : RH::UB + qh * 18 + cu0;
             const int u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
             const bool od = mine && typ == 0 && q < 2;              // the folded owner rows come from the double block
             const TG rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0), um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
-            const TG wkm = (P.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
+            const TG wkm = (sp.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
             const int sl_off = mine ? RH::SLO : RH::SLP;
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
@@ -1415,7 +1431,7 @@ struct LaneProgram {
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
                 contact_coef(Q[c], c, R.cc[c], r58[c]);
-                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += cold.G134[c][6 * a + i] * Q[c].k0[a];
+                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += ccold(c).G134[6 * a + i] * Q[c].k0[a];
             }
         }
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0);
@@ -1440,7 +1456,7 @@ struct LaneProgram {
             if (c < P.ncontact) {
                 const ContactP<T>& K = CP[P.contact[c]];
                 T cw[3];
-                for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += cold.C134[c][6 * a + j] * D.dv[j] + cold.C134[c][6 * a + 3 + j] * D.dw[j]; }
+                for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += ccold(c).C134[6 * a + j] * D.dv[j] + ccold(c).C134[6 * a + 3 + j] * D.dw[j]; }
                 const CCoef& q = Q[c];
                 T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
                 T dg1 = q.a1 + q.b1 * cw[0];
@@ -1559,7 +1575,12 @@ struct LaneProgram {
             L.q2[0] = T(1); L.q2[1] = L.q2[2] = L.q2[3] = T(0);
         }
         T own7[7] = {L.x2[0], L.x2[1], L.x2[2], L.q2[0], L.q2[1], L.q2[2], L.q2[3]}, par7[7];
-        shfl_vec<7>(wv, par7, own7, plane);
+        if (lane_slots) {
+            wv.sync();
+            const Lane<T, MAXC>& Lp = parent_state();
+            for (int i = 0; i < 3; ++i) par7[i] = Lp.x2[i];
+            for (int i = 0; i < 4; ++i) par7[3 + i] = Lp.q2[i];
+        } else shfl_vec<7>(wv, par7, own7, plane);
         if (has_parent) { for (int i = 0; i < 3; ++i) L.xa2[i] = par7[i]; for (int i = 0; i < 4; ++i) L.qa2[i] = par7[3 + i]; }
         else { L.xa2[0] = L.xa2[1] = L.xa2[2] = T(0); L.qa2[0] = T(1); L.qa2[1] = L.qa2[2] = L.qa2[3] = T(0); }
         joint_cfg(cfg, P, L.xa2, L.qa2, L.x2, L.q2);
@@ -1764,7 +1785,11 @@ struct LaneProgram {
         DJ_PB();
         // ---- kinematics of the solution (chain) ----
         T own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6], va[3], wa[3];
-        shfl_vec<6>(wv, par6, own6, plane);
+        if (lane_slots) {
+            wv.sync();
+            const Lane<T, MAXC>& Lp = parent_state();
+            for (int i = 0; i < 3; ++i) { par6[i] = Lp.v[i]; par6[3 + i] = Lp.w[i]; }
+        } else shfl_vec<6>(wv, par6, own6, plane);
         for (int i = 0; i < 3; ++i) { va[i] = has_parent ? par6[i] : T(0); wa[i] = has_parent ? par6[3 + i] : T(0); }
         Kin<T> kb0, ka0;
         kin_of(kb0, L.x2, L.q2, L.v, L.w, dt);
@@ -1879,16 +1904,23 @@ struct LaneProgram {
                 CCoef Q;
                 if (c < P.ncontact) contact_coef(Q, c, rc0, e); else { Q.k0[0] = Q.k0[1] = Q.k0[2] = T(0); }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) GK[c][i][j] = (c < P.ncontact) ? cold.G134[c][i] * Q.k0[0] + cold.G134[c][6 + i] * Q.k0[1] + cold.G134[c][12 + i] * Q.k0[2] : T(0);
+                for (int i = 0; i < 6; ++i) GK[c][i][j] = (c < P.ncontact) ? ccold(c).G134[i] * Q.k0[0] + ccold(c).G134[6 + i] * Q.k0[1] + ccold(c).G134[12 + i] * Q.k0[2] : T(0);
             }
         }
         if (P.nlim_r > 0) wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
         typedef typename KA::io_type TB;
         if constexpr (QUAD) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
-            wv.sync();                                              // aliases Cold: not needed below
-            QuadRhs<TB>& R = *(QuadRhs<TB>*)gb_lds;
+            // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
+            SweepP sp;
+            sp.level = P.level; sp.parent = P.parent; sp.pb = has_parent ? base + stride * P.parent : qb; sp.u_off = P.u_off;
+            sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild;
+#pragma unroll
+            for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
             const bool lim = P.nlim_r > 0;
+            const int ncon = P.ncontact;
+            wv.sync();
+            QuadRhs<TB>& R = *(QuadRhs<TB>*)gb_lds;
             if (q == 0) {
 #pragma unroll
                 for (int cI = 0; cI < 6; ++cI) { R.a[QuadRhs<TB>::SLO + cI] = TB(lim ? sl_own[cI] : T(0)); R.a[QuadRhs<TB>::SLP + cI] = TB(lim ? sl_par[cI] : T(0)); }
@@ -1901,7 +1933,7 @@ struct LaneProgram {
                         if (row < 6) {
                             T v = OwnB[row][cc];
 #pragma unroll
-                            for (int cn = 0; cn < MAXC; ++cn) if (cn < P.ncontact) for (int j = 0; j < 4; ++j) v += GK[cn][row][j] * Cc[cn][j][cI];
+                            for (int cn = 0; cn < MAXC; ++cn) if (cn < ncon) for (int j = 0; j < 4; ++j) v += GK[cn][row][j] * Cc[cn][j][cI];
                             R.own_cfg[o_ + cI] = (double)v;
                             R.a[QuadRhs<TB>::ROWNV + o_ + cI] = TB(OwnB[row][cc + 3]);
                             R.a[QuadRhs<TB>::UOWN + o_ + cI] = TB(UpOwn[row][cI]);
@@ -1918,7 +1950,7 @@ struct LaneProgram {
             }
             wv.sync();
             DJ_PE(5); DJ_PB();
-            gradient_columns_quad(A, env, R, wk, kb0);
+            gradient_columns_quad(A, env, R, wk, kb0, sp);
             DJ_PE(6);
             return;
         }
@@ -2044,36 +2076,47 @@ struct KernelArgs {
 #endif
 };
 
-// LDS layout of one wavefront of the step kernel (quad mapping).
-// LOCKSTEP (the GPU): everything the four lanes of a supernode hold identically — the solver state
-// (Lane) and the cold linearization data (Cold) — exists once per supernode in LDS; the four lanes
-// read it with broadcast ds_reads and write identical values in the same instruction.  The SIMT
-// emulator's threads are not in lock step, so there Lane stays per-lane and Cold is per-lane in "LDS".
-//   [0, node_bytes)            : NodeP x 16 supernodes (copied once from the table in global memory; LOCKSTEP only)
-//   [node_bytes, lane_bytes)   : Lane  x 16 supernodes            (LOCKSTEP only)
-//   [lane_bytes, +max(cold,gb)): Cold x 16 (or x 64), overlaid by GradBlocks x 16 in the IFT phase
+// LDS layout of one workgroup (= one wavefront, or NW wavefronts for mechanisms of 17..32 bodies) in the quad mapping.
+// LOCKSTEP (the GPU): everything the four lanes of a supernode hold identically exists once per supernode in LDS; the
+// four lanes read it with broadcast ds_reads and write identical values in the same instruction.  The SIMT emulator's
+// threads are not in lock step, so there NodeP / Lane stay per-lane and Cold is per-lane in "LDS".
+//   phase A (Newton loop; data blocks of the IFT):
+//     [NodeP x NSN][Lane x NSN][Cold x NSN (or per lane)][ContactCold pool][mailbox (step kernel)]
+//   IFT column sweeps (overlay from offset 0: NodeP / Lane / Cold are dead by then, the few NodeP fields the sweeps
+//   need are cached in registers):
+//     [QuadRhs x NSN][mailbox]
+//   [reduction scratch, 64 B] at the end
 template <class T, int MAXC>
 struct LaneSlot { Lane<T, MAXC> L; T pad_[(sizeof(Lane<T, MAXC>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };   // odd stride in 8-byte words
 template <class T>
 struct NodeSlot { NodeP<T> P; char pad_[(sizeof(NodeP<T>) / 8) % 2 == 0 ? 8 : 16]; };                    // odd stride in 8-byte words
-template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP>
+constexpr int lds_imax(int a, int b) { return a > b ? a : b; }
+template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP, int NW = 1>
 struct StepLds {
-    static constexpr int node_bytes = (QUAD && LOCKSTEP) ? (int)sizeof(NodeSlot<T>) * 16 : 0;      // the supernode's constants
-    static constexpr int lane_bytes = node_bytes + ((QUAD && LOCKSTEP) ? (int)sizeof(LaneSlot<T, MAXC>) * 16 : 0);
-    static constexpr int cold_n = LOCKSTEP ? 16 : 64;
-    static constexpr bool cold_in_lds = QUAD && ((int)sizeof(Cold<T, MAXC>) * cold_n + lane_bytes <= 40 * 1024);
-    static constexpr int cold_bytes = cold_in_lds ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
-    static constexpr int gb_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * 16 : 0;
-    // mailbox of the tree exchanges: 32 slots (16 supernodes x 2 body-row roles) x 20 doubles.  In the IFT kernel it
-    // overlays the Lane block (the solver state is dead once the column sweeps start); elsewhere it has its own room.
-    static constexpr int mail_need = QUAD ? 32 * 20 * 8 : 0;
-    static constexpr bool mail_on_lane = QUAD && LOCKSTEP && GRAD && (lane_bytes - node_bytes >= mail_need);
-    static constexpr int mail_off = mail_on_lane ? node_bytes : lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes);
-    static constexpr int bytes = (mail_on_lane ? mail_off : mail_off + mail_need) + 16 > lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16
-                               ? (mail_on_lane ? mail_off : mail_off + mail_need) + 16 : lane_bytes + (cold_bytes > gb_bytes ? cold_bytes : gb_bytes) + 16;
+    static constexpr int NSN = 16 * NW;                                                     // supernode slots of the workgroup
+    static constexpr bool share = QUAD && LOCKSTEP;
+    static constexpr int node_bytes = share ? (int)sizeof(NodeSlot<T>) * NSN : 0;
+    static constexpr int lane_off = node_bytes;
+    static constexpr int lane_bytes = node_bytes + (share ? (int)sizeof(LaneSlot<T, MAXC>) * NSN : 0);   // end of the Lane block
+    static constexpr int cold_n = LOCKSTEP ? NSN : 64 * NW;
+    static constexpr bool cold_in_lds = QUAD;
+    static constexpr int cold_off = lane_bytes;
+    static constexpr int cold_bytes = QUAD ? (int)sizeof(Cold<T, MAXC>) * cold_n : 0;
+    // contact rows: one slot per (supernode, contact) for a single-wave workgroup, one slot per contact of the
+    // environment (at most 16) for NW > 1 -- there the per-supernode array would not fit
+    static constexpr bool pool_by_id = NW > 1;
+    static constexpr int pool_n = !QUAD ? 0 : (pool_by_id ? 16 : cold_n * MAXC);
+    static constexpr int pool_off = cold_off + cold_bytes;
+    static constexpr int pool_bytes = (int)sizeof(ContactCold<T>) * pool_n;
+    static constexpr int a_end = pool_off + pool_bytes;
+    static constexpr int rhs_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * NSN : 0;
+    static constexpr int mail_need = QUAD ? 2 * NSN * 20 * 8 : 0;
+    static constexpr int mail_off = (QUAD && GRAD) ? rhs_bytes : a_end;
+    static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
+    static constexpr int bytes = red_off + 64;
 };
-template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true>
-constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP>::bytes; }
+template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
+constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
 
 // doubles per supernode in the step -> IFT hand-off record: v ω λ(6), s,γ of the joint limit, s,γ of the contacts, μ,
 // and the pieces of the final linearization the IFT needs besides the factors: t_a, t_b (limit condensation), G134
@@ -2088,13 +2131,13 @@ constexpr int FAC_PER_LANE = 72;
 #define DJ_LANE_SETUP(GRAD_LAYOUT)                                                                                        \
     const Globals<T>& G = A.G;                                                                                            \
     const int stride = QUAD ? 4 : 1;                                                                                      \
-    const int envl = stride * G.S, E = wv.width() / envl;        /* lanes per environment, environments per wave */       \
+    const int envl = stride * G.S, E = wv.width() / envl;        /* lanes per environment, environments per workgroup */  \
     const int lane = wv.lane();                                                                                           \
     const int slot = lane / envl, k = (lane % envl) / stride, q = lane % stride;                                          \
     const int env = wave_index * E + slot;                                                                                \
     const bool active = (env < A.B) && (k < G.Nb);                                                                        \
     const int base = slot * envl;                                                                                         \
-    typedef StepLds<TIO, T, MAXC, GRAD_LAYOUT, QUAD, Wave::kLockstep> LY;                                                 \
+    typedef StepLds<TIO, T, MAXC, GRAD_LAYOUT, QUAD, Wave::kLockstep, Wave::kWaves> LY;                                   \
     constexpr bool SHARE = QUAD && Wave::kLockstep;                                                                       \
     char* lds = (char*)wv.lds();                                                                                          \
     const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];                                                                       \
@@ -2102,11 +2145,17 @@ constexpr int FAC_PER_LANE = 72;
     const NodeP<T>& P = SHARE ? ((NodeSlot<T>*)lds)[lane / 4].P : Pg;                                                     \
     Lane<T, MAXC> lane_local;                                                                                             \
     Cold<T, MAXC> cold_local;                                                                                             \
-    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)(lds + LY::node_bytes))[lane / 4].L : lane_local;           \
-    Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::lane_bytes))[SHARE ? lane / 4 : lane] : cold_local; \
+    ContactCold<T> pool_local[QUAD ? 1 : MAXC];                                                                           \
+    Lane<T, MAXC>& lane_state = SHARE ? ((LaneSlot<T, MAXC>*)(lds + LY::lane_off))[lane / 4].L : lane_local;             \
+    Cold<T, MAXC>& cold = LY::cold_in_lds ? ((Cold<T, MAXC>*)(lds + LY::cold_off))[SHARE ? lane / 4 : lane] : cold_local; \
     LaneProgram<T, TL, MAXC, QUAD, Wave> prog(wv, G, P, A.contacts, base, k, q, active, lane_state, cold);                \
-    if (QUAD) prog.gb_lds = (void*)(((QuadRhs<TIO>*)(lds + LY::lane_bytes)) + lane / 4);                                  \
-    if (QUAD) prog.mail = (double*)(lds + LY::mail_off);                                                                  \
+    if (QUAD) {                                                                                                           \
+        prog.cpool = (ContactCold<T>*)(lds + LY::pool_off); prog.pool_by_id = LY::pool_by_id;                             \
+        prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
+        prog.gb_lds = (void*)(((QuadRhs<TIO>*)lds) + lane / 4);                                                           \
+        prog.mail = (double*)(lds + LY::mail_off);                                                                        \
+        if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
+    } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
     const bool has_u = A.u != nullptr;                                                                                    \
@@ -2130,7 +2179,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
                 const T* r2 = r + 17 + 8 * MAXC;
                 for (int i = 0; i < 6; ++i) { prog.F.t_a[i] = r2[i]; prog.F.t_b[i] = r2[6 + i]; }
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 18; ++i) cold.G134[c][i] = r2[12 + 18 * c + i];
+                for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) for (int i = 0; i < 18; ++i) prog.ccold(c).G134[i] = r2[12 + 18 * c + i];
             }
         }
     }
@@ -2183,7 +2232,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
             T* r2 = r + 17 + 8 * MAXC;
             for (int i = 0; i < 6; ++i) { r2[i] = prog.F.t_a[i]; r2[6 + i] = prog.F.t_b[i]; }
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 18; ++i) r2[12 + 18 * c + i] = cold.G134[c][i];
+            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) for (int i = 0; i < 18; ++i) r2[12 + 18 * c + i] = prog.ccold(c).G134[i];
         }
     }
     if (QUAD && A.fac) {

@@ -19,7 +19,8 @@
 namespace {
 
 struct GpuWave {
-    static constexpr bool kLockstep = true;     // the 64 lanes execute every instruction together
+    static constexpr bool kLockstep = true;     // the 64 lanes of a wave (so the 4 lanes of a quad) execute every instruction together
+    static constexpr int kWaves = 1;            // wavefronts per workgroup (= per environment group)
     void* lds_;
     __device__ __forceinline__ void* lds() const { return lds_; }
     // The workgroup IS one wavefront and LDS instructions of a wave execute in issue order, so lanes only need the

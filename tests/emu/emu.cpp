@@ -32,6 +32,7 @@ struct Shared {
 
 struct EmuWave {
     static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
+    static constexpr int kWaves = 1;            // (the emulated shuffles span the whole workgroup, whatever its width)
     Shared* sh; int l;
     int lane() const { return l; }
     int width() const { return sh->W; }
