@@ -692,10 +692,12 @@ template <class T> DJ_HD T soc_step(const T* l, const T* d, T tau) {
 // Wave-level helpers.  `Wave` provides: lane(), shfl(v, src_lane), any(pred).
 // ------------------------------------------------------------------------------------------------
 template <class Wave, class T> DJ_HD T lane_xor(Wave& w, T v, int o) { return o == 1 ? w.quad_xor(v, 1) : o == 2 ? w.quad_xor(v, 2) : w.shfl(v, w.lane() ^ o); }
-template <class Wave, class T> DJ_HD T env_max(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmax(v, lane_xor(w, v, o)); return v; }
-template <class Wave, class T> DJ_HD T env_min(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = tmin(v, lane_xor(w, v, o)); return v; }
-template <class Wave, class T> DJ_HD T env_sum(Wave& w, T v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v + lane_xor(w, v, o); return v; }
-template <class Wave> DJ_HD int env_or(Wave& w, int v, int S) { for (int o = S >> 1; o > 0; o >>= 1) v = v | lane_xor(w, v, o); return v; }
+// reductions over the lanes of one environment.  Several wavefronts per environment (Wave::kWaves > 1, one environment
+// per workgroup): through the workgroup reductions of the Wave.
+template <class Wave, class T> DJ_HD T env_max(Wave& w, T v, int S) { if constexpr (Wave::kWaves > 1) return T(w.wg_max((double)v)); else { for (int o = S >> 1; o > 0; o >>= 1) v = tmax(v, lane_xor(w, v, o)); return v; } }
+template <class Wave, class T> DJ_HD T env_min(Wave& w, T v, int S) { if constexpr (Wave::kWaves > 1) return T(w.wg_min((double)v)); else { for (int o = S >> 1; o > 0; o >>= 1) v = tmin(v, lane_xor(w, v, o)); return v; } }
+template <class Wave, class T> DJ_HD T env_sum(Wave& w, T v, int S) { if constexpr (Wave::kWaves > 1) return T(w.wg_sum((double)v)); else { for (int o = S >> 1; o > 0; o >>= 1) v = v + lane_xor(w, v, o); return v; } }
+template <class Wave> DJ_HD int env_or(Wave& w, int v, int S) { if constexpr (Wave::kWaves > 1) return w.wg_or(v); else { for (int o = S >> 1; o > 0; o >>= 1) v = v | lane_xor(w, v, o); return v; } }
 
 template <int N, class Wave, class T> DJ_HD void shfl_vec(Wave& w, T* out, const T* in, int src) {
 #pragma unroll
@@ -1627,7 +1629,9 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) L.dconst[i] -= sb[i];
         T up[6], acc[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -(ina[i] + sa[i]) : T(0);
-        gather_children<6>(wv, acc, up, P, base, G.maxch, active, stride, q);
+        if constexpr (QUAD) { mail_post_node<6>(up); mail_add_children_node<6>(acc, active, G.maxch); }
+        else gather_children<6>(wv, acc, up, P, base, G.maxch, active, stride, q);
+        wv.sync();                                             // (the four lanes of a quad update the shared dconst with the same values)
         for (int i = 0; i < 6; ++i) L.dconst[i] += acc[i];
         mu = T(0);
     }

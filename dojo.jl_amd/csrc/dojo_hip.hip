@@ -26,6 +26,7 @@ extern "C" {
 DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launch_float_8_1)
 DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
 DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
+DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2)
 #undef DJ_DECL
 }
 
@@ -68,6 +69,13 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     return DOJO_OK;
 }
 
+// wavefronts per workgroup of the quad mapping for this mechanism; 0 = lane mapping
+int mapping_waves(const dj::HostModel& M) {
+    if (M.S <= 16) return 1;
+    if (M.S <= 32 && M.maxc <= 4 && M.Nc <= 16) return 2;
+    return 0;
+}
+
 int drain_slot(DojoSim* s, DojoSim::Ev3& e) {
     if (!e.used) return DOJO_OK;
     HIPCHK(hipEventSynchronize(e.b));
@@ -103,11 +111,14 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
     A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu);
-    // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront), else one lane per supernode
-    const bool quad = s->M.S <= 16;
-    int E = 64 / (s->M.S * (quad ? 4 : 1));
+    // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
+    // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
+    // else one lane per supernode
+    const int NW = mapping_waves(s->M);
+    const bool quad = NW > 0;
+    int E = 64 * (quad ? NW : 1) / (s->M.S * (quad ? 4 : 1));
     dim3 grid((nenv + E - 1) / E);
-    const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;
+    const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;        // workgroups, each 64 * NW lanes
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = dz != nullptr;
@@ -115,13 +126,14 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
         A.sol = (T*)s->d_sol + env0 * s->M.S * dj::sol_record<8>();          // any record size <= sol_record<8> fits this spacing
-        if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * sizeof(T)));
+        if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
     }
-    A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 : nullptr;
+    A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
     typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
     launcher_t fn;
-    if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
+    if (NW == 2) fn = f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2;
+    else if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
                  : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_1 : dojo_launch_double_4_1)
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
     else      fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_0 : dojo_launch_double_4_0)
@@ -294,8 +306,8 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     // Environments are independent, so the batch is rolled out as NG groups on internal streams: a group whose step
     // contains an environment that runs into max_iter (one wavefront, ~5x the mean step time) delays only itself while
     // the other groups' launches keep the GPU busy.  (ROCm runs at most GPU_MAX_HW_QUEUES streams concurrently.)
-    const bool quad_ = s->M.S <= 16;
-    const size_t E_ = 64 / (s->M.S * (quad_ ? 4 : 1));
+    const int NW_ = mapping_waves(s->M);
+    const size_t E_ = 64 * (NW_ > 0 ? NW_ : 1) / (s->M.S * (NW_ > 0 ? 4 : 1));
     size_t NG = (H >= 2 && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
     {   // streams beyond the hardware queues serialize behind each other: stay below GPU_MAX_HW_QUEUES (ROCm default 4)
         const char* hq = getenv("GPU_MAX_HW_QUEUES");

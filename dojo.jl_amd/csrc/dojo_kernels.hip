@@ -13,27 +13,61 @@
 #define DJ_MAXC 1
 #endif
 #ifndef DJ_QUAD
-#define DJ_QUAD 1      // 1: four lanes per supernode (<= 16 bodies), 0: one lane per supernode (<= 64 bodies)
+#define DJ_QUAD 1      // 1: four lanes per supernode, one wavefront per workgroup (<= 16 bodies); 2: the same over two wavefronts (<= 32 bodies);
+                       // 0: one lane per supernode (<= 64 bodies)
 #endif
 
 namespace {
 
+// NW = wavefronts per workgroup.  NW = 1: the workgroup is one wavefront (<= 16 supernodes x 4 roles).  NW = 2: one
+// environment of 17..32 bodies spans two wavefronts; quads never straddle a wave, so everything quad-local is unchanged,
+// and the exchanges between quads (LDS mailbox, reductions, votes) go through LDS with real barriers.
+template <int NW>
 struct GpuWave {
     static constexpr bool kLockstep = true;     // the 64 lanes of a wave (so the 4 lanes of a quad) execute every instruction together
-    static constexpr int kWaves = 1;            // wavefronts per workgroup (= per environment group)
+    static constexpr int kWaves = NW;
     void* lds_;
+    double* red_;                               // reduction / vote scratch at the end of the LDS block (NW > 1)
     __device__ __forceinline__ void* lds() const { return lds_; }
-    // The workgroup IS one wavefront and LDS instructions of a wave execute in issue order, so lanes only need the
-    // compiler to keep LDS accesses in program order.  (__syncthreads() would also drain the outstanding global
-    // stores -- vmcnt(0) -- which costs the IFT sweeps a memory round trip per pipeline step.)
-    __device__ __forceinline__ void sync() const { __asm__ volatile("" ::: "memory"); }
-    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
-    __device__ __forceinline__ int width() const { return 64; }
+    // NW = 1: LDS instructions of a wave execute in issue order, so lanes only need the compiler to keep LDS accesses in
+    // program order.  (__syncthreads() would also drain the outstanding global stores -- vmcnt(0) -- which costs the IFT
+    // sweeps a memory round trip per pipeline step.)  NW > 1: wait for this wave's LDS traffic, then the hardware barrier.
+    __device__ __forceinline__ void sync() const {
+        if (NW == 1) __asm__ volatile("" ::: "memory");
+        else __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }              // lane index inside the workgroup
+    __device__ __forceinline__ int width() const { return 64 * NW; }
     __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
-    __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src, 64); }
-    __device__ __forceinline__ bool   any(bool p) const { return __any(p ? 1 : 0) != 0; }
+    // shuffles inside the wavefront only (the quad mapping with NW > 1 does not use them across quads)
+    __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src & 63, 64); }
+    __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src & 63, 64); }
+    __device__ __forceinline__ int    shfl(int v, int src) const { return __shfl(v, src & 63, 64); }
+    __device__ __forceinline__ bool   any(bool p) const {
+        bool a = __any(p ? 1 : 0) != 0;
+        if (NW == 1) return a;
+        int* r = (int*)red_;
+        sync(); if ((threadIdx.x & 63u) == 0) r[threadIdx.x >> 6] = a ? 1 : 0; sync();
+        int o = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) o |= r[w];
+        return o != 0;
+    }
+    // workgroup-wide reductions: butterfly inside the wave, then NW partial results through LDS
+    template <class OP> __device__ __forceinline__ double wg_reduce(double v, OP op) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+        if (NW == 1) return v;
+        sync(); if ((threadIdx.x & 63u) == 0) red_[threadIdx.x >> 6] = v; sync();
+        double r = red_[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) r = op(r, red_[w]);
+        return r;
+    }
+    __device__ __forceinline__ double wg_max(double v) const { return wg_reduce(v, [](double a, double b) { return a > b ? a : b; }); }
+    __device__ __forceinline__ double wg_min(double v) const { return wg_reduce(v, [](double a, double b) { return a < b ? a : b; }); }
+    __device__ __forceinline__ double wg_sum(double v) const { return wg_reduce(v, [](double a, double b) { return a + b; }); }
+    __device__ __forceinline__ int wg_or(int v) const { return any(v != 0) ? 1 : 0; }
     // quad-local data movement on the DPP path (v_mov_b32 quad_perm): no LDS traffic, VALU latency
     template <int CTRL> static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
     template <int CTRL> static __device__ __forceinline__ float dppf(float v) { return __int_as_float(dpp<CTRL>(__float_as_int(v))); }
@@ -64,21 +98,23 @@ struct GpuWave {
 #ifndef DJ_GRAD_WAVES
 #define DJ_GRAD_WAVES 1
 #endif
-template <class TIO, class TS, class TL, int MAXC, bool QUAD>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DJ_FWD_WAVES, DJ_FWD_WAVES)))
+template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_FWD_WAVES, DJ_FWD_WAVES)))
 dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
-    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, false, QUAD>() + 7) / 8];
-    GpuWave w;
-    w.lds_ = (void*)lds_buf;
-    dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave>(w, A, (int)blockIdx.x);
+    typedef dj::StepLds<TIO, TS, MAXC, false, QUAD, true, NW> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<NW> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
-template <class TIO, class TS, class TL, int MAXC, bool QUAD>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
+template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
 dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
-    __shared__ double lds_buf[(dj::step_lds_bytes<TIO, TS, MAXC, true, QUAD>() + 7) / 8];
-    GpuWave w;
-    w.lds_ = (void*)lds_buf;
-    dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave>(w, A, (int)blockIdx.x);
+    typedef dj::StepLds<TIO, TS, MAXC, true, QUAD, true, NW> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<NW> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
 
 } // namespace
@@ -90,8 +126,9 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
 // mid_event (may be null) is recorded between the two kernels so that each can be timed on its own
 extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, void* mid_event) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
-    hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    constexpr int NW = DJ_QUAD == 2 ? 2 : 1;
+    hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
     if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
-    if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }

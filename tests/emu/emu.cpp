@@ -30,9 +30,10 @@ struct Shared {
     explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(160 * 1024 / 8) {}
 };
 
-struct EmuWave {
+template <int NW>
+struct EmuWaveT {
     static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
-    static constexpr int kWaves = 1;            // (the emulated shuffles span the whole workgroup, whatever its width)
+    static constexpr int kWaves = NW;           // selects the LDS layout and the workgroup-reduction code paths of the multi-wave kernels
     Shared* sh; int l;
     int lane() const { return l; }
     int width() const { return sh->W; }
@@ -61,9 +62,20 @@ struct EmuWave {
         sh->bar.wait();
         return r != 0;
     }
+    // workgroup reductions (used when kWaves > 1)
+    template <class OP> double wg_reduce(double v, OP op) {
+        sh->slot[l] = v; sh->bar.wait();
+        double r = sh->slot[0]; for (int i = 1; i < sh->W; ++i) r = op(r, sh->slot[i]);
+        sh->bar.wait();
+        return r;
+    }
+    double wg_max(double v) { return wg_reduce(v, [](double a, double b) { return a > b ? a : b; }); }
+    double wg_min(double v) { return wg_reduce(v, [](double a, double b) { return a < b ? a : b; }); }
+    double wg_sum(double v) { return wg_reduce(v, [](double a, double b) { return a + b; }); }
+    int wg_or(int v) { return any(v != 0) ? 1 : 0; }
 };
 
-template <class TIO, class T, class TL, int MAXC, bool QUAD>
+template <class TIO, class T, class TL, int MAXC, bool QUAD, int NW = 1>
 void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
          const double* z, const double* u, double* z_next, int* status, int* iters,
          double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg) {
@@ -91,7 +103,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
         Shared sh(W);
         std::vector<std::thread> th;
         for (int l = 0; l < W; ++l) th.emplace_back([&, l, pass]() {
-            EmuWave w{&sh, l};
+            EmuWaveT<NW> w{&sh, l};
             if (pass == 0) dj::step_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi); else dj::grad_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi);
         });
         for (auto& t : th) t.join();
@@ -113,10 +125,12 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     dj::HostModel M;
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
-    if (quad && M.S > 16) { if (err) std::strncpy(err, "quad mapping needs <= 16 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
-#define RUN(TIO, TS, TL, MC) do { if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
+#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
+                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
                                   else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); } while (0)
     // dtype 0: fp64 everywhere; dtype 1: fp32 I/O with fp64 internals (the product's "f32" mode); dtype 3: fp32 factorization (experiments)
     if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }

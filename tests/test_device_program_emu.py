@@ -10,15 +10,16 @@ from emu_wrap import emu_step
 TIGHT = d.SolverOptions(rtol=1e-8, btol=1e-8)
 
 
-@pytest.mark.parametrize("cfg,steps", [(1, 3), (2, 3), (3, 2)])
-def test_forward_matches_oracle(cfg, steps):
+# quad = True: four lanes per supernode (the mapping the product uses up to 32 bodies); False: one lane per supernode (> 32 bodies)
+@pytest.mark.parametrize("cfg,steps,quad", [(1, 3, True), (2, 3, True), (3, 1, True), (2, 2, False), (3, 1, False)])
+def test_forward_matches_oracle(cfg, steps, quad):
     spec = d.baseline_config(cfg)
     o = Oracle(spec, opts=TIGHT)
     Z, U = d.synthetic_inputs(spec, 1)
     z, u = Z[0], U[0]
     for _ in range(steps):
         zo, info = o.step(z, u)
-        r = emu_step(spec, z, u, opts=TIGHT)
+        r = emu_step(spec, z, u, opts=TIGHT, quad=quad)
         assert r["status"][0] == info["status"] == 0
         assert np.abs(r["z_next"][0] - zo).max() < 1e-7
         sol = o.get_solution()
@@ -35,15 +36,15 @@ def test_block_in_contact_two_envs_per_wave():
     z1 = d.initialize(spec, position=[0, 0, 0.6], velocity=[0.0, 0.0, 0.0], angular_velocity=[0.0, 0.0, 0.0])
     Z = np.stack([z0, z1]); U = np.zeros((2, 6))
     for _ in range(4):
-        r = emu_step(spec, Z, U, opts=TIGHT, envs_per_wave=2)
+        r = emu_step(spec, Z, U, opts=TIGHT, envs_per_wave=2, quad=True)
         Zo = np.stack([o.step(Z[b], U[b])[0] for b in range(2)])
         assert np.abs(r["z_next"] - Zo).max() < 1e-7
         Z = Zo
     assert r["iters"][0] != r["iters"][1]        # different Newton iteration counts inside one wave
 
 
-@pytest.mark.parametrize("cfg,pre,mode", [(1, 2, 0), (2, 1, 1), (3, 0, 0)])
-def test_gradients_match_oracle(cfg, pre, mode):
+@pytest.mark.parametrize("cfg,pre,mode,quad", [(1, 2, 0, True), (2, 1, 1, True), (3, 0, 0, True), (2, 1, 0, False)])
+def test_gradients_match_oracle(cfg, pre, mode, quad):
     spec = d.baseline_config(cfg)
     opts = d.SolverOptions(rtol=1e-7, btol=1e-7)
     o = Oracle(spec, opts=opts)
@@ -53,6 +54,18 @@ def test_gradients_match_oracle(cfg, pre, mode):
         z, _ = o.step(z, u)
     o.step(z, u)
     dz, du = o.gradients(mode)
-    r = emu_step(spec, z, u, opts=opts, grad=True, grad_mode=mode)
+    r = emu_step(spec, z, u, opts=opts, grad=True, grad_mode=mode, quad=quad)
     assert np.abs(r["dz"][0] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
     assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
+
+
+def test_atlas_two_wavefront_quad_mapping():
+    """31 bodies: one environment over two wavefronts' worth of lanes (128 emulated threads) -- the NW = 2 LDS layout,
+    the contact-row pool by contact index and the workgroup reductions of the device source."""
+    spec = d.baseline_config(5)
+    o = Oracle(spec, opts=TIGHT)
+    Z, U = d.synthetic_inputs(spec, 1)
+    zo, info = o.step(Z[0], U[0])
+    r = emu_step(spec, Z[0], U[0], opts=TIGHT, quad=True)
+    assert r["status"][0] == info["status"] == 0
+    assert np.abs(r["z_next"][0] - zo).max() < 1e-7
