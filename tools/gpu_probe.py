@@ -144,3 +144,17 @@ if what == "rollout":
         print("rollout ant B=%d H=%d: kernel time per step %.2f ms -> %.0f env-steps/s (host wall incl. copies %.1f ms/step); converged %.4f" % (
             B, H, gm.last_kernel_ms(), B / (gm.last_kernel_ms() * 1e-3), 1e3 * el / H, (st == 0).mean()), flush=True)
     gm.close()
+
+if what == "atlas":
+    spec = d.baseline_config(5)
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    for B in (256, 1024, 2048):
+        for grad in (False, True):
+            Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+            gm = api.BatchedMechanism(spec, B, dtype="f32")
+            z = Z.astype(np.float32); ms = []
+            for k in range(3):
+                zn, st, it = gm.step(z, U, with_gradient=grad); ms.append(gm.last_kernel_times()); z = zn
+            a, b = min(m[0] for m in ms), min(m[1] for m in ms)
+            print("atlas B=%d grad=%d: step kernel %.2f ms, IFT kernel %.2f ms -> %.0f env-steps/s; iters %.1f (max %d) ok %.3f" % (B, grad, a, b, B / ((a + b) * 1e-3), it.mean(), it.max(), (st == 0).mean()), flush=True)
+            gm.close()
