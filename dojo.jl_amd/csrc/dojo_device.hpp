@@ -21,9 +21,18 @@
 //   src/gradients/state.jl:78-126, src/gradients/data.jl (data Jacobian blocks)
 #pragma once
 #include "dojo_math.hpp"
+#include <type_traits>
 #ifdef DJ_DEBUG
 #include <cstdio>
 #include <cstdlib>
+#endif
+
+#ifndef DJ_FUSE_LS
+#define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
+                           // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
+#endif
+#ifndef DJ_LS_IN_LDS
+#define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
 
 namespace dj {
@@ -150,6 +159,10 @@ struct QuadBlocks {
     template <class V> DJ_HD void addL(int r, int c, V v) { if (c / 3 == q) L[r][c % 3] += T(v); }
     template <class V> DJ_HD void addD(int r, int c, V v) { if (r / 3 == q) D[r % 3][c] += T(v); }
 };
+
+struct NullQuad { template <class A, class B, class C> DJ_HD NullQuad(A&, B&, C&, int) {} };   // stands in for QuadBlocks in the lane mapping
+template <class T, bool QUAD> struct QuadKType { typedef QuadBlocks<T> type; };
+template <class T> struct QuadKType<T, false> { typedef NullQuad type; };
 
 // kinematic quantities of a body at the candidate velocity
 template <class T>
@@ -783,6 +796,9 @@ struct LaneProgram {
     Cold<T, MAXC>& cold;
     ContactCold<T>* cpool = nullptr;   // contact rows: slot (supernode, c) [pool_by_id = false] or slot = contact index of the environment
     bool pool_by_id = false; int pool_base = 0;
+    // Newton step + line-search base iterate once per supernode in LDS (single-wave quad mapping with one contact per body: there is room)
+    static constexpr bool kLsInLds = DJ_LS_IN_LDS && QUAD && Wave::kLockstep && Wave::kWaves == 1 && MAXC == 1;
+    char* ls_lds = nullptr;
     char* lane_slots = nullptr; int lane_slot_stride = 0;   // lock-step quad mapping: the Lane blocks of all supernodes of the workgroup (parents are read in place)
     DJ_HD const Lane<T, MAXC>& parent_state() const { return *(const Lane<T, MAXC>*)(lane_slots + (size_t)((has_parent ? base + stride * P.parent : qb) >> 2) * lane_slot_stride); }
     DJ_HD ContactCold<T>& ccold(int c) const { return cpool[pool_by_id ? P.contact[c] : pool_base + c]; }
@@ -1678,6 +1694,7 @@ struct LaneProgram {
         int no_progress = 0;
         mu = T(0);
         linearize();
+        typename QuadKType<TL, QUAD>::type Kq(F.Sq, F.Uq, F.Lq, q);   // quad mapping: the lane's rows, assembled in place in the factor storage
 #ifdef DJ_DEBUG
         if (dbg_on) { iters_out = 0; return 0; }   // wave-uniform early exit of the test hook
 #endif
@@ -1696,7 +1713,8 @@ struct LaneProgram {
             if (!done) iters = n;
             ConeRhs R;
             cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
-            Step<T, MAXC> D;
+            Step<T, MAXC> D_local;
+            Step<T, MAXC>& D = kLsInLds ? *(Step<T, MAXC>*)ls_lds : D_local;
             DJ_PB();
             solve(R, D);                                            // affine direction
             DJ_PE(4);
@@ -1738,16 +1756,18 @@ struct LaneProgram {
             T alpha = cone_line_search(D, tau, tmin(tau, T(0.95)));
             // line_search!  src/solver/line_search.jl:1-34 (halving; the last trial is taken if all are rejected)
             T rc = rvio, bc = bvio;
+            int lin_trials = 0;                                     // residual evaluations of this line search (1: the Jacobian blocks of trial 0 are those of the new iterate)
             {
                 bool searching = !done;
                 T f = done ? T(0) : alpha;
-                SolSnap<T, MAXC> base_sol;
+                SolSnap<T, MAXC> base_local;
+                SolSnap<T, MAXC>& base_sol = kLsInLds ? *(SolSnap<T, MAXC>*)(ls_lds + sizeof(Step<T, MAXC>)) : base_local;
                 snapshot(base_sol);
                 DJ_PB();
-                for (int ls = 0; ls < G.max_ls; ++ls) {
-                    if (!wv.any(active && searching)) break;
+                // one trial: candidate, residual (with the Jacobian blocks when WITH_JAC), violations, accept / halve
+                auto trial = [&](int ls, auto with_jac) {
                     int bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
-                    { NullBlocks nk; evaluate<false>(nk); }
+                    if constexpr (decltype(with_jac)::value) evaluate<true>(Kq); else { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
                     int anybad = env_or(wv, (active && searching) ? bad : 0, envl);
@@ -1756,17 +1776,38 @@ struct LaneProgram {
                         rc = r2; bc = b2;
                         if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
                     }
+                };
+                // Quad mapping: the first trial already assembles the Jacobian blocks (they do not depend on μ).  Most line
+                // searches accept it, and the set_entries! evaluation at the new iterate is then this one.
+                bool first_is_final = false;
+                if constexpr (QUAD && DJ_FUSE_LS) {
+                    if (G.max_ls > 0 && wv.any(active && searching)) {
+                        trial(0, std::true_type());
+                        first_is_final = !wv.any(active && searching) || G.max_ls == 1;
+                        lin_trials = 1;
+                    }
+                }
+                if (!first_is_final) {
+                    for (int ls = lin_trials; ls < G.max_ls; ++ls) {
+                        if (!wv.any(active && searching)) break;
+                        trial(ls, std::false_type());
+                        ++lin_trials;
+                    }
                 }
                 DJ_PE(3);
+                if (!done) {
+                    bool made = (!(rc < G.rtol) && rc < T(0.8) * rvio) || (!(bc < G.btol) && bc < T(0.8) * bvio);
+                    if (made) no_progress = no_progress > 0 ? no_progress - 1 : 0; else no_progress += 1;
+                    rvio = rc; bvio = bc;
+                    if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
+                    mu = mutarget;
+                }
+                // set_entries! + factorization (cone rows now carry the new μ)
+                if constexpr (QUAD && DJ_FUSE_LS) {
+                    if (first_is_final && lin_trials == 1) { DJ_PB(); condense(Kq); DJ_PE(0); DJ_PB(); factorize_quad(Kq); DJ_PE(1); }
+                    else linearize();
+                } else linearize();
             }
-            if (!done) {
-                bool made = (!(rc < G.rtol) && rc < T(0.8) * rvio) || (!(bc < G.btol) && bc < T(0.8) * bvio);
-                if (made) no_progress = no_progress > 0 ? no_progress - 1 : 0; else no_progress += 1;
-                rvio = rc; bvio = bc;
-                if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
-                mu = mutarget;
-            }
-            linearize();                                            // set_entries! + factorization (cone rows now carry the new μ)
         }
         if (excessive) status = DJ_STATUS_EXCESSIVE_W;
         iters_out = iters;
@@ -2112,7 +2153,12 @@ struct StepLds {
     static constexpr int pool_n = !QUAD ? 0 : (pool_by_id ? 16 : cold_n * MAXC);
     static constexpr int pool_off = cold_off + cold_bytes;
     static constexpr int pool_bytes = (int)sizeof(ContactCold<T>) * pool_n;
-    static constexpr int a_end = pool_off + pool_bytes;
+    // Newton step and the iterate at the start of the line search, once per supernode (step kernel, when there is room:
+    // frees ~100 registers during the residual evaluations of the line search)
+    static constexpr int ls_slot = (int)((sizeof(Step<T, MAXC>) + sizeof(SolSnap<T, MAXC>)) / 8 + (((sizeof(Step<T, MAXC>) + sizeof(SolSnap<T, MAXC>)) / 8) % 2 == 0 ? 1 : 0)) * 8;
+    static constexpr bool ls_in_lds = DJ_LS_IN_LDS && share && !GRAD && NW == 1 && MAXC == 1;                 // (must match LaneProgram::kLsInLds)
+    static constexpr int ls_off = pool_off + pool_bytes;
+    static constexpr int a_end = ls_off + (ls_in_lds ? ls_slot * NSN : 0);
     static constexpr int rhs_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * NSN : 0;
     static constexpr int mail_need = QUAD ? 2 * NSN * 20 * 8 : 0;
     static constexpr int mail_off = (QUAD && GRAD) ? rhs_bytes : a_end;
@@ -2158,6 +2204,7 @@ constexpr int FAC_PER_LANE = 72;
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
         prog.gb_lds = (void*)(((QuadRhs<TIO>*)lds) + lane / 4);                                                           \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
+        if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
