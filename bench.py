@@ -132,8 +132,16 @@ def main():
                     "traffic_source": t["source"] if t else None,
                     "kernel": kernel, "avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes}
         Bl = B // NCH                                                 # environments per launch
+        util = measured_valu_utilization()
+
+        def with_valu(r):
+            if r is not None and r["kernel"] in util:
+                r["valu_active_frac"] = util[r["kernel"]]["valu_active_frac"]      # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the committed PMC pass
+                r["valu_source"] = util[r["kernel"]]["source"]
+            return r
         r_step = roof("dojo_step_kernel", step_ms, bytes_fwd * Bl)
         r_ift = roof("dojo_grad_kernel", ift_ms, bytes_grad * Bl) if grad else None
+        r_step, r_ift = with_valu(r_step), with_valu(r_ift)
         dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
         dominant["note"] = ("VALU-issue-bound fp64 lane program (DESIGN.md §8; tools/ubench): the KKT systems never leave registers/LDS, "
                             "so the algorithmic HBM bytes are tiny and frac against HBM is reported only because the contract asks for it")
@@ -170,6 +178,22 @@ def measured_traffic():
                 out[k] = {"bytes_per_launch": v["bytes_per_launch"], "envs_per_launch": v.get("envs_per_launch", 4096), "source": os.path.relpath(f, ROOT)}
         except Exception:
             pass
+    return out
+
+
+def measured_valu_utilization():
+    """What actually bounds the kernels: the fraction of wave cycles with a VALU instruction in flight, from the committed
+    PMC pass (profiles/*_pmc_summary.txt: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, both in quad-cycles)."""
+    import glob
+    import re
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt"))):
+        txt = open(f).read()
+        for kn in ("dojo_step_kernel", "dojo_grad_kernel"):
+            a = re.search(kn + r"\s+SQ_ACTIVE_INST_VALU\s+per-dispatch mean ([0-9.e+-]+)", txt)
+            c = re.search(kn + r"\s+SQ_WAVE_CYCLES\s+per-dispatch mean ([0-9.e+-]+)", txt)
+            if a and c:
+                out[kn] = {"valu_active_frac": float(a.group(1)) / float(c.group(1)), "source": os.path.relpath(f, ROOT)}
     return out
 
 

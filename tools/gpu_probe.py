@@ -158,3 +158,20 @@ if what == "atlas":
             a, b = min(m[0] for m in ms), min(m[1] for m in ms)
             print("atlas B=%d grad=%d: step kernel %.2f ms, IFT kernel %.2f ms -> %.0f env-steps/s; iters %.1f (max %d) ok %.3f" % (B, grad, a, b, B / ((a + b) * 1e-3), it.mean(), it.max(), (st == 0).mean()), flush=True)
             gm.close()
+
+if what == "pcie":
+    # host-pointer entry points (dojo_step + dojo_gradients): the rate including the PCIe copies, for DESIGN.md
+    spec = d.baseline_config(3)
+    B = 4096
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (B // 64, 1)).astype(np.float32); U = np.tile(U0, (B // 64, 1)).astype(np.float32)
+    gm = api.BatchedMechanism(spec, B, dtype="f32")
+    for grad in (False, True):
+        ts = []
+        for k in range(4):
+            t0 = time.perf_counter()
+            zn, st, it = gm.step(Z, U, with_gradient=grad)
+            if grad: dz, du = gm.gradients()
+            ts.append(time.perf_counter() - t0)
+        print("host-pointer path ant B=%d grad=%d: %.1f ms per step (kernels %.2f ms) -> %.0f env-steps/s including PCIe + host transposes" % (B, grad, 1e3 * min(ts), gm.last_kernel_ms(), B / min(ts)), flush=True)
+    gm.close()
