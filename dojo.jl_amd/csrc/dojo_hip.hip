@@ -39,7 +39,8 @@ struct DojoSim {
     DojoSolverOptions opts;
     int B = 0, dtype = 0, device = 0, grad_mode = DOJO_GRAD_REFERENCE;
     size_t w = 8;                       // bytes per scalar
-    void* d_nodes = nullptr; void* d_contacts = nullptr;
+    void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
+    void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     // internal device buffers used by the host-pointer entry points
     void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
@@ -57,6 +58,120 @@ struct DojoSim {
 
 namespace {
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Minimal <-> maximal coordinate maps.  HBM-bound helper kernels around the step: every
+// DojoEnvironments step! goes through them (src/simulation/step.jl:42-60).
+//   minimal_to_maximal  src/mechanism/state.jl:9-22  + set_minimal_coordinates/velocities! src/joints/minimal.jl:160-232
+//   maximal_to_minimal  src/mechanism/state.jl:44-66 + translational/minimal.jl:56-113, rotational/minimal.jl:62-118
+// x per joint (mechanism.joints order): [Δx(nu_t); Δθ(nu_r); Δv(nu_t); Δω(nu_r)]
+// ---------------------------------------------------------------------------------------------------------------
+namespace coords {
+using namespace dj;
+__device__ __forceinline__ void vrotq(double* o, const double* v, const double* q) { double R[9]; qrot(R, q); m3vec(o, R, v); }
+__device__ __forceinline__ void vrotq_inv(double* o, const double* v, const double* q) { double R[9]; qrot(R, q); m3tvec(o, R, v); }
+__device__ __forceinline__ void aa2q(double* q, const double* r) {                       // axis_angle_to_quaternion, axis_angle.jl:1-11
+    double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th > 0) { double s = sin(0.5 * th) / th; q[0] = cos(0.5 * th); q[1] = s * r[0]; q[2] = s * r[1]; q[3] = s * r[2]; }
+    else { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+}
+__device__ __forceinline__ void next_q(double* o, const double* q, const double* w, double dt) {   // next_orientation, integrator.jl:15
+    double xi[4] = {sqrt(4.0 / (dt * dt) - (w[0] * w[0] + w[1] * w[1] + w[2] * w[2])), w[0], w[1], w[2]};
+    qmul(o, q, xi);
+    for (int i = 0; i < 4; ++i) o[i] *= 0.5 * dt;
+}
+__device__ __forceinline__ void mask_t(double* o, const double* A, int n, const double* c) {       // o = Aᵀ c  (A: n rows of 3)
+    o[0] = o[1] = o[2] = 0;
+    for (int i = 0; i < 3; ++i) if (i < n) for (int j = 0; j < 3; ++j) o[j] += A[3 * i + j] * c[i];
+}
+struct PoseVel { double x[3], v[3], q[4], w[3]; };
+template <class TIO> __device__ __forceinline__ PoseVel load_body(const TIO* z, int b) {
+    PoseVel p;
+    for (int i = 0; i < 3; ++i) { p.x[i] = (double)z[13 * b + i]; p.v[i] = (double)z[13 * b + 3 + i]; p.w[i] = (double)z[13 * b + 10 + i]; }
+    for (int i = 0; i < 4; ++i) p.q[i] = (double)z[13 * b + 6 + i];
+    return p;
+}
+__device__ __forceinline__ PoseVel origin_body() { PoseVel p; for (int i = 0; i < 3; ++i) p.x[i] = p.v[i] = p.w[i] = 0; p.q[0] = 1; p.q[1] = p.q[2] = p.q[3] = 0; return p; }
+
+// one thread per environment: bodies in root -> leaves order (the parent's maximal state must exist first)
+template <class TIO>
+__global__ void min2max_kernel(const NodeP<double>* nodes, const int* order, int Nb, int nu, double dt, int B, const TIO* x, TIO* z) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= B) return;
+    const TIO* xe = x + (size_t)env * 2 * nu; TIO* ze = z + (size_t)env * 13 * Nb;
+    for (int oi = 0; oi < Nb; ++oi) {
+        const int k = order[oi];
+        const NodeP<double>& P = nodes[k];
+        const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
+        const TIO* xm = xe + 2 * P.u_off;
+        double dx[3] = {0, 0, 0}, dth[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dw[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i) { if (i < nt) { dx[i] = (double)xm[i]; dv[i] = (double)xm[n + i]; } if (i < nr) { dth[i] = (double)xm[nt + i]; dw[i] = (double)xm[n + nt + i]; } }
+        const PoseVel a = P.parent >= 0 ? load_body(ze, P.parent) : origin_body();
+        // positions (minimal.jl:205-207)
+        double r[3], dq[4], t[4], qb[4], xb[3], e[3], u[3], s1[3], s2[3];
+        mask_t(r, P.Ar, nr, dth); aa2q(dq, r);
+        qmul(t, a.q, P.qoff); qmul(qb, t, dq);
+        mask_t(e, P.At, nt, dx); for (int i = 0; i < 3; ++i) u[i] = P.pa[i] + e[i];
+        vrotq(s1, u, a.q); vrotq(s2, P.pb, qb);
+        for (int i = 0; i < 3; ++i) xb[i] = a.x[i] + s1[i] - s2[i];
+        // previous configuration (minimal.jl:210-218)
+        double xa1[3], qa1[4], nw[3] = {-a.w[0], -a.w[1], -a.w[2]}, dx1[3], rw[3], dqw[4], dqwc[4], dq1[4], qb1[4], xb1[3];
+        for (int i = 0; i < 3; ++i) { xa1[i] = a.x[i] - a.v[i] * dt; dx1[i] = dx[i] - dv[i] * dt; }
+        next_q(qa1, a.q, nw, dt);
+        double dwt[3] = {dw[0] * dt, dw[1] * dt, dw[2] * dt};
+        mask_t(rw, P.Ar, nr, dwt); aa2q(dqw, rw); qconj(dqwc, dqw);           // unit quaternion: inverse = conjugate
+        qmul(dq1, dq, dqwc);
+        qmul(t, qa1, P.qoff); qmul(qb1, t, dq1);
+        mask_t(e, P.At, nt, dx1); for (int i = 0; i < 3; ++i) u[i] = P.pa[i] + e[i];
+        vrotq(s1, u, qa1); vrotq(s2, P.pb, qb1);
+        for (int i = 0; i < 3; ++i) xb1[i] = xa1[i] + s1[i] - s2[i];
+        double qd[4]; qcmul(qd, qb1, qb);                                     // angular_velocity, integrator.jl:25-27
+        for (int i = 0; i < 3; ++i) { ze[13 * k + i] = (TIO)xb[i]; ze[13 * k + 3 + i] = (TIO)((xb[i] - xb1[i]) / dt); ze[13 * k + 10 + i] = (TIO)(2.0 / dt * qd[1 + i]); }
+        for (int i = 0; i < 4; ++i) ze[13 * k + 6 + i] = (TIO)qb[i];
+    }
+}
+
+__device__ __forceinline__ void joint_disp(double* o, const PoseVel& a, const double* xa, const double* qa, const double* xb, const double* qb, const NodeP<double>& P) {
+    double s1[3], s2[3], d[3];
+    vrotq(s1, P.pb, qb); vrotq(s2, P.pa, qa);
+    for (int i = 0; i < 3; ++i) d[i] = xb[i] + s1[i] - (xa[i] + s2[i]);
+    vrotq_inv(o, d, qa);
+    (void)a;
+}
+// one thread per (environment, joint): the joints are independent
+template <class TIO>
+__global__ void max2min_kernel(const NodeP<double>* nodes, int Nb, int nu, double dt, int B, const TIO* z, TIO* x) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = tid / Nb, k = tid % Nb;
+    if (env >= B) return;
+    const NodeP<double>& P = nodes[k];
+    const TIO* ze = z + (size_t)env * 13 * Nb; TIO* xm = x + (size_t)env * 2 * nu + 2 * P.u_off;
+    const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
+    const PoseVel b = load_body(ze, k), a = P.parent >= 0 ? load_body(ze, P.parent) : origin_body();
+    double xa1[3], xb1[3], qa1[4], qb1[4], nwa[3] = {-a.w[0], -a.w[1], -a.w[2]}, nwb[3] = {-b.w[0], -b.w[1], -b.w[2]};
+    for (int i = 0; i < 3; ++i) { xa1[i] = a.x[i] - a.v[i] * dt; xb1[i] = b.x[i] - b.v[i] * dt; }
+    next_q(qa1, a.q, nwa, dt); next_q(qb1, b.q, nwb, dt);
+    double t[4], q[4], q1[4], d2[3], d1[3], rv[3], qd[4], rvd[3];
+    qcmul(t, a.q, b.q); qcmul(q, P.qoff, t);                                  // qoff⁻¹ ⊗ qa⁻¹ ⊗ qb (unit quaternions)
+    qcmul(t, qa1, qb1); qcmul(q1, P.qoff, t);
+    joint_disp(d2, a, a.x, a.q, b.x, b.q, P); joint_disp(d1, a, xa1, qa1, xb1, qb1, P);
+    rotvec(rv, q);
+    qcmul(qd, q1, q); rotvec(rvd, qd);
+    for (int i = 0; i < 3; ++i) {
+        if (i < nt) {
+            double c = 0, v = 0;
+            for (int j = 0; j < 3; ++j) { c += P.At[3 * i + j] * d2[j]; v += P.At[3 * i + j] * (d2[j] - d1[j]); }
+            xm[i] = (TIO)c; xm[n + i] = (TIO)(v / dt);
+        }
+        if (i < nr) {
+            double c = 0, v = 0;
+            for (int j = 0; j < 3; ++j) { c += P.Ar[3 * i + j] * rv[j]; v += P.Ar[3 * i + j] * rvd[j]; }
+            xm[nt + i] = (TIO)c; xm[n + nt + i] = (TIO)(v / dt);
+        }
+    }
+}
+} // namespace coords
+
 template <class T>
 int upload_tables(DojoSim* s) {   // tables are stored in the state precision (fp64)
     std::vector<dj::NodeP<T>> nodes; for (auto& n : s->M.nodes) nodes.push_back(dj::cast_node<T>(n));
@@ -66,6 +181,10 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     HIPCHK(hipMalloc(&s->d_contacts, contacts.size() * sizeof(dj::ContactP<T>)));
     HIPCHK(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * sizeof(dj::NodeP<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_contacts, contacts.data(), contacts.size() * sizeof(dj::ContactP<T>), hipMemcpyHostToDevice));
+    std::vector<int> order;
+    for (int lev = 0; lev <= s->M.maxlevel; ++lev) for (int b = 0; b < s->M.Nb; ++b) if (s->M.nodes[b].level == lev) order.push_back(b);
+    HIPCHK(hipMalloc((void**)&s->d_order, order.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(s->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
     return DOJO_OK;
 }
 
@@ -189,7 +308,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     hipSetDevice(s->device);
-    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac};
+    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn};
     for (void* p : ps) if (p) hipFree(p);
     for (auto g_ : s->gstreams) hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) hipEventDestroy(gev_);
@@ -372,6 +491,80 @@ int dojo_get_state(DojoHandle s, void* z) {
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(z, s->d_zn, (size_t)s->B * 13 * s->M.Nb * s->w, hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
+// ---- minimal <-> maximal coordinates ----
+int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stream) {
+    if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const int B = s->B, T_ = 64;
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((coords::min2max_kernel<float>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const float*)x, (float*)z);
+    else hipLaunchKernelGGL((coords::min2max_kernel<double>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const double*)x, (double*)z);
+    HIPCHK(hipGetLastError());
+    return DOJO_OK;
+}
+int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stream) {
+    if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((coords::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x);
+    else hipLaunchKernelGGL((coords::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x);
+    HIPCHK(hipGetLastError());
+    return DOJO_OK;
+}
+// step_minimal_coordinates!  src/simulation/step.jl:42-60: x -> z -> step! -> z' -> x'
+int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {
+    if (!s || !x || !x_next) { g_err = "dojo_step_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nz = 13 * s->M.Nb;
+    int rc;
+    if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
+    if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, nullptr, nullptr, stream))) return rc;
+    return dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream);
+}
+static int coords_host(DojoHandle s, const void* in, void* out, size_t n_in, size_t n_out, bool to_max) {
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w;
+    int rc;
+    if ((rc = ensure(&s->d_x, B * (2 * s->M.nu + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_z, B * 13 * s->M.Nb * w))) return rc;
+    void* din = to_max ? s->d_x : s->d_z; void* dout = to_max ? s->d_z : s->d_x;
+    HIPCHK(hipMemcpy(din, in, B * n_in * w, hipMemcpyHostToDevice));
+    rc = to_max ? dojo_minimal_to_maximal_dev(s, din, dout, nullptr) : dojo_maximal_to_minimal_dev(s, din, dout, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, B * n_out * w, hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+int dojo_minimal_to_maximal(DojoHandle s, const void* x, void* z) {
+    if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal: bad argument"; return DOJO_ERR_INVALID; }
+    return coords_host(s, x, z, 2 * s->M.nu, 13 * s->M.Nb, true);
+}
+int dojo_maximal_to_minimal(DojoHandle s, const void* z, void* x) {
+    if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal: bad argument"; return DOJO_ERR_INVALID; }
+    return coords_host(s, z, x, 13 * s->M.Nb, 2 * s->M.nu, false);
+}
+int dojo_step_minimal(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters) {
+    if (!s || !x || !x_next) { g_err = "dojo_step_minimal: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nm = 2 * s->M.nu, nu = s->M.nu;
+    int rc;
+    if ((rc = ensure(&s->d_x, B * (nm + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_xn, B * (nm + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_u, B * (nu + 1) * w))) return rc;
+    if ((rc = ensure((void**)&s->d_status, B * sizeof(int)))) return rc;
+    if ((rc = ensure((void**)&s->d_iters, B * sizeof(int)))) return rc;
+    HIPCHK(hipMemcpy(s->d_x, x, B * nm * w, hipMemcpyHostToDevice));
+    if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
+    rc = dojo_step_minimal_dev(s, s->d_x, (u && nu) ? s->d_u : nullptr, s->d_xn, s->d_status, s->d_iters, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x_next, s->d_xn, B * nm * w, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
     return DOJO_OK;
 }
 

@@ -36,7 +36,9 @@ def lib():
         L.dojo_last_error.restype = C.c_char_p
         for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_step",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
-                  "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals"):
+                  "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
+                  "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
+                  "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev"):
             getattr(L, f).restype = C.c_int
         L.dojo_destroy.restype = None
         _lib = L
@@ -45,7 +47,9 @@ def lib():
 
 EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
                     "dojo_set_gradient_mode", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
-                    "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals"]
+                    "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
+                    "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
+                    "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev"]
 
 
 def device_count():
@@ -137,6 +141,31 @@ class BatchedMechanism:
         st = np.empty((H, B), np.int32)
         _chk(lib().dojo_rollout(self.h, _p(z0), _p(U), H, _p(Z), _p(st)))
         return Z, st
+
+    # ---- minimal <-> maximal coordinates (src/mechanism/state.jl:9-66, src/simulation/step.jl:42-60) ----
+    def minimal_to_maximal(self, x):
+        B, s = self.batch, self.spec
+        x = self._arr(x, (B, 2 * s.nu))
+        z = np.empty((B, s.nz), self.np_dtype)
+        _chk(lib().dojo_minimal_to_maximal(self.h, _p(x), _p(z)))
+        return z
+
+    def maximal_to_minimal(self, z):
+        B, s = self.batch, self.spec
+        z = self._arr(z, (B, s.nz))
+        x = np.empty((B, 2 * s.nu), self.np_dtype)
+        _chk(lib().dojo_maximal_to_minimal(self.h, _p(z), _p(x)))
+        return x
+
+    def step_minimal(self, x, u=None):
+        """step_minimal_coordinates!: x [B, 2 nu] -> x_next, status, iters"""
+        B, s = self.batch, self.spec
+        x = self._arr(x, (B, 2 * s.nu))
+        u = self._arr(u, (B, s.nu)) if (u is not None and s.nu) else None
+        xn = np.empty((B, 2 * s.nu), self.np_dtype)
+        st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        _chk(lib().dojo_step_minimal(self.h, _p(x), _p(u), _p(xn), _p(st), _p(it)))
+        return xn, st, it
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

@@ -126,6 +126,28 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     return Z, status
 end
 
+"minimal_to_maximal(mechanism, x): batched, x is 2nu x B (per joint [Δx; Δθ; Δv; Δω]) -> z (13Nb x B)"
+function Dojo.minimal_to_maximal(bm::BatchedMechanism{T}, x::Matrix{T}) where T
+    z = Matrix{T}(undef, bm.nz, bm.batch)
+    check(@ccall LIB.dojo_minimal_to_maximal(bm.handle::Ptr{Cvoid}, x::Ptr{T}, z::Ptr{T})::Cint)
+    return z
+end
+
+"maximal_to_minimal(mechanism, z): batched"
+function Dojo.maximal_to_minimal(bm::BatchedMechanism{T}, z::Matrix{T}) where T
+    x = Matrix{T}(undef, 2 * bm.nu, bm.batch)
+    check(@ccall LIB.dojo_maximal_to_minimal(bm.handle::Ptr{Cvoid}, z::Ptr{T}, x::Ptr{T})::Cint)
+    return x
+end
+
+"step_minimal_coordinates!(mechanism, x, u; opts): batched, returns (x_next, status)"
+function Dojo.step_minimal_coordinates!(bm::BatchedMechanism{T}, x::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
+    set_options!(bm, opts)
+    xn = similar(x); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
+    check(@ccall LIB.dojo_step_minimal(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32})::Cint)
+    return xn, status
+end
+
 # ---- opt-in single-Mechanism drop-in ------------------------------------------------------------
 # DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) round-trip through the library (B = 1,
 # fp64) and write the solution back: body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual),

@@ -187,6 +187,19 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
 
+/* Minimal <-> maximal coordinates.  x [B, 2*nu]: per joint, in mechanism.joints order,
+ * [dx(nu_tra); dtheta(nu_rot); dv(nu_tra); domega(nu_rot)].
+ *   minimal_to_maximal(mechanism, x)   src/mechanism/state.jl:9-22  (+ src/joints/minimal.jl:160-232)
+ *   maximal_to_minimal(mechanism, z)   src/mechanism/state.jl:44-66
+ *   step_minimal_coordinates!(mechanism, x, u)   src/simulation/step.jl:42-60   (x -> z -> step! -> z' -> x') */
+int  dojo_minimal_to_maximal(DojoHandle h, const void* x, void* z);
+int  dojo_maximal_to_minimal(DojoHandle h, const void* z, void* x);
+int  dojo_step_minimal(DojoHandle h, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters);
+int  dojo_minimal_to_maximal_dev(DojoHandle h, const void* x, void* z, void* stream);
+int  dojo_maximal_to_minimal_dev(DojoHandle h, const void* z, void* x, void* stream);
+int  dojo_step_minimal_dev(DojoHandle h, const void* x, const void* u, void* x_next,
+                           int32_t* status, int32_t* iters, void* stream);
+
 /* timing helper for bench.py: average duration in ms of the last `n` launches of the
  * step kernel measured with hipEvents on the launch stream (roofline.achieved) */
 int  dojo_last_kernel_ms(DojoHandle h, double* ms);

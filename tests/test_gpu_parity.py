@@ -240,3 +240,40 @@ def test_gradient_is_the_derivative_of_the_gpu_step():
     err = np.max(np.stack(err), axis=0) / np.maximum(1.0, np.abs(jv[ok]).max(axis=1))
     assert np.quantile(err, 0.9) < 1e-4, np.quantile(err, 0.9)
     gm.close()
+
+
+@pytest.mark.parametrize("cfg,batch", [(1, 64), (2, 64), (3, 4096), (4, 256), (5, 64)])
+def test_minimal_maximal_maps(cfg, batch):
+    """minimal_to_maximal / maximal_to_minimal on the device (src/mechanism/state.jl:9-66) against the host restatement
+    (dojo_amd.coords, numpy) on the same inputs, plus the round trip at the full batch."""
+    from dojo_amd import coords
+    spec = d.baseline_config(cfg)
+    Z0, U0 = d.synthetic_inputs(spec, min(batch, 64))
+    reps = batch // len(Z0)
+    Z = np.tile(Z0, (reps, 1))
+    gm = api.BatchedMechanism(spec, batch, dtype="f64")
+    X = gm.maximal_to_minimal(Z)
+    for b in range(0, min(batch, 64), 7):
+        assert np.abs(X[b] - coords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
+    Zr = gm.minimal_to_maximal(X)
+    for b in range(0, min(batch, 64), 7):
+        assert np.abs(Zr[b] - coords.minimal_to_maximal(spec, X[b])).max() < 1e-10
+    # the synthetic states were built from minimal coordinates, so the round trip reproduces them (joints closed)
+    assert np.abs(Zr - Z).max() < 1e-8, np.abs(Zr - Z).max()
+    assert np.abs(gm.maximal_to_minimal(Zr) - X).max() < 1e-9
+    gm.close()
+
+
+def test_step_minimal_coordinates():
+    """step_minimal_coordinates! (src/simulation/step.jl:42-60) = maximal_to_minimal(step!(minimal_to_maximal(x), u))"""
+    spec = d.baseline_config(3)
+    B = 256
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    X = gm.maximal_to_minimal(Z)
+    xn, st, it = gm.step_minimal(X, U)
+    zn, st2, it2 = gm.step(gm.minimal_to_maximal(X), U)
+    assert np.array_equal(st, st2) and np.array_equal(it, it2)
+    assert np.array_equal(xn, gm.maximal_to_minimal(zn))
+    gm.close()
