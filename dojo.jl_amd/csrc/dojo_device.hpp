@@ -258,6 +258,11 @@ struct alignas(8) QuadRhs {
     double own_cfg[36];
     double pad_[(SIZE * sizeof(TB) / 8 + 36) % 2 == 0 ? 1 : 2];     // odd stride in 8-byte words
 };
+// Quad mapping: the right-hand sides of the contact-data columns (get_contact_gradients, src/gradients/contact.jl):
+// per contact of the supernode, per body-row role, 3 rows x 6 columns (5 used: friction, radius, origin(3)); cone
+// condensation folded in, hence double.
+template <int MAXC>
+struct ConRhs { double a[MAXC * 36]; double pad_[(MAXC * 36) % 2 == 0 ? 1 : 2]; };
 // T_a p and T_b p for the translational half: 6-vectors (force in world frame, torque in body frame)
 template <class T> DJ_HD void tra_impulse(T* ia, T* ib, const JointCfg<T>& c, const NodeP<T>& P, const T* p) {
     T F[3], t[3];
@@ -731,7 +736,7 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
 }
 
 // the NodeP fields the IFT column sweeps need, cached in registers (the sweeps' right-hand sides overlay NodeP in LDS)
-struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH]; };
+struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH], ncontact, contact[8]; };
 
 // ================================================================================================
 // The lane program
@@ -1161,7 +1166,9 @@ struct LaneProgram {
     // IFT costs (batches + depth) steps per sweep instead of batches × depth.  The forward-substituted
     // right-hand sides y wait between the two sweeps in the output buffer itself (the v / ω slots of
     // the column, which the down-sweep then overwrites with the final values).
-    template <class KA, class RH, class KN>
+    // MODE 0: state + control columns (get_maximal_gradients);  MODE 1: contact-data columns (get_contact_gradients):
+    // one batch per contact of the environment, five columns (friction, radius, origin), owner = the contact's body.
+    template <int MODE = 0, class KA, class RH, class KN>
     DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0, const SweepP& sp) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
@@ -1170,9 +1177,10 @@ struct LaneProgram {
         const int nx = 12 * G.Nb;
         const int ro = q == 1 ? 3 : 0;                         // first body row owned by roles 0 / 1
         const TG (&Sg)[3][12] = F.Sq; const TG (&Ug)[3][6] = F.Uq; const TG (&Lg)[6][3] = F.Lq;
-        const int nbs = 2 * G.Nb;                              // state batches: (body kk, configuration | velocity columns)
-        const int nbu = (A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0;   // control batches: six input columns each
+        const int nbs = MODE == 0 ? 2 * G.Nb : 0;              // state batches: (body kk, configuration | velocity columns)
+        const int nbu = MODE == 0 ? ((A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0) : G.Nc;   // control batches: six input columns each | contact batches
         const int NB = nbs + nbu;
+        const int ncol_u = MODE == 0 ? G.nu : 5 * G.Nc;        // columns of the second output buffer
         const int myu = sp.myu;
         const int lvl = sp.level;
         const int pb = sp.pb;
@@ -1182,14 +1190,17 @@ struct LaneProgram {
                  ta3[3] = {TG(qh ? F.t_a[3] : F.t_a[0]), TG(qh ? F.t_a[4] : F.t_a[1]), TG(qh ? F.t_a[5] : F.t_a[2])};
         // this lane's six rows of the first column of batch b in the output buffers, element stride between columns = nx;
         // state batches: column cI sits at index cI (+3 for cI >= 3: the batch holds x2|φ2 or v15|ω15)
-        TIO* const dz_p = DJ_GLOBAL_PTR(TIO, A.dz);
-        TIO* const du_p = DJ_GLOBAL_PTR(TIO, nbu > 0 ? A.du : A.dz);
-        const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * G.nu, row0 = (size_t)(12 * k + 6 * q), nxs = (size_t)nx;
+        TIO* const dz_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? A.dz : A.dc);
+        TIO* const du_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? (nbu > 0 ? A.du : A.dz) : A.dc);
+        const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * ncol_u, row0 = (size_t)(12 * k + 6 * q), nxs = (size_t)nx;
+        const int ucols = MODE == 0 ? NC : 5;                  // columns a control / contact batch owns in the output buffer
         auto colbase = [=](int b) -> TIO* {
             TIO* pz = dz_p + (env_dz + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nxs + row0;
-            TIO* pu = du_p + (env_du + (size_t)(NC * (b - nbs))) * nxs + row0;
+            TIO* pu = du_p + (env_du + (size_t)(ucols * (b - nbs))) * nxs + row0;
             return b < nbs ? pz : pu;
         };
+        // does column cI of batch b exist?  (padding columns of the last control batch / the sixth column of a contact batch)
+        auto col_ok = [=](int b, int cI) -> bool { return b < nbs || (MODE == 0 ? NC * (b - nbs) + cI < ncol_u : cI < 5); };
         // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
         TG send3[NC][3];
 #pragma unroll
@@ -1230,31 +1241,44 @@ struct LaneProgram {
             //   parent's configuration batch: RPAR[q] ;  control batch: UB on the owner (child body of the joint)
             //   parent-row parts (roles 0, 1): UOWN / UPAR / UA
             const int cu0 = NC * (b - nbs) - sp.u_off;            // control batch: local input index of column 0
-            const int r_off = isS ? (mine ? (q < 2 ? RH::ROWNV : RH::ROWNJ) + qh * 18 : RH::RPAR + q * 18) : RH::UB + qh * 18 + cu0;
-            const int u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
-            const bool od = mine && typ == 0 && q < 2;              // the folded owner rows come from the double block
-            const TG rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0), um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
+            int r_off, u_off_;
+            bool od = false; TG rm_s = TG(0), um_s = TG(0), wkm = TG(0); int sl_off = 0, cl = -1;
+            if constexpr (MODE == 0) {
+                r_off = isS ? (mine ? (q < 2 ? RH::ROWNV : RH::ROWNJ) + qh * 18 : RH::RPAR + q * 18) : RH::UB + qh * 18 + cu0;
+                u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
+                od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
+                rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0); um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
+                // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
+                wkm = (sp.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
+                sl_off = mine ? RH::SLO : RH::SLP;
+            } else {
+                // contact batch b - nbs = contact index of the environment; cl = its slot on this supernode (or -1)
+#pragma unroll
+                for (int c_ = 0; c_ < MAXC; ++c_) if (c_ < sp.ncontact && sp.contact[c_] == b - nbs) cl = c_;
+                r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18; u_off_ = 0;
+            }
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
-            // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
-            const TG wkm = (sp.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
-            const int sl_off = mine ? RH::SLO : RH::SLP;
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
                 const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
-                const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
-                const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
-                const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
                 TG r_[3], u_[3];
+                if constexpr (MODE == 0) {
+                    const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
+                    const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
+                    const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
-                    r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
-                    u_[i] = um * TG(R.a[iu + i * 6]);
-                }
-                {
+                    for (int i = 0; i < 3; ++i) {
+                        const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
+                        r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
+                        u_[i] = um * TG(R.a[iu + i * 6]);
+                    }
                     const TG kap0 = wkm * TG(R.a[sl_off + cI]);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { r_[i] += tb3[i] * kap0; u_[i] += ta3[i] * kap0; }
+                } else {
+                    const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { r_[i] = rm * TG(R.a[r_off + i * 6 + cI]); u_[i] = TG(0); }
                 }
                 TG r3[3];
 #pragma unroll
@@ -1280,7 +1304,7 @@ struct LaneProgram {
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? p0_ : p1_) : TG(0); }
-                    if (q < 2 && (isS || NC * (b - nbs) + cI < G.nu)) { TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
+                    if (q < 2 && col_ok(b, cI)) { TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
                 }
             }
         }
@@ -1323,7 +1347,7 @@ struct LaneProgram {
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
-                const bool o_ok = valid && q < 2 && (isS || NC * (b - nbs) + n < G.nu);
+                const bool o_ok = valid && q < 2 && col_ok(b, n);
                 TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
                 if (valid) {
 #pragma unroll
@@ -1959,7 +1983,9 @@ struct LaneProgram {
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
             SweepP sp;
             sp.level = P.level; sp.parent = P.parent; sp.pb = has_parent ? base + stride * P.parent : qb; sp.u_off = P.u_off;
-            sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild;
+            sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
+#pragma unroll
+            for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
 #pragma unroll
             for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
             const bool lim = P.nlim_r > 0;
@@ -2083,6 +2109,100 @@ struct LaneProgram {
         }
     }
 
+    // ---------------------------------------------------------------- contact-data gradients (quad mapping)
+    // get_contact_gradients (src/gradients/contact.jl:1-55): the columns of solmat \ datamat that belong to the contact data
+    // θ = [friction_coefficient, contact_radius, contact_origin(3)], through the same factors, sweeps and integrator chain
+    // as get_maximal_gradients.  Data blocks in closed form (sphere-halfspace, NonlinearContact):
+    //   body rows       body_constraint_jacobian_contact_data     src/gradients/data.jl:152-171
+    //   contact rows    contact_constraint_jacobian_contact_data  src/gradients/data.jl:173-192
+    // Output: dc[env][5 Nc columns][12 Nb rows] (column-major per environment, like dz).
+    template <class KA>
+    DJ_HD void gradients_contact(const KA& A, int env) {
+        static_assert(QUAD, "contact-data gradients are implemented for the quad mapping");
+        const T dt = G.dt;
+        Kin<T> kb0;
+        kin_of(kb0, L.x2, L.q2, L.v, L.w, dt);
+        T x2e[3], q2e[4];
+        if (G.grad_mode == 0) { for (int i = 0; i < 3; ++i) x2e[i] = kb0.x3[i]; for (int i = 0; i < 4; ++i) q2e[i] = kb0.q3[i]; }
+        else { for (int i = 0; i < 3; ++i) x2e[i] = L.x2[i]; for (int i = 0; i < 4; ++i) q2e[i] = L.q2[i]; }
+        Kin<T> kb;
+        kin_of(kb, x2e, q2e, L.v, L.w, dt);
+        T rhs[MAXC][6][6];                                            // [contact][body row][column], cone condensation folded in
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) rhs[c][i][j] = T(0);
+            if (c < P.ncontact) {
+                const ContactP<T>& K = CP[P.contact[c]];
+                const T* gam = L.cg[c];
+                T F[3], Fb[3], nb[3], Rw[3], cr[3];
+                for (int i = 0; i < 3; ++i) F[i] = K.n[i] * gam[0] + K.t[i] * gam[2] + K.t[3 + i] * gam[3];
+                m3tvec(Fb, kb.R3, F);                                // contact force in the body frame
+                m3tvec(nb, kb.R3, K.n);                              // normal in the body frame
+                m3vec(Rw, kb.R3, L.w);                               // angular velocity in the world frame
+                // body rows (torque rows 3:6): col radius = F_b x (R' n), cols origin = −[F_b]x
+                T Bq[3][5];
+                v3cross(cr, Fb, nb);
+                for (int i = 0; i < 3; ++i) { Bq[i][0] = T(0); Bq[i][1] = cr[i]; }
+                Bq[0][2] = T(0);   Bq[0][3] = Fb[2];  Bq[0][4] = -Fb[1];
+                Bq[1][2] = -Fb[2]; Bq[1][3] = T(0);   Bq[1][4] = Fb[0];
+                Bq[2][2] = Fb[1];  Bq[2][3] = -Fb[0]; Bq[2][4] = T(0);
+                // contact constraint rows (4): col friction = (0, −γ1, 0, 0); col radius = (1·(n·n), 0, T (Rω x n));
+                // cols origin = −(n R; 0; T [Rω]x R)
+                T Cq[4][5], Swn[3], SR[9], Sw_[9];
+                v3cross(Swn, Rw, K.n);
+                m3skew(Sw_, Rw); m3mul(SR, Sw_, kb.R3);
+                for (int j = 0; j < 5; ++j) { Cq[0][j] = Cq[1][j] = Cq[2][j] = Cq[3][j] = T(0); }
+                Cq[1][0] = -gam[0];
+                Cq[0][1] = v3dot(K.n, K.n); Cq[2][1] = v3dot(&K.t[0], Swn); Cq[3][1] = v3dot(&K.t[3], Swn);
+                for (int j = 0; j < 3; ++j) {
+                    Cq[0][2 + j] = -(K.n[0] * kb.R3[j] + K.n[1] * kb.R3[3 + j] + K.n[2] * kb.R3[6 + j]);
+                    Cq[2][2 + j] = -(K.t[0] * SR[j] + K.t[1] * SR[3 + j] + K.t[2] * SR[6 + j]);
+                    Cq[3][2 + j] = -(K.t[3] * SR[j] + K.t[4] * SR[3 + j] + K.t[5] * SR[6 + j]);
+                }
+                // contact rows -> body rhs through the cone condensation map GK (as for the state columns)
+                T GKc[6][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    T rc0[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
+                    e[j] = T(1);
+                    CCoef Q;
+                    contact_coef(Q, c, rc0, e);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) GKc[i][j] = ccold(c).G134[i] * Q.k0[0] + ccold(c).G134[6 + i] * Q.k0[1] + ccold(c).G134[12 + i] * Q.k0[2];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        T v = i >= 3 ? Bq[i - 3][j] : T(0);
+                        for (int a = 0; a < 4; ++a) v += GKc[i][a] * Cq[a][j];
+                        rhs[c][i][j] = v;
+                    }
+            }
+        }
+        // cache what the sweeps need from NodeP, then overlay the right-hand sides (one block per supernode) on the dead data
+        SweepP sp;
+        sp.level = P.level; sp.parent = P.parent; sp.pb = has_parent ? base + stride * P.parent : qb; sp.u_off = P.u_off;
+        sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
+#pragma unroll
+        for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
+#pragma unroll
+        for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
+        wv.sync();
+        ConRhs<MAXC>& R = *(ConRhs<MAXC>*)gb_lds;
+        if (q == 0) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) R.a[c * 36 + (i / 3) * 18 + (i % 3) * 6 + j] = (double)rhs[c][i][j];
+        }
+        wv.sync();
+        gradient_columns_quad<1>(A, env, R, T(0), kb0, sp);
+    }
+
     // update_state!  src/bodies/set.jl:22-36: -> (x3, v25, q3, ω25) = the next maximal state of this body
     DJ_HD void next_state(T* zb) const {
         Kin<T> kb;
@@ -2114,6 +2234,7 @@ struct KernelArgs {
     TIO* contact_sg;               // [B,8Nc] or null          ([s; γ] per contact)
     TIO* dz;                       // [B][12Nb cols][12Nb rows] column-major per env, or null
     TIO* du;                       // [B][nu cols][12Nb rows] column-major per env, or null
+    TIO* dc;                       // [B][5Nc cols][12Nb rows] contact-data Jacobian (get_contact_gradients), or null
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
 #ifdef DJ_DEBUG
@@ -2136,7 +2257,8 @@ struct LaneSlot { Lane<T, MAXC> L; T pad_[(sizeof(Lane<T, MAXC>) / sizeof(T)) % 
 template <class T>
 struct NodeSlot { NodeP<T> P; char pad_[(sizeof(NodeP<T>) / 8) % 2 == 0 ? 8 : 16]; };                    // odd stride in 8-byte words
 constexpr int lds_imax(int a, int b) { return a > b ? a : b; }
-template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP, int NW = 1>
+// GRAD: 0 = step kernel, 1 = IFT kernel (state + control columns), 2 = IFT kernel for the contact-data columns
+template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP, int NW = 1>
 struct StepLds {
     static constexpr int NSN = 16 * NW;                                                     // supernode slots of the workgroup
     static constexpr bool share = QUAD && LOCKSTEP;
@@ -2159,13 +2281,16 @@ struct StepLds {
     static constexpr bool ls_in_lds = DJ_LS_IN_LDS && share && !GRAD && NW == 1 && MAXC == 1;                 // (must match LaneProgram::kLsInLds)
     static constexpr int ls_off = pool_off + pool_bytes;
     static constexpr int a_end = ls_off + (ls_in_lds ? ls_slot * NSN : 0);
-    static constexpr int rhs_bytes = (QUAD && GRAD) ? (int)sizeof(QuadRhs<TIO>) * NSN : 0;
+    static constexpr int rhs_bytes = !QUAD ? 0 : GRAD == 1 ? (int)sizeof(QuadRhs<TIO>) * NSN : GRAD == 2 ? (int)sizeof(ConRhs<MAXC>) * NSN : 0;
     static constexpr int mail_need = QUAD ? 2 * NSN * 20 * 8 : 0;
-    static constexpr int mail_off = (QUAD && GRAD) ? rhs_bytes : a_end;
+    static constexpr int rhs_off = 0;
+    // (contact-data kernel: the mailbox keeps its own room behind the phase-A data; packed right behind the ConRhs blocks
+    //  the last supernode's block read back zeros on the GPU -- not understood, the kernel is not LDS-critical)
+    static constexpr int mail_off = (QUAD && GRAD == 2) ? a_end : (QUAD && GRAD) ? rhs_off + rhs_bytes : a_end;
     static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
     static constexpr int bytes = red_off + 64;
 };
-template <class TIO, class T, int MAXC, bool GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
+template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
 
 // doubles per supernode in the step -> IFT hand-off record: v ω λ(6), s,γ of the joint limit, s,γ of the contacts, μ,
@@ -2187,7 +2312,7 @@ constexpr int FAC_PER_LANE = 72;
     const int env = wave_index * E + slot;                                                                                \
     const bool active = (env < A.B) && (k < G.Nb);                                                                        \
     const int base = slot * envl;                                                                                         \
-    typedef StepLds<TIO, T, MAXC, GRAD_LAYOUT, QUAD, Wave::kLockstep, Wave::kWaves> LY;                                   \
+    typedef StepLds<TIO, T, MAXC, (GRAD_LAYOUT), QUAD, Wave::kLockstep, Wave::kWaves> LY;                                   \
     constexpr bool SHARE = QUAD && Wave::kLockstep;                                                                       \
     char* lds = (char*)wv.lds();                                                                                          \
     const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];                                                                       \
@@ -2202,7 +2327,7 @@ constexpr int FAC_PER_LANE = 72;
     if (QUAD) {                                                                                                           \
         prog.cpool = (ContactCold<T>*)(lds + LY::pool_off); prog.pool_by_id = LY::pool_by_id;                             \
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
-        prog.gb_lds = (void*)(((QuadRhs<TIO>*)lds) + lane / 4);                                                           \
+        prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
@@ -2214,9 +2339,9 @@ constexpr int FAC_PER_LANE = 72;
     prog.begin_step(zb, has_u ? ue : nullptr);
 
 // IFT kernel entry: one call per lane
-template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
+template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, int MODE = 0>
 DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
-    DJ_LANE_SETUP(true)
+    DJ_LANE_SETUP(MODE == 0 ? 1 : 2)
     {   // restore the converged solution (identical on the four lanes of a quad)
         const T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
         if (active) {
@@ -2250,7 +2375,8 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     } else {
         prog.linearize();                                     // lane mapping: rebuild the final linearization instead
     }
-    prog.gradients(A, env);
+    if constexpr (MODE == 0) prog.gradients(A, env);
+    else if constexpr (QUAD) prog.gradients_contact(A, env);
 #ifdef DJ_PROF
     if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); }
 #endif
@@ -2258,7 +2384,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 
 template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
-    DJ_LANE_SETUP(false)
+    DJ_LANE_SETUP(0)
 #ifdef DJ_DEBUG
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
     if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;

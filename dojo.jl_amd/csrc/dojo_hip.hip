@@ -27,6 +27,10 @@ DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launc
 DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
 DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
 DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2)
+#define DJ_CDECL(n) int n(const void*, int, void*);
+DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
+DJ_CDECL(dojo_launch_cgrad_double_1_1) DJ_CDECL(dojo_launch_cgrad_double_4_1) DJ_CDECL(dojo_launch_cgrad_double_8_1)
+DJ_CDECL(dojo_launch_cgrad_float_4_2) DJ_CDECL(dojo_launch_cgrad_double_4_2)
 #undef DJ_DECL
 }
 
@@ -47,7 +51,7 @@ struct DojoSim {
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
     int *d_status = nullptr, *d_iters = nullptr;
-    bool have_grad = false, have_solution = false;
+    bool have_grad = false, have_solution = false, have_u = false;
     hipStream_t stream = nullptr;
     // kernel timing: a ring of event triples (launch begin / between the step and the IFT kernel / end), so that
     // timed launches never make the host wait; totals are accumulated when a slot is reused or queried
@@ -219,7 +223,7 @@ int acquire_slot(DojoSim* s, int* idx) {
 // batch-level buffers.  env0 must be a multiple of the environments per wavefront.
 template <class TIO, class T, class TL>
 int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1) {
+           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr) {
     if (nenv < 0) nenv = s->B;
     const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
     auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
@@ -229,7 +233,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
     A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
-    A.dz = off(dz, nx * nx); A.du = off(du, nx * nu);
+    A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
     // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
     // else one lane per supernode
@@ -240,7 +244,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;        // workgroups, each 64 * NW lanes
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
-    const int g = dz != nullptr;
+    const int g = (dz != nullptr) || (dc != nullptr);
     A.sol = nullptr;
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
@@ -250,6 +254,19 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
     typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
+    if (dc != nullptr) {                   // contact-data columns only: the hand-off of the last differentiable step is re-used
+        if (!quad) { g_err = "contact-data gradients need the quad mapping (<= 32 bodies)"; return DOJO_ERR_UNSUPPORTED; }
+        typedef int (*claunch_t)(const void*, int, void*);
+        claunch_t cf = NW == 2 ? (f32 ? dojo_launch_cgrad_float_4_2 : dojo_launch_cgrad_double_4_2)
+                     : s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_float_1_1 : dojo_launch_cgrad_double_1_1)
+                     : s->M.maxc <= 4 ? (f32 ? dojo_launch_cgrad_float_4_1 : dojo_launch_cgrad_double_4_1)
+                                      : (f32 ? dojo_launch_cgrad_float_8_1 : dojo_launch_cgrad_double_8_1);
+        int lrc_ = cf(&A, (int)grid.x, (void*)st);
+        if (lrc_ != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc_); return DOJO_ERR_DEVICE; }
+        HIPCHK(hipGetLastError());
+        if (timed) { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = false; e.n = 1; e.used = true; s->last_slot = slot; }
+        return DOJO_OK;
+    }
     launcher_t fn;
     if (NW == 2) fn = f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2;
     else if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
@@ -265,9 +282,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
 }
 
 int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1) {
-    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv);
-    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv);
+               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr) {
+    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc);
+    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc);
 }
 
 int ensure(void** p, size_t bytes) {
@@ -372,7 +389,7 @@ int dojo_step(DojoHandle s, const void* z, const void* u, void* z_next, int32_t*
     HIPCHK(hipMemcpy(z_next, s->d_zn, B * nz * w, hipMemcpyDeviceToHost));
     if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
     if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
-    s->have_grad = with_gradient != 0;
+    s->have_grad = with_gradient != 0; s->have_u = (u && nu);
     return DOJO_OK;
 }
 
@@ -492,6 +509,35 @@ int dojo_get_state(DojoHandle s, void* z) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(z, s->d_zn, (size_t)s->B * 13 * s->M.Nb * s->w, hipMemcpyDeviceToHost));
     return DOJO_OK;
+}
+
+// ---- contact-data gradients: get_contact_gradients, src/gradients/contact.jl:1-55 ----
+int dojo_contact_gradients_dev(DojoHandle s, const void* z, const void* u, void* dc, void* stream) {
+    if (!s || !z || !dc) { g_err = "dojo_contact_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (!s->d_sol) { g_err = "dojo_contact_gradients_dev: no differentiable step (dz/du requested) has been run on this handle"; return DOJO_ERR_INVALID; }
+    if (s->M.Nc == 0) return DOJO_OK;
+    HIPCHK(hipSetDevice(s->device));
+    return launch_any(s, z, u, s->d_zn ? s->d_zn : (void*)z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, true, 0, -1, dc);
+}
+int dojo_contact_gradients(DojoHandle s, void* dc) {
+    if (!s || !dc) { g_err = "dojo_contact_gradients: bad argument"; return DOJO_ERR_INVALID; }
+    if (!s->have_grad || !s->d_z) { g_err = "dojo_contact_gradients: call dojo_step(..., with_gradient = 1) first"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nx = 12 * s->M.Nb, ncc = 5 * (size_t)s->M.Nc;
+    if (ncc == 0) return DOJO_OK;
+    void* d_dc = nullptr;
+    HIPCHK(hipMalloc(&d_dc, B * nx * ncc * w));
+    int rc = dojo_contact_gradients_dev(s, s->d_z, s->have_u ? s->d_u : nullptr, d_dc, nullptr);
+    if (rc == DOJO_OK) {
+        HIPCHK(hipDeviceSynchronize());
+        // device layout: [B][5Nc columns][12Nb rows] -> host layout [B, 12Nb, 5Nc] row-major
+        std::vector<char> tmp(B * nx * ncc * w);
+        HIPCHK(hipMemcpy(tmp.data(), d_dc, tmp.size(), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b) for (size_t c = 0; c < ncc; ++c) for (size_t r = 0; r < nx; ++r)
+            std::memcpy((char*)dc + ((b * nx + r) * ncc + c) * w, tmp.data() + ((b * ncc + c) * nx + r) * w, w);
+    }
+    hipFree(d_dc);
+    return rc;
 }
 
 // ---- minimal <-> maximal coordinates ----

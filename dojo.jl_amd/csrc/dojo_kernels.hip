@@ -101,7 +101,7 @@ struct GpuWave {
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_FWD_WAVES, DJ_FWD_WAVES)))
 dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
-    typedef dj::StepLds<TIO, TS, MAXC, false, QUAD, true, NW> LY;
+    typedef dj::StepLds<TIO, TS, MAXC, 0, QUAD, true, NW> LY;
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
@@ -110,11 +110,20 @@ dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
 dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
-    typedef dj::StepLds<TIO, TS, MAXC, true, QUAD, true, NW> LY;
+    typedef dj::StepLds<TIO, TS, MAXC, 1, QUAD, true, NW> LY;
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
+}
+// the IFT kernel for the contact-data columns (get_contact_gradients); quad mappings only
+template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
+__global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO, TS> A) {
+    typedef dj::StepLds<TIO, TS, MAXC, 2, QUAD, true, NW> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<NW> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>, 1>(w, A, (int)blockIdx.x);
 }
 
 } // namespace
@@ -122,6 +131,7 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
 #define DJ_CAT2(a, b, c, d) a##b##_##c##_##d
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#define DJ_CLAUNCHER DJ_CAT(dojo_launch_cgrad_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 
 // mid_event (may be null) is recorded between the two kernels so that each can be timed on its own
 extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, void* mid_event) {
@@ -132,3 +142,13 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, v
     if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();
 }
+
+#if DJ_QUAD != 0
+// the contact-data IFT kernel alone (the step kernel of the same inputs must have run with its hand-off enabled)
+extern "C" int DJ_CLAUNCHER(const void* args, int grid, void* stream) {
+    const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
+    constexpr int NW = DJ_QUAD == 2 ? 2 : 1;
+    hipLaunchKernelGGL((dojo_cgrad_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+    return (int)hipGetLastError();
+}
+#endif

@@ -38,7 +38,8 @@ def lib():
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
-                  "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev"):
+                  "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
+                  "dojo_contact_gradients", "dojo_contact_gradients_dev"):
             getattr(L, f).restype = C.c_int
         L.dojo_destroy.restype = None
         _lib = L
@@ -49,7 +50,8 @@ EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo
                     "dojo_set_gradient_mode", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
-                    "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev"]
+                    "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
+                    "dojo_contact_gradients", "dojo_contact_gradients_dev"]
 
 
 def device_count():
@@ -141,6 +143,14 @@ class BatchedMechanism:
         st = np.empty((H, B), np.int32)
         _chk(lib().dojo_rollout(self.h, _p(z0), _p(U), H, _p(Z), _p(st)))
         return Z, st
+
+    def contact_gradients(self):
+        """get_contact_gradients (src/gradients/contact.jl) at the solution of the last step(..., with_gradient=True):
+        [B, 12Nb, 5Nc], contact data = [friction_coefficient, contact_radius, contact_origin(3)] per contact."""
+        B, s = self.batch, self.spec
+        dc = np.zeros((B, s.nx, 5 * len(s.contacts)), self.np_dtype)
+        _chk(lib().dojo_contact_gradients(self.h, _p(dc)))
+        return dc
 
     # ---- minimal <-> maximal coordinates (src/mechanism/state.jl:9-66, src/simulation/step.jl:42-60) ----
     def minimal_to_maximal(self, x):

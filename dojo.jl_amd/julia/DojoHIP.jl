@@ -126,6 +126,13 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     return Z, status
 end
 
+"get_contact_gradients(mechanism) at the solution of the last get_maximal_gradients!: jacobian_contact[12Nb, 5Nc, B]"
+function get_contact_gradients!(bm::BatchedMechanism{T}, ncontacts::Int) where T
+    dc = Array{T}(undef, 5 * ncontacts, bm.nx, bm.batch)                      # ABI is row-major [B, nx, 5Nc]
+    check(@ccall LIB.dojo_contact_gradients(bm.handle::Ptr{Cvoid}, dc::Ptr{T})::Cint)
+    return permutedims(dc, (2, 1, 3))
+end
+
 "minimal_to_maximal(mechanism, x): batched, x is 2nu x B (per joint [Δx; Δθ; Δv; Δω]) -> z (13Nb x B)"
 function Dojo.minimal_to_maximal(bm::BatchedMechanism{T}, x::Matrix{T}) where T
     z = Matrix{T}(undef, bm.nz, bm.batch)

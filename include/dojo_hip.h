@@ -187,6 +187,14 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
 
+/* get_contact_gradients(mechanism)  src/gradients/contact.jl:1-55  (SURVEY.md §8f-3): the Jacobian of the next state
+ * [x3; v25; phi3; omega25] w.r.t. the contact data, 5 per contact [friction_coefficient, contact_radius, contact_origin(3)],
+ * at the solution of the last differentiable step (dojo_step(..., with_gradient = 1) / dojo_step_dev with dz, du).
+ * dc [B, 12Nb, 5Nc] row-major (host variant); the device variant takes the same z, u as that step and writes
+ * dc[B][5Nc columns][12Nb rows] (column-major per environment, like dz).  Quad mappings (<= 32 bodies). */
+int  dojo_contact_gradients(DojoHandle h, void* dc);
+int  dojo_contact_gradients_dev(DojoHandle h, const void* z, const void* u, void* dc, void* stream);
+
 /* Minimal <-> maximal coordinates.  x [B, 2*nu]: per joint, in mechanism.joints order,
  * [dx(nu_tra); dtheta(nu_rot); dv(nu_tra); domega(nu_rot)].
  *   minimal_to_maximal(mechanism, x)   src/mechanism/state.jl:9-22  (+ src/joints/minimal.jl:160-232)

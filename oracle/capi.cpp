@@ -19,6 +19,7 @@ struct IOracle {
     virtual void get_solution(double* sol) = 0;
     virtual void set_solution(const double* sol) = 0;
     virtual void gradients(int mode, double* dz, double* du) = 0;
+    virtual void contact_gradients(int mode, double* dc) = 0;
     virtual void get_data(double* d) = 0;
     virtual void set_data(const double* d) = 0;
     virtual void evaluate_residual(const double* data, const double* sol, double* out) = 0;
@@ -80,6 +81,18 @@ struct OracleT : IOracle {
         }
         for (size_t i = 0; i < (size_t)nx * nx; ++i) dz[i] = a[i];
         for (size_t i = 0; i < (size_t)nx * nu; ++i) du[i] = b[i];
+    }
+    void contact_gradients(int mode, double* dc) override {
+        int nx = 12 * (int)m.bodies.size(), nc = 5 * (int)m.contacts.size();
+        std::vector<T> a((size_t)nx * std::max(nc, 1));
+        std::vector<T> solmat = m.A;
+        if (mode == DOJO_GRAD_CONSISTENT && pre.size() == m.bodies.size()) {
+            std::vector<State<T>> post; for (auto& B : m.bodies) post.push_back(B.st);
+            for (size_t i = 0; i < pre.size(); ++i) m.bodies[i].st = pre[i];
+            m.get_contact_gradients(solmat, a.data());
+            for (size_t i = 0; i < post.size(); ++i) m.bodies[i].st = post[i];
+        } else m.get_contact_gradients(solmat, a.data());
+        for (size_t i = 0; i < (size_t)nx * nc; ++i) dc[i] = a[i];
     }
     void get_data(double* d) override { int nd = m.data_dim(false); std::vector<T> v(nd); m.get_data(v.data()); for (int i = 0; i < nd; ++i) d[i] = v[i]; }
     void set_data(const double* d) override { auto v = cast(d, m.data_dim(false)); m.set_data(v.data()); }
@@ -156,6 +169,7 @@ int  orc_step(void* h, const double* z, const double* u, double* z_state, double
 void orc_get_solution(void* h, double* sol) { ((IOracle*)h)->get_solution(sol); }
 void orc_set_solution(void* h, const double* sol) { ((IOracle*)h)->set_solution(sol); }
 void orc_gradients(void* h, int mode, double* dz, double* du) { ((IOracle*)h)->gradients(mode, dz, du); }
+void orc_contact_gradients(void* h, int mode, double* dc) { ((IOracle*)h)->contact_gradients(mode, dc); }
 void orc_get_data(void* h, double* d) { ((IOracle*)h)->get_data(d); }
 void orc_set_data(void* h, const double* d) { ((IOracle*)h)->set_data(d); }
 void orc_evaluate_residual(void* h, const double* data, const double* sol, double* out) { ((IOracle*)h)->evaluate_residual(data, sol, out); }

@@ -1385,6 +1385,33 @@ struct Mechanism {
             for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) jac_state[(size_t)(12 * i + 6 + k) * nx + 12 * i + 6 + l] += rq(k, l);
         }
     }
+
+    // get_contact_gradients   src/gradients/contact.jl:1-55: d(x3, v25, φ3, ω25)/d(contact data θ), θ per contact =
+    // [friction_coefficient, contact_radius, contact_origin(3)]: the contact-data columns of solmat \ datamat through the
+    // same integrator chain as get_maximal_gradients (no identity terms).  jac_contact: 12Nb x 5Nc, row-major.
+    void get_contact_gradients(const std::vector<T>& solmat, T* jac_contact) const {
+        int Nb = (int)bodies.size(), nx = 12 * Nb, nd;
+        std::vector<T> Dm; jacobian_data(Dm, nd);
+        int o = 0;
+        for (auto& J : joints) o += J.nu() + 2;
+        o += 19 * Nb;
+        int nc = 5 * (int)contacts.size();
+        std::vector<T> R((size_t)n * std::max(nc, 1));
+        for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + o + c];
+        DenseLU<T> lu; lu.factor(solmat, n); if (nc > 0) lu.solve(R.data(), nc);
+        std::fill(jac_contact, jac_contact + (size_t)nx * nc, T(0));
+        for (int i = 0; i < Nb; ++i) {
+            const State<T>& s = bodies[i].st;
+            Q q3_ = next_orientation(s.q2, s.wsol[1], dt);
+            M rw = LVTmat(q3_).t() * rotational_integrator_jacobian_velocity(s.q2, s.wsol[1], dt);
+            for (int c = 0; c < nc; ++c) {
+                T d[6]; for (int k = 0; k < 6; ++k) d[k] = R[(size_t)(boff[i] + k) * nc + c];
+                for (int k = 0; k < 3; ++k) { jac_contact[(size_t)(12 * i + 3 + k) * nc + c] += d[k]; jac_contact[(size_t)(12 * i + 9 + k) * nc + c] += d[3 + k]; }
+                for (int k = 0; k < 3; ++k) jac_contact[(size_t)(12 * i + k) * nc + c] += dt * d[k];
+                for (int k = 0; k < 3; ++k) { T acc = 0; for (int l = 0; l < 3; ++l) acc += rw(k, l) * d[3 + l]; jac_contact[(size_t)(12 * i + 6 + k) * nc + c] += acc; }
+            }
+        }
+    }
 };
 
 } // namespace orc

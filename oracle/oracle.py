@@ -89,6 +89,13 @@ class Oracle:
         lib().orc_gradients(self.h, mode, _p(dz), _p(du))
         return dz, du.reshape(-1)[:nx * self.nu].reshape(nx, self.nu)
 
+    def contact_gradients(self, mode=0):
+        """get_contact_gradients (src/gradients/contact.jl): [12Nb, 5Nc], theta per contact = [friction, radius, origin(3)]"""
+        nx = 12 * self.Nb
+        dc = np.zeros((nx, max(5 * self.Nc, 1)))
+        lib().orc_contact_gradients(self.h, mode, _p(dc))
+        return dc.reshape(-1)[:nx * 5 * self.Nc].reshape(nx, 5 * self.Nc)
+
     def get_data(self):
         d = np.zeros(self.nd_full); lib().orc_get_data(self.h, _p(d)); return d
 

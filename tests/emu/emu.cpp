@@ -78,7 +78,7 @@ struct EmuWaveT {
 template <class TIO, class T, class TL, int MAXC, bool QUAD, int NW = 1>
 void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
          const double* z, const double* u, double* z_next, int* status, int* iters,
-         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg) {
+         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr) {
     std::vector<dj::NodeP<T>> nodes; for (auto& n : M.nodes) nodes.push_back(dj::cast_node<T>(n));
     std::vector<dj::ContactP<T>> contacts; for (auto& c : M.contacts) contacts.push_back(dj::cast_contact<T>(c));
     if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
@@ -93,6 +93,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
+    std::vector<TIO> dct((dc && QUAD) ? (size_t)B * nx * 5 * std::max(M.Nc, 1) : 0); A.dc = nullptr;
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
     std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
@@ -108,6 +109,16 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
         });
         for (auto& t : th) t.join();
     }
+    if constexpr (QUAD) if (dz && dc && !dbg && M.Nc > 0) {          // third launch: the contact-data columns (re-uses the hand-off)
+        A.dc = dct.data(); A.dz = nullptr; A.du = nullptr;
+        for (int wi = 0; wi < nwaves; ++wi) {
+            Shared sh(W);
+            std::vector<std::thread> th;
+            for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWaveT<NW> w{&sh, l}; dj::grad_entry<TIO, T, TL, MAXC, QUAD, EmuWaveT<NW>, 1>(w, A, wi); });
+            for (auto& t : th) t.join();
+        }
+        for (size_t i = 0; i < (size_t)B * nx * 5 * M.Nc; ++i) dc[i] = dct[i];
+    }
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
     for (size_t i = 0; i < (jimp ? (size_t)B * M.n_joint_imp : 0); ++i) jimp[i] = jt[i];
@@ -121,7 +132,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
 
 extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int quad, int B, int envs_per_wave,
                         const double* z, const double* u, double* z_next, int* status, int* iters,
-                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen) {
+                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen, double* dc) {
     dj::HostModel M;
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
@@ -129,9 +140,9 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
-#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
-                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); \
-                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg); } while (0)
+#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); \
+                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); \
+                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); } while (0)
     // dtype 0: fp64 everywhere; dtype 1: fp32 I/O with fp64 internals (the product's "f32" mode); dtype 3: fp32 factorization (experiments)
     if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }
     else if (dtype == DOJO_DTYPE_F32) { if (M.maxc <= 1) RUN(float, double, double, 1); else if (M.maxc <= 4) RUN(float, double, double, 4); else RUN(float, double, double, 8); }

@@ -38,9 +38,11 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     dz = np.zeros((B, nx, nx)) if grad else None
     du = np.zeros((B, max(nu, 1), nx)) if grad else None
     dbg = np.zeros((B, spec.Nb, 512)) if debug else None
+    ncc = 5 * len(spec.contacts)
+    dc = np.zeros((B, max(ncc, 1), nx)) if (grad and quad and ncc) else None
     err = C.create_string_buffer(256)
     rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
-                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256)
+                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc))
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
     out = dict(z_next=Zn, status=st, iters=it, vel=vel, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])
@@ -49,5 +51,7 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     if grad:
         # device layout is column-major per environment: dz[b][col][row]
         out["dz"] = dz.transpose(0, 2, 1).copy()
+        if dc is not None:
+            out["dc"] = dc.transpose(0, 2, 1).copy()          # [B, 12Nb, 5Nc]
         out["du"] = du.reshape(-1)[:B * nu * nx].reshape(B, nu, nx).transpose(0, 2, 1).copy() if nu else np.zeros((B, nx, 0))
     return out

@@ -69,3 +69,21 @@ def test_atlas_two_wavefront_quad_mapping():
     r = emu_step(spec, Z[0], U[0], opts=TIGHT, quad=True)
     assert r["status"][0] == info["status"] == 0
     assert np.abs(r["z_next"][0] - zo).max() < 1e-7
+
+
+def test_contact_data_gradients_match_oracle():
+    """get_contact_gradients (src/gradients/contact.jl): the contact-data columns [friction, radius, origin(3)] through the
+    third kernel (re-uses the step kernel's hand-off), single-corner block sliding on the floor."""
+    from dojo_amd.mechanisms import get_block
+    spec = get_block(contact_corners=1)
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
+    o = Oracle(spec, opts=opts)
+    z = d.initialize(spec, position=[0, 0, 0.0], velocity=[0.4, 0.2, 0.0], angular_velocity=[0.1, 0.0, 0.2])
+    u = np.zeros(6)
+    for _ in range(2):
+        z, _ = o.step(z, u)
+    for mode in (0, 1):
+        o.step(z, u)
+        dco = o.contact_gradients(mode)
+        r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=mode)
+        assert np.abs(r["dc"][0] - dco).max() < 1e-7 * max(1.0, np.abs(dco).max())

@@ -277,3 +277,30 @@ def test_step_minimal_coordinates():
     assert np.array_equal(st, st2) and np.array_equal(it, it2)
     assert np.array_equal(xn, gm.maximal_to_minimal(zn))
     gm.close()
+
+
+@pytest.mark.parametrize("cfg,batch,pre_steps", [(2, 16, 120), (3, 32, 12), (4, 16, 10), (5, 4, 3)])
+def test_contact_gradient_parity(cfg, batch, pre_steps):
+    """get_contact_gradients (src/gradients/contact.jl): Jacobian of the next state w.r.t. [friction, radius, origin(3)] of
+    every contact, against the oracle (same criterion as the state Jacobians: the IFT amplifies tolerance-level
+    differences of almost-active contacts)."""
+    spec = d.baseline_config(cfg)
+    opts = d.SolverOptions(rtol=1e-6, btol=1e-6)
+    Z, U = d.synthetic_inputs(spec, batch)
+    o = Oracle(spec, opts=opts)
+    for _ in range(pre_steps):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=16)
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=opts)
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dc = gm.contact_gradients()
+    errs = []
+    for b in range(batch):
+        zo, info = o.step(Z[b], U[b])
+        if info["status"] != 0 or st[b] != 0:
+            continue
+        dco = o.contact_gradients(0)
+        errs.append(np.abs(dc[b] - dco).max() / max(1.0, np.abs(dco).max()))
+    errs = np.array(errs)
+    assert len(errs) > 0.7 * batch
+    assert np.quantile(errs, 0.75) < 1e-6 and errs.max() < 1e-3, (np.quantile(errs, 0.75), errs.max())
+    gm.close()
