@@ -14,14 +14,20 @@
 
 namespace {
 
+// Sense-reversing barrier: spin briefly, then yield.  (A mutex + condition variable costs two context switches per
+// thread per barrier; the lane program crosses tens of thousands of barriers per step.)
 struct Barrier {
-    std::mutex m; std::condition_variable cv; int n, count = 0, gen = 0;
+    std::atomic<int> count{0}; std::atomic<int> gen{0}; int n;
     explicit Barrier(int n_) : n(n_) {}
     void wait() {
-        std::unique_lock<std::mutex> lk(m);
-        int g = gen;
-        if (++count == n) { count = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == g) { if (++spins > 64) std::this_thread::yield(); }
+        }
     }
 };
 

@@ -11,7 +11,7 @@ TIGHT = d.SolverOptions(rtol=1e-8, btol=1e-8)
 
 
 # quad = True: four lanes per supernode (the mapping the product uses up to 32 bodies); False: one lane per supernode (> 32 bodies)
-@pytest.mark.parametrize("cfg,steps,quad", [(1, 3, True), (2, 3, True), (3, 1, True), (2, 2, False), (3, 1, False)])
+@pytest.mark.parametrize("cfg,steps,quad", [(1, 3, True), (2, 3, True), (3, 3, True), (4, 2, True), (5, 2, True), (2, 2, False), (3, 1, False)])
 def test_forward_matches_oracle(cfg, steps, quad):
     spec = d.baseline_config(cfg)
     o = Oracle(spec, opts=TIGHT)
@@ -43,7 +43,7 @@ def test_block_in_contact_two_envs_per_wave():
     assert r["iters"][0] != r["iters"][1]        # different Newton iteration counts inside one wave
 
 
-@pytest.mark.parametrize("cfg,pre,mode,quad", [(1, 2, 0, True), (2, 1, 1, True), (3, 0, 0, True), (2, 1, 0, False)])
+@pytest.mark.parametrize("cfg,pre,mode,quad", [(1, 2, 0, True), (2, 1, 1, True), (3, 0, 0, True), (3, 1, 1, True), (4, 4, 0, True), (5, 2, 0, True), (2, 1, 0, False)])
 def test_gradients_match_oracle(cfg, pre, mode, quad):
     spec = d.baseline_config(cfg)
     opts = d.SolverOptions(rtol=1e-7, btol=1e-7)
@@ -63,10 +63,11 @@ def test_atlas_two_wavefront_quad_mapping():
     """31 bodies: one environment over two wavefronts' worth of lanes (128 emulated threads) -- the NW = 2 LDS layout,
     the contact-row pool by contact index and the workgroup reductions of the device source."""
     spec = d.baseline_config(5)
-    o = Oracle(spec, opts=TIGHT)
+    opts = TIGHT
+    o = Oracle(spec, opts=opts)
     Z, U = d.synthetic_inputs(spec, 1)
     zo, info = o.step(Z[0], U[0])
-    r = emu_step(spec, Z[0], U[0], opts=TIGHT, quad=True)
+    r = emu_step(spec, Z[0], U[0], opts=opts, quad=True)
     assert r["status"][0] == info["status"] == 0
     assert np.abs(r["z_next"][0] - zo).max() < 1e-7
 
@@ -87,3 +88,19 @@ def test_contact_data_gradients_match_oracle():
         dco = o.contact_gradients(mode)
         r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=mode)
         assert np.abs(r["dc"][0] - dco).max() < 1e-7 * max(1.0, np.abs(dco).max())
+
+
+def test_contact_data_gradients_ant():
+    """the same for a tree (13 supernodes, four foot contacts on different bodies), Ant standing on the floor"""
+    spec = d.baseline_config(3)
+    opts = d.SolverOptions(rtol=1e-7, btol=1e-7)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z, u = Z[0], U[0]
+    for _ in range(12):
+        z, _ = o.step(z, u)
+    _, info = o.step(z, u)
+    dco = o.contact_gradients(0)
+    r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=0)
+    assert info["status"] == 0 and r["status"][0] == 0
+    assert np.abs(r["dc"][0] - dco).max() < 1e-6 * max(1.0, np.abs(dco).max())
