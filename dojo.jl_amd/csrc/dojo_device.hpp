@@ -1,13 +1,16 @@
 // dojo_device.hpp -- the per-lane algorithm of the batched contact-implicit step.
 //
-// Mapping: one wavefront lane = one (environment, supernode) pair.  A supernode
-// is a body together with its parent joint and the contacts attached to it.  S = next power
-// of two >= #bodies lanes cooperate on one environment, 64/S environments share a wavefront.
-// All per-lane data (state, KKT blocks, factors) lives in VGPRs; lanes of one environment talk
-// through wave shuffles only (ds_bpermute), along the edges of the kinematic tree:
+// Mapping.  A supernode is a body together with its parent joint and the contacts attached to it.
+//   quad mapping (<= 32 bodies): four lanes per supernode, lane role q owns rows 3q..3q+2 of its 12x12 system; one
+//     environment per wavefront (or per two wavefronts, 17..32 bodies; 16 tiny environments per wavefront).  Factors and
+//     working vectors live in VGPRs; what the four lanes would hold identically (constants, solver state, cold
+//     linearization data) lives once per supernode in LDS; quads exchange along tree edges through an LDS mailbox,
+//     inside a quad through DPP.
+//   lane mapping (33..64 bodies): one lane per supernode, exchanges through wave shuffles.
 //   children -> parent : impulses on the parent body, Schur complements (6x6 + 6)
 //   parent -> children : configuration / velocity of the parent body, Newton step of the parent
-// HBM is touched only for the algorithmic bytes: state in, state/solution/gradient out.
+// HBM is touched for the algorithmic bytes (state in, state/solution/gradient out) and one hand-off between the
+// step kernel and the IFT kernels.
 //
 // The same source runs under tests/emu (threads + barriers implement the Wave interface) so the
 // device algorithm is checked against the CPU oracle without a GPU.
@@ -756,7 +759,7 @@ struct LaneProgram {
     int plane;                   // wave lane of the parent (or own lane)
     Lane<T, MAXC>& L;            // per lane, or one copy per supernode in LDS (lock-step quad mapping)
     Factors<T, TL, MAXC, QUAD> F;
-    void* gb_lds = nullptr;      // LDS home of this supernode's GradBlocks (quad mapping)
+    void* gb_lds = nullptr;      // LDS home of this supernode's IFT right-hand sides (QuadRhs / ConRhs, quad mapping)
     // LDS mailbox (quad mapping): one slot of MAIL_N doubles per (supernode, body-row role).  Tree neighbours exchange
     // their 3-row pieces through it with wide ds_read/ds_write instead of one ds_bpermute per dword.
     enum { MAIL_N = 18, MAIL_STRIDE = 20 };
