@@ -1715,7 +1715,9 @@ struct LaneProgram {
         }
     }
 
-    DJ_HD int mehrotra(int& iters_out) {
+    // need_factors: the caller goes on to the IFT (which re-uses the final factors); a forward-only step may skip the
+    // set_entries! + factorization after the iteration that converged.
+    DJ_HD int mehrotra(int& iters_out, bool need_factors = true) {
         int status = DJ_STATUS_FAILED, excessive = 0;
         T mutarget = T(0), undercut = G.undercut;
         int no_progress = 0;
@@ -1828,6 +1830,12 @@ struct LaneProgram {
                     rvio = rc; bvio = bc;
                     if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
                     mu = mutarget;
+                }
+                // Forward-only launch, every environment of the workgroup converged with this step: the next iteration would only
+                // flag success (mehrotra.jl:23-27) -- do that here and skip the linearization nobody will use.
+                if (!need_factors && n < G.max_iter) {
+                    const bool conv = done || (rvio < G.rtol && bvio < G.btol);
+                    if (!wv.any(active && !conv)) { if (!done) { status = DJ_STATUS_SUCCESS; done = true; } break; }
                 }
                 // set_entries! + factorization (cone rows now carry the new μ)
                 if constexpr (QUAD && DJ_FUSE_LS) {
@@ -2396,7 +2404,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #ifdef DJ_PROF
     unsigned long long t_all = wv.clock();
 #endif
-    int status = prog.mehrotra(iters);
+    int status = prog.mehrotra(iters, /*need_factors=*/A.sol != nullptr);
 #ifdef DJ_PROF
     prog.pc[7] = wv.clock() - t_all;
 #endif
