@@ -8,6 +8,7 @@
 // fails with DOJO_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include "dojo_host.hpp"
+#include "dojo_coords.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,7 @@ struct DojoSim {
     size_t w = 8;                       // bytes per scalar
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
+    void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
     // internal device buffers used by the host-pointer entry points
     void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
@@ -64,38 +66,28 @@ namespace {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Minimal <-> maximal coordinate maps.  HBM-bound helper kernels around the step: every
-// DojoEnvironments step! goes through them (src/simulation/step.jl:42-60).
-//   minimal_to_maximal  src/mechanism/state.jl:9-22  + set_minimal_coordinates/velocities! src/joints/minimal.jl:160-232
-//   maximal_to_minimal  src/mechanism/state.jl:44-66 + translational/minimal.jl:56-113, rotational/minimal.jl:62-118
-// x per joint (mechanism.joints order): [Δx(nu_t); Δθ(nu_r); Δv(nu_t); Δω(nu_r)]
+// Minimal <-> maximal coordinates: HBM-bound helper kernels around the step; every DojoEnvironments
+// step! goes through them (src/simulation/step.jl:42-60).  The per-joint maps live in dojo_coords.hpp, written for any
+// scalar: double gives the values, forward-mode dual numbers give the chain-rule Jacobians of get_minimal_gradients!
+// (src/gradients/state.jl:9-56, 136-217).  x per joint (mechanism.joints order): [dx(nu_t); dtheta(nu_r); dv(nu_t); domega(nu_r)]
 // ---------------------------------------------------------------------------------------------------------------
-namespace coords {
+namespace ckern {
 using namespace dj;
-__device__ __forceinline__ void vrotq(double* o, const double* v, const double* q) { double R[9]; qrot(R, q); m3vec(o, R, v); }
-__device__ __forceinline__ void vrotq_inv(double* o, const double* v, const double* q) { double R[9]; qrot(R, q); m3tvec(o, R, v); }
-__device__ __forceinline__ void aa2q(double* q, const double* r) {                       // axis_angle_to_quaternion, axis_angle.jl:1-11
-    double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (th > 0) { double s = sin(0.5 * th) / th; q[0] = cos(0.5 * th); q[1] = s * r[0]; q[2] = s * r[1]; q[3] = s * r[2]; }
-    else { q[0] = 1; q[1] = q[2] = q[3] = 0; }
-}
-__device__ __forceinline__ void next_q(double* o, const double* q, const double* w, double dt) {   // next_orientation, integrator.jl:15
-    double xi[4] = {sqrt(4.0 / (dt * dt) - (w[0] * w[0] + w[1] * w[1] + w[2] * w[2])), w[0], w[1], w[2]};
-    qmul(o, q, xi);
-    for (int i = 0; i < 4; ++i) o[i] *= 0.5 * dt;
-}
-__device__ __forceinline__ void mask_t(double* o, const double* A, int n, const double* c) {       // o = Aᵀ c  (A: n rows of 3)
-    o[0] = o[1] = o[2] = 0;
-    for (int i = 0; i < 3; ++i) if (i < n) for (int j = 0; j < 3; ++j) o[j] += A[3 * i + j] * c[i];
-}
-struct PoseVel { double x[3], v[3], q[4], w[3]; };
-template <class TIO> __device__ __forceinline__ PoseVel load_body(const TIO* z, int b) {
-    PoseVel p;
-    for (int i = 0; i < 3; ++i) { p.x[i] = (double)z[13 * b + i]; p.v[i] = (double)z[13 * b + 3 + i]; p.w[i] = (double)z[13 * b + 10 + i]; }
-    for (int i = 0; i < 4; ++i) p.q[i] = (double)z[13 * b + 6 + i];
+using namespace dj::coords;
+template <class S, class TIO> __device__ __forceinline__ PoseVel<S> load_body(const TIO* z, int b) {
+    PoseVel<S> p;
+    for (int i = 0; i < 3; ++i) { p.x[i] = S((double)z[13 * b + i]); p.v[i] = S((double)z[13 * b + 3 + i]); p.w[i] = S((double)z[13 * b + 10 + i]); }
+    for (int i = 0; i < 4; ++i) p.q[i] = S((double)z[13 * b + 6 + i]);
     return p;
 }
-__device__ __forceinline__ PoseVel origin_body() { PoseVel p; for (int i = 0; i < 3; ++i) p.x[i] = p.v[i] = p.w[i] = 0; p.q[0] = 1; p.q[1] = p.q[2] = p.q[3] = 0; return p; }
+template <class S> __device__ __forceinline__ PoseVel<S> origin_body() {
+    PoseVel<S> p; for (int i = 0; i < 3; ++i) { p.x[i] = S(0.0); p.v[i] = S(0.0); p.w[i] = S(0.0); } p.q[0] = S(1.0); p.q[1] = S(0.0); p.q[2] = S(0.0); p.q[3] = S(0.0); return p;
+}
+// get_next_state (src/mechanism/get.jl:126-134) of a body whose velocities are its solution: x + dt v, q (x) xi(w)
+template <class S> __device__ __forceinline__ void advance_body(PoseVel<S>& p, double dt) {
+    for (int i = 0; i < 3; ++i) p.x[i] = p.x[i] + p.v[i] * dt;
+    S qn[4]; next_qS(qn, p.q, p.w, dt); for (int i = 0; i < 4; ++i) p.q[i] = qn[i];
+}
 
 // one thread per environment: bodies in root -> leaves order (the parent's maximal state must exist first)
 template <class TIO>
@@ -110,37 +102,12 @@ __global__ void min2max_kernel(const NodeP<double>* nodes, const int* order, int
         const TIO* xm = xe + 2 * P.u_off;
         double dx[3] = {0, 0, 0}, dth[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dw[3] = {0, 0, 0};
         for (int i = 0; i < 3; ++i) { if (i < nt) { dx[i] = (double)xm[i]; dv[i] = (double)xm[n + i]; } if (i < nr) { dth[i] = (double)xm[nt + i]; dw[i] = (double)xm[n + nt + i]; } }
-        const PoseVel a = P.parent >= 0 ? load_body(ze, P.parent) : origin_body();
-        // positions (minimal.jl:205-207)
-        double r[3], dq[4], t[4], qb[4], xb[3], e[3], u[3], s1[3], s2[3];
-        mask_t(r, P.Ar, nr, dth); aa2q(dq, r);
-        qmul(t, a.q, P.qoff); qmul(qb, t, dq);
-        mask_t(e, P.At, nt, dx); for (int i = 0; i < 3; ++i) u[i] = P.pa[i] + e[i];
-        vrotq(s1, u, a.q); vrotq(s2, P.pb, qb);
-        for (int i = 0; i < 3; ++i) xb[i] = a.x[i] + s1[i] - s2[i];
-        // previous configuration (minimal.jl:210-218)
-        double xa1[3], qa1[4], nw[3] = {-a.w[0], -a.w[1], -a.w[2]}, dx1[3], rw[3], dqw[4], dqwc[4], dq1[4], qb1[4], xb1[3];
-        for (int i = 0; i < 3; ++i) { xa1[i] = a.x[i] - a.v[i] * dt; dx1[i] = dx[i] - dv[i] * dt; }
-        next_q(qa1, a.q, nw, dt);
-        double dwt[3] = {dw[0] * dt, dw[1] * dt, dw[2] * dt};
-        mask_t(rw, P.Ar, nr, dwt); aa2q(dqw, rw); qconj(dqwc, dqw);           // unit quaternion: inverse = conjugate
-        qmul(dq1, dq, dqwc);
-        qmul(t, qa1, P.qoff); qmul(qb1, t, dq1);
-        mask_t(e, P.At, nt, dx1); for (int i = 0; i < 3; ++i) u[i] = P.pa[i] + e[i];
-        vrotq(s1, u, qa1); vrotq(s2, P.pb, qb1);
-        for (int i = 0; i < 3; ++i) xb1[i] = xa1[i] + s1[i] - s2[i];
-        double qd[4]; qcmul(qd, qb1, qb);                                     // angular_velocity, integrator.jl:25-27
-        for (int i = 0; i < 3; ++i) { ze[13 * k + i] = (TIO)xb[i]; ze[13 * k + 3 + i] = (TIO)((xb[i] - xb1[i]) / dt); ze[13 * k + 10 + i] = (TIO)(2.0 / dt * qd[1 + i]); }
-        for (int i = 0; i < 4; ++i) ze[13 * k + 6 + i] = (TIO)qb[i];
+        const PoseVel<double> a = P.parent >= 0 ? load_body<double>(ze, P.parent) : origin_body<double>();
+        PoseVel<double> b;
+        joint_min2max(b, P, dt, a, dx, dth, dv, dw);
+        for (int i = 0; i < 3; ++i) { ze[13 * k + i] = (TIO)b.x[i]; ze[13 * k + 3 + i] = (TIO)b.v[i]; ze[13 * k + 10 + i] = (TIO)b.w[i]; }
+        for (int i = 0; i < 4; ++i) ze[13 * k + 6 + i] = (TIO)b.q[i];
     }
-}
-
-__device__ __forceinline__ void joint_disp(double* o, const PoseVel& a, const double* xa, const double* qa, const double* xb, const double* qb, const NodeP<double>& P) {
-    double s1[3], s2[3], d[3];
-    vrotq(s1, P.pb, qb); vrotq(s2, P.pa, qa);
-    for (int i = 0; i < 3; ++i) d[i] = xb[i] + s1[i] - (xa[i] + s2[i]);
-    vrotq_inv(o, d, qa);
-    (void)a;
 }
 // one thread per (environment, joint): the joints are independent
 template <class TIO>
@@ -151,30 +118,121 @@ __global__ void max2min_kernel(const NodeP<double>* nodes, int Nb, int nu, doubl
     const NodeP<double>& P = nodes[k];
     const TIO* ze = z + (size_t)env * 13 * Nb; TIO* xm = x + (size_t)env * 2 * nu + 2 * P.u_off;
     const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
-    const PoseVel b = load_body(ze, k), a = P.parent >= 0 ? load_body(ze, P.parent) : origin_body();
-    double xa1[3], xb1[3], qa1[4], qb1[4], nwa[3] = {-a.w[0], -a.w[1], -a.w[2]}, nwb[3] = {-b.w[0], -b.w[1], -b.w[2]};
-    for (int i = 0; i < 3; ++i) { xa1[i] = a.x[i] - a.v[i] * dt; xb1[i] = b.x[i] - b.v[i] * dt; }
-    next_q(qa1, a.q, nwa, dt); next_q(qb1, b.q, nwb, dt);
-    double t[4], q[4], q1[4], d2[3], d1[3], rv[3], qd[4], rvd[3];
-    qcmul(t, a.q, b.q); qcmul(q, P.qoff, t);                                  // qoff⁻¹ ⊗ qa⁻¹ ⊗ qb (unit quaternions)
-    qcmul(t, qa1, qb1); qcmul(q1, P.qoff, t);
-    joint_disp(d2, a, a.x, a.q, b.x, b.q, P); joint_disp(d1, a, xa1, qa1, xb1, qb1, P);
-    rotvec(rv, q);
-    qcmul(qd, q1, q); rotvec(rvd, qd);
-    for (int i = 0; i < 3; ++i) {
-        if (i < nt) {
-            double c = 0, v = 0;
-            for (int j = 0; j < 3; ++j) { c += P.At[3 * i + j] * d2[j]; v += P.At[3 * i + j] * (d2[j] - d1[j]); }
-            xm[i] = (TIO)c; xm[n + i] = (TIO)(v / dt);
+    const PoseVel<double> b = load_body<double>(ze, k), a = P.parent >= 0 ? load_body<double>(ze, P.parent) : origin_body<double>();
+    double ct[3], cr[3], vt[3], vr[3];
+    joint_max2min(ct, cr, vt, vr, P, dt, a, b);
+    for (int i = 0; i < 3; ++i) { if (i < nt) { xm[i] = (TIO)ct[i]; xm[n + i] = (TIO)vt[i]; } if (i < nr) { xm[nt + i] = (TIO)cr[i]; xm[n + nt + i] = (TIO)vr[i]; } }
+}
+
+// ---- Jacobians by forward-mode differentiation of the same maps ----
+typedef Dual<24> D24;
+// a body state seeded with its 12 attitude-reduced directions [x, v, phi, omega] starting at direction d0
+template <class TIO> __device__ __forceinline__ PoseVel<D24> seed_body(const PoseVel<double>& p, int d0) {
+    PoseVel<D24> s;
+    for (int i = 0; i < 3; ++i) { s.x[i] = D24::seed(p.x[i], d0 + i); s.v[i] = D24::seed(p.v[i], d0 + 3 + i); s.w[i] = D24::seed(p.w[i], d0 + 9 + i); }
+    D24 e[4] = {D24(1.0), D24::seed(0.0, d0 + 6), D24::seed(0.0, d0 + 7), D24::seed(0.0, d0 + 8)}, q0[4] = {D24(p.q[0]), D24(p.q[1]), D24(p.q[2]), D24(p.q[3])};
+    qmulS(s.q, q0, e);                                                        // q (x) (1, phi)
+    return s;
+}
+// minimal_to_maximal_jacobian (src/gradients/state.jl:136-181): one thread per environment, root -> leaves;
+// Jm[env][12 Nb rows][2 nu columns] row-major.  z must already hold minimal_to_maximal(x).
+template <class TIO>
+__global__ void min2max_jac_kernel(const NodeP<double>* nodes, const int* order, int Nb, int nu, double dt, int B, const TIO* x, const TIO* z, double* Jm) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= B) return;
+    const int nm = 2 * nu;
+    const TIO* xe = x + (size_t)env * nm; const TIO* ze = z + (size_t)env * 13 * Nb;
+    double* J = Jm + (size_t)env * 12 * Nb * nm;
+    for (int oi = 0; oi < Nb; ++oi) {
+        const int k = order[oi];
+        const NodeP<double>& P = nodes[k];
+        const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
+        const TIO* xm = xe + 2 * P.u_off;
+        // directions 0..11: the parent's reduced state; 12..12+2n-1: the joint's own minimal coordinates in layout order
+        D24 dx[3], dth[3], dv[3], dw[3];
+        for (int i = 0; i < 3; ++i) {
+            dx[i] = i < nt ? D24::seed((double)xm[i], 12 + i) : D24(0.0);             dv[i] = i < nt ? D24::seed((double)xm[n + i], 12 + n + i) : D24(0.0);
+            dth[i] = i < nr ? D24::seed((double)xm[nt + i], 12 + nt + i) : D24(0.0);    dw[i] = i < nr ? D24::seed((double)xm[n + nt + i], 12 + n + nt + i) : D24(0.0);
         }
-        if (i < nr) {
-            double c = 0, v = 0;
-            for (int j = 0; j < 3; ++j) { c += P.Ar[3 * i + j] * rv[j]; v += P.Ar[3 * i + j] * rvd[j]; }
-            xm[nt + i] = (TIO)c; xm[n + nt + i] = (TIO)(v / dt);
+        const PoseVel<double> a0 = P.parent >= 0 ? load_body<double>(ze, P.parent) : origin_body<double>();
+        PoseVel<D24> a = seed_body<TIO>(a0, 0), b;
+        joint_min2max(b, P, dt, a, dx, dth, dv, dw);
+        // rows of the child: x, v, phi = V(q_b^-1 (x) dq_b), omega
+        double Pm[12][24];
+        for (int d = 0; d < 24; ++d) {
+            for (int i = 0; i < 3; ++i) { Pm[i][d] = b.x[i].d[d]; Pm[3 + i][d] = b.v[i].d[d]; Pm[9 + i][d] = b.w[i].d[d]; }
+            const double q0 = b.q[0].v, q1 = b.q[1].v, q2 = b.q[2].v, q3 = b.q[3].v, e0 = b.q[0].d[d], e1 = b.q[1].d[d], e2 = b.q[2].d[d], e3 = b.q[3].d[d];
+            Pm[6][d] = q0 * e1 - q1 * e0 - q2 * e3 + q3 * e2;                 // vector part of conj(q) (x) dq
+            Pm[7][d] = q0 * e2 + q1 * e3 - q2 * e0 - q3 * e1;
+            Pm[8][d] = q0 * e3 - q1 * e2 + q2 * e1 - q3 * e0;
+        }
+        for (int r = 0; r < 12; ++r) {
+            double* Jr = J + (size_t)(12 * k + r) * nm;
+            for (int c = 0; c < nm; ++c) {
+                double acc = 0.0;
+                if (P.parent >= 0) { const double* Jp = J + (size_t)(12 * P.parent) * nm + c; for (int m = 0; m < 12; ++m) acc += Pm[r][m] * Jp[(size_t)m * nm]; }
+                const int lc = c - 2 * P.u_off;
+                if (lc >= 0 && lc < 2 * n) acc += Pm[r][12 + lc];
+                Jr[c] = acc;
+            }
         }
     }
 }
-} // namespace coords
+// maximal_to_minimal_jacobian (src/gradients/state.jl:9-56) at z (advanced by one integrator step when `advance`):
+// one thread per (environment, joint); Jb[env][joint k][2n rows in layout order][24]: d/d(parent reduced state), d/d(child)
+template <class TIO>
+__global__ void max2min_jac_kernel(const NodeP<double>* nodes, int Nb, double dt, int B, const TIO* z, int advance, double* Jb) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = tid / Nb, k = tid % Nb;
+    if (env >= B) return;
+    const NodeP<double>& P = nodes[k];
+    const TIO* ze = z + (size_t)env * 13 * Nb;
+    const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
+    PoseVel<double> b0 = load_body<double>(ze, k), a0 = P.parent >= 0 ? load_body<double>(ze, P.parent) : origin_body<double>();
+    if (advance) { advance_body(b0, dt); if (P.parent >= 0) advance_body(a0, dt); }
+    PoseVel<D24> a = seed_body<TIO>(a0, 0), b = seed_body<TIO>(b0, 12);
+    D24 ct[3], cr[3], vt[3], vr[3];
+    joint_max2min(ct, cr, vt, vr, P, dt, a, b);
+    double* o = Jb + ((size_t)env * Nb + k) * 12 * 24;
+    for (int i = 0; i < 3; ++i) for (int d = 0; d < 24; ++d) {
+        if (i < nt) { o[(size_t)i * 24 + d] = ct[i].d[d]; o[(size_t)(n + i) * 24 + d] = vt[i].d[d]; }
+        if (i < nr) { o[(size_t)(nt + i) * 24 + d] = cr[i].d[d]; o[(size_t)(n + nt + i) * 24 + d] = vr[i].d[d]; }
+    }
+}
+// T = dz * Jm  (12Nb x 2nu per environment); dz is column-major per environment: dz(r, c) = dz[c * nx + r]
+template <class TIO>
+__global__ void chain_mid_kernel(int nx, int nm, int B, const TIO* dz, const double* Jm, double* T) {
+    const int env = blockIdx.x;
+    const TIO* D = dz + (size_t)env * nx * nx; const double* J = Jm + (size_t)env * nx * nm; double* Te = T + (size_t)env * nx * nm;
+    for (int e = threadIdx.x; e < nx * nm; e += blockDim.x) {
+        const int r = e % nx, j = e / nx;                                       // consecutive threads -> consecutive rows (coalesced dz reads)
+        double acc = 0.0;
+        for (int c = 0; c < nx; ++c) acc += (double)D[(size_t)c * nx + r] * J[(size_t)c * nm + j];
+        Te[(size_t)r * nm + j] = acc;
+    }
+}
+// jx = M2m * T, ju = M2m * du with the block-sparse M2m (each joint's rows touch its parent's and its child's 12 columns);
+// outputs row-major per environment: jx[env][2nu][2nu], ju[env][2nu][nu]; du(r, c) = du[c * nx + r]
+template <class TIO>
+__global__ void chain_out_kernel(const NodeP<double>* nodes, int Nb, int nu, int B, const double* Jb, const double* T, const TIO* du, TIO* jx, TIO* ju) {
+    const int env = blockIdx.x, nx = 12 * Nb, nm = 2 * nu;
+    const double* Te = T + (size_t)env * nx * nm; const TIO* Du = du ? du + (size_t)env * nx * nu : nullptr;
+    for (int e = threadIdx.x; e < nm * (nm + nu); e += blockDim.x) {
+        const int i = e / (nm + nu), j = e % (nm + nu);
+        // joint owning minimal row i
+        int k = 0, lr = 0;
+        for (int b = 0; b < Nb; ++b) { const int o = 2 * nodes[b].u_off, nn = 2 * (nodes[b].nu_t + nodes[b].nu_r); if (i >= o && i < o + nn) { k = b; lr = i - o; } }
+        const double* Jr = Jb + (((size_t)env * Nb + k) * 12 + lr) * 24;
+        const int par = nodes[k].parent;
+        double acc = 0.0;
+        for (int m = 0; m < 12; ++m) {
+            if (j < nm) { if (par >= 0) acc += Jr[m] * Te[(size_t)(12 * par + m) * nm + j]; acc += Jr[12 + m] * Te[(size_t)(12 * k + m) * nm + j]; }
+            else if (Du) { const int c = j - nm; if (par >= 0) acc += Jr[m] * (double)Du[(size_t)c * nx + 12 * par + m]; acc += Jr[12 + m] * (double)Du[(size_t)c * nx + 12 * k + m]; }
+        }
+        if (j < nm) jx[((size_t)env * nm + i) * nm + j] = (TIO)acc; else if (ju) ju[((size_t)env * nm + i) * nu + (j - nm)] = (TIO)acc;
+    }
+}
+} // namespace ckern
 
 template <class T>
 int upload_tables(DojoSim* s) {   // tables are stored in the state precision (fp64)
@@ -325,7 +383,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     hipSetDevice(s->device);
-    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn};
+    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) hipFree(p);
     for (auto g_ : s->gstreams) hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) hipEventDestroy(gev_);
@@ -545,8 +603,8 @@ int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stre
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const int B = s->B, T_ = 64;
-    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((coords::min2max_kernel<float>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const float*)x, (float*)z);
-    else hipLaunchKernelGGL((coords::min2max_kernel<double>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const double*)x, (double*)z);
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::min2max_kernel<float>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const float*)x, (float*)z);
+    else hipLaunchKernelGGL((ckern::min2max_kernel<double>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const double*)x, (double*)z);
     HIPCHK(hipGetLastError());
     return DOJO_OK;
 }
@@ -554,8 +612,8 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
-    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((coords::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x);
-    else hipLaunchKernelGGL((coords::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x);
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x);
+    else hipLaunchKernelGGL((ckern::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x);
     HIPCHK(hipGetLastError());
     return DOJO_OK;
 }
@@ -571,6 +629,75 @@ int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_ne
     if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, nullptr, nullptr, stream))) return rc;
     return dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream);
 }
+// get_minimal_gradients!(mechanism, y, u; opts)  src/gradients/state.jl:183-217: steps in minimal coordinates and chains
+//   max_to_min_jacobian(z+) * maximal Jacobians * min_to_max_jacobian(x).
+// DOJO_GRAD_REFERENCE reproduces the reference literally: after its update_state! the "current" state is already the new
+// one, so it evaluates min_to_max at maximal_to_minimal(z_new) and max_to_min at get_next_state = z_new advanced by one
+// more integrator step.  DOJO_GRAD_CONSISTENT: min_to_max at x, max_to_min at z_new.
+// jx [B][2nu][2nu], ju [B][2nu][nu] row-major per environment.
+int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters,
+                               void* jx, void* ju, void* stream) {
+    if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, w = s->w, Nb = s->M.Nb, nz = 13 * Nb, nx = 12 * Nb, nu = s->M.nu, nm = 2 * nu;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_dz, B * nx * nx * w))) return rc;
+    if ((rc = ensure(&s->d_du, B * nx * (nu + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_jm, B * nx * (nm + 1) * sizeof(double)))) return rc;
+    if ((rc = ensure(&s->d_jt, B * nx * (nm + 1) * sizeof(double)))) return rc;
+    if ((rc = ensure(&s->d_jb, B * Nb * 12 * 24 * sizeof(double)))) return rc;
+    if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
+    if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, s->d_dz, s->d_du, stream))) return rc;
+    if ((rc = dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream))) return rc;
+    const bool literal = s->grad_mode == DOJO_GRAD_REFERENCE;
+    const void* xj = literal ? (const void*)x_next : x;                // where the min -> max Jacobian is evaluated ...
+    const void* zj = literal ? (const void*)s->d_zn : (const void*)s->d_z;   // ... and the maximal state that belongs to it
+    const int T1 = 64, T2 = 256;
+    const dj::NodeP<double>* nodes = (const dj::NodeP<double>*)s->d_nodes;
+    if (s->dtype == DOJO_DTYPE_F32) {
+        hipLaunchKernelGGL((ckern::min2max_jac_kernel<float>), dim3((B + T1 - 1) / T1), dim3(T1), 0, st, nodes, s->d_order, (int)Nb, (int)nu, s->M.dt, (int)B, (const float*)xj, (const float*)zj, (double*)s->d_jm);
+        hipLaunchKernelGGL((ckern::max2min_jac_kernel<float>), dim3((unsigned)((B * Nb + T2 - 1) / T2)), dim3(T2), 0, st, nodes, (int)Nb, s->M.dt, (int)B, (const float*)s->d_zn, literal ? 1 : 0, (double*)s->d_jb);
+        hipLaunchKernelGGL((ckern::chain_mid_kernel<float>), dim3((unsigned)B), dim3(T2), 0, st, (int)nx, (int)nm, (int)B, (const float*)s->d_dz, (const double*)s->d_jm, (double*)s->d_jt);
+        hipLaunchKernelGGL((ckern::chain_out_kernel<float>), dim3((unsigned)B), dim3(T2), 0, st, nodes, (int)Nb, (int)nu, (int)B, (const double*)s->d_jb, (const double*)s->d_jt, (const float*)s->d_du, (float*)jx, (float*)ju);
+    } else {
+        hipLaunchKernelGGL((ckern::min2max_jac_kernel<double>), dim3((B + T1 - 1) / T1), dim3(T1), 0, st, nodes, s->d_order, (int)Nb, (int)nu, s->M.dt, (int)B, (const double*)xj, (const double*)zj, (double*)s->d_jm);
+        hipLaunchKernelGGL((ckern::max2min_jac_kernel<double>), dim3((unsigned)((B * Nb + T2 - 1) / T2)), dim3(T2), 0, st, nodes, (int)Nb, s->M.dt, (int)B, (const double*)s->d_zn, literal ? 1 : 0, (double*)s->d_jb);
+        hipLaunchKernelGGL((ckern::chain_mid_kernel<double>), dim3((unsigned)B), dim3(T2), 0, st, (int)nx, (int)nm, (int)B, (const double*)s->d_dz, (const double*)s->d_jm, (double*)s->d_jt);
+        hipLaunchKernelGGL((ckern::chain_out_kernel<double>), dim3((unsigned)B), dim3(T2), 0, st, nodes, (int)Nb, (int)nu, (int)B, (const double*)s->d_jb, (const double*)s->d_jt, (const double*)s->d_du, (double*)jx, (double*)ju);
+    }
+    HIPCHK(hipGetLastError());
+    return DOJO_OK;
+}
+int dojo_minimal_gradients(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* jx, void* ju) {
+    if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    size_t B = s->B, w = s->w, nu = s->M.nu, nm = 2 * nu;
+    int rc;
+    if ((rc = ensure(&s->d_x, B * (nm + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_xn, B * (nm + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_u, B * (nu + 1) * w))) return rc;
+    if ((rc = ensure((void**)&s->d_status, B * sizeof(int)))) return rc;
+    if ((rc = ensure((void**)&s->d_iters, B * sizeof(int)))) return rc;
+    void *d_jx = nullptr, *d_ju = nullptr;
+    HIPCHK(hipMalloc(&d_jx, B * nm * nm * w)); HIPCHK(hipMalloc(&d_ju, B * nm * (nu + 1) * w));
+    HIPCHK(hipMemcpy(s->d_x, x, B * nm * w, hipMemcpyHostToDevice));
+    if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
+    rc = dojo_minimal_gradients_dev(s, s->d_x, (u && nu) ? s->d_u : nullptr, s->d_xn, s->d_status, s->d_iters, d_jx, d_ju, nullptr);
+    if (rc == DOJO_OK) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(x_next, s->d_xn, B * nm * w, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(jx, d_jx, B * nm * nm * w, hipMemcpyDeviceToHost));
+        if (ju && nu) HIPCHK(hipMemcpy(ju, d_ju, B * nm * nu * w, hipMemcpyDeviceToHost));
+        if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
+        if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    hipFree(d_jx); hipFree(d_ju);
+    return rc;
+}
+
 static int coords_host(DojoHandle s, const void* in, void* out, size_t n_in, size_t n_out, bool to_max) {
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w;

@@ -39,7 +39,7 @@ def lib():
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                   "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
-                  "dojo_contact_gradients", "dojo_contact_gradients_dev"):
+                  "dojo_contact_gradients", "dojo_contact_gradients_dev", "dojo_minimal_gradients", "dojo_minimal_gradients_dev"):
             getattr(L, f).restype = C.c_int
         L.dojo_destroy.restype = None
         _lib = L
@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
-                    "dojo_contact_gradients", "dojo_contact_gradients_dev"]
+                    "dojo_contact_gradients", "dojo_contact_gradients_dev", "dojo_minimal_gradients", "dojo_minimal_gradients_dev"]
 
 
 def device_count():
@@ -176,6 +176,17 @@ class BatchedMechanism:
         st = np.empty(B, np.int32); it = np.empty(B, np.int32)
         _chk(lib().dojo_step_minimal(self.h, _p(x), _p(u), _p(xn), _p(st), _p(it)))
         return xn, st, it
+
+    def minimal_gradients(self, x, u=None):
+        """get_minimal_gradients!: one step in minimal coordinates -> (x_next, status, iters, jx [B,2nu,2nu], ju [B,2nu,nu])"""
+        B, s = self.batch, self.spec
+        nm = 2 * s.nu
+        x = self._arr(x, (B, nm))
+        u = self._arr(u, (B, s.nu)) if (u is not None and s.nu) else None
+        xn = np.empty((B, nm), self.np_dtype); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        jx = np.empty((B, nm, nm), self.np_dtype); ju = np.empty((B, nm, max(s.nu, 1)), self.np_dtype)
+        _chk(lib().dojo_minimal_gradients(self.h, _p(x), _p(u), _p(xn), _p(st), _p(it), _p(jx), _p(ju)))
+        return xn, st, it, jx, ju.reshape(-1)[:B * nm * s.nu].reshape(B, nm, s.nu)
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

@@ -155,6 +155,16 @@ function Dojo.step_minimal_coordinates!(bm::BatchedMechanism{T}, x::Matrix{T}, u
     return xn, status
 end
 
+"get_minimal_gradients!(mechanism, x, u; opts): batched -> (jacobian_state[2nu, 2nu, B], jacobian_control[2nu, nu, B]); also returns x_next"
+function Dojo.get_minimal_gradients!(bm::BatchedMechanism{T}, x::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
+    set_options!(bm, opts)
+    nm = 2 * bm.nu
+    xn = similar(x); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
+    jx = Array{T}(undef, nm, nm, bm.batch); ju = Array{T}(undef, bm.nu, nm, bm.batch)         # ABI is row-major [B, 2nu, 2nu] / [B, 2nu, nu]
+    check(@ccall LIB.dojo_minimal_gradients(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, jx::Ptr{T}, ju::Ptr{T})::Cint)
+    return permutedims(jx, (2, 1, 3)), permutedims(ju, (2, 1, 3)), xn, status
+end
+
 # ---- opt-in single-Mechanism drop-in ------------------------------------------------------------
 # DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) round-trip through the library (B = 1,
 # fp64) and write the solution back: body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual),

@@ -208,6 +208,15 @@ int  dojo_maximal_to_minimal_dev(DojoHandle h, const void* z, void* x, void* str
 int  dojo_step_minimal_dev(DojoHandle h, const void* x, const void* u, void* x_next,
                            int32_t* status, int32_t* iters, void* stream);
 
+/* get_minimal_gradients!(mechanism, y, u; opts)  src/gradients/state.jl:183-217: one step in minimal coordinates and the
+ * Jacobians of x_next w.r.t. x and u, = max_to_min_jacobian * (jacobian_state | jacobian_control) * min_to_max_jacobian
+ * (src/gradients/state.jl:9-56, 136-181).  jx [B, 2nu, 2nu], ju [B, 2nu, nu], row-major.  With DOJO_GRAD_REFERENCE the
+ * two coordinate Jacobians are evaluated where the reference evaluates them (post-update_state! states). */
+int  dojo_minimal_gradients(DojoHandle h, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters,
+                            void* jx, void* ju);
+int  dojo_minimal_gradients_dev(DojoHandle h, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters,
+                                void* jx, void* ju, void* stream);
+
 /* timing helper for bench.py: average duration in ms of the last `n` launches of the
  * step kernel measured with hipEvents on the launch stream (roofline.achieved) */
 int  dojo_last_kernel_ms(DojoHandle h, double* ms);

@@ -304,3 +304,80 @@ def test_contact_gradient_parity(cfg, batch, pre_steps):
     assert len(errs) > 0.7 * batch
     assert np.quantile(errs, 0.75) < 1e-6 and errs.max() < 1e-3, (np.quantile(errs, 0.75), errs.max())
     gm.close()
+
+
+def _fd_coordinate_jacobians(spec, xp, zp, h=1e-6):
+    """Finite-difference restatement of minimal_to_maximal_jacobian(x) [12Nb x 2nu] and maximal_to_minimal_jacobian(z)
+    [2nu x 12Nb] (the reference tests its analytic ones the same way) with the attitude convention dq = q (x) (0, phi)."""
+    from dojo_amd import coords
+    from dojo_amd.quat import qmul, qconj
+    Nb, nm = spec.Nb, 2 * spec.nu
+
+    def reduce(zd, z0):                       # maximal difference quotient -> [x v phi w] per body
+        out = np.zeros(12 * Nb)
+        for b in range(Nb):
+            out[12 * b:12 * b + 6] = zd[13 * b:13 * b + 6]
+            out[12 * b + 6:12 * b + 9] = qmul(qconj(z0[13 * b + 6:13 * b + 10]), zd[13 * b + 6:13 * b + 10])[1:]
+            out[12 * b + 9:12 * b + 12] = zd[13 * b + 10:13 * b + 13]
+        return out
+    z0 = coords.minimal_to_maximal(spec, xp)
+    Jm = np.zeros((12 * Nb, nm))
+    for j in range(nm):
+        e = np.zeros(nm); e[j] = h
+        Jm[:, j] = reduce((coords.minimal_to_maximal(spec, xp + e) - coords.minimal_to_maximal(spec, xp - e)) / (2 * h), z0)
+    JM = np.zeros((nm, 12 * Nb))
+    for b in range(Nb):
+        for i in range(12):
+            zs = []
+            for sgn in (1.0, -1.0):
+                z = zp.copy()
+                if i < 6: z[13 * b + i] += sgn * h
+                elif i < 9:
+                    ph = np.zeros(3); ph[i - 6] = sgn * h
+                    z[13 * b + 6:13 * b + 10] = qmul(zp[13 * b + 6:13 * b + 10], np.concatenate([[np.sqrt(1 - h * h)], ph]))
+                else: z[13 * b + 10 + (i - 9)] += sgn * h
+                zs.append(coords.maximal_to_minimal(spec, z))
+            JM[:, 12 * b + i] = (zs[0] - zs[1]) / (2 * h)
+    return Jm, JM
+
+
+@pytest.mark.parametrize("cfg,pre_steps,mode", [(1, 3, 1), (1, 3, 0), (2, 2, 1), (3, 2, 1), (3, 2, 0), (4, 2, 1)])
+def test_minimal_gradients(cfg, pre_steps, mode):
+    """get_minimal_gradients! (src/gradients/state.jl:183-217) on the device: coordinate Jacobians by forward-mode
+    differentiation of the device maps, chained with the IFT Jacobians; against the oracle's maximal Jacobians chained with
+    finite-difference coordinate Jacobians of the host restatement.  mode 0 = literal reference evaluation points."""
+    from dojo_amd import coords
+    from dojo_amd.quat import next_orientation
+    spec = d.baseline_config(cfg)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    B = 4
+    Z, U = d.synthetic_inputs(spec, B)
+    o = Oracle(spec, opts=opts)
+    for _ in range(pre_steps):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    X = np.stack([coords.maximal_to_minimal(spec, Z[b]) for b in range(B)])
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    gm.set_gradient_mode(mode)
+    xn, st, it, jx, ju = gm.minimal_gradients(X, U)
+    dt = spec.timestep
+    for b in range(B):
+        z = coords.minimal_to_maximal(spec, X[b])
+        zn, info = o.step(z, U[b])
+        if info["status"] != 0 or st[b] != 0:
+            continue
+        dz, du = o.gradients(mode)
+        assert np.abs(xn[b] - coords.maximal_to_minimal(spec, zn)).max() < 1e-6
+        if mode == 1:
+            xp, zp = X[b], zn
+        else:                                   # literal: min->max at the new state, max->min at get_next_state of it
+            xp = coords.maximal_to_minimal(spec, zn); zp = zn.copy()
+            for k in range(spec.Nb):
+                zp[13 * k:13 * k + 3] = zn[13 * k:13 * k + 3] + dt * zn[13 * k + 3:13 * k + 6]
+                zp[13 * k + 6:13 * k + 10] = next_orientation(zn[13 * k + 6:13 * k + 10], zn[13 * k + 10:13 * k + 13], dt)
+        Jm, JM = _fd_coordinate_jacobians(spec, xp, zp)
+        jx_ref = JM @ dz @ Jm; ju_ref = JM @ du
+        sx = max(1.0, np.abs(jx_ref).max()); su = max(1.0, np.abs(ju_ref).max())
+        assert np.abs(jx[b] - jx_ref).max() < 2e-5 * sx, (b, np.abs(jx[b] - jx_ref).max(), sx)
+        if spec.nu:
+            assert np.abs(ju[b] - ju_ref).max() < 2e-5 * su, (b, np.abs(ju[b] - ju_ref).max(), su)
+    gm.close()
