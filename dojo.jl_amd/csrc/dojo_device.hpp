@@ -34,6 +34,9 @@
 #define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
                            // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
 #endif
+#ifndef DJ_LDS_REDUCE
+#define DJ_LDS_REDUCE 1     // quad mapping: environment reductions through LDS (one slot per supernode) instead of shuffle butterflies
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -764,7 +767,27 @@ struct LaneProgram {
     // their 3-row pieces through it with wide ds_read/ds_write instead of one ds_bpermute per dword.
     enum { MAIL_N = 18, MAIL_STRIDE = 20 };
     double* mail = nullptr;
+    double* qred = nullptr;            // [3][supernode slots]: reduction scratch (quad mapping)
     DJ_HD double* mail_slot(int supernode_lane0, int role) const { return mail + (size_t)((supernode_lane0 >> 2) * 2 + role) * MAIL_STRIDE; }
+    // Reduction over the supernodes of this lane's environment of NV values that the four lanes of a supernode hold
+    // identically (quad mapping): one LDS write per supernode, then every lane folds the S values of its environment --
+    // instead of log2(4S) butterfly steps of two ds_bpermute each.
+    template <int NV, class OP> DJ_HD void env_reduce_quad(T (&v)[NV], OP op) {
+        const int nsn = wv.width() >> 2;
+        wv.sync();
+        if (q == 0) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) qred[n * nsn + (wv.lane() >> 2)] = (double)v[n];
+        }
+        wv.sync();
+        const int s0 = base >> 2;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            T r = T(qred[n * nsn + s0]);
+            for (int i = 1; i < G.S; ++i) r = op(r, T(qred[n * nsn + s0 + i]));
+            v[n] = r;
+        }
+    }
     // the two body-row roles of every supernode post N values ...
     template <int N, class TV> DJ_HD void mail_post_roles(const TV* v) {
         wv.sync();
@@ -939,8 +962,8 @@ struct LaneProgram {
             }
             if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
         }
-        rvio = env_max(wv, r, envl);
-        bvio = env_max(wv, b, envl);
+        if constexpr (QUAD && DJ_LDS_REDUCE) { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
+        else { rvio = env_max(wv, r, envl); bvio = env_max(wv, b, envl); }
     }
 
     // ---------------------------------------------------------------- condensation of cone rows
@@ -1581,7 +1604,8 @@ struct LaneProgram {
                 a = tmin(a, ort_step(L.lg[i], D.dlg[i], tort));
             }
         }
-        return env_min(wv, a, envl);
+        if constexpr (QUAD && DJ_LDS_REDUCE) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
+        else return env_min(wv, a, envl);
     }
 
     // candidate_step!  src/solver/line_search.jl:141-163: candidate = base + f Δ (base = the current iterate,
@@ -1758,7 +1782,8 @@ struct LaneProgram {
                 }
                 if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
             }
-            p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl);
+            if constexpr (QUAD && DJ_LDS_REDUCE) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
+            else { p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl); }
             T munew = G.btol / undercut;
             if (p2 > T(0)) {
                 T nu = p0 / p2, nuaff = p1 / p2;
@@ -1799,7 +1824,9 @@ struct LaneProgram {
                     if constexpr (decltype(with_jac)::value) evaluate<true>(Kq); else { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
-                    int anybad = env_or(wv, (active && searching) ? bad : 0, envl);
+                    int anybad;
+                    if constexpr (QUAD && DJ_LDS_REDUCE) { T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)}; env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); anybad = vb[0] > T(0.5) ? 1 : 0; }
+                    else anybad = env_or(wv, (active && searching) ? bad : 0, envl);
                     if (searching) {
                         excessive |= anybad;
                         rc = r2; bc = b2;
@@ -2299,7 +2326,8 @@ struct StepLds {
     //  the last supernode's block read back zeros on the GPU -- not understood, the kernel is not LDS-critical)
     static constexpr int mail_off = (QUAD && GRAD == 2) ? a_end : (QUAD && GRAD) ? rhs_off + rhs_bytes : a_end;
     static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
-    static constexpr int bytes = red_off + 64;
+    static constexpr int qred_off = red_off + 64;                    // per-supernode values of the environment reductions (3 at a time)
+    static constexpr int bytes = qred_off + (QUAD ? 3 * NSN * 8 : 0);
 };
 template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
@@ -2340,6 +2368,7 @@ constexpr int FAC_PER_LANE = 72;
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
         prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
+        prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
