@@ -19,13 +19,20 @@
  *                         src/gradients/state.jl:69-126
  *   dojo_rollout       <- simulate!(mechanism, steps, storage, control!)  src/simulation/simulate.jl:16-36
  *                         with the control callback replaced by pre-sampled inputs U[k]
+ *   dojo_contact_gradients <- get_contact_gradients(mechanism) src/gradients/contact.jl:1-55
+ *   dojo_minimal_to_maximal / dojo_maximal_to_minimal / dojo_step_minimal / dojo_minimal_gradients
+ *                      <- minimal_to_maximal, maximal_to_minimal  src/mechanism/state.jl:9-66,
+ *                         step_minimal_coordinates!               src/simulation/step.jl:42-60,
+ *                         get_minimal_gradients!                  src/gradients/state.jl:183-217
  *   dojo_destroy       <- (GC of the Mechanism)
  *
  * All matrices at the ABI are row-major with the environment (batch) index slowest:
- * z[B][13*Nb], u[B][nu], dz[B][12*Nb][12*Nb], du[B][12*Nb][nu].  Scalars are fp64
+ * z[B][13*Nb], u[B][nu], dz[B][12*Nb][12*Nb], du[B][12*Nb][nu] -- except the Jacobians the `_dev` variants leave on
+ * the device, which are column-major per environment (dz[B][column][row]: Julia-native, and what the kernels write coalesced).  Scalars are fp64
  * (dtype 0) or fp32 (dtype 1) as chosen at dojo_create; topology/option structs are
  * always fp64 and are cast on upload.  No exception crosses the boundary: every entry
- * point returns DOJO_OK (0) or a negative error code and dojo_last_error() gives text.
+ * point returns DOJO_OK (0) or a negative error code and dojo_last_error() gives text (one
+ * process-wide string: call the library from one thread per process, as Julia does).
  *
  * Pointer arguments are *host* pointers for the plain entry points and *device*
  * pointers for the `_dev` variants (used by bench.py / torch so that inputs are
