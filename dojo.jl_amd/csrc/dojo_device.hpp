@@ -34,6 +34,9 @@
 #define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
                            // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
 #endif
+#ifndef DJ_FAST_RCP
+#define DJ_FAST_RCP 1       // Gauss-Jordan pivots: v_rcp_f64 + two Newton steps instead of the division expansion
+#endif
 #ifndef DJ_LDS_REDUCE
 #define DJ_LDS_REDUCE 1     // quad mapping: environment reductions through LDS (one slot per supernode) instead of shuffle butterflies
 #endif
@@ -1123,7 +1126,11 @@ struct LaneProgram {
                 TL prow[12];
 #pragma unroll
                 for (int c = 0; c < 12; ++c) prow[c] = wv.quad_bcast(A[ro][c], o);
+#if DJ_FAST_RCP
+                const TL ip = Wave::rcp(at ? prow[p] : TL(1));
+#else
                 const TL ip = TL(1) / (at ? prow[p] : TL(1));
+#endif
                 if (own) ipown[ro] = ip;
 #pragma unroll
                 for (int c = 0; c < 12; ++c) if (c != p) prow[c] *= ip;

@@ -39,6 +39,10 @@ struct GpuWave {
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }              // lane index inside the workgroup
     __device__ __forceinline__ int width() const { return 64 * NW; }
     __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
+    // 1/x: v_rcp_f64 (4.6e-8 relative) + two Newton steps = the IEEE quotient to the last bit on 2^20 random inputs
+    // (tools/ubench/rcp_test.hip), 5 instructions instead of the ~11 of the division expansion
+    static __device__ __forceinline__ double rcp(double a) { double r = __builtin_amdgcn_rcp(a); double e = fma(-a, r, 1.0); r = fma(r, e, r); e = fma(-a, r, 1.0); return fma(r, e, r); }
+    static __device__ __forceinline__ float rcp(float a) { return 1.0f / a; }
     // shuffles inside the wavefront only (the quad mapping with NW > 1 does not use them across quads)
     __device__ __forceinline__ float  shfl(float v, int src) const { return __shfl(v, src & 63, 64); }
     __device__ __forceinline__ double shfl(double v, int src) const { return __shfl(v, src & 63, 64); }

@@ -41,6 +41,8 @@ struct EmuWaveT {
     static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
     static constexpr int kWaves = NW;           // selects the LDS layout and the workgroup-reduction code paths of the multi-wave kernels
     Shared* sh; int l;
+    static double rcp(double a) { return 1.0 / a; }
+    static float rcp(float a) { return 1.0f / a; }
     int lane() const { return l; }
     int width() const { return sh->W; }
     void* lds() const { return (void*)sh->lds.data(); }
