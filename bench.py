@@ -150,8 +150,9 @@ def main():
             "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * el / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: Ant (13 bodies as built by the reference, 8 revolute+limits, 4 fixed, 4 foot contacts), "
-                                   "batch=%d per GPU, fwd + IFT gradients, closed-loop rollout with random controls" % B,
+            "config": {"workload": (("BASELINE.json configs[2]: Ant (13 bodies as built by the reference, 8 revolute+limits, 4 fixed, 4 foot contacts), "
+                                     if args.config == 3 else "BASELINE.json configs[%d]: %s (%d bodies, %d contacts), " % (args.config - 1, spec.name, spec.Nb, len(spec.contacts)))
+                                    + "batch=%d per GPU, %s, closed-loop rollout with random controls" % (B, "fwd + IFT gradients" if grad else "forward only")),
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
                        "parallelism": "batch-sharded x%d, no data-path collective; per GPU %d independent environment groups of %d on their own HIP streams" % (world, NCH, B // NCH),
