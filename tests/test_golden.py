@@ -1,0 +1,42 @@
+"""Golden fixtures (tests/golden/oracle_steps.npz, made by tools/make_golden.py): frozen oracle outputs on seeded inputs.
+They are oracle outputs, not reference outputs -- the reference needs Julia.  CPU tier: the oracle still
+reproduces them; GPU tier: the HIP path, through the C ABI, matches them."""
+import os
+import numpy as np
+import pytest
+import dojo_amd as d
+from oracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "oracle_steps.npz"))
+OPTS = d.SolverOptions(rtol=1e-8, btol=1e-8)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_oracle_reproduces_golden(cfg):
+    spec = d.baseline_config(cfg)
+    Z, U = G["c%d_z" % cfg], G["c%d_u" % cfg]
+    o = Oracle(spec, opts=OPTS)
+    Zn, st, it, dz, du = o.step_batch(Z, U, with_grad=True, grad_mode=0, nthreads=4)
+    assert np.array_equal(st, G["c%d_status" % cfg]) and np.array_equal(it, G["c%d_iters" % cfg])
+    assert np.abs(Zn - G["c%d_zn" % cfg]).max() < 1e-12
+    ref = G["c%d_dz0" % cfg].astype(np.float64)
+    assert np.abs(dz[0] - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())      # the larger fixtures are stored in fp32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_gpu_matches_golden(cfg):
+    from dojo_amd import api
+    spec = d.baseline_config(cfg)
+    Z, U = G["c%d_z" % cfg], G["c%d_u" % cfg]
+    gm = api.BatchedMechanism(spec, len(Z), dtype="f64", opts=OPTS)
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dz, du = gm.gradients()
+    gm.close()
+    ok = (st == 0) & (G["c%d_status" % cfg] == 0)
+    assert ok.any()
+    assert np.abs(zn[ok] - G["c%d_zn" % cfg][ok]).max() < 1e-5            # parity criterion of DESIGN.md §7 (almost-active contacts)
+    if ok[0]:
+        ref = G["c%d_dz0" % cfg].astype(np.float64)
+        assert np.abs(dz[0] - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/oracle_steps.npz: seeded inputs and the oracle's outputs for the five BASELINE configurations.
+
+The reference itself cannot be run here (no Julia), so these are NOT reference outputs: they freeze the
+oracle (which is pinned by the reference's own finite-difference property tests, tests/test_oracle_*.py) so that a change
+of the oracle or of the host-side mechanism builders shows up as a diff, and they give the GPU tests one fixed set of
+vectors that does not depend on the oracle being rebuilt the same way.  Usage: python tools/make_golden.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import dojo_amd as d
+from oracle import Oracle
+
+out = {}
+for cfg, B, pre in ((1, 4, 2), (2, 4, 60), (3, 4, 12), (4, 2, 8), (5, 2, 2)):
+    spec = d.baseline_config(cfg)
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, B)
+    for _ in range(pre):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    Zn, st, it, dz, du = o.step_batch(Z, U, with_grad=True, grad_mode=0, nthreads=4)
+    out["c%d_z" % cfg] = Z; out["c%d_u" % cfg] = U; out["c%d_zn" % cfg] = Zn; out["c%d_status" % cfg] = st; out["c%d_iters" % cfg] = it
+    # Jacobians: keep them small -- the first environment, fp32 is plenty for a 1e-6 relative comparison
+    out["c%d_dz0" % cfg] = dz[0].astype(np.float64) if cfg <= 2 else dz[0].astype(np.float32)
+    out["c%d_du0" % cfg] = du[0].astype(np.float64) if cfg <= 2 else du[0].astype(np.float32)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps.npz"), **out)
+print("wrote tests/golden/oracle_steps.npz", {k: v.shape for k, v in out.items() if k.endswith("_z")})
