@@ -1348,9 +1348,29 @@ struct LaneProgram {
         TG d3[NC][3];
 #pragma unroll
         for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
+        // the parked y of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
+        // away and nothing else hides it with one wave per SIMD)
+        TIO ynext[NC][3];
+        auto fetch_y = [&](int b_) {
+            const bool v_ = active && q < 2 && b_ >= 0 && b_ < NB;
+            TIO* const cbn = colbase(v_ ? b_ : 0);
+            const bool isS_ = b_ < nbs;
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                const bool ok_ = v_ && col_ok(b_, n);
+                const TIO* o_ = cbn + (size_t)((isS_ && n >= 3) ? n + 3 : n) * nx;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? o_[3 + i] : TIO(0);
+            }
+        };
+        fetch_y(0 - lvl);
         for (int t = 0; t < NB + G.maxlevel; ++t) {
             const int b = t - lvl;
             const bool valid = active && b >= 0 && b < NB;
+            TIO ycur[NC][3];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ycur[n][i] = ynext[n][i];
+            fetch_y(b + 1);
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
@@ -1388,7 +1408,7 @@ struct LaneProgram {
                         TG a_ = TG(0);
 #pragma unroll
                         for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * tf[m_];
-                        TG y = o_ok ? TG(o[3 + i]) : TG(0);
+                        TG y = o_ok ? TG(ycur[n][i]) : TG(0);
                         d3[n][i] = has_parent ? y - a_ : y;
                     }
                 }
