@@ -1350,6 +1350,9 @@ struct LaneProgram {
         for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
         // the parked y of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
         // away and nothing else hides it with one wave per SIMD)
+        T Mq[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Mq[i] = q == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
         TIO ynext[NC][3];
         auto fetch_y = [&](int b_) {
             const bool v_ = active && q < 2 && b_ >= 0 && b_ < NB;
@@ -1413,13 +1416,14 @@ struct LaneProgram {
                     }
                 }
                 if (o_ok) {
+                    // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows)
                     T d_[3] = {T(d3[n][0]), T(d3[n][1]), T(d3[n][2])};
-                    if (q == 0) {
-                        for (int i = 0; i < 3; ++i) { T x = dt * d_[i]; if (mine && n == i) x += T(1); o[i] = TIO(x); o[3 + i] = TIO(d_[i]); }
-                    } else {
-                        T pw[3];
-                        m3vec(pw, kb0.Phi, d_);
-                        for (int i = 0; i < 3; ++i) { T ph = pw[i]; if (mine && n >= 3) ph += kb0.Xi[3 * i + (n - 3)]; o[i] = TIO(ph); o[3 + i] = TIO(d_[i]); }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        T x = Mq[3 * i] * d_[0] + Mq[3 * i + 1] * d_[1] + Mq[3 * i + 2] * d_[2];
+                        const T idt = q == 0 ? (n == i ? T(1) : T(0)) : (n >= 3 ? kb0.Xi[3 * i + (n >= 3 ? n - 3 : 0)] : T(0));
+                        if (mine) x += idt;
+                        o[i] = TIO(x); o[3 + i] = TIO(d_[i]);
                     }
                 }
             }
