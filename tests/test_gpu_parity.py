@@ -381,3 +381,29 @@ def test_minimal_gradients(cfg, pre_steps, mode):
         if spec.nu:
             assert np.abs(ju[b] - ju_ref).max() < 2e-5 * su, (b, np.abs(ju[b] - ju_ref).max(), su)
     gm.close()
+
+
+@pytest.mark.parametrize("cfg,batch,grad", [(4, 8192, False), (5, 2048, True), (2, 1024, False)])
+def test_baseline_sizes_size_independent_properties(cfg, batch, grad):
+    """The other BASELINE.json configurations at their full batch sizes (quadruped 8192 forward, Atlas 2048 forward + IFT,
+    block 1024 forward), through properties that do not need the oracle at that size: environments with equal inputs give
+    bit-equal outputs wherever they sit in the batch, unit quaternions stay unit, the gradients are finite and the Jacobian
+    of an environment does not depend on its neighbours."""
+    spec = d.baseline_config(cfg)
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (batch // 64, 1)); U = np.tile(U0, (batch // 64, 1))
+    gm = api.BatchedMechanism(spec, batch, dtype="f32")
+    z = Z.astype(np.float32)
+    for k in range(2):
+        zn, st, it = gm.step(z, U.astype(np.float32), with_gradient=(grad and k == 1))
+        z = zn
+    assert (st == 0).mean() > 0.9
+    q = zn.reshape(batch, spec.Nb, 13)[:, :, 6:10].astype(np.float64)
+    assert np.abs(np.linalg.norm(q, axis=2) - 1.0).max() < 1e-5
+    assert np.array_equal(zn[:64], zn[-64:]) and np.array_equal(st[:64], st[-64:]) and np.array_equal(it[:64], it[-64:])
+    if grad:
+        dz, du = gm.gradients()
+        ok = np.nonzero(st[:64] == 0)[0]
+        assert np.isfinite(dz[ok]).all() and np.isfinite(du[ok]).all()
+        assert np.array_equal(dz[ok], dz[batch - 64 + ok])
+    gm.close()
