@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=16, help="the per-GPU batch is stepped as this many independent groups of environments, "
                     "each on its own HIP stream, so that the few environments that run into max_iter do not idle the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1: nccl (= RCCL, production) or gloo "
+                    "(plumbing check of the N > 1 path on a box with fewer GPUs than ranks: ranks share devices, the gather goes through the host)")
     args = ap.parse_args()
 
     # one hardware queue per environment group: ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware
@@ -47,7 +49,9 @@ def main():
 
     from dojo_amd import distributed as D
     import torch.distributed as dist
-    rank, world, local = D.init_from_env(backend="nccl")          # "nccl" IS RCCL on ROCm
+    rank, world, local = D.init_from_env(backend=args.backend)    # "nccl" IS RCCL on ROCm
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()                 # plumbing check only: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -106,9 +110,12 @@ def main():
         one_step(k)
     for g in groups:
         torch.cuda.current_stream().wait_stream(g["stream"])
-    z_all = D.all_gather_states(z, world)      # all-gather of the final states over RCCL/xGMI, once per rollout chunk
+    if args.backend == "nccl":
+        z_all = D.all_gather_states(z, world)  # all-gather of the final states over RCCL/xGMI, once per rollout chunk
+    else:
+        torch.cuda.synchronize(); z_all = D.all_gather_states(z.cpu(), world)
     barrier()
-    el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev)
+    el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
     tot = [g["gm"].kernel_time_totals() for g in groups]
     kernel_ms = [(a / n, b / n) for a, b, n in tot if n > 0]
     ok_frac = float((status == 0).float().mean().item())
