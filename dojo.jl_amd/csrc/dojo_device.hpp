@@ -1150,6 +1150,7 @@ struct LaneProgram {
 #pragma unroll
                     for (int c = 0; c < 12; ++c) A[i][c] *= ipown[i];
             }
+            if (lev > 0) {   // level 0 = the roots of the trees: nothing to pass up (wave-uniform skip)
             // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero)
             TL Uf[12][6];
 #pragma unroll
@@ -1187,6 +1188,7 @@ struct LaneProgram {
                         TL rowv = (q == 0) ? pa0_ : pa1_;
                         up[i][j] = (q < 2) ? TL(K.D[i][j]) - rowv : TL(0);
                     }
+            }
             }
         }
     }
@@ -1459,16 +1461,16 @@ struct LaneProgram {
 #pragma unroll
                 for (int m_ = 0; m_ < 12; ++m_) a_ += F.Sq[i][m_] * rf[m_];
                 yy[i] = a_; }
-            TL part[6];
+            if (at) { y3[0] = yy[0]; y3[1] = yy[1]; y3[2] = yy[2]; }
+            if (lev > 0) {   // the roots have nothing to pass up (wave-uniform skip)
+                TL part[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) part[i] = F.Lq[i][0] * yy[0] + F.Lq[i][1] * yy[1] + F.Lq[i][2] * yy[2];
+                for (int i = 0; i < 6; ++i) part[i] = F.Lq[i][0] * yy[0] + F.Lq[i][1] * yy[1] + F.Lq[i][2] * yy[2];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
-            if (at) {
-                y3[0] = yy[0]; y3[1] = yy[1]; y3[2] = yy[2];
-                if (has_parent) {
+                for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
+                if (at && has_parent) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const TL s0_ = TL(upv[i]) - part[i], s1_ = TL(upv[3 + i]) - part[3 + i];
