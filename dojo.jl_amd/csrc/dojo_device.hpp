@@ -2283,6 +2283,53 @@ struct LaneProgram {
     }
 };
 
+// save_to_storage! (src/simulation/storage.jl:50-67) for one body at the solved step, before update_state!:
+// row = [x2(3) q2(4) v15(3) ω15(3) px(3) pq(3) vl(3) ωl(3)].  momentum(mechanism, body) (src/mechanics/momentum.jl:17-41)
+// is D2 − ½(inputs + joint impulses); with the body residual d = D1 + D2 − inputs − joint impulses − contact impulses of
+// the solved step at hand (the step kernel's `res` output),  p = ½(D2 − D1 + contact impulses + d)  needs no joint at
+// all: gravity and the external force cancel in
+//   D2 − D1 = [m(v25 + v15); ½Δt(c25 Jω25 + ω25×Jω25) + ½Δt(c15 Jω15 − ω15×Jω15)].
+// zb = the body's 13 state values the step was solved at, v/w = its solution (v25, ω25), csg = [s(4); γ(4)] per contact
+// of the environment, rb = the body's six residual rows.  Shared by the HIP storage kernel and the SIMT emulator.
+template <class T, class TC>
+DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb) {
+    const T x2[3] = {zb[0], zb[1], zb[2]}, v15[3] = {zb[3], zb[4], zb[5]}, q2[4] = {zb[6], zb[7], zb[8], zb[9]}, w15[3] = {zb[10], zb[11], zb[12]};
+    Kin<T> kb;
+    kin_of(kb, x2, q2, v, w, dt);
+    T p[6], J25[3], J15[3], x25[3], x15[3];
+    m3vec(J25, P.J, w); v3cross(x25, w, J25);
+    m3vec(J15, P.J, w15); v3cross(x15, w15, J15);
+    const T c15 = tsqrt(T(4) / (dt * dt) - v3dot(w15, w15));
+    for (int i = 0; i < 3; ++i) {
+        p[i] = P.m * (v[i] + v15[i]) + rb[i];
+        p[3 + i] = T(0.5) * dt * (kb.c * J25[i] + x25[i] + c15 * J15[i] - x15[i]) + rb[3 + i];
+    }
+    for (int c = 0; c < P.ncontact; ++c) {
+        const int id = P.contact[c];
+        T cs[4], cg[4];
+        for (int i = 0; i < 4; ++i) { cs[i] = T(csg[8 * id + i]); cg[i] = T(csg[8 * id + 4 + i]); }
+        ContactEval<T> CE;
+        contact_eval<false>(CE, CP[id], kb, v, w, cs, cg, dt);
+        for (int i = 0; i < 6; ++i) p[i] += CE.imp[i];
+    }
+    for (int i = 0; i < 6; ++i) p[i] *= T(0.5);
+    T R2[9], pw[3];
+    qrot(R2, q2);
+    m3vec(pw, R2, p + 3);                                      // vector_rotate(p_angular_body, q2)
+    // ω2 = inertia \ (angular momentum in the body frame): adjugate of the 3x3
+    const T* Jm = P.J;
+    const T a0 = Jm[4] * Jm[8] - Jm[5] * Jm[7], a1 = Jm[2] * Jm[7] - Jm[1] * Jm[8], a2 = Jm[1] * Jm[5] - Jm[2] * Jm[4];
+    const T b0 = Jm[5] * Jm[6] - Jm[3] * Jm[8], b1 = Jm[0] * Jm[8] - Jm[2] * Jm[6], b2 = Jm[2] * Jm[3] - Jm[0] * Jm[5];
+    const T c0 = Jm[3] * Jm[7] - Jm[4] * Jm[6], c1 = Jm[1] * Jm[6] - Jm[0] * Jm[7], c2 = Jm[0] * Jm[4] - Jm[1] * Jm[3];
+    const T idet = T(1) / (Jm[0] * a0 + Jm[1] * b0 + Jm[2] * c0);
+    const T wl[3] = {(a0 * p[3] + a1 * p[4] + a2 * p[5]) * idet, (b0 * p[3] + b1 * p[4] + b2 * p[5]) * idet, (c0 * p[3] + c1 * p[4] + c2 * p[5]) * idet};
+    for (int i = 0; i < 3; ++i) {
+        row[i] = x2[i]; row[7 + i] = v15[i]; row[10 + i] = w15[i];
+        row[13 + i] = p[i]; row[16 + i] = pw[i]; row[19 + i] = p[i] / P.m; row[22 + i] = wl[i];
+    }
+    for (int i = 0; i < 4; ++i) row[3 + i] = q2[i];
+}
+
 // ================================================================================================
 // Kernel-level entry: one call per lane.  Shared by the HIP kernel (dojo_hip.hip) and the
 // thread-based SIMT emulator (tests/emu).
@@ -2306,6 +2353,7 @@ struct KernelArgs {
     TIO* dz;                       // [B][12Nb cols][12Nb rows] column-major per env, or null
     TIO* du;                       // [B][nu cols][12Nb rows] column-major per env, or null
     TIO* dc;                       // [B][5Nc cols][12Nb rows] contact-data Jacobian (get_contact_gradients), or null
+    TIO* res;                      // [B,6Nb] or null          body residual rows at the solution (for the Storage kernel)
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
 #ifdef DJ_DEBUG
@@ -2503,6 +2551,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         for (int i = 0; i < 13; ++i) o[i] = TIO(zn[i]);
         if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; }
         if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[i]); vo[3 + i] = TIO(prog.L.w[i]); } }
+        if (A.res) { TIO* ro = A.res + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 6; ++i) ro[i] = TIO(prog.rb[i]); }
 #ifdef DJ_PROF
         if (A.vel && k == 0) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb; for (int i = 0; i < 6; ++i) vo[i] = TIO((double)prog.pc[i]); }   // phases 0-5 (cycles)
         if (A.vel && k == 1) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6; vo[0] = TIO((double)prog.pc[7]); vo[1] = TIO((double)iters); vo[2] = TIO((double)prog.pc[6]); }

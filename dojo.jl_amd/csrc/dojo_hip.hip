@@ -48,7 +48,7 @@ struct DojoSim {
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
     // internal device buffers used by the host-pointer entry points
-    void *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
+    void *d_res = nullptr, *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
@@ -111,17 +111,46 @@ __global__ void min2max_kernel(const NodeP<double>* nodes, const int* order, int
 }
 // one thread per (environment, joint): the joints are independent
 template <class TIO>
-__global__ void max2min_kernel(const NodeP<double>* nodes, int Nb, int nu, double dt, int B, const TIO* z, TIO* x) {
+__global__ void max2min_kernel(const NodeP<double>* nodes, int Nb, int nu, double dt, int B, const TIO* z, TIO* x, int ldx) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int env = tid / Nb, k = tid % Nb;
     if (env >= B) return;
     const NodeP<double>& P = nodes[k];
-    const TIO* ze = z + (size_t)env * 13 * Nb; TIO* xm = x + (size_t)env * 2 * nu + 2 * P.u_off;
+    const TIO* ze = z + (size_t)env * 13 * Nb; TIO* xm = x + (size_t)env * ldx + 2 * P.u_off;
     const int nt = P.nu_t, nr = P.nu_r, n = nt + nr;
     const PoseVel<double> b = load_body<double>(ze, k), a = P.parent >= 0 ? load_body<double>(ze, P.parent) : origin_body<double>();
     double ct[3], cr[3], vt[3], vr[3];
     joint_max2min(ct, cr, vt, vr, P, dt, a, b);
     for (int i = 0; i < 3; ++i) { if (i < nt) { xm[i] = (TIO)ct[i]; xm[n + i] = (TIO)vt[i]; } if (i < nr) { xm[nt + i] = (TIO)cr[i]; xm[n + nt + i] = (TIO)vr[i]; } }
+}
+
+// the contact part of get_state(::AntARS) (DojoEnvironments/src/environments/ant_ars.jl:72-80): the normal impulse of
+// every contact, clamped to [-1, 1], behind the minimal state.  csg = [s(4); gamma(4)] per contact of the last step.
+template <class TIO>
+__global__ void contact_obs_kernel(int Nc, int B, const TIO* csg, TIO* obs, int ldx, int off) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = tid / Nc, c = tid % Nc;
+    if (env >= B) return;
+    const double g = (double)csg[(size_t)env * 8 * Nc + 8 * c + 4];
+    obs[(size_t)env * ldx + off + c] = (TIO)(g < -1.0 ? -1.0 : g > 1.0 ? 1.0 : g);
+}
+
+// save_to_storage! (src/simulation/storage.jl:50-67): one thread per (environment, body); inputs are the state the step
+// was solved at and what the step kernel left behind (solution velocities, cone variables, body residual rows)
+template <class TIO>
+__global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double>* contacts, int Nb, int Nc, double dt, int env0, int nenv,
+                               const TIO* z, const TIO* vel, const TIO* csg, const TIO* res, TIO* storage) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / Nb, k = tid % Nb;
+    if (e >= nenv) return;
+    const size_t env = (size_t)env0 + e;
+    double zb[13], v[3], w[3], rb[6], row[25];
+    for (int i = 0; i < 13; ++i) zb[i] = (double)z[env * 13 * Nb + 13 * k + i];
+    for (int i = 0; i < 3; ++i) { v[i] = (double)vel[env * 6 * Nb + 6 * k + i]; w[i] = (double)vel[env * 6 * Nb + 6 * k + 3 + i]; }
+    for (int i = 0; i < 6; ++i) rb[i] = (double)res[env * 6 * Nb + 6 * k + i];
+    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb);
+    TIO* o = storage + (env * Nb + k) * 25;
+    for (int i = 0; i < 25; ++i) o[i] = (TIO)row[i];
 }
 
 // ---- Jacobians by forward-mode differentiation of the same maps ----
@@ -281,7 +310,7 @@ int acquire_slot(DojoSim* s, int* idx) {
 // batch-level buffers.  env0 must be a multiple of the environments per wavefront.
 template <class TIO, class T, class TL>
 int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr) {
+           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr) {
     if (nenv < 0) nenv = s->B;
     const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
     auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
@@ -292,6 +321,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
     A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
+    A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
     // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
     // else one lane per supernode
@@ -336,13 +366,20 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
     if (timed) { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = g != 0; e.n = 1; e.used = true; s->last_slot = slot; }
+    if (storage) {                         // record: the Storage rows of the environments of this launch
+        const long long n = (long long)nenv * Nb; const int T_ = 128;
+        hipLaunchKernelGGL((ckern::storage_kernel<TIO>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, st, (const dj::NodeP<double>*)s->d_nodes,
+                           (const dj::ContactP<double>*)s->d_contacts, (int)Nb, s->M.Nc, s->M.dt, (int)env0, nenv,
+                           (const TIO*)z, (const TIO*)vel, (const TIO*)csg, (const TIO*)s->d_res, (TIO*)storage);
+        HIPCHK(hipGetLastError());
+    }
     return DOJO_OK;
 }
 
 int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr) {
-    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc);
-    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc);
+               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr) {
+    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage);
+    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage);
 }
 
 int ensure(void** p, size_t bytes) {
@@ -383,7 +420,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     hipSetDevice(s->device);
-    void* ps[] = {s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) hipFree(p);
     for (auto g_ : s->gstreams) hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) hipEventDestroy(gev_);
@@ -482,7 +519,9 @@ int dojo_gradients(DojoHandle s, void* dz, void* du) {
     return DOJO_OK;
 }
 
-int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* stream) {
+// simulate! with pre-sampled controls (src/simulation/simulate.jl:16-37): H steps, each fed with the previous step's
+// internal next state; storage != null records save_to_storage! rows [H][B][Nb][25] of every solved step
+static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* storage, void* stream) {
     if (!s || !z0 || H < 1) { g_err = "dojo_rollout_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
@@ -492,6 +531,7 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
     if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    if (storage && (rc = ensure(&s->d_res, B * 6 * s->M.Nb * w))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const char* cur = (const char*)z0;
     int slot = -1;
@@ -526,7 +566,8 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
         for (int k = 0; k < H; ++k) {
             char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
             const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
-            rc = launch_any(s, c, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, gs, false, env0, nenv);
+            void* sk = storage ? (char*)storage + (size_t)k * B * 25 * s->M.Nb * w : nullptr;
+            rc = launch_any(s, c, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, gs, false, env0, nenv, nullptr, sk);
             if (rc != DOJO_OK) return rc;
             c = nxt;
         }
@@ -540,24 +581,47 @@ int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, voi
     return DOJO_OK;
 }
 
+int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* stream) {
+    return rollout_core(s, z0, U, H, Z, status, nullptr, stream);
+}
+
+int dojo_simulate_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status, void* stream) {
+    if (!storage) { g_err = "dojo_simulate_dev: storage must not be NULL (use dojo_rollout_dev for record = false)"; return DOJO_ERR_INVALID; }
+    return rollout_core(s, z0, U, H, Z, status, storage, stream);
+}
+
+static int rollout_host(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status);
+
 int dojo_rollout(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status) {
+    return rollout_host(s, z0, U, H, Z, nullptr, status);
+}
+
+int dojo_simulate(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status) {
+    if (!storage) { g_err = "dojo_simulate: storage must not be NULL (use dojo_rollout for record = false)"; return DOJO_ERR_INVALID; }
+    return rollout_host(s, z0, U, H, Z, storage, status);
+}
+
+static int rollout_host(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status) {
     if (!s || !z0 || H < 1) { g_err = "dojo_rollout: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
-    void *dz0 = nullptr, *dU = nullptr, *dZ = nullptr; int* dS = nullptr;
+    void *dz0 = nullptr, *dU = nullptr, *dZ = nullptr, *dSt = nullptr; int* dS = nullptr;
+    const size_t nst = (size_t)H * B * 25 * s->M.Nb * w;
+    if (storage) HIPCHK(hipMalloc(&dSt, nst));
     HIPCHK(hipMalloc(&dz0, B * nz * w));
     HIPCHK(hipMemcpy(dz0, z0, B * nz * w, hipMemcpyHostToDevice));
     if (U && nu) { HIPCHK(hipMalloc(&dU, (size_t)H * B * nu * w)); HIPCHK(hipMemcpy(dU, U, (size_t)H * B * nu * w, hipMemcpyHostToDevice)); }
     if (Z) HIPCHK(hipMalloc(&dZ, (size_t)H * B * nz * w));
     if (status) HIPCHK(hipMalloc((void**)&dS, (size_t)H * B * sizeof(int)));
-    int rc = dojo_rollout_dev(s, dz0, dU, H, dZ, dS, nullptr);
+    int rc = rollout_core(s, dz0, dU, H, dZ, dS, dSt, nullptr);
     if (rc == DOJO_OK) {
         HIPCHK(hipDeviceSynchronize());
+        if (storage) HIPCHK(hipMemcpy(storage, dSt, nst, hipMemcpyDeviceToHost));
         if (Z) HIPCHK(hipMemcpy(Z, dZ, (size_t)H * B * nz * w, hipMemcpyDeviceToHost));
         if (status) HIPCHK(hipMemcpy(status, dS, (size_t)H * B * sizeof(int), hipMemcpyDeviceToHost));
         if (Z) HIPCHK(hipMemcpy(s->d_zn, (char*)dZ + (size_t)(H - 1) * B * nz * w, B * nz * w, hipMemcpyDeviceToDevice));
     }
-    hipFree(dz0); if (dU) hipFree(dU); if (dZ) hipFree(dZ); if (dS) hipFree(dS);
+    hipFree(dz0); if (dU) hipFree(dU); if (dZ) hipFree(dZ); if (dS) hipFree(dS); if (dSt) hipFree(dSt);
     return rc;
 }
 
@@ -612,10 +676,40 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
-    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x);
-    else hipLaunchKernelGGL((ckern::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x);
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x, 2 * s->M.nu);
+    else hipLaunchKernelGGL((ckern::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x, 2 * s->M.nu);
     HIPCHK(hipGetLastError());
     return DOJO_OK;
+}
+// get_state(environment) of DojoEnvironments: the minimal state of z (environments.jl:100-102, quadruped_sampling.jl:67-72)
+// and, with contact_forces != 0, the clamped normal impulses of the last step behind it (ant_ars.jl:72-80).
+// obs [B, 2nu (+ Nc)]
+int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_forces, void* stream) {
+    if (!s || !z || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const int Nc = contact_forces ? s->M.Nc : 0, ld = 2 * s->M.nu + Nc;
+    const long long n = (long long)s->B * s->M.Nb, nc = (long long)s->B * Nc; const int T_ = 256;
+    if (s->dtype == DOJO_DTYPE_F32) {
+        hipLaunchKernelGGL((ckern::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)obs, ld);
+        if (Nc) hipLaunchKernelGGL((ckern::contact_obs_kernel<float>), dim3((unsigned)((nc + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, Nc, s->B, (const float*)s->d_csg, (float*)obs, ld, 2 * s->M.nu);
+    } else {
+        hipLaunchKernelGGL((ckern::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)obs, ld);
+        if (Nc) hipLaunchKernelGGL((ckern::contact_obs_kernel<double>), dim3((unsigned)((nc + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, Nc, s->B, (const double*)s->d_csg, (double*)obs, ld, 2 * s->M.nu);
+    }
+    HIPCHK(hipGetLastError());
+    return DOJO_OK;
+}
+int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
+    if (!s || !obs || !s->d_zn || !s->have_solution) { g_err = "dojo_observe: no step has been taken on this handle"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const size_t ld = 2 * s->M.nu + (contact_forces ? s->M.Nc : 0), bytes = (size_t)s->B * ld * s->w;
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
+    int rc = dojo_observe_dev(s, s->d_zn, d, contact_forces, s->stream);
+    if (rc == DOJO_OK) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(obs, d, bytes, hipMemcpyDeviceToHost)); }
+    hipFree(d);
+    return rc;
 }
 // step_minimal_coordinates!  src/simulation/step.jl:42-60: x -> z -> step! -> z' -> x'
 int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {

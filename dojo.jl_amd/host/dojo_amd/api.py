@@ -51,7 +51,13 @@ EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
-                    "dojo_contact_gradients", "dojo_contact_gradients_dev", "dojo_minimal_gradients", "dojo_minimal_gradients_dev"]
+                    "dojo_contact_gradients", "dojo_contact_gradients_dev", "dojo_minimal_gradients", "dojo_minimal_gradients_dev",
+                    "dojo_simulate", "dojo_simulate_dev", "dojo_observe", "dojo_observe_dev"]
+
+
+# columns of a Storage row (src/simulation/storage.jl:15-24)
+STORAGE_FIELDS = {"x": slice(0, 3), "q": slice(3, 7), "v": slice(7, 10), "w": slice(10, 13), "px": slice(13, 16), "pq": slice(16, 19),
+                  "vl": slice(19, 22), "wl": slice(22, 25)}
 
 
 def device_count():
@@ -143,6 +149,31 @@ class BatchedMechanism:
         st = np.empty((H, B), np.int32)
         _chk(lib().dojo_rollout(self.h, _p(z0), _p(U), H, _p(Z), _p(st)))
         return Z, st
+
+    def simulate(self, z0, U=None, steps=None):
+        """simulate!(mechanism, 1:H, storage, control!; record=true) with pre-sampled controls (simulate.jl:16-37).
+        Returns (Z [H,B,13Nb], storage [H,B,Nb,25], status [H,B]); a Storage row is
+        x2(3) q2(4) v15(3) w15(3) px(3) pq(3) vl(3) wl(3) of the solved step (storage.jl:50-67), see STORAGE_FIELDS."""
+        B, s = self.batch, self.spec
+        z0 = self._arr(z0, (B, s.nz))
+        if U is not None and s.nu:
+            U = np.ascontiguousarray(U, dtype=self.np_dtype); H = U.shape[0]
+            assert U.shape == (H, B, s.nu)
+        else:
+            U = None; H = int(steps)
+        Z = np.empty((H, B, s.nz), self.np_dtype)
+        S = np.empty((H, B, s.Nb, 25), self.np_dtype)
+        st = np.empty((H, B), np.int32)
+        _chk(lib().dojo_simulate(self.h, _p(z0), _p(U), H, _p(Z), _p(S), _p(st)))
+        return Z, S, st
+
+    def observe(self, contact_forces=False):
+        """get_state(environment): minimal state of the handle's current state [B, 2nu], followed (contact_forces=True,
+        get_state(::AntARS), ant_ars.jl:72-80) by the clamped normal impulses of the last step [B, 2nu + Nc]."""
+        B, s = self.batch, self.spec
+        obs = np.empty((B, 2 * s.nu + (len(s.contacts) if contact_forces else 0)), self.np_dtype)
+        _chk(lib().dojo_observe(self.h, _p(obs), int(bool(contact_forces))))
+        return obs
 
     def contact_gradients(self):
         """get_contact_gradients (src/gradients/contact.jl) at the solution of the last step(..., with_gradient=True):

@@ -126,6 +126,23 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     return Z, status
 end
 
+"simulate!(...; record=true): as above plus the Storage rows [25, Nb, B, H] (x q v ω px pq vl ωl, storage.jl:50-67)"
+function simulate_storage!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; opts=Dojo.SolverOptions{Float64}()) where T
+    set_options!(bm, opts)
+    H = size(U, 3); Nb = length(bm.mechanism.bodies)
+    Z = Array{T}(undef, bm.nz, bm.batch, H); S = Array{T}(undef, 25, Nb, bm.batch, H); status = Matrix{Int32}(undef, bm.batch, H)
+    check(@ccall LIB.dojo_simulate(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, S::Ptr{T}, status::Ptr{Int32})::Cint)
+    return Z, S, status
+end
+
+"get_state(environment): minimal state (+ clamped contact normal impulses, as get_state(::AntARS)) of the last step, [2nu (+Nc), B]"
+function get_state(bm::BatchedMechanism{T}; contact_forces::Bool=false) where T
+    n = 2 * bm.nu + (contact_forces ? length(bm.mechanism.contacts) : 0)
+    obs = Matrix{T}(undef, n, bm.batch)
+    check(@ccall LIB.dojo_observe(bm.handle::Ptr{Cvoid}, obs::Ptr{T}, Int32(contact_forces)::Int32)::Cint)
+    return obs
+end
+
 "get_contact_gradients(mechanism) at the solution of the last get_maximal_gradients!: jacobian_contact[12Nb, 5Nc, B]"
 function get_contact_gradients!(bm::BatchedMechanism{T}, ncontacts::Int) where T
     dc = Array{T}(undef, 5 * ncontacts, bm.nx, bm.batch)                      # ABI is row-major [B, nx, 5Nc]

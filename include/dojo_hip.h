@@ -19,6 +19,10 @@
  *                         src/gradients/state.jl:69-126
  *   dojo_rollout       <- simulate!(mechanism, steps, storage, control!)  src/simulation/simulate.jl:16-36
  *                         with the control callback replaced by pre-sampled inputs U[k]
+ *   dojo_simulate      <- simulate!(...; record = true): the same rollout, recording save_to_storage! rows
+ *                         src/simulation/storage.jl:50-67, momentum(mechanism, body) src/mechanics/momentum.jl:17-41
+ *   dojo_observe       <- get_state(environment)  DojoEnvironments/src/environments.jl:100-102,
+ *                         environments/ant_ars.jl:72-80, environments/quadruped_sampling.jl:67-72
  *   dojo_contact_gradients <- get_contact_gradients(mechanism) src/gradients/contact.jl:1-55
  *   dojo_minimal_to_maximal / dojo_maximal_to_minimal / dojo_step_minimal / dojo_minimal_gradients
  *                      <- minimal_to_maximal, maximal_to_minimal  src/mechanism/state.jl:9-66,
@@ -193,6 +197,24 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
                    int32_t* status, int32_t* iters, void* dz, void* du, void* stream);
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
+
+/* simulate!(mechanism, 1:H, storage, control!; record = true)  src/simulation/simulate.jl:16-37  (SURVEY.md §8f-2):
+ * dojo_rollout plus the Storage of the trajectory, written by the step kernel itself.  storage [H, B, Nb, 25], one
+ * save_to_storage! row (src/simulation/storage.jl:50-67) per solved step and body, taken BEFORE update_state! as
+ * simulate! does:  x2(3) q2(4) v15(3) omega15(3) | px(3) pq(3) (momentum(mechanism, body), world frame,
+ * src/mechanics/momentum.jl:17-41) | vl(3) = px / m, omegal(3) = J \ (pq in the body frame).
+ * Z and status as for dojo_rollout (both may be NULL). */
+int  dojo_simulate(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status);
+int  dojo_simulate_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z, void* storage,
+                       int32_t* status, void* stream);
+
+/* get_state(environment) of DojoEnvironments (environments.jl:100-102; quadruped_sampling.jl:67-72): the minimal state
+ * of the mechanism, and with contact_forces != 0 the normal impulse of every contact of the last step clamped to
+ * [-1, 1] behind it (get_state(::AntARS), ant_ars.jl:72-80).  obs [B, 2*nu (+ Nc)].
+ * dojo_observe reads the state the last dojo_step / dojo_step_minimal / dojo_rollout left on the handle; the device
+ * variant takes that state z [B, 13Nb] explicitly (the z_next of the step enqueued before it on `stream`). */
+int  dojo_observe(DojoHandle h, void* obs, int32_t contact_forces);
+int  dojo_observe_dev(DojoHandle h, const void* z, void* obs, int32_t contact_forces, void* stream);
 
 /* get_contact_gradients(mechanism)  src/gradients/contact.jl:1-55  (SURVEY.md §8f-3): the Jacobian of the next state
  * [x3; v25; phi3; omega25] w.r.t. the contact data, 5 per contact [friction_coefficient, contact_radius, contact_origin(3)],

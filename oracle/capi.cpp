@@ -30,7 +30,9 @@ struct IOracle {
     virtual void get_state(double* z) = 0;
     virtual void set_external_force(int body, const double* force, const double* torque, const double* vertex) = 0;
     virtual int simulate_step(const double* u, int last) = 0;
+    virtual int simulate_step_record(const double* u, int last, double* row) = 0;
     virtual void body_velocity_solution(double* v) = 0;
+    virtual void save_to_storage(double* out) = 0;
     virtual void debug_assemble(const double* z, const double* u, double* A, double* b) = 0;
     virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
@@ -126,8 +128,18 @@ struct OracleT : IOracle {
         if (u) { auto uu = cast(u, m.nu()); return m.simulate_step(uu.data(), last != 0); }
         return m.simulate_step(nullptr, last != 0);
     }
+    int simulate_step_record(const double* u, int last, double* row) override {
+        std::vector<T> o(25 * m.bodies.size()), uu(m.nu(), T(0)); if (u) uu = cast(u, m.nu());
+        int st = m.simulate_step(uu.data(), last != 0, o.data());
+        for (size_t i = 0; i < o.size(); ++i) row[i] = (double)o[i];
+        return st;
+    }
     void body_velocity_solution(double* v) override {
         for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { v[6 * i + k] = m.bodies[i].st.vsol[1][k]; v[6 * i + 3 + k] = m.bodies[i].st.wsol[1][k]; }
+    }
+    void save_to_storage(double* out) override {
+        std::vector<T> o(25 * m.bodies.size()); m.save_to_storage(o.data());
+        for (size_t i = 0; i < o.size(); ++i) out[i] = (double)o[i];
     }
     void debug_assemble(const double* z, const double* u, double* A, double* b) override {
         // state of mehrotra! right after its first set_entries! (mehrotra.jl:10-21)
@@ -180,7 +192,9 @@ void orc_set_state(void* h, const double* z) { ((IOracle*)h)->set_state(z); }
 void orc_get_state(void* h, double* z) { ((IOracle*)h)->get_state(z); }
 void orc_set_external_force(void* h, int body, const double* f, const double* t, const double* v) { ((IOracle*)h)->set_external_force(body, f, t, v); }
 int  orc_simulate_step(void* h, const double* u, int last) { return ((IOracle*)h)->simulate_step(u, last); }
+int  orc_simulate_step_record(void* h, const double* u, int last, double* row) { return ((IOracle*)h)->simulate_step_record(u, last, row); }
 void orc_body_velocity_solution(void* h, double* v) { ((IOracle*)h)->body_velocity_solution(v); }
+void orc_save_to_storage(void* h, double* out) { ((IOracle*)h)->save_to_storage(out); }
 
 void orc_debug_assemble(void* h, const double* z, const double* u, double* A, double* b) { ((IOracle*)h)->debug_assemble(z, u, A, b); }
 

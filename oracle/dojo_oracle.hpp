@@ -1116,13 +1116,49 @@ struct Mechanism {
         return status;
     }
     // one iteration of simulate!'s loop  simulation/simulate.jl:25-33 (control already set through set_input / Fext)
-    int simulate_step(const T* u, bool last) {
+    int simulate_step(const T* u, bool last, T* record = nullptr) {
         if (u) { int off = 0; for (auto& J : joints) { set_input(J, u + off); off += J.nu(); } }
         for (auto& J : joints) input_impulse(J, true);
         int status = mehrotra();
         for (auto& B : bodies) { B.st.Fext = M(3, 1); B.st.text = M(3, 1); }
+        if (record) save_to_storage(record);                  // record && save_to_storage!  simulate.jl:31
         if (!last) update_state();
         return status;
+    }
+    // momentum(mechanism, body)  src/mechanics/momentum.jl:17-41: linear and (world-frame) angular momentum of one body
+    // at the solved step, from the discrete Legendre transform D2 minus half of the input and joint impulses
+    void body_momentum(int ib, M& p_lin, M& p_ang_world) const {
+        const Body<T>& B = bodies[ib]; const State<T>& s = B.st;
+        M x3_ = x3(s); Q q3_ = q3(s);
+        M D2x = (T(1) / dt * B.mass) * (x3_ - s.x2) - (T(0.5) * dt) * (B.mass * gravity + s.Fext);
+        M D2q = (T(-2) / dt) * (LVTmat(s.q2).t() * Tmat<T>() * Rmat(q3_).t() * VTmat<T>() * B.inertia * Vmat<T>() * Lmat(s.q2).t() * vector(q3_)) - (T(0.5) * dt) * s.text;
+        p_lin = D2x - T(0.5) * s.JF2;
+        M p_ang = D2q - T(0.5) * s.Jt2;
+        for (auto& J : joints) {                              // joint_impulses  momentum.jl:43-53
+            bool parent = (J.parent == ib), child = (J.child == ib);
+            if (!parent && !child) continue;
+            M f(6, 1);
+            if (J.N() > 0) f += joint_impulse_map(J, parent) * J.imp[1];
+            if (J.spring) f += joint_spring_impulses(J, parent, false);
+            if (J.damper) f += joint_damper_impulses(J, parent, false);
+            p_lin -= T(0.5) * sub(f, 0, 3); p_ang -= T(0.5) * sub(f, 3, 3);
+        }
+        p_ang_world = vector_rotate(p_ang, s.q2);
+    }
+    // save_to_storage!  src/simulation/storage.jl:50-67: one Storage row per body =
+    // [x2(3) q2(4) v15(3) ω15(3) px(3) pq(3) vl(3) ωl(3)]  (25 scalars), from the body states as they are now
+    void save_to_storage(T* out) const {
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            const Body<T>& B = bodies[i]; const State<T>& s = B.st; T* p = out + 25 * i;
+            M pl, pq; body_momentum((int)i, pl, pq);
+            M vl = (T(1) / B.mass) * pl;
+            M wb = vector_rotate(pq, inv(s.q2));
+            std::vector<T> A(9); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = B.inertia(r, c);
+            T rhs[3] = {wb[0], wb[1], wb[2]};
+            DenseLU<T> lu; lu.factor(A, 3); lu.solve(rhs, 1);                  // inertia \ (…)
+            for (int k = 0; k < 3; ++k) { p[k] = s.x2[k]; p[7 + k] = s.v15[k]; p[10 + k] = s.w15[k]; p[13 + k] = pl[k]; p[16 + k] = pq[k]; p[19 + k] = vl[k]; p[22 + k] = rhs[k]; }
+            p[3] = s.q2.s; p[4] = s.q2.v1; p[5] = s.q2.v2; p[6] = s.q2.v3;
+        }
     }
     void initialize_simulation() {   // simulate.jl:53-58
         for (auto& B : bodies) { set_previous_configuration(B.st); B.st.JF2 = M(3, 1); B.st.Jt2 = M(3, 1); }

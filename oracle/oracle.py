@@ -34,10 +34,11 @@ def lib():
         for name in ("orc_destroy", "orc_set_options", "orc_dims", "orc_get_solution", "orc_set_solution", "orc_gradients",
                      "orc_get_data", "orc_set_data", "orc_evaluate_residual", "orc_full_matrix", "orc_data_matrix",
                      "orc_data_attjac", "orc_set_state", "orc_get_state", "orc_set_external_force",
-                     "orc_body_velocity_solution", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
+                     "orc_body_velocity_solution", "orc_save_to_storage", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
             getattr(_lib, name).restype = None
         _lib.orc_step.restype = C.c_int
         _lib.orc_simulate_step.restype = C.c_int
+        _lib.orc_simulate_step_record.restype = C.c_int
     return _lib
 
 
@@ -145,6 +146,11 @@ class Oracle:
     def velocity_solution(self):
         v = np.zeros(6 * self.Nb); lib().orc_body_velocity_solution(self.h, _p(v)); return v
 
+    def storage_row(self):
+        """save_to_storage!(mechanism, storage, k) (storage.jl:50-67) for the body states as they are now:
+        [Nb, 25] = x2(3) q2(4) v15(3) w15(3) px(3) pq(3) vl(3) wl(3)."""
+        out = np.zeros((self.Nb, 25)); lib().orc_save_to_storage(self.h, _p(out)); return out
+
     def simulate(self, z0, steps, control=None):
         """simulate!(mechanism, steps, storage, control!)  -> list of maximal states after each step.
         The last step is not followed by update_state! (simulate.jl:32), as in the reference."""
@@ -155,6 +161,16 @@ class Oracle:
             status.append(self.simulate_step(u, last=(k == steps)))
             traj.append(self.get_state())
         return traj, status
+
+    def simulate_storage(self, z0, U):
+        """simulate!(mechanism, 1:H, storage, control!; record=true) with pre-sampled controls U [H, nu]:
+        the solve, then save_to_storage! BEFORE update_state! (simulate.jl:28-32).  Returns ([H, Nb, 25], status)."""
+        self.set_state(z0)
+        H = len(U); rows = []; status = []
+        for k in range(H):
+            status.append(lib().orc_simulate_step_record(self.h, _p(np.ascontiguousarray(U[k], dtype=np.float64)), int(k == H - 1), _p(row := np.zeros((self.Nb, 25)))))
+            rows.append(row)
+        return np.stack(rows), status
 
     def step_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1):
         Z = np.ascontiguousarray(Z, dtype=np.float64); B = Z.shape[0]

@@ -86,7 +86,7 @@ struct EmuWaveT {
 template <class TIO, class T, class TL, int MAXC, bool QUAD, int NW = 1>
 void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
          const double* z, const double* u, double* z_next, int* status, int* iters,
-         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr) {
+         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr, double* storage = nullptr) {
     std::vector<dj::NodeP<T>> nodes; for (auto& n : M.nodes) nodes.push_back(dj::cast_node<T>(n));
     std::vector<dj::ContactP<T>> contacts; for (auto& c : M.contacts) contacts.push_back(dj::cast_contact<T>(c));
     if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
@@ -101,6 +101,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
+    std::vector<TIO> rest(storage ? (size_t)B * 6 * M.Nb : 0); A.res = storage ? rest.data() : nullptr;
     std::vector<TIO> dct((dc && QUAD) ? (size_t)B * nx * 5 * std::max(M.Nc, 1) : 0); A.dc = nullptr;
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
     std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
@@ -128,6 +129,15 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
         for (size_t i = 0; i < (size_t)B * nx * 5 * M.Nc; ++i) dc[i] = dct[i];
     }
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
+    if (storage && vel && csg)                                      // the Storage kernel's body, per (environment, body)
+        for (int e = 0; e < B; ++e) for (int k = 0; k < M.Nb; ++k) {
+            T zb[13], v[3], w[3], rb[6], row[25];
+            for (int i = 0; i < 13; ++i) zb[i] = T(zt[(size_t)e * nz + 13 * k + i]);
+            for (int i = 0; i < 3; ++i) { v[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + i]); w[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + 3 + i]); }
+            for (int i = 0; i < 6; ++i) rb[i] = T(rest[(size_t)e * 6 * M.Nb + 6 * k + i]);
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * 8 * M.Nc, rb);
+            for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
+        }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
     for (size_t i = 0; i < (jimp ? (size_t)B * M.n_joint_imp : 0); ++i) jimp[i] = jt[i];
     for (size_t i = 0; i < (csg ? (size_t)B * 8 * M.Nc : 0); ++i) csg[i] = ct[i];
@@ -140,7 +150,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
 
 extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int quad, int B, int envs_per_wave,
                         const double* z, const double* u, double* z_next, int* status, int* iters,
-                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen, double* dc) {
+                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen, double* dc, double* storage) {
     dj::HostModel M;
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
@@ -148,9 +158,9 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
-#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); \
-                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); \
-                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc); } while (0)
+#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); \
+                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); \
+                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); } while (0)
     // dtype 0: fp64 everywhere; dtype 1: fp32 I/O with fp64 internals (the product's "f32" mode); dtype 3: fp32 factorization (experiments)
     if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }
     else if (dtype == DOJO_DTYPE_F32) { if (M.maxc <= 1) RUN(float, double, double, 1); else if (M.maxc <= 4) RUN(float, double, double, 4); else RUN(float, double, double, 8); }

@@ -40,12 +40,13 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     dbg = np.zeros((B, spec.Nb, 512)) if debug else None
     ncc = 5 * len(spec.contacts)
     dc = np.zeros((B, max(ncc, 1), nx)) if (grad and quad and ncc) else None
+    stor = np.zeros((B, spec.Nb, 25))
     err = C.create_string_buffer(256)
     rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
-                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc))
+                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor))
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
-    out = dict(z_next=Zn, status=st, iters=it, vel=vel, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])
+    out = dict(z_next=Zn, status=st, iters=it, vel=vel, storage=stor, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])
     if debug:
         out["dbg"] = dbg
     if grad:

@@ -104,3 +104,20 @@ def test_contact_data_gradients_ant():
     r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=0)
     assert info["status"] == 0 and r["status"][0] == 0
     assert np.abs(r["dc"][0] - dco).max() < 1e-6 * max(1.0, np.abs(dco).max())
+
+
+@pytest.mark.parametrize("cfg,pre,quad", [(1, 0, True), (2, 40, True), (4, 10, True), (2, 40, False)])
+def test_storage_rows_match_oracle(cfg, pre, quad):
+    """save_to_storage! rows (storage.jl:50-67): the device computes the momenta from the body residual of the solved
+    step (dj::storage_row), the oracle from the joint impulses as momentum.jl:17-53 does."""
+    spec = d.baseline_config(cfg)
+    opts = d.SolverOptions(rtol=1e-10, btol=1e-10)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z = Z[0].copy()
+    for _ in range(pre):
+        z, _ = o.step(z, U[0])
+    S, st = o.simulate_storage(z, U[:1])
+    r = emu_step(spec, z[None], U[:1], opts=opts, quad=quad)
+    assert st[0] == 0 and r["status"][0] == 0
+    assert np.abs(r["storage"][0] - S[0]).max() < 1e-9 * max(1.0, np.abs(S[0]).max())

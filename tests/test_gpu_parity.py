@@ -407,3 +407,93 @@ def test_baseline_sizes_size_independent_properties(cfg, batch, grad):
         assert np.isfinite(dz[ok]).all() and np.isfinite(du[ok]).all()
         assert np.array_equal(dz[ok], dz[batch - 64 + ok])
     gm.close()
+
+
+@pytest.mark.parametrize("cfg,batch,H,pre", [(1, 16, 6, 0), (2, 16, 6, 60), (3, 32, 5, 4), (4, 16, 5, 6), (5, 4, 3, 2)])
+def test_simulate_storage_matches_oracle(cfg, batch, H, pre):
+    """dojo_simulate = simulate!(...; record=true) (simulate.jl:16-37): the Storage rows written on the
+    device against the oracle's save_to_storage! (storage.jl:50-67; momenta from the joint impulses, momentum.jl:17-53),
+    and the trajectory against dojo_rollout bit for bit."""
+    spec = d.baseline_config(cfg)
+    Z, U = d.synthetic_inputs(spec, batch)
+    o = Oracle(spec, opts=TIGHT)
+    for _ in range(pre):
+        Z, _, _, _, _ = o.step_batch(Z, U, nthreads=16)
+    Uh = np.random.default_rng(5).normal(size=(H, batch, spec.nu)) * 0.3
+    if spec.nu >= 6 and cfg != 1:
+        Uh[:, :, :6] = 0.0
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=TIGHT)
+    Zt, S, st = gm.simulate(Z, Uh)
+    Zr, st_r = gm.rollout(Z, Uh)
+    assert np.array_equal(Zt, Zr) and np.array_equal(st, st_r)
+    nchecked = 0; errs0 = []; errs = []
+    for b in range(batch):
+        So, st_o = o.simulate_storage(Z[b], Uh[:, b])
+        good = 0
+        while good < H and st[good, b] == 0 and st_o[good] == 0:
+            good += 1
+        if good == 0:
+            continue
+        scale = max(1.0, np.abs(So[:good]).max())
+        # the pose / velocity columns of row 0 are the inputs themselves; later rows follow the two solvers' own
+        # trajectories (parity criterion above: an almost-active contact moves a light foot by ~btol/(s m) per step)
+        assert np.abs(S[0, b, :, 0:13] - So[0, :, 0:13]).max() < 1e-12
+        errs0.append(np.abs(S[0, b] - So[0]).max() / scale)
+        errs.append(np.abs(S[:good, b] - So[:good]).max() / scale)
+        nchecked += good
+    assert nchecked >= batch * H // 2
+    errs0, errs = np.array(errs0), np.array(errs)
+    assert np.quantile(errs0, 0.9) < 1e-6 and errs0.max() < 1e-4, (np.quantile(errs0, 0.9), errs0.max())
+    assert np.quantile(errs, 0.8) < 1e-5 and errs.max() < 1e-3, (np.quantile(errs, 0.8), errs.max())
+    # row k holds the state step k was solved at: x2/q2/v15/w15 of row k+1 = z after step k (simulate.jl:32 updates after saving)
+    zt = Zt.reshape(H, batch, spec.Nb, 13)
+    assert np.array_equal(S[1:, :, :, 0:3], zt[:-1, :, :, 0:3]) and np.array_equal(S[1:, :, :, 3:7], zt[:-1, :, :, 6:10])
+    assert np.array_equal(S[1:, :, :, 7:10], zt[:-1, :, :, 3:6]) and np.array_equal(S[1:, :, :, 10:13], zt[:-1, :, :, 10:13])
+    gm.close()
+
+
+@pytest.mark.parametrize("name,batch", [("ant", 4096), ("atlas", 256)])
+def test_storage_momentum_conservation_full_batch(name, batch):
+    """Size-independent property at the BASELINE batch (test/momentum.jl:45-68): no gravity, no contacts => the total linear
+    and angular momentum recorded in the device Storage stay constant under joint forces, dampers, limits and controls."""
+    spec = d.get_mechanism(name, gravity=0.0, contact_feet=False, contact_body=False)
+    Z0, _ = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (batch // 64, 1))
+    H = 6
+    Uh = np.random.default_rng(9).normal(size=(H, batch, spec.nu)) * 0.5
+    Uh[:, :, :6] = 0.0
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=opts)
+    Zt, S, st = gm.simulate(Z, Uh)
+    ok = (st == 0).all(axis=0)
+    assert ok.mean() > 0.95
+    P = S[:, :, :, 13:16].sum(axis=2)
+    L = (S[:, :, :, 16:19] + np.cross(S[:, :, :, 0:3], S[:, :, :, 13:16])).sum(axis=2)
+    assert np.abs(P - P[0])[:, ok].max() < 1e-7 and np.abs(L - L[0])[:, ok].max() < 1e-7
+    m = np.array([b.mass for b in spec.bodies])
+    assert np.abs(S[..., 19:22] * m[None, None, :, None] - S[..., 13:16])[:, ok].max() < 1e-12 * max(1.0, np.abs(S[..., 13:16]).max())
+    gm.close()
+
+
+def test_observe_ant_ars_state():
+    """get_state(::AntARS) (DojoEnvironments ant_ars.jl:72-80) = [minimal state; clamp(normal impulse, -1, 1) per contact]."""
+    from dojo_amd import coords
+    spec = d.baseline_config(3)
+    B = 256
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    for _ in range(6):
+        Z, st, it = gm.step(Z, U)
+    obs = gm.observe(contact_forces=True)
+    vel, ji, cs = gm.get_solution()
+    Nc = len(spec.contacts)
+    assert obs.shape == (B, 2 * spec.nu + Nc)
+    assert np.array_equal(obs[:, :2 * spec.nu], gm.maximal_to_minimal(Z))
+    gam_n = cs.reshape(B, Nc, 8)[:, :, 4]
+    assert np.array_equal(obs[:, 2 * spec.nu:], np.clip(gam_n, -1.0, 1.0))
+    assert (gam_n > 1.0).any() or (gam_n > 1e-3).any()         # some feet are on the ground in this batch
+    for b in range(0, 64, 9):
+        assert np.abs(obs[b, :2 * spec.nu] - coords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
+    assert np.array_equal(gm.observe(), obs[:, :2 * spec.nu])
+    gm.close()

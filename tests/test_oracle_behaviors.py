@@ -149,3 +149,22 @@ def test_ift_gradient_matches_finite_difference_of_step(cfg, steps_before):
     scale = max(1.0, np.abs(dz).max())
     assert np.abs(fd_dz - dz).max() / scale < 2e-4, (np.abs(fd_dz - dz).max(), scale)
     assert np.abs(fd_du - du).max() / max(1.0, np.abs(du).max()) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["ant", "quadruped", "atlas"])
+def test_storage_momentum_is_conserved(name):
+    """test/momentum.jl:45-68 in spirit, on the Storage the oracle records (save_to_storage!, storage.jl:50-67): without
+    gravity and contacts the total linear momentum Σ px and the total angular momentum Σ (pq + x × px) stay constant
+    under joint forces, dampers, limits and controls on the actuated joints (reference bound: 1e-8)."""
+    spec = d.get_mechanism(name, gravity=0.0, contact_feet=False, contact_body=False)
+    o = Oracle(spec, opts=d.SolverOptions(rtol=1e-12, btol=1e-12))
+    Z, _ = d.synthetic_inputs(spec, 1)
+    U = np.random.default_rng(3).normal(size=(6, spec.nu)) * 0.5
+    U[:, :6] = 0.0                                            # the floating base is not actuated
+    S, st = o.simulate_storage(Z[0], U)
+    assert all(s == 0 for s in st)
+    P = S[:, :, 13:16].sum(axis=1)
+    L = (S[:, :, 16:19] + np.cross(S[:, :, 0:3], S[:, :, 13:16])).sum(axis=1)
+    assert np.abs(P - P[0]).max() < 1e-8 and np.abs(L - L[0]).max() < 1e-8
+    # vl = px / m and the stored pose / velocity columns are the pre-update state of each step
+    assert np.abs(S[0, :, 0:3] - Z[0].reshape(spec.Nb, 13)[:, 0:3]).max() == 0.0
