@@ -685,7 +685,9 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
 // and, with contact_forces != 0, the clamped normal impulses of the last step behind it (ant_ars.jl:72-80).
 // obs [B, 2nu (+ Nc)]
 int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_forces, void* stream) {
-    if (!s || !z || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (!s || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (!z) z = s->d_zn;                   // the state the last host-buffer / minimal-coordinate step left on the handle
+    if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
     if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const int Nc = contact_forces ? s->M.Nc : 0, ld = 2 * s->M.nu + Nc;

@@ -212,7 +212,8 @@ int  dojo_simulate_dev(DojoHandle h, const void* z0, const void* U, int32_t H, v
  * of the mechanism, and with contact_forces != 0 the normal impulse of every contact of the last step clamped to
  * [-1, 1] behind it (get_state(::AntARS), ant_ars.jl:72-80).  obs [B, 2*nu (+ Nc)].
  * dojo_observe reads the state the last dojo_step / dojo_step_minimal / dojo_rollout left on the handle; the device
- * variant takes that state z [B, 13Nb] explicitly (the z_next of the step enqueued before it on `stream`). */
+ * variant takes that state z [B, 13Nb] explicitly (the z_next of the step enqueued before it on `stream`; NULL = the
+ * state kept on the handle, e.g. after dojo_step_minimal_dev). */
 int  dojo_observe(DojoHandle h, void* obs, int32_t contact_forces);
 int  dojo_observe_dev(DojoHandle h, const void* z, void* obs, int32_t contact_forces, void* stream);
 

@@ -497,3 +497,49 @@ def test_observe_ant_ars_state():
         assert np.abs(obs[b, :2 * spec.nu] - coords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
     assert np.array_equal(gm.observe(), obs[:, :2 * spec.nu])
     gm.close()
+
+
+def test_batched_environment_ant_ars_rollout():
+    """DojoEnvironments' AntARS through dojo_amd.envs.BatchedEnvironment (step! / get_state on device tensors) and the
+    batched rollout_policy of examples/ant_ars_device.py against the same loop driven by the oracle, one environment at a time
+    (examples/learning/ant_ars.jl:78-115)."""
+    import sys, os
+    import torch
+    from dojo_amd import coords
+    from dojo_amd.envs import BatchedEnvironment
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import ant_ars_device as ars
+    B, H = 8, 6
+    env = BatchedEnvironment("ant_ars", B, dtype="f64", opts=TIGHT)
+    spec = env.spec
+    assert env.nx == 28 and env.nobs == 37                    # ant_ars.jl:53-56, examples/learning/ant_ars.jl:181
+    na = spec.nu - 6
+    rng = np.random.default_rng(11)
+    theta = rng.normal(size=(B, na, env.nobs)) * 0.05
+    norm = ars.Normalizer(env.nobs, env.torch_dtype, env.device)
+    R = ars.rollout_policy(torch.tensor(theta, device=env.device), env, norm, H, observe=False).cpu().numpy()
+    final = env.get_state().cpu().numpy()
+    # the oracle-driven loop
+    o = Oracle(spec, opts=TIGHT)
+    Nc = len(spec.contacts)
+    dt = spec.timestep
+    ferr = []
+    for b in range(B):
+        x = coords.nominal_minimal(spec)
+        gam = np.ones(Nc)
+        reward = 0.0
+        for k in range(H):
+            state = np.concatenate([x, np.clip(gam, -1, 1)])
+            action = theta[b] @ (state / np.sqrt(1e-2))          # untouched Normalizer: mean 0, var clamped to 1e-2
+            zn, info = o.step(coords.minimal_to_maximal(spec, x), np.concatenate([np.zeros(6), action]))
+            assert info["status"] == 0
+            sol = o.get_solution()
+            gam = sol[spec.n_joint_impulses + 6 * spec.Nb:].reshape(Nc, 8)[:, 4]
+            xa = coords.maximal_to_minimal(spec, zn)
+            reward += 100.0 * (xa[0] - x[0]) / dt - 0.005 * action @ action - 0.5e-3 * (np.clip(gam, -1, 1) ** 2).sum() + 0.05
+            x = xa
+        assert abs(R[b] - reward) < 1e-4 * max(1.0, abs(reward)), (b, R[b], reward)
+        ferr.append(np.abs(final[b] - np.concatenate([x, np.clip(gam, -1, 1)])).max())
+    # six closed-loop steps of two solvers that agree to the solver tolerance per step (parity criterion above)
+    assert np.median(ferr) < 1e-5 and max(ferr) < 1e-3, ferr
+    env.close()
