@@ -432,7 +432,9 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
     }
     // ---------------- rotational damper (implicit in the candidate velocities): rotational/dampers.jl:4-30 ----------------
     if (P.damper_on && P.nl_r < 3 && P.damper_r != T(0)) {
-        T ca = tsqrt(T(4) / (dt * dt) - v3dot(wa, wa)), cb = tsqrt(T(4) / (dt * dt) - v3dot(wb, wb));
+        const T idt = trcp(dt), four_dt2 = T(4) * idt * idt;
+        T ca = tsqrt(four_dt2 - v3dot(wa, wa)), cb = tsqrt(four_dt2 - v3dot(wb, wb));
+        const T ica = trcp(ca), icb = trcp(cb);
         T h = dt * T(0.5);
         T wab[3];
         m3vec(wab, cfg.Rba, wa);                     // ωa expressed in the child frame
@@ -444,7 +446,7 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
         rotvec(rv, qd);
         T force[3] = {0, 0, 0};                      // damper · Aᵀ A rotvec / Δt   (offset frame)
         const int nur = 3 - P.nl_r;
-        for (int i = 0; i < 3; ++i) if (i < nur) { T vel = v3dot(&P.Ar[3 * i], rv) / dt; for (int k = 0; k < 3; ++k) force[k] += P.damper_r * P.Ar[3 * i + k] * vel; }
+        for (int i = 0; i < 3; ++i) if (i < nur) { T vel = v3dot(&P.Ar[3 * i], rv) * idt; for (int k = 0; k < 3; ++k) force[k] += P.damper_r * P.Ar[3 * i + k] * vel; }
         T ta[3], tb[3];
         m3vec(ta, cfg.Roff, force);                  // parent: vector_rotate(force, qoff)
         m3vec(tb, cfg.Rba, ta);                      // child: −R(qb⁻¹ qa qoff) force
@@ -459,12 +461,12 @@ DJ_HD void joint_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg
                 rowR(r1, row, roa);                  // row · R(ρa) : δqd = R(ρa) δξb⁻¹
                 rowL(r2, row, xbi);                  // row · L(ξb⁻¹): δqd = L(ξb⁻¹) δρa
                 for (int j = 0; j < 3; ++j) {
-                    gb[j] = (T(0.5)) * (-r1[0] * wb[j] / cb + r1[1 + j]);                 // (1/Δt)(Δt/2)[−ωbᵀ/cb; I]
+                    gb[j] = (T(0.5)) * (-r1[0] * wb[j] * icb + r1[1 + j]);                 // (1/Δt)(Δt/2)[−ωbᵀ/cb; I]
                     ga0[j] = r2[1 + j];
                 }
                 // [−ωaᵀ/ca; −Rba]: contribution −r2[0] ωa/ca − Rbaᵀ r2[1:3]
                 m3tvec(ga, cfg.Rba, ga0);
-                for (int j = 0; j < 3; ++j) ga[j] = T(0.5) * (-r2[0] * wa[j] / ca - ga[j]);
+                for (int j = 0; j < 3; ++j) ga[j] = T(0.5) * (-r2[0] * wa[j] * ica - ga[j]);
                 for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) {
                     dFa[3 * k + j] += P.damper_r * P.Ar[3 * i + k] * ga[j];
                     dFb[3 * k + j] += P.damper_r * P.Ar[3 * i + k] * gb[j];
@@ -699,19 +701,20 @@ DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& k
 }
 
 // second-order-cone helpers: src/contacts/cone.jl, src/solver/line_search.jl:98-139
-template <class T> DJ_HD T ort_step(T lam, T dl, T tau) { return dl < T(0) ? tmin(T(1), -tau * lam / dl) : T(1); }
+template <class T> DJ_HD T ort_step(T lam, T dl, T tau) { return dl < T(0) ? tmin(T(1), -tau * lam * trcp(dl)) : T(1); }
 template <class T> DJ_HD T soc_step(const T* l, const T* d, T tau) {
     const T eps = T(1e-14);
     T l0 = l[0];
     T ll = tmax(l0 * l0 - (l[1] * l[1] + l[2] * l[2]), T(1e-25));
     ll += eps;
     T ld = l0 * d[0] - (l[1] * d[1] + l[2] * d[2]) + eps;
-    T rs = ld / ll, sq = tsqrt(ll);
-    T f = (ld / sq + d[0]) / (l0 / sq + T(1));
-    T r1 = d[1] / sq - f * l[1] / ll, r2 = d[2] / sq - f * l[2] / ll;
+    const T ill = trcp(ll), sq = tsqrt(ll), isq = trcp(sq);
+    T rs = ld * ill;
+    T f = (ld * isq + d[0]) * trcp(l0 * isq + T(1));
+    T r1 = d[1] * isq - f * l[1] * ill, r2 = d[2] * isq - f * l[2] * ill;
     T nr = tsqrt(r1 * r1 + r2 * r2);
     T a = T(1);
-    if (nr - rs > T(0)) a = tmin(a, tau / (nr - rs));
+    if (nr - rs > T(0)) a = tmin(a, tau * trcp(nr - rs));
     return a;
 }
 
@@ -918,8 +921,9 @@ struct LaneProgram {
             {
                 T Sw[9], SJw[9], SwJ[9];
                 m3skew(Sw, L.w); m3skew(SJw, Jw); m3mul(SwJ, Sw, P.J);
+                const T ic = trcp(kb.c);
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
-                    Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[j] / kb.c + SwJ[3 * i + j] - SJw[3 * i + j]);
+                    Dw[3 * i + j] = T(0.5) * dt * (kb.c * P.J[3 * i + j] - Jw[i] * L.w[j] * ic + SwJ[3 * i + j] - SJw[3 * i + j]);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -996,15 +1000,16 @@ struct LaneProgram {
         Q.g0 = gam[1] + T(REG); Q.g1 = gam[2]; Q.g2 = gam[3];
         Q.h0 = s[1] + T(REG); Q.h1 = s[2]; Q.h2 = s[3];
         // Δγ1 = a1 + b1 (C1Δw):  γ̃1 Δs1 + s̃1 Δγ1 = r1, Δs1 = C1Δw − r5
-        Q.a1 = (rc[0] + g1t * r58[0]) / s1t; Q.b1 = -g1t / s1t;
-        T ih = T(1) / Q.h0;
+        const T is1 = trcp(s1t);
+        Q.a1 = (rc[0] + g1t * r58[0]) * is1; Q.b1 = -g1t * is1;
+        T ih = trcp(Q.h0);
         Q.al3 = Q.g1 - Q.h1 * Q.g0 * ih; Q.al4 = Q.g2 - Q.h2 * Q.g0 * ih; Q.al2 = Q.h0 - (Q.h1 * Q.h1 + Q.h2 * Q.h2) * ih;
         Q.den = Q.g0 - (Q.h1 * Q.g1 + Q.h2 * Q.g2) * ih;
         // Δγ2 = μf Δγ1 − r6 = (μf a1 − r6) + μf b1 (C1Δw); Δs3 = C3Δw − r7; Δs4 = C4Δw − r8
         T r2p = rc[1] - (Q.h1 * rc[2] + Q.h2 * rc[3]) * ih;
         T dg2_0 = K.mu * Q.a1 - r58[1], dg2_1 = K.mu * Q.b1;
         // Δs2 = [r2p − al3 Δs3 − al4 Δs4 − al2 Δγ2] / den
-        T id = T(1) / Q.den;
+        T id = trcp(Q.den);
         T s2_0 = (r2p + Q.al3 * r58[2] + Q.al4 * r58[3] - Q.al2 * dg2_0) * id;
         T s2_c1 = -Q.al2 * dg2_1 * id, s2_c3 = -Q.al3 * id, s2_c4 = -Q.al4 * id;
         // Δγ3 = (r3 − g1Δs2 − g0Δs3 − h1Δγ2)/h0 ; Δγ4 = (r4 − g2Δs2 − g0Δs4 − h2Δγ2)/h0
@@ -1042,7 +1047,7 @@ struct LaneProgram {
         }
         // limit condensation: rows x get + wκ t_x (θ_a Δω_a + θ_b Δω_b)
         if (P.nlim_r > 0) {
-            T wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
+            T wk = (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG));
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1535,10 +1540,11 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += ccold(c).G134[6 * a + i] * Q[c].k0[a];
             }
         }
-        T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0);
+        T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0), isu = T(0), isl = T(0);
         if (P.nlim_r > 0) {
             su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
-            kap0 = (R.lim[1] - gl * rsl) / sl - (R.lim[0] - gu * rsu) / su;
+            isu = trcp(su); isl = trcp(sl);
+            kap0 = (R.lim[1] - gl * rsl) * isl - (R.lim[0] - gu * rsu) * isu;
             for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; up[i] += F.t_a[i] * kap0; }
         }
         T dk[12], dva[6];
@@ -1549,8 +1555,8 @@ struct LaneProgram {
         if (P.nlim_r > 0) {
             T thd = v3dot(F.th_a, dva + 3) + v3dot(F.th_b, D.dw);
             D.dls[0] = rsu - thd; D.dls[1] = rsl + thd;
-            D.dlg[0] = (R.lim[0] - gu * D.dls[0]) / su;
-            D.dlg[1] = (R.lim[1] - gl * D.dls[1]) / sl;
+            D.dlg[0] = (R.lim[0] - gu * D.dls[0]) * isu;
+            D.dlg[1] = (R.lim[1] - gl * D.dls[1]) * isl;
         } else { D.dls[0] = D.dls[1] = D.dlg[0] = D.dlg[1] = T(0); }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -1562,9 +1568,9 @@ struct LaneProgram {
                 T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
                 T dg1 = q.a1 + q.b1 * cw[0];
                 T dg2 = K.mu * dg1 - r58[c][1];
-                T ih = T(1) / q.h0;
+                T ih = trcp(q.h0);
                 T r2p = R.cc[c][1] - (q.h1 * R.cc[c][2] + q.h2 * R.cc[c][3]) * ih;
-                T ds2 = (r2p - q.al3 * ds3 - q.al4 * ds4 - q.al2 * dg2) / q.den;
+                T ds2 = (r2p - q.al3 * ds3 - q.al4 * ds4 - q.al2 * dg2) * trcp(q.den);
                 T dg3 = (R.cc[c][2] - q.g1 * ds2 - q.g0 * ds3 - q.h1 * dg2) * ih;
                 T dg4 = (R.cc[c][3] - q.g2 * ds2 - q.g0 * ds4 - q.h2 * dg2) * ih;
                 D.dcs[c][0] = ds1; D.dcs[c][1] = ds2; D.dcs[c][2] = ds3; D.dcs[c][3] = ds4;

@@ -35,6 +35,13 @@ DJ_CDECL(dojo_launch_cgrad_float_4_2) DJ_CDECL(dojo_launch_cgrad_double_4_2)
 #undef DJ_DECL
 }
 
+// temporary device buffer of a host-pointer entry point: freed on every return path
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return DOJO_ERR_DEVICE; } } while (0)
 
 } // namespace
@@ -400,6 +407,8 @@ int dojo_device_count(void) {
     return n;
 }
 
+void dojo_destroy(DojoHandle s);
+
 int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t device, DojoHandle* out) {
     if (!topo || !out || batch < 1 || (dtype != DOJO_DTYPE_F64 && dtype != DOJO_DTYPE_F32)) { g_err = "dojo_create: bad argument"; return DOJO_ERR_INVALID; }
     int ndev = dojo_device_count();
@@ -410,22 +419,22 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
     s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
     s->opts = dj::default_options();
-    HIPCHK(hipSetDevice(device));
+    if (hipSetDevice(device) != hipSuccess) { g_err = "dojo_create: hipSetDevice failed"; delete s; return DOJO_ERR_DEVICE; }
     rc = upload_tables<double>(s);
-    if (rc != DOJO_OK) { delete s; return rc; }
+    if (rc != DOJO_OK) { dojo_destroy(s); return rc; }          // frees whatever part of the tables was uploaded
     *out = s;
     return DOJO_OK;
 }
 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
-    hipSetDevice(s->device);
+    (void)hipSetDevice(s->device);
     void* ps[] = {s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
-    for (void* p : ps) if (p) hipFree(p);
-    for (auto g_ : s->gstreams) hipStreamDestroy(g_);
-    for (auto gev_ : s->gevents) hipEventDestroy(gev_);
-    if (s->fork_event) hipEventDestroy(s->fork_event);
-    for (auto& e : s->ring) { if (e.a) hipEventDestroy(e.a); if (e.m) hipEventDestroy(e.m); if (e.b) hipEventDestroy(e.b); }
+    for (void* p : ps) if (p) (void)hipFree(p);
+    for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
+    for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
+    if (s->fork_event) (void)hipEventDestroy(s->fork_event);
+    for (auto& e : s->ring) { if (e.a) (void)hipEventDestroy(e.a); if (e.m) (void)hipEventDestroy(e.m); if (e.b) (void)hipEventDestroy(e.b); }
     delete s;
 }
 
@@ -605,24 +614,22 @@ static int rollout_host(DojoHandle s, const void* z0, const void* U, int32_t H, 
     if (!s || !z0 || H < 1) { g_err = "dojo_rollout: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
-    void *dz0 = nullptr, *dU = nullptr, *dZ = nullptr, *dSt = nullptr; int* dS = nullptr;
+    DevBuf dz0, dU, dZ, dSt, dS;
     const size_t nst = (size_t)H * B * 25 * s->M.Nb * w;
-    if (storage) HIPCHK(hipMalloc(&dSt, nst));
-    HIPCHK(hipMalloc(&dz0, B * nz * w));
-    HIPCHK(hipMemcpy(dz0, z0, B * nz * w, hipMemcpyHostToDevice));
-    if (U && nu) { HIPCHK(hipMalloc(&dU, (size_t)H * B * nu * w)); HIPCHK(hipMemcpy(dU, U, (size_t)H * B * nu * w, hipMemcpyHostToDevice)); }
-    if (Z) HIPCHK(hipMalloc(&dZ, (size_t)H * B * nz * w));
-    if (status) HIPCHK(hipMalloc((void**)&dS, (size_t)H * B * sizeof(int)));
-    int rc = rollout_core(s, dz0, dU, H, dZ, dS, dSt, nullptr);
-    if (rc == DOJO_OK) {
-        HIPCHK(hipDeviceSynchronize());
-        if (storage) HIPCHK(hipMemcpy(storage, dSt, nst, hipMemcpyDeviceToHost));
-        if (Z) HIPCHK(hipMemcpy(Z, dZ, (size_t)H * B * nz * w, hipMemcpyDeviceToHost));
-        if (status) HIPCHK(hipMemcpy(status, dS, (size_t)H * B * sizeof(int), hipMemcpyDeviceToHost));
-        if (Z) HIPCHK(hipMemcpy(s->d_zn, (char*)dZ + (size_t)(H - 1) * B * nz * w, B * nz * w, hipMemcpyDeviceToDevice));
-    }
-    hipFree(dz0); if (dU) hipFree(dU); if (dZ) hipFree(dZ); if (dS) hipFree(dS); if (dSt) hipFree(dSt);
-    return rc;
+    if (storage) HIPCHK(dSt.alloc(nst));
+    HIPCHK(dz0.alloc(B * nz * w));
+    HIPCHK(hipMemcpy(dz0.p, z0, B * nz * w, hipMemcpyHostToDevice));
+    if (U && nu) { HIPCHK(dU.alloc((size_t)H * B * nu * w)); HIPCHK(hipMemcpy(dU.p, U, (size_t)H * B * nu * w, hipMemcpyHostToDevice)); }
+    if (Z) HIPCHK(dZ.alloc((size_t)H * B * nz * w));
+    if (status) HIPCHK(dS.alloc((size_t)H * B * sizeof(int)));
+    int rc = rollout_core(s, dz0.p, dU.p, H, dZ.p, (int32_t*)dS.p, dSt.p, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (storage) HIPCHK(hipMemcpy(storage, dSt.p, nst, hipMemcpyDeviceToHost));
+    if (Z) HIPCHK(hipMemcpy(Z, dZ.p, (size_t)H * B * nz * w, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, dS.p, (size_t)H * B * sizeof(int), hipMemcpyDeviceToHost));
+    if (Z) HIPCHK(hipMemcpy(s->d_zn, (char*)dZ.p + (size_t)(H - 1) * B * nz * w, B * nz * w, hipMemcpyDeviceToDevice));
+    return DOJO_OK;
 }
 
 int dojo_get_state(DojoHandle s, void* z) {
@@ -647,19 +654,17 @@ int dojo_contact_gradients(DojoHandle s, void* dc) {
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nx = 12 * s->M.Nb, ncc = 5 * (size_t)s->M.Nc;
     if (ncc == 0) return DOJO_OK;
-    void* d_dc = nullptr;
-    HIPCHK(hipMalloc(&d_dc, B * nx * ncc * w));
-    int rc = dojo_contact_gradients_dev(s, s->d_z, s->have_u ? s->d_u : nullptr, d_dc, nullptr);
-    if (rc == DOJO_OK) {
-        HIPCHK(hipDeviceSynchronize());
-        // device layout: [B][5Nc columns][12Nb rows] -> host layout [B, 12Nb, 5Nc] row-major
-        std::vector<char> tmp(B * nx * ncc * w);
-        HIPCHK(hipMemcpy(tmp.data(), d_dc, tmp.size(), hipMemcpyDeviceToHost));
-        for (size_t b = 0; b < B; ++b) for (size_t c = 0; c < ncc; ++c) for (size_t r = 0; r < nx; ++r)
-            std::memcpy((char*)dc + ((b * nx + r) * ncc + c) * w, tmp.data() + ((b * ncc + c) * nx + r) * w, w);
-    }
-    hipFree(d_dc);
-    return rc;
+    DevBuf d_dc;
+    HIPCHK(d_dc.alloc(B * nx * ncc * w));
+    int rc = dojo_contact_gradients_dev(s, s->d_z, s->have_u ? s->d_u : nullptr, d_dc.p, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    // device layout: [B][5Nc columns][12Nb rows] -> host layout [B, 12Nb, 5Nc] row-major
+    std::vector<char> tmp(B * nx * ncc * w);
+    HIPCHK(hipMemcpy(tmp.data(), d_dc.p, tmp.size(), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b) for (size_t c = 0; c < ncc; ++c) for (size_t r = 0; r < nx; ++r)
+        std::memcpy((char*)dc + ((b * nx + r) * ncc + c) * w, tmp.data() + ((b * ncc + c) * nx + r) * w, w);
+    return DOJO_OK;
 }
 
 // ---- minimal <-> maximal coordinates ----
@@ -706,12 +711,13 @@ int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
     if (!s || !obs || !s->d_zn || !s->have_solution) { g_err = "dojo_observe: no step has been taken on this handle"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const size_t ld = 2 * s->M.nu + (contact_forces ? s->M.Nc : 0), bytes = (size_t)s->B * ld * s->w;
-    void* d = nullptr;
-    HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
-    int rc = dojo_observe_dev(s, s->d_zn, d, contact_forces, s->stream);
-    if (rc == DOJO_OK) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(obs, d, bytes, hipMemcpyDeviceToHost)); }
-    hipFree(d);
-    return rc;
+    DevBuf d;
+    HIPCHK(d.alloc(bytes));
+    int rc = dojo_observe_dev(s, s->d_zn, d.p, contact_forces, s->stream);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(obs, d.p, bytes, hipMemcpyDeviceToHost));
+    return DOJO_OK;
 }
 // step_minimal_coordinates!  src/simulation/step.jl:42-60: x -> z -> step! -> z' -> x'
 int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {
@@ -777,8 +783,9 @@ int dojo_minimal_gradients(DojoHandle s, const void* x, const void* u, void* x_n
     if ((rc = ensure(&s->d_u, B * (nu + 1) * w))) return rc;
     if ((rc = ensure((void**)&s->d_status, B * sizeof(int)))) return rc;
     if ((rc = ensure((void**)&s->d_iters, B * sizeof(int)))) return rc;
-    void *d_jx = nullptr, *d_ju = nullptr;
-    HIPCHK(hipMalloc(&d_jx, B * nm * nm * w)); HIPCHK(hipMalloc(&d_ju, B * nm * (nu + 1) * w));
+    DevBuf bjx, bju;
+    HIPCHK(bjx.alloc(B * nm * nm * w)); HIPCHK(bju.alloc(B * nm * (nu + 1) * w));
+    void *d_jx = bjx.p, *d_ju = bju.p;
     HIPCHK(hipMemcpy(s->d_x, x, B * nm * w, hipMemcpyHostToDevice));
     if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
     rc = dojo_minimal_gradients_dev(s, s->d_x, (u && nu) ? s->d_u : nullptr, s->d_xn, s->d_status, s->d_iters, d_jx, d_ju, nullptr);
@@ -790,7 +797,6 @@ int dojo_minimal_gradients(DojoHandle s, const void* x, const void* u, void* x_n
         if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
         if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
     }
-    hipFree(d_jx); hipFree(d_ju);
     return rc;
 }
 
