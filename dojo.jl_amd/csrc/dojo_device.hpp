@@ -55,7 +55,7 @@ constexpr double REG = 1e-10;     // src/Dojo.jl:4
 
 template <class T>
 struct Globals {
-    T dt, input_scaling, g[3];
+    T dt, idt2 /* 1/dt² */, input_scaling, g[3];
     T rtol, btol, undercut, no_progress_undercut;
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
@@ -1659,10 +1659,10 @@ struct LaneProgram {
     DJ_HD int candidate_step(const SolSnap<T, MAXC>& B, const Step<T, MAXC>& D, T f) {
         int bad = 0;
         for (int i = 0; i < 3; ++i) { L.v[i] = B.v[i] + f * D.dv[i]; L.w[i] = B.w[i] + f * D.dw[i]; }
-        T wmax = T(3.9) / (G.dt * G.dt);
+        T wmax = T(3.9) * G.idt2;
         T wd = v3dot(L.w, L.w);
         if (wd > wmax) { T sc = wmax / wd; for (int i = 0; i < 3; ++i) L.w[i] *= sc; }
-        if (v3dot(L.w, L.w) > T(3.91) / (G.dt * G.dt)) bad = 1;
+        if (v3dot(L.w, L.w) > T(3.91) * G.idt2) bad = 1;
         for (int i = 0; i < 6; ++i) L.lam[i] = B.lam[i] + f * D.dlam[i];
         for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
 #pragma unroll

@@ -123,7 +123,7 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
 }
 template <class T> inline Globals<T> make_globals(const HostModel& M, const DojoSolverOptions& o, int grad_mode) {
     Globals<T> G;
-    G.dt = T(M.dt); G.input_scaling = T(M.input_scaling);
+    G.dt = T(M.dt); G.idt2 = T(1.0 / (M.dt * M.dt)); G.input_scaling = T(M.input_scaling);
     for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
     G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);
     G.max_iter = o.max_iter; G.max_ls = o.max_ls; G.no_progress_max = o.no_progress_max;

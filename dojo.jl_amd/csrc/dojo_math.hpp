@@ -127,22 +127,22 @@ template <class T> DJ_HD void phi_of(T* P, const T* w, T c, T dt) {
 }
 // rotation_vector(q) = 4 atan(|m|) m/|m|, m = v/(1+s)   (src/orientation/mrp.jl:61-64)
 template <class T> DJ_HD void rotvec(T* r, const T* q) {
-    T d = T(1) / (q[0] + T(1));
+    T d = trcp(q[0] + T(1));
     T m[3] = {q[1] * d, q[2] * d, q[3] * d};
     T mag = tsqrt(v3dot(m, m));
-    if (mag > T(0)) { T f = T(4) * tatan(mag) / mag; r[0] = f * m[0]; r[1] = f * m[1]; r[2] = f * m[2]; }
+    if (mag > T(0)) { T f = T(4) * tatan(mag) * trcp(mag); r[0] = f * m[0]; r[1] = f * m[1]; r[2] = f * m[2]; }
     else { r[0] = r[1] = r[2] = T(0); }
 }
 // aᵀ · drotation_vectordq(q): the 1x4 row  a·∂rotvec/∂q   (src/orientation/mrp.jl:66-78)
 template <class T> DJ_HD void rotvec_jac_row(T* row, const T* a, const T* q) {
-    T s1 = q[0] + T(1), di = T(1) / s1, d1 = di * di;
+    T s1 = q[0] + T(1), di = trcp(s1), d1 = di * di;
     T m[3] = {q[1] * di, q[2] * di, q[3] * di};
     T n2 = v3dot(m, m);
     if (n2 > T(0)) {
         T n = tsqrt(n2), th = T(4) * tatan(n);
         // d rotvec / d m = (4/(1+n²)) m̂ m̂ᵀ + (θ/n)(I − m̂ m̂ᵀ)
-        T am = v3dot(a, m) / n2;            // (a·m̂)/n ... times m gives (a·m̂) m̂
-        T k1 = T(4) / (T(1) + n2), k2 = th / n;
+        T am = v3dot(a, m) * trcp(n2);            // (a·m̂)/n ... times m gives (a·m̂) m̂
+        T k1 = T(4) * trcp(T(1) + n2), k2 = th * trcp(n);
         T g[3];                              // g = aᵀ · d rotvec/d m
         for (int i = 0; i < 3; ++i) g[i] = k2 * a[i] + (k1 - k2) * am * m[i];
         // d m / d q = [ −v/(1+s)² | I/(1+s) ]
