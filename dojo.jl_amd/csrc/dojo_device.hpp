@@ -1672,7 +1672,7 @@ struct LaneProgram {
 
     // ---------------------------------------------------------------- set-up of one step
     // set_maximal_state! + set_input! (src/mechanism/set.jl:10-53): loads z, applies u, builds dconst.
-    DJ_HD void begin_step(const T* zb /*13 values of this body*/, const T* u /*this joint's inputs (<= 6) or null*/) {
+    DJ_HD void begin_step(const T* zb /*13 values of this body*/, const T* u /*this joint's inputs (<= 6) or null*/, const T* fe = nullptr /*[Fext(3) world; τext(3) body] or null*/) {
         const T dt = G.dt;
         T v15[3] = {0, 0, 0}, w15[3] = {0, 0, 0};
         if (active) {
@@ -1712,6 +1712,8 @@ struct LaneProgram {
             L.dconst[i] = -P.m * v15[i] - dt * P.m * G.g[i];
             L.dconst[3 + i] = T(-0.5) * dt * (c15 * J15[i] - wxJ[i]);
         }
+        // external force / torque of the body (state.Fext, state.τext): −½Δt in D1 and again in D2 (constraint.jl:15-18)
+        if (fe != nullptr) for (int i = 0; i < 6; ++i) L.dconst[i] -= dt * fe[i];
         // control input: set_input! + input_impulse!  (joints/joint.jl:96-99, translational/input.jl:5-27, rotational/input.jl:5-17)
         T ina[6] = {0, 0, 0, 0, 0, 0};                          // what this joint's input applies to the parent body
         if (active && u != nullptr) {
@@ -2298,7 +2300,7 @@ struct LaneProgram {
 // zb = the body's 13 state values the step was solved at, v/w = its solution (v25, ω25), csg = [s(4); γ(4)] per contact
 // of the environment, rb = the body's six residual rows.  Shared by the HIP storage kernel and the SIMT emulator.
 template <class T, class TC>
-DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb) {
+DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb, const T* fe = nullptr) {
     const T x2[3] = {zb[0], zb[1], zb[2]}, v15[3] = {zb[3], zb[4], zb[5]}, q2[4] = {zb[6], zb[7], zb[8], zb[9]}, w15[3] = {zb[10], zb[11], zb[12]};
     Kin<T> kb;
     kin_of(kb, x2, q2, v, w, dt);
@@ -2319,6 +2321,8 @@ DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, c
         for (int i = 0; i < 6; ++i) p[i] += CE.imp[i];
     }
     for (int i = 0; i < 6; ++i) p[i] *= T(0.5);
+    // simulate! clears the external force before it records (simulate.jl:29-31): momentum's D2 is evaluated without it
+    if (fe != nullptr) for (int i = 0; i < 6; ++i) p[i] += T(0.5) * dt * fe[i];
     T R2[9], pw[3];
     qrot(R2, q2);
     m3vec(pw, R2, p + 3);                                      // vector_rotate(p_angular_body, q2)
@@ -2350,6 +2354,7 @@ struct KernelArgs {
     int B;                       // number of environments
     const TIO* z;                  // [B,13Nb]
     const TIO* u;                  // [B,nu] or null
+    const TIO* fext;               // [B,6Nb] or null          external force (world) and torque (body frame) per body
     TIO* z_next;                   // [B,13Nb]
     int* status;                 // [B] or null
     int* iters;                  // [B] or null
@@ -2463,7 +2468,10 @@ constexpr int FAC_PER_LANE = 72;
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
     const bool has_u = A.u != nullptr;                                                                                    \
     if (active && has_u) for (int i = 0; i < 6; ++i) if (i < P.nu_t + P.nu_r) ue[i] = T(A.u[(size_t)env * G.nu + P.u_off + i]); \
-    prog.begin_step(zb, has_u ? ue : nullptr);
+    T fe[6] = {0, 0, 0, 0, 0, 0};                                                                                         \
+    const bool has_f = A.fext != nullptr;                                                                                 \
+    if (active && has_f) for (int i = 0; i < 6; ++i) fe[i] = T(A.fext[(size_t)env * 6 * G.Nb + 6 * k + i]);             \
+    prog.begin_step(zb, has_u ? ue : nullptr, has_f ? fe : nullptr);
 
 // IFT kernel entry: one call per lane
 template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, int MODE = 0>

@@ -55,7 +55,8 @@ struct DojoSim {
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
     // internal device buffers used by the host-pointer entry points
-    void *d_res = nullptr, *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
+    const void* fext = nullptr;                     // device [B,6Nb] external forces applied by every step, or null (dojo_set_external_force)
+    void *d_fext = nullptr, *d_res = nullptr, *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
@@ -146,16 +147,17 @@ __global__ void contact_obs_kernel(int Nc, int B, const TIO* csg, TIO* obs, int 
 // was solved at and what the step kernel left behind (solution velocities, cone variables, body residual rows)
 template <class TIO>
 __global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double>* contacts, int Nb, int Nc, double dt, int env0, int nenv,
-                               const TIO* z, const TIO* vel, const TIO* csg, const TIO* res, TIO* storage) {
+                               const TIO* z, const TIO* vel, const TIO* csg, const TIO* res, const TIO* fext, TIO* storage) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / Nb, k = tid % Nb;
     if (e >= nenv) return;
     const size_t env = (size_t)env0 + e;
-    double zb[13], v[3], w[3], rb[6], row[25];
+    double zb[13], v[3], w[3], rb[6], row[25], fe[6];
+    if (fext) for (int i = 0; i < 6; ++i) fe[i] = (double)fext[env * 6 * Nb + 6 * k + i];
     for (int i = 0; i < 13; ++i) zb[i] = (double)z[env * 13 * Nb + 13 * k + i];
     for (int i = 0; i < 3; ++i) { v[i] = (double)vel[env * 6 * Nb + 6 * k + i]; w[i] = (double)vel[env * 6 * Nb + 6 * k + 3 + i]; }
     for (int i = 0; i < 6; ++i) rb[i] = (double)res[env * 6 * Nb + 6 * k + i];
-    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb);
+    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb, fext ? fe : (const double*)nullptr);
     TIO* o = storage + (env * Nb + k) * 25;
     for (int i = 0; i < 25; ++i) o[i] = (TIO)row[i];
 }
@@ -324,7 +326,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     dj::KernelArgs<TIO, T> A;
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode);
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
-    A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb);
+    A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
     A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
@@ -377,7 +379,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         const long long n = (long long)nenv * Nb; const int T_ = 128;
         hipLaunchKernelGGL((ckern::storage_kernel<TIO>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, st, (const dj::NodeP<double>*)s->d_nodes,
                            (const dj::ContactP<double>*)s->d_contacts, (int)Nb, s->M.Nc, s->M.dt, (int)env0, nenv,
-                           (const TIO*)z, (const TIO*)vel, (const TIO*)csg, (const TIO*)s->d_res, (TIO*)storage);
+                           (const TIO*)z, (const TIO*)vel, (const TIO*)csg, (const TIO*)s->d_res, (const TIO*)s->fext, (TIO*)storage);
         HIPCHK(hipGetLastError());
     }
     return DOJO_OK;
@@ -429,7 +431,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
@@ -449,6 +451,26 @@ int dojo_get_dims(DojoHandle s, DojoDims* d) {
 int dojo_set_options(DojoHandle s, const DojoSolverOptions* o) {
     if (!s || !o || o->max_iter < 1 || o->max_ls < 1) { g_err = "dojo_set_options: bad argument"; return DOJO_ERR_INVALID; }
     s->opts = *o; return DOJO_OK;
+}
+
+// set_external_force!(body; force, torque, vertex) (src/bodies/set.jl:110-115) for every body of every environment: state.Fext
+// (world frame) and state.τext (body frame) as they enter the body residual (integrators/constraint.jl:15-18)
+int dojo_set_external_force_dev(DojoHandle s, const void* fext) {
+    if (!s) { g_err = "dojo_set_external_force_dev: bad argument"; return DOJO_ERR_INVALID; }
+    s->fext = fext;
+    return DOJO_OK;
+}
+int dojo_set_external_force(DojoHandle s, const void* fext) {
+    if (!s) { g_err = "dojo_set_external_force: bad argument"; return DOJO_ERR_INVALID; }
+    if (!fext) { s->fext = nullptr; return DOJO_OK; }
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)s->B * 6 * s->M.Nb * s->w;
+    int rc;
+    if ((rc = ensure(&s->d_fext, bytes))) return rc;
+    HIPCHK(hipDeviceSynchronize());                          // steps still in flight read the previous forces
+    HIPCHK(hipMemcpy(s->d_fext, fext, bytes, hipMemcpyHostToDevice));
+    s->fext = s->d_fext;
+    return DOJO_OK;
 }
 
 int dojo_set_gradient_mode(DojoHandle s, int32_t mode) {

@@ -52,7 +52,8 @@ EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
                     "dojo_contact_gradients", "dojo_contact_gradients_dev", "dojo_minimal_gradients", "dojo_minimal_gradients_dev",
-                    "dojo_simulate", "dojo_simulate_dev", "dojo_observe", "dojo_observe_dev"]
+                    "dojo_simulate", "dojo_simulate_dev", "dojo_observe", "dojo_observe_dev",
+                    "dojo_set_external_force", "dojo_set_external_force_dev"]
 
 
 # columns of a Storage row (src/simulation/storage.jl:15-24)
@@ -149,6 +150,14 @@ class BatchedMechanism:
         st = np.empty((H, B), np.int32)
         _chk(lib().dojo_rollout(self.h, _p(z0), _p(U), H, _p(Z), _p(st)))
         return Z, st
+
+    def set_external_force(self, fext):
+        """set_external_force!(body; force, torque) for all bodies: fext [B, Nb, 6] = [Fext (world); τext (body frame)],
+        None removes them.  In effect for every following step (bodies/set.jl:110-115, constraint.jl:15-18)."""
+        if fext is None:
+            _chk(lib().dojo_set_external_force(self.h, None)); return
+        f = self._arr(np.asarray(fext).reshape(self.batch, 6 * self.spec.Nb), (self.batch, 6 * self.spec.Nb))
+        _chk(lib().dojo_set_external_force(self.h, _p(f)))
 
     def simulate(self, z0, U=None, steps=None):
         """simulate!(mechanism, 1:H, storage, control!; record=true) with pre-sampled controls (simulate.jl:16-37).

@@ -126,6 +126,11 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     return Z, status
 end
 
+"external forces for every body of every environment: fext[6, Nb, B] = [state.Fext (world); state.τext (body frame)]; `nothing` removes them"
+function set_external_force!(bm::BatchedMechanism{T}, fext::Union{Nothing,Array{T,3}}) where T
+    check(@ccall LIB.dojo_set_external_force(bm.handle::Ptr{Cvoid}, (fext === nothing ? C_NULL : pointer(fext))::Ptr{T})::Cint)
+end
+
 "simulate!(...; record=true): as above plus the Storage rows [25, Nb, B, H] (x q v ω px pq vl ωl, storage.jl:50-67)"
 function simulate_storage!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; opts=Dojo.SolverOptions{Float64}()) where T
     set_options!(bm, opts)
@@ -193,6 +198,9 @@ function hip_mehrotra!(m::Dojo.Mechanism; opts=Dojo.SolverOptions{Float64}())
     bm = HANDLES[m]
     z = reshape(Dojo.get_maximal_state(m), :, 1)
     u = reshape(zeros(bm.nu), :, 1)          # inputs were already applied to JF2/Jτ2 by set_input!; pass them via dojo_step's u in step! overloads
+    fext = Array{Float64,3}(undef, 6, length(m.bodies), 1)
+    for (i, b) in enumerate(m.bodies); fext[1:3, i, 1] = b.state.Fext; fext[4:6, i, 1] = b.state.τext; end
+    set_external_force!(bm, fext)
     zn, status = Dojo.step!(bm, z, u; opts)
     Nb = length(m.bodies)
     vel = Vector{Float64}(undef, 6Nb); ji = Vector{Float64}(undef, max(1, sum(length.(m.joints)))); cs = Vector{Float64}(undef, max(1, 8length(m.contacts)))

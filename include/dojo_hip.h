@@ -19,6 +19,7 @@
  *                         src/gradients/state.jl:69-126
  *   dojo_rollout       <- simulate!(mechanism, steps, storage, control!)  src/simulation/simulate.jl:16-36
  *                         with the control callback replaced by pre-sampled inputs U[k]
+ *   dojo_set_external_force <- set_external_force!(body; force, torque, vertex)  src/bodies/set.jl:110-115
  *   dojo_simulate      <- simulate!(...; record = true): the same rollout, recording save_to_storage! rows
  *                         src/simulation/storage.jl:50-67, momentum(mechanism, body) src/mechanics/momentum.jl:17-41
  *   dojo_observe       <- get_state(environment)  DojoEnvironments/src/environments.jl:100-102,
@@ -197,6 +198,15 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
                    int32_t* status, int32_t* iters, void* dz, void* du, void* stream);
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
+
+/* set_external_force!(body; force, torque, vertex)  src/bodies/set.jl:110-115, read by the body residual
+ * src/integrators/constraint.jl:15-18 (state.Fext, state.τext; a3 of SURVEY.md §8a).  fext [B, 6Nb]: per body the force
+ * in the world frame and the torque in the body frame, i.e. the two state fields after the reference's
+ * `vertex` arithmetic.  The forces stay in effect for every following step of the handle (step!, which never clears
+ * them; a rollout applies them at every step, as a controller that sets them at every step) until they are replaced
+ * or removed with NULL.  The host variant copies; the device variant keeps the caller's pointer. */
+int  dojo_set_external_force(DojoHandle h, const void* fext);
+int  dojo_set_external_force_dev(DojoHandle h, const void* fext);
 
 /* simulate!(mechanism, 1:H, storage, control!; record = true)  src/simulation/simulate.jl:16-37  (SURVEY.md §8f-2):
  * dojo_rollout plus the Storage of the trajectory, written by the step kernel itself.  storage [H, B, Nb, 25], one

@@ -86,7 +86,7 @@ struct EmuWaveT {
 template <class TIO, class T, class TL, int MAXC, bool QUAD, int NW = 1>
 void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, int B, int W,
          const double* z, const double* u, double* z_next, int* status, int* iters,
-         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr, double* storage = nullptr) {
+         double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr, double* storage = nullptr, const double* fext = nullptr) {
     std::vector<dj::NodeP<T>> nodes; for (auto& n : M.nodes) nodes.push_back(dj::cast_node<T>(n));
     std::vector<dj::ContactP<T>> contacts; for (auto& c : M.contacts) contacts.push_back(dj::cast_contact<T>(c));
     if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
@@ -98,6 +98,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     dj::KernelArgs<TIO, T> A;
     A.G = dj::make_globals<T>(M, opts, grad_mode);
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
+    std::vector<TIO> fet = castv(fext, (size_t)B * 6 * M.Nb); A.fext = fext ? fet.data() : nullptr;
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
@@ -131,11 +132,12 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     for (size_t i = 0; i < zn.size(); ++i) z_next[i] = zn[i];
     if (storage && vel && csg)                                      // the Storage kernel's body, per (environment, body)
         for (int e = 0; e < B; ++e) for (int k = 0; k < M.Nb; ++k) {
-            T zb[13], v[3], w[3], rb[6], row[25];
+            T zb[13], v[3], w[3], rb[6], row[25], fe[6];
+            if (fext) for (int i = 0; i < 6; ++i) fe[i] = T(fet[(size_t)e * 6 * M.Nb + 6 * k + i]);
             for (int i = 0; i < 13; ++i) zb[i] = T(zt[(size_t)e * nz + 13 * k + i]);
             for (int i = 0; i < 3; ++i) { v[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + i]); w[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + 3 + i]); }
             for (int i = 0; i < 6; ++i) rb[i] = T(rest[(size_t)e * 6 * M.Nb + 6 * k + i]);
-            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * 8 * M.Nc, rb);
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * 8 * M.Nc, rb, fext ? fe : (const T*)nullptr);
             for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
         }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
@@ -150,7 +152,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
 
 extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, int grad_mode, int dtype, int quad, int B, int envs_per_wave,
                         const double* z, const double* u, double* z_next, int* status, int* iters,
-                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen, double* dc, double* storage) {
+                        double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, char* err, int errlen, double* dc, double* storage, const double* fext) {
     dj::HostModel M;
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
@@ -158,9 +160,9 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
-#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); \
-                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); \
-                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage); } while (0)
+#define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage, fext); \
+                                  else if (quad) run<TIO, TS, TL, MC, true>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage, fext); \
+                                  else      run<TIO, TS, TL, MC, false>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage, fext); } while (0)
     // dtype 0: fp64 everywhere; dtype 1: fp32 I/O with fp64 internals (the product's "f32" mode); dtype 3: fp32 factorization (experiments)
     if (dtype == DOJO_DTYPE_F64) { if (M.maxc <= 1) RUN(double, double, double, 1); else if (M.maxc <= 4) RUN(double, double, double, 4); else RUN(double, double, double, 8); }
     else if (dtype == DOJO_DTYPE_F32) { if (M.maxc <= 1) RUN(float, double, double, 1); else if (M.maxc <= 4) RUN(float, double, double, 4); else RUN(float, double, double, 8); }

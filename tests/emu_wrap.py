@@ -27,7 +27,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False, quad=False):
+def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False, quad=False, fext=None):
     Z = np.ascontiguousarray(np.atleast_2d(Z), dtype=np.float64); B = Z.shape[0]
     U = None if U is None else np.ascontiguousarray(np.atleast_2d(U), dtype=np.float64)
     topo, keep = spec.to_ctypes()
@@ -41,9 +41,10 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     ncc = 5 * len(spec.contacts)
     dc = np.zeros((B, max(ncc, 1), nx)) if (grad and quad and ncc) else None
     stor = np.zeros((B, spec.Nb, 25))
+    fext = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(B, 6 * spec.Nb))
     err = C.create_string_buffer(256)
     rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
-                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor))
+                        _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
     out = dict(z_next=Zn, status=st, iters=it, vel=vel, storage=stor, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])

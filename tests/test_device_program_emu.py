@@ -121,3 +121,34 @@ def test_storage_rows_match_oracle(cfg, pre, quad):
     r = emu_step(spec, z[None], U[:1], opts=opts, quad=quad)
     assert st[0] == 0 and r["status"][0] == 0
     assert np.abs(r["storage"][0] - S[0]).max() < 1e-9 * max(1.0, np.abs(S[0]).max())
+
+
+@pytest.mark.parametrize("cfg,pre", [(2, 0), (4, 5)])
+def test_external_force_matches_oracle(cfg, pre):
+    """state.Fext / state.τext in the body residual (integrators/constraint.jl:15-18, set_external_force!
+    bodies/set.jl:110-115), and the Storage row of a step with an external force (simulate! clears it before it records)."""
+    import oracle as om
+    from dojo_amd.quat import vrot
+    spec = d.baseline_config(cfg)
+    opts = d.SolverOptions(rtol=1e-10, btol=1e-10)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z = Z[0].copy()
+    for _ in range(pre):
+        z, _ = o.step(z, U[0])
+    rng = np.random.default_rng(1)
+    F = rng.normal(size=(spec.Nb, 3)); Tq = rng.normal(size=(spec.Nb, 3)) * 0.1
+    o.set_state(z)
+    fe = np.zeros((spec.Nb, 6))
+    for b in range(spec.Nb):
+        o.set_external_force(b, force=F[b], torque=Tq[b])        # force in the body frame, as the reference takes it
+        fe[b, :3] = vrot(F[b], z[13 * b + 6:13 * b + 10]); fe[b, 3:] = Tq[b]
+    row = np.zeros((spec.Nb, 25))
+    st = om.lib().orc_simulate_step_record(o.h, om._p(np.ascontiguousarray(U[0])), 1, om._p(row))
+    r = emu_step(spec, z[None], U[:1], opts=opts, quad=True, fext=fe[None])
+    assert st == 0 and r["status"][0] == 0
+    assert np.abs(r["vel"][0] - o.velocity_solution()).max() < 1e-9
+    assert np.abs(r["storage"][0] - row).max() < 1e-9 * max(1.0, np.abs(row).max())
+    # and the force does change the step
+    r0 = emu_step(spec, z[None], U[:1], opts=opts, quad=True)
+    assert np.abs(r0["vel"][0] - r["vel"][0]).max() > 1e-4

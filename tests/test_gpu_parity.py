@@ -543,3 +543,59 @@ def test_batched_environment_ant_ars_rollout():
     # six closed-loop steps of two solvers that agree to the solver tolerance per step (parity criterion above)
     assert np.median(ferr) < 1e-5 and max(ferr) < 1e-3, ferr
     env.close()
+
+
+def test_external_force_behaviour_and_parity():
+    """set_external_force! on the device.  (1) The reference's own anchor, test/behaviors.jl:42-55: 1 N for 0.5 s on a
+    1 kg block gives v = 0.5, 1 Nm on a unit inertia gives ω = 0.5.  (2) Random forces and torques on every body of a
+    Quadruped batch against the oracle, and the Storage rows of those steps."""
+    from dojo_amd.quat import vrot
+    import oracle as om
+    spec = d.get_block(gravity=0.0, contact=False, mass=1.0)
+    spec.bodies[0].inertia = np.eye(3)
+    rz = np.array([np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    B = 2
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    z = np.zeros((B, 13)); z[:, 6:10] = rz
+    fe = np.zeros((B, 1, 6))
+    fe[0, 0, :3] = vrot(np.array([1.0, 0, 0]), rz)              # env 0: force along body x (= world y)
+    fe[1, 0, 3:] = [1.0, 0, 0]                                   # env 1: torque
+    gm.set_external_force(fe)
+    for k in range(50):
+        z, st, _ = gm.step(z)
+        # the force follows the body frame (set_external_force! rotates with the current q2); the block does not rotate in env 0
+    gm.set_external_force(None)
+    for k in range(50):
+        z, st, _ = gm.step(z)
+    assert abs(z[0, 4] - 0.5) < 1e-3 and abs(z[1, 10] - 0.5) < 1e-3
+    gm.close()
+
+    spec = d.baseline_config(4)
+    B, H = 32, 3
+    Z, U = d.synthetic_inputs(spec, B)
+    o = Oracle(spec, opts=TIGHT)
+    for _ in range(4):
+        Z, _, _, _, _ = o.step_batch(Z, U, nthreads=16)
+    rng = np.random.default_rng(2)
+    F = rng.normal(size=(B, spec.Nb, 3)) * 2.0; Tq = rng.normal(size=(B, spec.Nb, 3)) * 0.2
+    fe = np.zeros((B, spec.Nb, 6))
+    for b in range(B):
+        for k in range(spec.Nb):
+            fe[b, k, :3] = vrot(F[b, k], Z[b, 13 * k + 6:13 * k + 10]); fe[b, k, 3:] = Tq[b, k]
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    gm.set_external_force(fe)
+    Zt, S, st = gm.simulate(Z, U[None])
+    zn_free, _, _ = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT).step(Z, U)
+    assert np.abs(Zt[0] - zn_free).max() > 1e-3                  # the forces act
+    errs = []
+    for b in range(B):
+        o.set_state(Z[b])
+        for k in range(spec.Nb):
+            o.set_external_force(k, force=F[b, k], torque=Tq[b, k])
+        row = np.zeros((spec.Nb, 25))
+        s_o = om.lib().orc_simulate_step_record(o.h, om._p(np.ascontiguousarray(U[b])), 1, om._p(row))
+        if s_o == 0 and st[0, b] == 0:
+            errs.append(max(np.abs(S[0, b] - row).max() / max(1.0, np.abs(row).max()), np.abs(Zt[0, b, 3:6] - o.velocity_solution()[0:3]).max()))
+    errs = np.array(errs)
+    assert len(errs) >= B // 2 and np.quantile(errs, 0.9) < 1e-6 and errs.max() < 1e-4, (len(errs), errs.max())
+    gm.close()
