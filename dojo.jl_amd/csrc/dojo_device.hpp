@@ -1122,7 +1122,6 @@ struct LaneProgram {
             // The owner keeps its pivot row UNSCALED until all twelve pivots are done (a row that has been a
             // pivot only ever receives row operations afterwards, so the factor 1/pivot commutes to the end):
             // every row then takes the same update A −= fe·prow with fe = 0 on the pivot row itself.
-            const TL atf = at ? TL(1) : TL(0);
             TL ipown[3] = {TL(1), TL(1), TL(1)};
 #pragma unroll
             for (int p = 0; p < 12; ++p) {
@@ -1137,16 +1136,18 @@ struct LaneProgram {
                 const TL ip = TL(1) / (at ? prow[p] : TL(1));
 #endif
                 if (own) ipown[ro] = ip;
-#pragma unroll
-                for (int c = 0; c < 12; ++c) if (c != p) prow[c] *= ip;
-                const TL ipc = at ? ip : TL(-1);               // lanes elsewhere: −f·(−1) = f, column p unchanged
+                // the multiplier f/pivot is formed once per row (three products) instead of scaling the eleven
+                // broadcast pivot-row entries; lanes elsewhere get 0 and keep column p
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const TL f = A[r][p];
-                    const TL fe = (r == ro) ? (own ? TL(0) : f * atf) : f * atf;
+                    const TL g = f * ip;
+                    const TL ge = at ? g : TL(0);
+                    const TL fe = (r == ro) ? (own ? TL(0) : ge) : ge;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) if (c != p) A[r][c] -= fe * prow[c];
-                    A[r][p] = (r == ro) ? (own ? (at ? TL(1) : f) : -f * ipc) : -f * ipc;
+                    const TL colp = at ? -g : f;
+                    A[r][p] = (r == ro) ? (own ? (at ? TL(1) : f) : colp) : colp;
                 }
             }
             if (at) {
