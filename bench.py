@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host"))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64: half the 157.3 TFLOP/s fp32 vector peak of the guide (32 flop/clk/SIMD; tools/ubench/valu_rate.hip measures one fp64 FMA per 4.5 cycles and wave)
 
 
 def main():
@@ -137,7 +138,14 @@ def main():
             return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": t["bytes_per_launch"] * (B // NCH) / t["envs_per_launch"] if t else None,     # scaled to this launch size
                     "traffic_source": t["source"] if t else None,
-                    "kernel": kernel, "avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes}
+                    "kernel": kernel, "avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                    # the bound that matters for this path: executed fp64 vector FLOPs (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of the
+                    # committed pass, scaled to this launch size) over the measured kernel time, against the 78.6 TFLOP/s vector-fp64 peak
+                    "valu_fp64": ({"executed_flops_per_launch": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"],
+                                   "achieved": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"] / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if ms > 0 else 0.0}
+                                  if (t and t.get("fp64_flops_per_launch")) else None)}
         Bl = B // NCH                                                 # environments per launch
         util = measured_valu_utilization()
 
@@ -183,7 +191,8 @@ def measured_traffic():
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             for k, v in json.load(open(f)).items():
-                out[k] = {"bytes_per_launch": v["bytes_per_launch"], "envs_per_launch": v.get("envs_per_launch", 4096), "source": os.path.relpath(f, ROOT)}
+                out[k] = {"bytes_per_launch": v["bytes_per_launch"], "envs_per_launch": v.get("envs_per_launch", 4096), "source": os.path.relpath(f, ROOT),
+                          "fp64_flops_per_launch": v.get("fp64_flops_per_launch")}
         except Exception:
             pass
     return out

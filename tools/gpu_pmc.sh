@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --chunks 1}"   # one launch = the whole batch of 4096 environments
 cd /tmp
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 600 rocprofv3 --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc/$name.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -name "*counter_collection.csv" | head -1)
@@ -37,6 +37,11 @@ for kn in ('dojo_step_kernel', 'dojo_grad_kernel'):
         # rocprofv3 reports KB; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is
         out[kn] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024.0, "envs_per_launch": 4096,
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB, per launch, mean over the dispatches of bench.py " + os.environ.get('BENCH_ARGS', '--steps 3 --warmup 1 --chunks 1')}
+    c = {n: re.search(kn + r'\s+SQ_INSTS_VALU_' + n + r'_F64\s+per-dispatch mean ([0-9.e+-]+)', txt) for n in ('FMA', 'ADD', 'MUL', 'TRANS')}
+    if kn in out and all(c.values()):
+        v = {n: float(m.group(1)) for n, m in c.items()}
+        # wave instructions x 64 lanes, FMA = 2 flops (the expression rocprofv3 itself uses for SQ_INSTS_VALU_FLOPS_FP64)
+        out[kn].update({"fp64_wave_instructions": v, "fp64_flops_per_launch": (2 * v['FMA'] + v['ADD'] + v['MUL'] + v['TRANS']) * 64.0})
 json.dump(out, open(os.path.join(root, 'gpurun_out/pmc/pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out))
 PY
