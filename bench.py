@@ -139,13 +139,7 @@ def main():
                     "traffic": t["bytes_per_launch"] * (B // NCH) / t["envs_per_launch"] if t else None,     # scaled to this launch size
                     "traffic_source": t["source"] if t else None,
                     "kernel": kernel, "avg_kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                    # the bound that matters for this path: executed fp64 vector FLOPs (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of the
-                    # committed pass, scaled to this launch size) over the measured kernel time, against the 78.6 TFLOP/s vector-fp64 peak
-                    "valu_fp64": ({"executed_flops_per_launch": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"],
-                                   "achieved": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"] / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if ms > 0 else 0.0}
-                                  if (t and t.get("fp64_flops_per_launch")) else None)}
+                    "executed_fp64_flops_per_launch": (t["fp64_flops_per_launch"] * (B // NCH) / t["envs_per_launch"]) if (t and t.get("fp64_flops_per_launch")) else None}
         Bl = B // NCH                                                 # environments per launch
         util = measured_valu_utilization()
 
@@ -160,6 +154,15 @@ def main():
         dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
         dominant["note"] = ("VALU-issue-bound fp64 lane program (DESIGN.md §8; tools/ubench): the KKT systems never leave registers/LDS, "
                             "so the algorithmic HBM bytes are tiny and frac against HBM is reported only because the contract asks for it")
+        # the bound that matters for this path: executed fp64 vector FLOPs (PMC pass SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of the committed
+        # profile, both kernels, all environment groups of this GPU) over the wall-clock step, against the vector-fp64 peak.  (The per-launch
+        # durations above overlap across the groups' streams, so a per-launch rate would under-state the device by the number of groups.)
+        fl = [r.get("executed_fp64_flops_per_launch") for r in (r_step, r_ift) if r is not None]
+        if all(f is not None for f in fl):
+            tot = sum(fl) * NCH
+            ach = tot / (el / K) / 1e12
+            dominant["valu_fp64"] = {"executed_flops_per_step": tot, "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "scope": "both kernels, all %d groups, wall-clock step" % NCH}
         res = {
             "metric": "differentiable env-steps/sec (fwd+grad) at batch=4096; grad inf-err vs CPU" if grad else "env-steps/sec (fwd only)",
             "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
