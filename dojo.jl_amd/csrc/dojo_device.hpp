@@ -59,6 +59,7 @@ struct Globals {
     T rtol, btol, undercut, no_progress_undercut;
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
+    int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
     unsigned char maxch_lev[64]; // largest number of children among the supernodes of each level (bounds the level sweeps' gathers)
 };
 
@@ -907,6 +908,7 @@ struct LaneProgram {
                 contact_eval<JAC>(CE[c], CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
                 for (int i = 0; i < 6; ++i) d[i] -= CE[c].imp[i];
                 for (int i = 0; i < 4; ++i) cres[c][i] = CE[c].c[i];
+                if (G.contact_model == 1) cres[c][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
             } else { for (int i = 0; i < 4; ++i) cres[c][i] = T(0); }
         }
         // what this lane's joint applies to the parent body travels up the tree
@@ -963,9 +965,11 @@ struct LaneProgram {
                 for (int i = 0; i < 4; ++i) r = tmax(r, tabs(cres[c][i]));
                 const T* g = L.cg[c]; const T* s = L.cs[c];
                 b = tmax(b, tabs(g[0] * s[0]));
-                b = tmax(b, tabs(g[1] * s[1] + g[2] * s[2] + g[3] * s[3]));
-                b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
-                b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
+                if (G.contact_model == 0) {
+                    b = tmax(b, tabs(g[1] * s[1] + g[2] * s[2] + g[3] * s[3]));
+                    b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
+                    b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
+                }
             }
             if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
         }
@@ -1574,8 +1578,9 @@ struct LaneProgram {
                 T ds2 = (r2p - q.al3 * ds3 - q.al4 * ds4 - q.al2 * dg2) * trcp(q.den);
                 T dg3 = (R.cc[c][2] - q.g1 * ds2 - q.g0 * ds3 - q.h1 * dg2) * ih;
                 T dg4 = (R.cc[c][3] - q.g2 * ds2 - q.g0 * ds4 - q.h2 * dg2) * ih;
-                D.dcs[c][0] = ds1; D.dcs[c][1] = ds2; D.dcs[c][2] = ds3; D.dcs[c][3] = ds4;
-                D.dcg[c][0] = dg1; D.dcg[c][1] = dg2; D.dcg[c][2] = dg3; D.dcg[c][3] = dg4;
+                const T fz = G.contact_model == 1 ? T(0) : T(1);      // ImpactContact: the friction block stays at the neutral vector
+                D.dcs[c][0] = ds1; D.dcs[c][1] = fz * ds2; D.dcs[c][2] = fz * ds3; D.dcs[c][3] = fz * ds4;
+                D.dcg[c][0] = dg1; D.dcg[c][1] = fz * dg2; D.dcg[c][2] = fz * dg3; D.dcg[c][3] = fz * dg4;
             } else { for (int i = 0; i < 4; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
         }
     }
@@ -1700,8 +1705,10 @@ struct LaneProgram {
             for (int i = 0; i < 2; ++i) { L.ls[i] = T(1); L.lg[i] = T(1); }            // joints/constraints.jl:440-448
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {                                                  // reset! to [1,1,0,0] then initialize! -> 1.5·[1,1,0,0]
-                L.cs[c][0] = L.cs[c][1] = T(1.5); L.cs[c][2] = L.cs[c][3] = T(0);
-                L.cg[c][0] = L.cg[c][1] = T(1.5); L.cg[c][2] = L.cg[c][3] = T(0);
+                // (the generic initialize! of an ImpactContact discards its result, initialization.jl:1-5: it starts from reset!'s 1)
+                const T c0_ = G.contact_model == 1 ? T(1) : T(1.5);
+                L.cs[c][0] = L.cs[c][1] = c0_; L.cs[c][2] = L.cs[c][3] = T(0);
+                L.cg[c][0] = L.cg[c][1] = c0_; L.cg[c][2] = L.cg[c][3] = T(0);
             }
         }
         // velocity-independent part of d: D1x + D1q (constraint.jl:15-18 in closed form) − gravity − inputs − springs
@@ -1819,8 +1826,11 @@ struct LaneProgram {
             if (active) {
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                    for (int i = 0; i < 4; ++i) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
-                    p2 += T(2);
+                    // cone_degree: 2 for NonlinearContact (nonlinear.jl:101), N½ = 1 for ImpactContact (contact.jl:203), whose
+                    // pinned friction variables do not take part
+                    const int nv_ = G.contact_model == 1 ? 1 : 4;
+                    for (int i = 0; i < 4; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
+                    p2 += G.contact_model == 1 ? T(1) : T(2);
                 }
                 if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
             }

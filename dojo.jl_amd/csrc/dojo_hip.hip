@@ -342,6 +342,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = (dz != nullptr) || (dc != nullptr);
+    if (g && s->M.contact_model == 1) {   // the reference has no data Jacobians for ImpactContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
+        g_err = "gradients are not available for ImpactContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
+    }
     A.sol = nullptr;
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record

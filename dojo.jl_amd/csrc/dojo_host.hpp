@@ -13,6 +13,7 @@ namespace dj {
 
 struct HostModel {
     int Nb = 0, Nc = 0, S = 1, nu = 0, n_joint_imp = 0, maxch = 0, maxlevel = 0, maxc = 0;
+    int contact_model = 0;       // 0: NonlinearContact, 1: ImpactContact (one model per mechanism)
     std::vector<NodeP<double>> nodes;
     std::vector<ContactP<double>> contacts;
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
@@ -95,8 +96,13 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         if (P.ncontact > M.maxc) M.maxc = P.ncontact;
         ContactP<double>& Q = M.contacts[c];
         for (int i = 0; i < 3; ++i) { Q.n[i] = K.normal[i]; Q.o[i] = K.origin[i]; Q.off[i] = K.offset[i]; }
-        for (int i = 0; i < 6; ++i) Q.t[i] = K.tangent[i];
-        Q.r = K.radius; Q.mu = K.friction_coefficient;
+        if (K.model != 0 && K.model != 1) { M.error = "unknown contact model (0 = NonlinearContact, 1 = ImpactContact)"; return DOJO_ERR_UNSUPPORTED; }
+        if (c > 0 && K.model != M.contact_model) { M.error = "mixing contact models in one mechanism is not supported"; return DOJO_ERR_UNSUPPORTED; }
+        M.contact_model = K.model;
+        // ImpactContact (src/contacts/impact.jl) runs as the nonlinear model without its friction block: no tangents,
+        // no friction coefficient, and the device pins the friction variables at the neutral vector
+        for (int i = 0; i < 6; ++i) Q.t[i] = K.model == 1 ? 0.0 : K.tangent[i];
+        Q.r = K.radius; Q.mu = K.model == 1 ? 0.0 : K.friction_coefficient;
     }
     return DOJO_OK;
 }
@@ -127,7 +133,7 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
     for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
     G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);
     G.max_iter = o.max_iter; G.max_ls = o.max_ls; G.no_progress_max = o.no_progress_max;
-    G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode;
+    G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode; G.contact_model = M.contact_model;
     for (int l = 0; l < 64; ++l) G.maxch_lev[l] = 0;
     for (int b = 0; b < M.Nb; ++b) { int l = M.nodes[b].level; if (l < 64 && M.nodes[b].nchild > G.maxch_lev[l]) G.maxch_lev[l] = (unsigned char)M.nodes[b].nchild; }
     return G;

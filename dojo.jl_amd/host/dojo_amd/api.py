@@ -87,7 +87,8 @@ class BatchedMechanism:
         d = CDims()
         _chk(lib().dojo_get_dims(self.h, C.byref(d)))
         self.dims = d
-        assert d.nu == spec.nu and d.n_solution == spec.n_solution and d.n_joint_impulses == spec.n_joint_impulses
+        # (the device exports [s(4); γ(4)] per contact for every contact model: an ImpactContact's entries are [s, 1, 0, 0, γ, 1, 0, 0])
+        assert d.nu == spec.nu and d.n_joint_impulses == spec.n_joint_impulses and d.n_solution == spec.n_joint_impulses + 6 * spec.Nb + 8 * len(spec.contacts)
         self.set_options(opts or SolverOptions())
 
     def close(self):

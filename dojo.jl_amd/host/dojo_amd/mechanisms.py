@@ -59,14 +59,19 @@ def box_inertia(x, y, z, m):                                          # src/bodi
     return m / 12.0 * np.diag([y * y + z * z, x * x + z * z, x * x + y * y])
 
 
+CONTACT_MODELS = {"nonlinear": 0, "impact": 1}
+
+
 def contact_constraint(name, body, normal, friction_coefficient=1.0, contact_origin=np.zeros(3), contact_radius=0.0,
-                       contact_offset=np.zeros(3)):
-    """NonlinearContact(body, normal, μ; ...)  src/contacts/nonlinear.jl:24-48"""
+                       contact_offset=np.zeros(3), contact_type="nonlinear"):
+    """NonlinearContact(body, normal, μ; ...)  src/contacts/nonlinear.jl:24-48;  contact_type="impact":
+    ImpactContact(body, normal; ...)  src/contacts/impact.jl:20-39 (no friction: μ and the tangents are unused)"""
     V1, V2, V3 = orthogonal_rows(normal)
     A = np.stack([V1, V2, V3], axis=1)          # orthogonal_columns
     Ainv = np.linalg.inv(A)
     return ContactSpec(name, body, float(friction_coefficient), Ainv[2].copy(), Ainv[0:2].copy(),
-                       np.array(contact_origin, float), float(contact_radius), np.array(contact_offset, float))
+                       np.array(contact_origin, float), float(contact_radius), np.array(contact_offset, float),
+                       CONTACT_MODELS[contact_type])
 
 
 def set_limits(spec, joint_limits):
@@ -108,7 +113,7 @@ def get_pendulum(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, lin
 
 
 def get_block(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, edge_length=0.5, friction_coefficient=0.8,
-              contact=True, contact_radius=0.0, contact_corners=8):
+              contact=True, contact_radius=0.0, contact_corners=8, contact_type="nonlinear"):
     """DojoEnvironments/src/mechanisms/block/mechanism.jl:1-70.  contact_corners=4 keeps the four
     bottom corners only (BASELINE.json config 2); the reference's default is all 8."""
     bodies = [BodySpec("block", mass, box_inertia(edge_length, edge_length, edge_length, mass))]
@@ -118,7 +123,7 @@ def get_block(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, edge_l
     contacts = []
     if contact:
         for i, o in enumerate(origins[:contact_corners]):
-            contacts.append(contact_constraint("contact%d" % (i + 1), 0, Z_AXIS, friction_coefficient, o, contact_radius))
+            contacts.append(contact_constraint("contact%d" % (i + 1), 0, Z_AXIS, friction_coefficient, o, contact_radius, contact_type=contact_type))
     return MechanismSpec("block", bodies, joints, contacts, timestep, input_scaling, gravity)
 
 

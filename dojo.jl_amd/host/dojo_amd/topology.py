@@ -34,7 +34,7 @@ class CJoint(C.Structure):
 
 
 class CContact(C.Structure):
-    _fields_ = [("body", C.c_int32), ("reserved", C.c_int32), ("friction_coefficient", C.c_double),
+    _fields_ = [("body", C.c_int32), ("model", C.c_int32), ("friction_coefficient", C.c_double),
                 ("normal", d3), ("tangent", d6), ("origin", d3), ("radius", C.c_double), ("offset", d3)]
 
 
@@ -147,6 +147,7 @@ class ContactSpec:
     origin: np.ndarray
     radius: float = 0.0
     offset: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    model: int = 0                 # 0: NonlinearContact, 1: ImpactContact (src/contacts/impact.jl)
 
 
 @dataclass
@@ -178,7 +179,7 @@ class MechanismSpec:
     @property
     def n_joint_impulses(self): return sum(j.N for j in self.joints)
     @property
-    def n_solution(self): return self.n_joint_impulses + 6 * self.Nb + 8 * len(self.contacts)
+    def n_solution(self): return self.n_joint_impulses + 6 * self.Nb + sum(2 if c.model == 1 else 8 for c in self.contacts)
 
     def body_index(self, name): return [b.name for b in self.bodies].index(name)
     def joint_index(self, name): return [j.name for j in self.joints].index(name)
@@ -224,6 +225,7 @@ class MechanismSpec:
             fill_half(J[i].rot, j.rot)
         for i, c in enumerate(self.contacts):
             K[i].body = c.body
+            K[i].model = int(c.model)
             K[i].friction_coefficient = float(c.friction_coefficient)
             K[i].normal = d3(*c.normal)
             K[i].tangent = d6(*np.asarray(c.tangent).reshape(6))

@@ -31,7 +31,7 @@ struct CJoint
     tra::CJointHalf; rot::CJointHalf
 end
 struct CContact
-    body::Int32; reserved::Int32; friction_coefficient::Cdouble
+    body::Int32; model::Int32; friction_coefficient::Cdouble
     normal::NTuple{3,Cdouble}; tangent::NTuple{6,Cdouble}; origin::NTuple{3,Cdouble}; radius::Cdouble; offset::NTuple{3,Cdouble}
 end
 struct CTopology
@@ -63,11 +63,12 @@ function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
                      pad(Dojo.vector(j.rotational.orientation_offset), 4), half(j.translational), half(j.rotational)) for j in m.joints]
     contacts = CContact[]
     for c in m.contacts
-        c.model isa Dojo.NonlinearContact || error("DojoHIP: only NonlinearContact is supported")
+        (c.model isa Dojo.NonlinearContact || c.model isa Dojo.ImpactContact) || error("DojoHIP: only NonlinearContact and ImpactContact are supported")
+        impact = c.model isa Dojo.ImpactContact
         col = c.model.collision
         col isa Dojo.SphereHalfSpaceCollision || error("DojoHIP: only SphereHalfSpaceCollision is supported")
-        push!(contacts, CContact(bidx(c.parent_id), 0, c.model.friction_coefficient, pad(col.contact_normal', 3),
-                                 pad(vec(permutedims(Matrix(col.contact_tangent))), 6), pad(col.contact_origin, 3),
+        push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : 0, impact ? 0.0 : c.model.friction_coefficient, pad(col.contact_normal', 3),
+                                 impact ? ntuple(_ -> 0.0, 6) : pad(vec(permutedims(Matrix(col.contact_tangent))), 6), pad(col.contact_origin, 3),
                                  col.contact_radius, pad(col.contact_offset, 3)))
     end
     return bodies, joints, contacts

@@ -110,7 +110,8 @@ typedef struct DojoJoint {
  * (src/contacts/nonlinear.jl:12-48, src/contacts/collisions/sphere_halfspace.jl:11-22) */
 typedef struct DojoContact {
     int32_t body;                 /* parent_id as index into bodies[]                      */
-    int32_t reserved;
+    int32_t model;                /* 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl;
+                                     forward only: the reference has no data Jacobians for it, src/gradients/data.jl:152-192) */
     double  friction_coefficient;
     double  normal[3];            /* collision.contact_normal (1x3)                        */
     double  tangent[6];           /* collision.contact_tangent (2x3, row-major)            */

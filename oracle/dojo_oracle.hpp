@@ -77,6 +77,8 @@ template <class T>
 struct Contact {
     using M = SM<T>;
     int body = 0;
+    int model = 0;                 // 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl)
+    int nh() const { return model == 1 ? 1 : 4; }     // N½: γ and s each
     T mu = 0;                      // friction_coefficient
     M normal, tangent, origin, offset; T radius = 0;   // 1x3, 2x3, 3, 3
     M gam[2] = {M(4, 1), M(4, 1)}; // impulses       (γ)
@@ -166,7 +168,7 @@ struct Mechanism {
         }
         for (int i = 0; i < tp.n_contacts; ++i) {
             const DojoContact& s = tp.contacts[i]; Contact<T> c;
-            c.body = s.body; c.mu = T(s.friction_coefficient); c.radius = T(s.radius);
+            c.body = s.body; c.model = s.model; c.mu = T(s.friction_coefficient); c.radius = T(s.radius);
             c.normal = M(1, 3); c.tangent = M(2, 3); c.origin = M(3, 1); c.offset = M(3, 1);
             for (int k = 0; k < 3; ++k) { c.normal.a[k] = T(s.normal[k]); c.origin[k] = T(s.origin[k]); c.offset[k] = T(s.offset[k]); }
             for (int k = 0; k < 6; ++k) c.tangent.a[k] = T(s.tangent[k]);
@@ -176,7 +178,7 @@ struct Mechanism {
         int off = 0;
         for (auto& J : joints) { joff.push_back(off); off += J.N(); }
         for (size_t i = 0; i < bodies.size(); ++i) { boff.push_back(off); off += 6; }
-        for (size_t i = 0; i < contacts.size(); ++i) { coff.push_back(off); off += 8; }
+        for (size_t i = 0; i < contacts.size(); ++i) { coff.push_back(off); off += 2 * contacts[i].nh(); }
         n = off; A.assign((size_t)n * n, T(0)); b.assign(n, T(0)); rcache.assign(n, T(0));
     }
 
@@ -648,6 +650,7 @@ struct Mechanism {
         T d = distance(c, xp, qp);
         M vt = relative_tangential_velocity(c, xp, qp, st.vsol[1], st.wsol[1]);
         const M& g = c.gam[1]; const M& s = c.s[1];
+        if (c.model == 1) return M::vec({d - s[0]});                      // impact.jl:41-54
         return M::vec({d - s[0], c.mu * g[0] - g[1], vt[0] - s[2], vt[1] - s[3]});
     }
     static M cone_product(const M& u, const M& v) {   // cone.jl:6-8 (3-vectors)
@@ -659,12 +662,17 @@ struct Mechanism {
     // complementarity(mechanism, contact)  complementarity.jl:16-22
     M contact_complementarity(const Contact<T>& c) const {
         const M& g = c.gam[1]; const M& s = c.s[1];
+        if (c.model == 1) return M::vec({g[0] * s[0]});                    // complementarity.jl:16 (γ .* s)
         M cp = cone_product(sub(g, 1, 3), sub(s, 1, 3));
         return M::vec({g[0] * s[0], cp[0], cp[1], cp[2]});
     }
     // constraint_jacobian(contact): 8x8  nonlinear.jl:78-97
     M contact_constraint_jacobian(const Contact<T>& c) const {
         M g = c.gam[1], s = c.s[1];
+        if (c.model == 1) {   // impact.jl:56-62: [γ s; −1 0] (columns s, γ) with γ, s + REG·neutral_vector
+            M D2(2, 2); D2(0, 0) = g[0] + T(REG); D2(0, 1) = s[0] + T(REG); D2(1, 0) = T(-1); D2(1, 1) = T(0);
+            return D2;
+        }
         g[0] += T(REG); g[1] += T(REG); s[0] += T(REG); s[1] += T(REG);   // + REG * neutral_vector = [1,1,0,0]
         M D(8, 8);
         // ∇s
@@ -681,7 +689,8 @@ struct Mechanism {
     M contact_impulse_map(const Contact<T>& c) const {
         const State<T>& st = bodies[c.body].st;
         M xp = x3(st); Q qp = q3(st);
-        M X = hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());   // [n' 0 T'] (friction_parameterization = I)
+        M X = c.model == 1 ? c.normal.t()                          // force_mapping(ImpactContact)  impact.jl:106-118
+                           : hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());   // [n' 0 T'] (friction_parameterization = I)
         M cp = contact_point_parent(c, xp, qp);
         M Qm = rotation_matrix(inv(qp)) * skew(cp - xp) * X;
         return vcat(X, Qm);
@@ -700,6 +709,7 @@ struct Mechanism {
         // "recover current orientation"
         Q q = next_orientation(qp, -wp, dt);
         M dq_dw = rotational_integrator_jacobian_velocity(q, wp, dt);
+        if (c.model == 1) return hcat(dt * dd_dx, dd_dq * dq_dw);   // impact.jl:76-104
         M V = vcat(vcat(dt * dd_dx, M(1, 3)), dvt_dv);
         M Om = vcat(vcat(dd_dq * dq_dw, M(1, 3)), dvt_dw + dvt_dq * dq_dw);
         return hcat(V, Om);
@@ -731,7 +741,7 @@ struct Mechanism {
     M contact_impulse_map_jacobian(const Contact<T>& c) const {
         const State<T>& st = bodies[c.body].st;
         M xp = x3(st); Q qp = q3(st); const M& lam = c.gam[1];
-        M X = hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());
+        M X = c.model == 1 ? c.normal.t() : hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());
         M Xx(3, 3), Xq(3, 4);     // ∂force_mapping_jvp∂x / ∂q vanish for a half-space
         M cp = contact_point_parent(c, xp, qp);
         M r = cp - xp; Q qi = inv(qp);
@@ -743,7 +753,7 @@ struct Mechanism {
         return vcat(hcat(Xx, Xq), hcat(Qx, Qq));
     }
     void reset_contact(Contact<T>& c) {   // contacts/constraints.jl:79-86, neutral_vector nonlinear.jl:99
-        M nv = M::vec({1, 1, 0, 0});
+        M nv = c.model == 1 ? M::vec({1}) : M::vec({1, 1, 0, 0});       // neutral_vector: contact.jl:202 / nonlinear.jl:99
         c.gam[0] = nv; c.gam[1] = nv; c.s[0] = nv; c.s[1] = nv;
     }
     // initialize!(contact)   solver/initialization.jl:7-49
@@ -764,6 +774,9 @@ struct Mechanism {
         s = sh; g = gh; s[0] += dhs; g[0] += dhg;
     }
     void initialize_contact(Contact<T>& c) {
+        // the generic initialize! (initialization.jl:1-5) discards what initialize_positive_orthant! returns: for an
+        // ImpactContact the variables stay at the neutral vector of reset!
+        if (c.model == 1) return;
         for (int k = 0; k < 2; ++k) {
             T g0 = c.gam[k][0], s0 = c.s[k][0]; initialize_positive_orthant(g0, s0);
             M gs = sub(c.gam[k], 1, 3), ss = sub(c.s[k], 1, 3); initialize_second_order_cone(gs, ss);
@@ -864,10 +877,10 @@ struct Mechanism {
         for (size_t k = 0; k < contacts.size(); ++k) {
             Contact<T>& c = contacts[k];
             put(coff[k], coff[k], contact_constraint_jacobian(c));
-            M comp = contact_complementarity(c); comp[0] -= mu; comp[1] -= mu;   // complementarityμ: − μ·neutral_vector
+            M comp = contact_complementarity(c); comp[0] -= mu; if (c.model == 0) comp[1] -= mu;   // complementarityμ: − μ·neutral_vector
             putv(coff[k], vcat(-comp, -contact_constraint(c)));
-            put(boff[c.body], coff[k], hcat(M(6, 4), -contact_impulse_map(c)));
-            put(coff[k], boff[c.body], vcat(M(4, 6), contact_constraint_jacobian_velocity(c)));
+            put(boff[c.body], coff[k], hcat(M(6, c.nh()), -contact_impulse_map(c)));
+            put(coff[k], boff[c.body], vcat(M(c.nh(), 6), contact_constraint_jacobian_velocity(c)));
         }
     }
 
@@ -929,6 +942,10 @@ struct Mechanism {
         for (size_t k = 0; k < contacts.size(); ++k) {
             Contact<T>& c = contacts[k]; const T* D = &b[coff[k]];
             const M& s = c.s[1]; const M& g = c.gam[1];
+            if (c.model == 1) {   // line_search.jl:68-83
+                a = std::fmin(std::fmin(a, positive_orthant_step_length(s[0], D[0], tort)), positive_orthant_step_length(g[0], D[1], tort));
+                continue;
+            }
             T as_ort = positive_orthant_step_length(s[0], D[0], tort);
             T ag_ort = positive_orthant_step_length(g[0], D[4], tort);
             T as_soc = second_order_cone_step_length(sub(s, 1, 3), M::vec({D[1], D[2], D[3]}), tsoc);
@@ -953,8 +970,9 @@ struct Mechanism {
         T p0 = 0, p1 = 0, p2 = 0;
         for (size_t k = 0; k < contacts.size(); ++k) {
             Contact<T>& c = contacts[k]; const T* D = &b[coff[k]];
-            for (int i = 0; i < 4; ++i) { p0 += c.s[1][i] * c.gam[1][i]; p1 += (c.s[1][i] + aaff * D[i]) * (c.gam[1][i] + aaff * D[4 + i]); }
-            p2 += T(2);   // cone_degree(NonlinearContact) = 2
+            const int nh = c.nh();
+            for (int i = 0; i < nh; ++i) { p0 += c.s[1][i] * c.gam[1][i]; p1 += (c.s[1][i] + aaff * D[i]) * (c.gam[1][i] + aaff * D[nh + i]); }
+            p2 += c.model == 1 ? T(1) : T(2);   // cone_degree: N½ (contact.jl:203) / 2 for NonlinearContact (nonlinear.jl:101)
         }
         for (size_t j = 0; j < joints.size(); ++j) {
             Joint<T>& J = joints[j]; int o = 0;
@@ -974,6 +992,7 @@ struct Mechanism {
     void correction() {
         for (size_t k = 0; k < contacts.size(); ++k) {
             const T* D = &b[coff[k]]; T* r = &rcache[coff[k]];
+            if (contacts[k].model == 1) { r[0] += -D[0] * D[1] + mu; continue; }   // correction.jl:13-19
             M cp = cone_product(M::vec({D[1], D[2], D[3]}), M::vec({D[5], D[6], D[7]}));
             r[0] += -D[0] * D[4] + mu; r[1] += -cp[0] + mu; r[2] += -cp[1]; r[3] += -cp[2];
         }
@@ -991,7 +1010,8 @@ struct Mechanism {
         T f = T(1) / std::pow(T(2), T(scale)) * alpha;
         for (size_t k = 0; k < contacts.size(); ++k) {
             Contact<T>& c = contacts[k];
-            for (int i = 0; i < 4; ++i) { c.s[1][i] = c.s[0][i] + f * b[coff[k] + i]; c.gam[1][i] = c.gam[0][i] + f * b[coff[k] + 4 + i]; }
+            const int nh = c.nh();
+            for (int i = 0; i < nh; ++i) { c.s[1][i] = c.s[0][i] + f * b[coff[k] + i]; c.gam[1][i] = c.gam[0][i] + f * b[coff[k] + nh + i]; }
         }
         for (size_t j = 0; j < joints.size(); ++j) { Joint<T>& J = joints[j]; for (int i = 0; i < J.N(); ++i) J.imp[1][i] = J.imp[0][i] + f * b[joff[j] + i]; }
         T wmax = T(3.9) / (dt * dt);
@@ -1170,13 +1190,13 @@ struct Mechanism {
         int o = 0;
         for (auto& J : joints) for (int i = 0; i < J.N(); ++i) sol[o++] = J.imp[1][i];
         for (auto& B : bodies) { for (int k = 0; k < 3; ++k) sol[o++] = B.st.vsol[1][k]; for (int k = 0; k < 3; ++k) sol[o++] = B.st.wsol[1][k]; }
-        for (auto& c : contacts) { for (int k = 0; k < 4; ++k) sol[o++] = c.s[1][k]; for (int k = 0; k < 4; ++k) sol[o++] = c.gam[1][k]; }
+        for (auto& c : contacts) { for (int k = 0; k < c.nh(); ++k) sol[o++] = c.s[1][k]; for (int k = 0; k < c.nh(); ++k) sol[o++] = c.gam[1][k]; }
     }
     void set_solution(const T* sol) {
         int o = 0;
         for (auto& J : joints) for (int i = 0; i < J.N(); ++i) J.imp[1][i] = sol[o++];
         for (auto& B : bodies) { for (int k = 0; k < 3; ++k) B.st.vsol[1][k] = sol[o++]; for (int k = 0; k < 3; ++k) B.st.wsol[1][k] = sol[o++]; }
-        for (auto& c : contacts) { for (int k = 0; k < 4; ++k) c.s[1][k] = sol[o++]; for (int k = 0; k < 4; ++k) c.gam[1][k] = sol[o++]; }
+        for (auto& c : contacts) { for (int k = 0; k < c.nh(); ++k) c.s[1][k] = sol[o++]; for (int k = 0; k < c.nh(); ++k) c.gam[1][k] = sol[o++]; }
     }
 
     // =====================================================================

@@ -152,3 +152,24 @@ def test_external_force_matches_oracle(cfg, pre):
     # and the force does change the step
     r0 = emu_step(spec, z[None], U[:1], opts=opts, quad=True)
     assert np.abs(r0["vel"][0] - r["vel"][0]).max() > 1e-4
+
+
+@pytest.mark.parametrize("corners,quad", [(4, True), (8, True), (4, False)])
+def test_impact_contact_matches_oracle(corners, quad):
+    """ImpactContact (src/contacts/impact.jl).  The oracle implements it as the reference does (one γ and one s per contact,
+    2x2 diagonal block, orthant line search, cone degree 1); the device runs the nonlinear rows with the friction block
+    pinned at the neutral vector.  Same Newton iterates: equal iteration counts, states to round-off."""
+    spec = d.get_block(contact_type="impact", contact_corners=corners)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    z = d.initialize(spec, position=[0, 0, 0.05], velocity=[1.0, 0.5, -0.5], angular_velocity=[0.5, 0.2, 0.3])
+    for k in range(8):
+        zo, info = o.step(z, np.zeros(6))
+        r = emu_step(spec, z[None], np.zeros((1, 6)), opts=opts, quad=quad)
+        assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+        sg = o.get_solution()[6:].reshape(corners, 2)                       # [s, γ] per contact
+        csg = r["contact_sg"][0].reshape(corners, 8)
+        assert np.abs(csg[:, 0] - sg[:, 0]).max() < 1e-9 and np.abs(csg[:, 4] - sg[:, 1]).max() < 1e-9
+        assert np.array_equal(csg[:, 1:4], np.tile([1.0, 0, 0], (corners, 1)))   # the pinned friction block
+        z = zo

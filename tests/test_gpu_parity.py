@@ -599,3 +599,40 @@ def test_external_force_behaviour_and_parity():
     errs = np.array(errs)
     assert len(errs) >= B // 2 and np.quantile(errs, 0.9) < 1e-6 and errs.max() < 1e-4, (len(errs), errs.max())
     gm.close()
+
+
+def test_impact_contact_parity_and_properties():
+    """ImpactContact blocks (src/contacts/impact.jl) against the oracle at batch 128, the size-independent
+    frictionless properties at batch 1024, and the loud refusal of gradients (the reference has no data Jacobians either)."""
+    spec = d.get_block(contact_type="impact", contact_corners=4)
+    B = 128
+    rng = np.random.default_rng(4)
+    Z = np.stack([d.initialize(spec, position=[0, 0, rng.uniform(0.0, 0.3)], velocity=rng.normal(size=3), angular_velocity=rng.normal(size=3) * 0.5)
+                  for _ in range(B)])
+    U = np.zeros((B, 6))
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    o = Oracle(spec, opts=opts)
+    z = Z.copy()
+    for k in range(25):
+        zg, st, it = gm.step(z, U)
+        zo, st_o, it_o, _, _ = o.step_batch(z, U, nthreads=16)
+        ok = (st == 0) & (st_o == 0)
+        assert ok.mean() > 0.98
+        assert np.array_equal(it[ok], it_o[ok])                    # the same Newton iterates
+        assert np.abs(zg[ok] - zo[ok]).max() < 1e-8
+        z = zo
+    with pytest.raises(api.DojoError):
+        gm.step(z, U, with_gradient=True)
+    gm.close()
+    B = 1024
+    Zb = np.tile(Z, (B // len(Z), 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    Zt, st = gm.rollout(Zb, None, steps=150)
+    ok = (st == 0).all(axis=0)
+    assert ok.mean() > 0.97
+    zb = Zt.reshape(150, B, 13)
+    # no friction: the horizontal velocity never changes; nothing penetrates the floor
+    assert np.abs(zb[:, ok, 3:5] - Zb[None, ok, 3:5]).max() < 1e-7
+    assert zb[:, ok, 2].min() > 0.25 * np.sqrt(3) * -1 and zb[-1, ok, 2].min() > 0.2
+    gm.close()

@@ -168,3 +168,19 @@ def test_storage_momentum_is_conserved(name):
     assert np.abs(P - P[0]).max() < 1e-8 and np.abs(L - L[0]).max() < 1e-8
     # vl = px / m and the stored pose / velocity columns are the pre-update state of each step
     assert np.abs(S[0, :, 0:3] - Z[0].reshape(spec.Nb, 13)[:, 0:3]).max() == 0.0
+
+
+def test_impact_contact_is_frictionless():
+    """ImpactContact (src/contacts/impact.jl): a block thrown onto the floor keeps its horizontal velocity and its spin about
+    the normal, comes to rest on its bottom face (z = edge/2, test/behaviors.jl:21-40 for the resting height), and the
+    normal impulses carry its weight."""
+    spec = d.get_block(contact_type="impact", contact_corners=4)
+    o = Oracle(spec, opts=d.SolverOptions(rtol=1e-10, btol=1e-10))
+    z = d.initialize(spec, position=[0, 0, 0.3], velocity=[1.0, 0.5, 0.0], angular_velocity=[0.0, 0.0, 0.3])
+    for _ in range(120):
+        z, info = o.step(z, np.zeros(6))
+        assert info["status"] == 0
+    assert abs(z[2] - 0.25) < 1e-8 and abs(z[5]) < 1e-8
+    assert abs(z[3] - 1.0) < 1e-9 and abs(z[4] - 0.5) < 1e-9 and abs(z[12] - 0.3) < 1e-9
+    gam = o.get_solution()[6:].reshape(4, 2)[:, 1]
+    assert abs(gam.sum() - 9.81 * spec.timestep) < 1e-6          # Σγ = m g Δt

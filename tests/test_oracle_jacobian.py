@@ -42,6 +42,7 @@ CASES = [
     ("pendulum", dict(springs=1.0, dampers=0.2)),
     ("pendulum", dict()),
     ("block", dict()),
+    ("block", dict(contact_type="impact")),      # test/jacobian.jl:93,114: contact_type=:impact (ImpactContact, src/contacts/impact.jl)
     ("ant", dict(timestep=0.01)),
     ("quadruped", dict()),
     ("quadruped", dict(parse_springs=False, parse_dampers=False, springs=1.0, dampers=0.2)),
