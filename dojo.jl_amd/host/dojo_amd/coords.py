@@ -121,10 +121,12 @@ def nominal_minimal(spec, **kw):
         for i in (1, 4): c["hip_%d" % i] = [0.0]; c["ankle_%d" % i] = [a]
         for i in (2, 3): c["hip_%d" % i] = [0.0]; c["ankle_%d" % i] = [-a]
         return minimal_state_dict(spec, c)
-    if n == "quadruped":                     # initialize_quadruped!: z = 0.43, thigh π/4, calf −π/2
-        c = {"floating_base": [0, 0, 0.43, 0, 0, 0]}
+    if n == "quadruped":                     # initialize_quadruped! (quadruped/mechanism.jl:111-126): z = 0.43 + body_position, thigh π/4, calf −π/2
+        bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, 0.43])
+        c = {"floating_base": [bp[0], bp[1], bp[2], 0, 0, 0]}
         for g in ("FR", "FL", "RR", "RL"):
-            c[g + "_hip_joint"] = [0.0]; c[g + "_thigh_joint"] = [np.pi / 4]; c[g + "_calf_joint"] = [-np.pi / 2]
+            c[g + "_hip_joint"] = [kw.get("hip_angle", 0.0)]; c[g + "_thigh_joint"] = [kw.get("thigh_angle", np.pi / 4)]
+            c[g + "_calf_joint"] = [kw.get("calf_angle", -np.pi / 2)]
         return minimal_state_dict(spec, c)
     if n == "atlas":                         # initialize_atlas!: z = 0.9385
         return minimal_state_dict(spec, {"floating_base": [0, 0, 0.9385, 0, 0, 0]})

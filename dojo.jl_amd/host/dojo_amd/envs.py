@@ -43,11 +43,13 @@ class BatchedEnvironment:
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def initialize(self, **kw):
-        """initialize!(environment, model; kwargs...) (environments.jl:112-114): every copy at the mechanism's nominal state."""
+    def initialize(self, x0=None, **kw):
+        """initialize!(environment, model; kwargs...) (environments.jl:112-114): every copy at the mechanism's nominal state
+        (keywords as the reference's initialize_<model>!), or at the given minimal states x0 [B, 2nu]."""
         import torch
-        x0 = nominal_minimal(self.spec, **kw)
-        self._x = torch.tensor(np.tile(x0, (self.batch, 1)), dtype=self.torch_dtype, device=self.device)
+        if x0 is None:
+            x0 = np.tile(nominal_minimal(self.spec, **kw), (self.batch, 1))
+        self._x = torch.as_tensor(x0, dtype=self.torch_dtype).to(self.device).reshape(self.batch, self.nx).contiguous()
         self._stepped = False
         return self._x
 
