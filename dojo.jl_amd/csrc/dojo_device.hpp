@@ -30,6 +30,9 @@
 #include <cstdlib>
 #endif
 
+#ifndef DJ_RHS_PREFETCH
+#define DJ_RHS_PREFETCH 1      // IFT up-sweep: fetch the next column's right-hand-side values from LDS before the current column's products (one wave per SIMD has nothing else to hide the LDS latency with)
+#endif
 #ifndef DJ_FUSE_LS
 #define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
                            // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
@@ -1303,6 +1306,9 @@ struct LaneProgram {
                 r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18; u_off_ = 0;
             }
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+#if DJ_RHS_PREFETCH
+            double pre_d[3] = {0, 0, 0}; typename std::remove_cv<typename std::remove_reference<decltype(R.a[0])>::type>::type pre_r[3] = {}, pre_u[3] = {}, pre_s = 0;
+#endif
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
                 const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
@@ -1311,6 +1317,30 @@ struct LaneProgram {
                     const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
                     const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
                     const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
+#if DJ_RHS_PREFETCH
+                    // raw right-hand-side values of the NEXT column are fetched from LDS before this column's products
+                    if (cI == 0) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { pre_d[i] = R.own_cfg[qh * 18 + i * 6]; pre_r[i] = R.a[ir + i * 6]; pre_u[i] = R.a[iu + i * 6]; }
+                        pre_s = R.a[sl_off];
+                    }
+                    double cur_d[3]; decltype(pre_r[0] + pre_r[0]) cur_r[3], cur_u[3], cur_s = pre_s;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { cur_d[i] = pre_d[i]; cur_r[i] = pre_r[i]; cur_u[i] = pre_u[i]; }
+                    if (cI + 1 < NC) {
+                        const bool uok1 = !isS && valid && q < 2 && (cu0 + cI + 1) >= 0 && (cu0 + cI + 1) < myu;
+                        const int ir1 = (isS || uok1) ? r_off + cI + 1 : 0, iu1 = (isS || uok1) ? u_off_ + cI + 1 : 0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { pre_d[i] = R.own_cfg[qh * 18 + i * 6 + cI + 1]; pre_r[i] = R.a[ir1 + i * 6]; pre_u[i] = R.a[iu1 + i * 6]; }
+                        pre_s = R.a[sl_off + cI + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        r_[i] = od ? TG(cur_d[i]) : rm * TG(cur_r[i]);
+                        u_[i] = um * TG(cur_u[i]);
+                    }
+                    const TG kap0 = wkm * TG(cur_s);
+#else
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
@@ -1318,6 +1348,7 @@ struct LaneProgram {
                         u_[i] = um * TG(R.a[iu + i * 6]);
                     }
                     const TG kap0 = wkm * TG(R.a[sl_off + cI]);
+#endif
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { r_[i] += tb3[i] * kap0; u_[i] += ta3[i] * kap0; }
                 } else {
