@@ -127,6 +127,9 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     return Z, status
 end
 
+"which states the IFT data blocks are evaluated at: 0 = as the reference does after step! (post-update_state!), 1 = at the solved step (consistent)"
+set_gradient_mode!(bm::BatchedMechanism, mode::Integer) = check(@ccall LIB.dojo_set_gradient_mode(bm.handle::Ptr{Cvoid}, Int32(mode)::Int32)::Cint)
+
 "external forces for every body of every environment: fext[6, Nb, B] = [state.Fext (world); state.τext (body frame)]; `nothing` removes them"
 function set_external_force!(bm::BatchedMechanism{T}, fext::Union{Nothing,Array{T,3}}) where T
     check(@ccall LIB.dojo_set_external_force(bm.handle::Ptr{Cvoid}, (fext === nothing ? C_NULL : pointer(fext))::Ptr{T})::Cint)
