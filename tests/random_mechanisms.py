@@ -1,0 +1,63 @@
+"""Random tree mechanisms for the parity tests (test infrastructure): bodies of random mass / inertia hanging on random
+Revolute / Spherical / Fixed joints (random axes, vertices, orientation offsets, springs, dampers, limits) below a Floating
+or a jointed root, with sphere-half-space contacts on random bodies, and a random closed-joint state."""
+import numpy as np
+import dojo_amd as d
+from dojo_amd import coords
+from dojo_amd.mechanisms import Floating, Fixed, Revolute, Spherical, box_inertia, contact_constraint, Z_AXIS
+
+
+def _rand_quat(rng, scale):
+    v = rng.normal(size=3) * scale
+    q = np.concatenate([[1.0], v]); return q / np.linalg.norm(q)
+
+
+def random_mechanism(seed, contact_type="nonlinear"):
+    rng = np.random.default_rng(seed)
+    nb = int(rng.integers(2, 8))
+    bodies = []; joints = []; contacts = []
+    nchild = [0] * nb
+    for k in range(nb):
+        dims = rng.uniform(0.1, 0.5, size=3); m = float(rng.uniform(0.3, 2.0))
+        bodies.append(d.BodySpec("b%d" % k, m, box_inertia(dims[0], dims[1], dims[2], m)))
+    floating = rng.random() < 0.6
+    for k in range(nb):
+        if k == 0:
+            parent = -1
+            kind = "floating" if floating else rng.choice(["revolute", "spherical"])
+        else:
+            cand = [p for p in range(k) if nchild[p] < 4]
+            parent = int(rng.choice(cand)); nchild[parent] += 1
+            kind = rng.choice(["revolute", "revolute", "spherical", "fixed"])
+        pv, cv = rng.uniform(-0.3, 0.3, size=3), rng.uniform(-0.3, 0.3, size=3)
+        qo = _rand_quat(rng, 0.3)
+        name = "j%d" % k
+        if kind == "floating":
+            joints.append(Floating(name, parent, k))
+        elif kind == "fixed":
+            joints.append(Fixed(name, parent, k, pv, cv, qo))
+        elif kind == "spherical":
+            joints.append(Spherical(name, parent, k, pv, cv, qo, spring=float(rng.choice([0.0, 2.0])), damper=float(rng.choice([0.0, 0.5]))))
+        else:
+            lim = ([-0.6], [0.9]) if rng.random() < 0.5 else None
+            joints.append(Revolute(name, parent, k, rng.normal(size=3), pv, cv, qo, spring=float(rng.choice([0.0, 3.0])),
+                                   damper=float(rng.choice([0.0, 0.3])), rot_spring_offset=np.array([rng.uniform(-0.2, 0.2)]), rot_joint_limits=lim))
+    if floating:
+        for _ in range(int(rng.integers(0, 4))):
+            b = int(rng.integers(0, nb))
+            if sum(c.body == b for c in contacts) < 2:
+                contacts.append(contact_constraint("c%d" % len(contacts), b, Z_AXIS, float(rng.uniform(0.2, 0.9)), rng.uniform(-0.2, 0.2, size=3),
+                                                   float(rng.uniform(0.0, 0.1)), contact_type=contact_type))
+    spec = d.MechanismSpec("random%d" % seed, bodies, joints, contacts, 0.01, None, -9.81)
+    # a state with closed joints from random minimal coordinates
+    x = np.zeros(2 * spec.nu); o = 0
+    for j in joints:
+        n = j.nu
+        if n == 6:
+            x[o:o + 6] = np.concatenate([[0, 0, rng.uniform(0.3, 0.8)], rng.normal(size=3) * 0.3]); x[o + 6:o + 12] = rng.normal(size=6) * 0.5
+        elif n > 0:
+            x[o:o + n] = rng.uniform(-0.5, 0.5, size=n); x[o + n:o + 2 * n] = rng.normal(size=n) * 0.5
+        o += 2 * n
+    z = coords.minimal_to_maximal(spec, x)
+    u = rng.normal(size=spec.nu) * 0.3
+    return spec, z, u

@@ -173,3 +173,24 @@ def test_impact_contact_matches_oracle(corners, quad):
         assert np.abs(csg[:, 0] - sg[:, 0]).max() < 1e-9 and np.abs(csg[:, 4] - sg[:, 1]).max() < 1e-9
         assert np.array_equal(csg[:, 1:4], np.tile([1.0, 0, 0], (corners, 1)))   # the pinned friction block
         z = zo
+
+
+@pytest.mark.parametrize("seed,quad", [(1, True), (2, True), (4, False), (6, True)])
+def test_random_tree_mechanisms(seed, quad):
+    """Random trees (tests/random_mechanisms.py): Revolute / Spherical / Fixed joints with random axes, vertices, offsets,
+    springs, dampers and limits below a Floating root with contacts.  Equal iteration counts, states and both gradient
+    conventions against the oracle."""
+    from random_mechanisms import random_mechanism
+    spec, z, u = random_mechanism(seed)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    for k in range(2):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z[None], u[None], opts=opts, quad=quad, grad=(k == 1), grad_mode=k % 2)
+        assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+        if k == 1:
+            dz, du = o.gradients(mode=1)
+            assert np.abs(r["dz"][0] - dz).max() < 1e-8 * max(1.0, np.abs(dz).max())
+            assert np.abs(r["du"][0] - du).max() < 1e-8 * max(1.0, np.abs(du).max())
+        z = zo

@@ -636,3 +636,42 @@ def test_impact_contact_parity_and_properties():
     assert np.abs(zb[:, ok, 3:5] - Zb[None, ok, 3:5]).max() < 1e-7
     assert zb[:, ok, 2].min() > 0.25 * np.sqrt(3) * -1 and zb[-1, ok, 2].min() > 0.2
     gm.close()
+
+
+@pytest.mark.parametrize("seed0", [0, 8, 16])
+def test_random_tree_mechanisms_gpu(seed0):
+    """Eight random tree mechanisms per case (tests/random_mechanisms.py; every supported joint type, springs, dampers, limits,
+    contacts, up to four children per body), four perturbed copies each: states, iteration counts and the IFT Jacobians in
+    both evaluation conventions against the oracle; one of them with ImpactContact (forward only)."""
+    from random_mechanisms import random_mechanism
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    rng = np.random.default_rng(seed0)
+    nok = 0
+    for seed in range(seed0, seed0 + 8):
+        impact = seed % 8 == 7
+        spec, z0, u0 = random_mechanism(seed, contact_type="impact" if impact else "nonlinear")
+        B = 4
+        Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
+        gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+        o = Oracle(spec, opts=opts)
+        for k in range(3):
+            mode = k % 2
+            gm.set_gradient_mode(mode)
+            zg, st, it = gm.step(Z, U, with_gradient=not impact)
+            dzg, dug = (None, None) if impact else gm.gradients()
+            Zo = np.zeros_like(Z)
+            for b in range(B):
+                zo, info = o.step(Z[b], U[b])
+                Zo[b] = zo
+                if info["status"] != 0 or st[b] != 0:
+                    continue
+                nok += 1
+                assert it[b] == info["iters"], (seed, k, b, it[b], info["iters"])
+                assert np.abs(zg[b] - zo).max() < 1e-9, (seed, k, b)
+                if not impact:
+                    dz, du = o.gradients(mode=mode)
+                    assert np.abs(dzg[b] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max()), (seed, k, b)
+                    assert np.abs(dug[b] - du).max() < 1e-7 * max(1.0, np.abs(du).max()), (seed, k, b)
+            Z = Zo
+        gm.close()
+    assert nok >= 80
