@@ -12,9 +12,9 @@ def _rand_quat(rng, scale):
     q = np.concatenate([[1.0], v]); return q / np.linalg.norm(q)
 
 
-def random_mechanism(seed, contact_type="nonlinear"):
+def random_mechanism(seed, contact_type="nonlinear", nb=None):
     rng = np.random.default_rng(seed)
-    nb = int(rng.integers(2, 8))
+    nb = int(rng.integers(2, 8)) if nb is None else int(nb)
     bodies = []; joints = []; contacts = []
     nchild = [0] * nb
     for k in range(nb):
@@ -27,7 +27,7 @@ def random_mechanism(seed, contact_type="nonlinear"):
             kind = "floating" if floating else rng.choice(["revolute", "spherical"])
         else:
             cand = [p for p in range(k) if nchild[p] < 4]
-            parent = int(rng.choice(cand)); nchild[parent] += 1
+            parent = int(rng.choice(cand[-3:] if (nb > 8 and rng.random() < 0.5) else cand)); nchild[parent] += 1
             kind = rng.choice(["revolute", "revolute", "spherical", "fixed"])
         pv, cv = rng.uniform(-0.3, 0.3, size=3), rng.uniform(-0.3, 0.3, size=3)
         qo = _rand_quat(rng, 0.3)

@@ -654,6 +654,15 @@ def test_random_tree_mechanisms_gpu(seed0):
         Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
         gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
         o = Oracle(spec, opts=opts)
+        # coordinate maps (spherical joints: rotation-vector coordinates) and the Storage row of the first step
+        from dojo_amd import coords
+        X = gm.maximal_to_minimal(Z)
+        assert np.abs(X[0] - coords.maximal_to_minimal(spec, Z[0])).max() < 1e-10
+        assert np.abs(gm.minimal_to_maximal(X) - Z).max() < 1e-8
+        _, S, st_s = gm.simulate(Z, U[None])
+        So, st_o = o.simulate_storage(Z[1], U[None, 1])
+        if st_s[0, 1] == 0 and st_o[0] == 0:
+            assert np.abs(S[0, 1] - So[0]).max() < 1e-7 * max(1.0, np.abs(So[0]).max()), seed
         for k in range(3):
             mode = k % 2
             gm.set_gradient_mode(mode)
@@ -675,3 +684,37 @@ def test_random_tree_mechanisms_gpu(seed0):
             Z = Zo
         gm.close()
     assert nok >= 80
+
+
+@pytest.mark.parametrize("nb,seed", [(1, 40), (12, 41), (16, 42), (17, 43), (24, 44), (31, 45), (33, 46), (40, 47)])
+def test_random_tree_mechanisms_all_mappings(nb, seed):
+    """Random trees across the three lane mappings: <= 16 bodies (four lanes per supernode, one wavefront per environment),
+    17..32 (two wavefronts per environment), > 32 (one lane per supernode); also the single-body case."""
+    from random_mechanisms import random_mechanism
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    spec, z0, u0 = random_mechanism(seed, nb=nb)
+    B = 3
+    rng = np.random.default_rng(seed)
+    Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    o = Oracle(spec, opts=opts)
+    nok = 0
+    for k in range(2):
+        gm.set_gradient_mode(k % 2)
+        zg, st, it = gm.step(Z, U, with_gradient=True)
+        dzg, dug = gm.gradients()
+        Zo = np.zeros_like(Z)
+        for b in range(B):
+            zo, info = o.step(Z[b], U[b])
+            Zo[b] = zo
+            if info["status"] != 0 or st[b] != 0:
+                continue
+            nok += 1
+            assert it[b] == info["iters"]
+            assert np.abs(zg[b] - zo).max() < 1e-8
+            dz, du = o.gradients(mode=k % 2)
+            assert np.abs(dzg[b] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
+            assert np.abs(dug[b] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
+        Z = Zo
+    assert nok >= 4
+    gm.close()
