@@ -346,8 +346,6 @@ def test_minimal_gradients(cfg, pre_steps, mode):
     """get_minimal_gradients! (src/gradients/state.jl:183-217) on the device: coordinate Jacobians by forward-mode
     differentiation of the device maps, chained with the IFT Jacobians; against the oracle's maximal Jacobians chained with
     finite-difference coordinate Jacobians of the host restatement.  mode 0 = literal reference evaluation points."""
-    from dojo_amd import coords
-    from dojo_amd.quat import next_orientation
     spec = d.baseline_config(cfg)
     opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
     B = 4
@@ -355,6 +353,15 @@ def test_minimal_gradients(cfg, pre_steps, mode):
     o = Oracle(spec, opts=opts)
     for _ in range(pre_steps):
         Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    assert _check_minimal_gradients(spec, Z, U, mode, opts) >= 1
+
+
+def _check_minimal_gradients(spec, Z, U, mode, opts):
+    from dojo_amd import coords
+    from dojo_amd.quat import next_orientation
+    B = len(Z)
+    o = Oracle(spec, opts=opts)
+    nchecked = 0
     X = np.stack([coords.maximal_to_minimal(spec, Z[b]) for b in range(B)])
     gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
     gm.set_gradient_mode(mode)
@@ -380,7 +387,34 @@ def test_minimal_gradients(cfg, pre_steps, mode):
         assert np.abs(jx[b] - jx_ref).max() < 2e-5 * sx, (b, np.abs(jx[b] - jx_ref).max(), sx)
         if spec.nu:
             assert np.abs(ju[b] - ju_ref).max() < 2e-5 * su, (b, np.abs(ju[b] - ju_ref).max(), su)
+        nchecked += 1
     gm.close()
+    return nchecked
+
+
+@pytest.mark.parametrize("seed", [3, 4, 9, 12, 21])
+def test_random_tree_mechanisms_minimal_and_contact_gradients(seed):
+    """get_minimal_gradients! (spherical joints: rotation-vector coordinates through the dual-number maps) and
+    get_contact_gradients on random tree mechanisms, both evaluation conventions."""
+    from random_mechanisms import random_mechanism
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    spec, z0, u0 = random_mechanism(seed)
+    B = 2
+    Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)); U[1] *= 0.5
+    o = Oracle(spec, opts=opts)
+    Z, _, _, _, _ = o.step_batch(Z, U, nthreads=2)
+    for mode in (1, 0):
+        assert _check_minimal_gradients(spec, Z, U, mode, opts) >= 1
+    if spec.contacts:
+        gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+        zn, st, it = gm.step(Z, U, with_gradient=True)
+        dc = gm.contact_gradients()
+        for b in range(B):
+            zo, info = o.step(Z[b], U[b])
+            if info["status"] == 0 and st[b] == 0:
+                dco = o.contact_gradients(0)
+                assert np.abs(dc[b] - dco).max() < 1e-6 * max(1.0, np.abs(dco).max())
+        gm.close()
 
 
 @pytest.mark.parametrize("cfg,batch,grad", [(4, 8192, False), (5, 2048, True), (2, 1024, False)])
