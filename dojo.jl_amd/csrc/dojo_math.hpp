@@ -5,6 +5,9 @@
 // (src/orientation/quaternion.jl `LVᵀmat`, so the rotation angle is 2|φ|).
 #pragma once
 #include <math.h>
+#ifndef DJ_FAST_SQRT
+#define DJ_FAST_SQRT 1
+#endif
 
 #if defined(__HIPCC__)
 #define DJ_HD __host__ __device__ __forceinline__
@@ -44,7 +47,20 @@ DJ_HD double trcp(double a) {
 }
 DJ_HD float trcp(float a) { return 1.0f / a; }
 DJ_HD float  tsqrt(float a)  { return sqrtf(a); }
-DJ_HD double tsqrt(double a) { return sqrt(a); }
+// sqrt(a).  Device, fp64: v_rsq_f64 + the Goldschmidt iterations of the backend's own f64 sqrt expansion, without its range
+// scaling and special-case selects (the arguments here are squared lengths and 4/Δt² − ω·ω; tools/ubench/sqrt_test.hip)
+DJ_HD double tsqrt(double a) {
+#if defined(__HIP_DEVICE_COMPILE__) && DJ_FAST_SQRT
+    double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5); g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, a); g = fma(d, h, g);
+    d = fma(-g, g, a); g = fma(d, h, g);
+    return a == 0.0 ? 0.0 : g;
+#else
+    return sqrt(a);
+#endif
+}
 DJ_HD float  tatan(float a)  { return atanf(a); }
 DJ_HD double tatan(double a) { return atan(a); }
 
