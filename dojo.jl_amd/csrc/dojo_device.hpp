@@ -2488,7 +2488,7 @@ constexpr int FAC_PER_LANE = 72;
     typedef StepLds<TIO, T, MAXC, (GRAD_LAYOUT), QUAD, Wave::kLockstep, Wave::kWaves> LY;                                   \
     constexpr bool SHARE = QUAD && Wave::kLockstep;                                                                       \
     char* lds = (char*)wv.lds();                                                                                          \
-    const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : 0];                                                                       \
+    const NodeP<T>& Pg = A.nodes[k < G.Nb ? k : G.Nb];         /* idle supernode slots: the table's extra entry (node 0 without contacts) */ \
     if (SHARE) ((NodeSlot<T>*)lds)[lane / 4].P = Pg;           /* the four lanes store identical values */                \
     const NodeP<T>& P = SHARE ? ((NodeSlot<T>*)lds)[lane / 4].P : Pg;                                                     \
     Lane<T, MAXC> lane_local;                                                                                             \

@@ -275,6 +275,9 @@ __global__ void chain_out_kernel(const NodeP<double>* nodes, int Nb, int nu, int
 template <class T>
 int upload_tables(DojoSim* s) {   // tables are stored in the state precision (fp64)
     std::vector<dj::NodeP<T>> nodes; for (auto& n : s->M.nodes) nodes.push_back(dj::cast_node<T>(n));
+    // one extra entry for the idle supernode slots of a workgroup: node 0 without contacts (a slot that kept node 0's
+    // contacts would write the same contact-pool rows as the real node 0 in the two-wavefront mapping)
+    { dj::NodeP<T> idle = nodes[0]; idle.ncontact = 0; for (int i = 0; i < 8; ++i) idle.contact[i] = 0; nodes.push_back(idle); }
     std::vector<dj::ContactP<T>> contacts; for (auto& c : s->M.contacts) contacts.push_back(dj::cast_contact<T>(c));
     if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
     HIPCHK(hipMalloc(&s->d_nodes, nodes.size() * sizeof(dj::NodeP<T>)));

@@ -88,6 +88,9 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
          const double* z, const double* u, double* z_next, int* status, int* iters,
          double* vel, double* jimp, double* csg, double* dz, double* du, double* dbg, double* dc = nullptr, double* storage = nullptr, const double* fext = nullptr) {
     std::vector<dj::NodeP<T>> nodes; for (auto& n : M.nodes) nodes.push_back(dj::cast_node<T>(n));
+    // one extra entry for the idle supernode slots of a workgroup: node 0 without contacts (a slot that kept node 0's
+    // contacts would write the same contact-pool rows as the real node 0 in the two-wavefront mapping)
+    { dj::NodeP<T> idle = nodes[0]; idle.ncontact = 0; for (int i = 0; i < 8; ++i) idle.contact[i] = 0; nodes.push_back(idle); }
     std::vector<dj::ContactP<T>> contacts; for (auto& c : M.contacts) contacts.push_back(dj::cast_contact<T>(c));
     if (contacts.empty()) contacts.push_back(dj::ContactP<T>());
     int nz = 13 * M.Nb, nx = 12 * M.Nb;

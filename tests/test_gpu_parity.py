@@ -752,3 +752,25 @@ def test_random_tree_mechanisms_all_mappings(nb, seed):
         Z = Zo
     assert nok >= 4
     gm.close()
+
+
+def test_two_wavefront_mapping_is_deterministic_with_a_contact_on_node_zero():
+    """Regression: in the two-wavefront mapping the idle supernode slot of a 31-body mechanism used node 0's table entry; with a
+    contact on node 0 it wrote the same contact-pool rows as the real node 0 from the other wavefront.  Repeating one step
+    must give bit-identical results."""
+    from random_mechanisms import random_mechanism
+    spec, z0, u0 = random_mechanism(45, nb=31)
+    assert any(c.body == 0 for c in spec.contacts)
+    B = 64
+    rng = np.random.default_rng(45)
+    Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=d.SolverOptions(rtol=1e-9, btol=1e-9))
+    ref = None
+    for r in range(12):
+        zn, st, it = gm.step(Z, U, with_gradient=True)
+        dz, du = gm.gradients()
+        if ref is None:
+            ref = (zn.copy(), it.copy(), dz.copy())
+        else:
+            assert np.array_equal(zn, ref[0]) and np.array_equal(it, ref[1]) and np.array_equal(dz, ref[2])
+    gm.close()
