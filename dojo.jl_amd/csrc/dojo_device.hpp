@@ -1052,18 +1052,20 @@ struct LaneProgram {
                     }
             }
         }
-        // limit condensation: rows x get + wκ t_x (θ_a Δω_a + θ_b Δω_b)
+        // joint limit: the pair (s, γ) of both sides is eliminated down to ONE unknown, the net limit impulse Δκ = Δγ_lo − Δγ_up
+        // = κ0 − wκ (θ_a Δω_a + θ_b Δω_b), wκ = γ_up/s_up + γ_lo/s_lo, which keeps its own row -- the third rotational multiplier
+        // slot, free for the one-dimensional rotational joints that may carry limits -- scaled by 1/(1 + wκ):
+        //     Δκ/(1 + wκ) + σ (θ_a Δω_a + θ_b Δω_b) = κ0/(1 + wκ),   σ = wκ/(1 + wκ);   body rows: −t_x Δκ.
+        // Entries stay in [0, 1] whether the limit is inactive (wκ ~ 1e-10: Δκ ≈ 0) or strongly active (wκ ~ 1e11: an equality
+        // row with a tiny regularisation); folding wκ t θᵀ into the body blocks instead costs the IFT its digits there.
         if (P.nlim_r > 0) {
-            T wk = (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG));
+            const T wk = (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG));
+            const T c_ = trcp(T(1) + wk), sg_ = wk * c_;
+            K.addS(11, 11, c_ - T(1));                              // (the padding put 1 there)
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 3; ++j) { K.addS(11, 3 + j, sg_ * F.th_b[j]); K.addU(11, 3 + j, sg_ * F.th_a[j]); }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    K.addS(i, 3 + j, wk * F.t_b[i] * F.th_b[j]);
-                    K.addU(i, 3 + j, wk * F.t_b[i] * F.th_a[j]);
-                    K.addL(i, 3 + j, wk * F.t_a[i] * F.th_b[j]);
-                    K.addD(i, 3 + j, wk * F.t_a[i] * F.th_a[j]);
-                }
+            for (int i = 0; i < 6; ++i) { K.addS(i, 11, -F.t_b[i]); K.addL(i, 11, -F.t_a[i]); }
         }
     }
 
@@ -1233,9 +1235,6 @@ struct LaneProgram {
         const int lvl = sp.level;
         const int pb = sp.pb;
         const int qh = q & 1;
-        // (selects, not F.t_b[3 * qh + i]: ONE dynamically indexed member keeps the whole LaneProgram object in scratch)
-        const TG tb3[3] = {TG(qh ? F.t_b[3] : F.t_b[0]), TG(qh ? F.t_b[4] : F.t_b[1]), TG(qh ? F.t_b[5] : F.t_b[2])},
-                 ta3[3] = {TG(qh ? F.t_a[3] : F.t_a[0]), TG(qh ? F.t_a[4] : F.t_a[1]), TG(qh ? F.t_a[5] : F.t_a[2])};
         // this lane's six rows of the first column of batch b in the output buffers, element stride between columns = nx;
         // state batches: column cI sits at index cI (+3 for cI >= 3: the batch holds x2|φ2 or v15|ω15)
         TIO* const dz_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? A.dz : A.dc);
@@ -1297,7 +1296,7 @@ struct LaneProgram {
                 od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
                 rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0); um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
                 // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
-                wkm = (sp.nlim_r > 0 && q < 2 && (mine || par) && typ == 0) ? TG(wk) : TG(0);
+                wkm = (sp.nlim_r > 0 && q == 3 && (mine || par) && typ == 0) ? TG(wk) : TG(0);       // σ on the Δκ row = row 2 of role 3
                 sl_off = mine ? RH::SLO : RH::SLP;
             } else {
                 // contact batch b - nbs = contact index of the environment; cl = its slot on this supernode (or -1)
@@ -1339,7 +1338,7 @@ struct LaneProgram {
                         r_[i] = od ? TG(cur_d[i]) : rm * TG(cur_r[i]);
                         u_[i] = um * TG(cur_u[i]);
                     }
-                    const TG kap0 = wkm * TG(cur_s);
+                    r_[2] += wkm * TG(cur_s);
 #else
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -1347,10 +1346,8 @@ struct LaneProgram {
                         r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
                         u_[i] = um * TG(R.a[iu + i * 6]);
                     }
-                    const TG kap0 = wkm * TG(R.a[sl_off + cI]);
+                    r_[2] += wkm * TG(R.a[sl_off + cI]);
 #endif
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { r_[i] += tb3[i] * kap0; u_[i] += ta3[i] * kap0; }
                 } else {
                     const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
 #pragma unroll
@@ -1581,12 +1578,13 @@ struct LaneProgram {
             su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
             isu = trcp(su); isl = trcp(sl);
             kap0 = (R.lim[1] - gl * rsl) * isl - (R.lim[0] - gu * rsu) * isu;
-            for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; up[i] += F.t_a[i] * kap0; }
+            rk[11] = kap0 * trcp(T(1) + gl * isl + gu * isu);      // the Δκ row (see evaluate)
         }
         T dk[12], dva[6];
         core_solve(rk, up, dk, dva);
         for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
+        if (P.nlim_r > 0) D.dlam[5] = T(0);                         // slot 11 carried Δκ, not a joint multiplier
         // recovery of the condensed variables
         if (P.nlim_r > 0) {
             T thd = v3dot(F.th_a, dva + 3) + v3dot(F.th_b, D.dw);
@@ -2097,7 +2095,8 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) GK[c][i][j] = (c < P.ncontact) ? ccold(c).G134[i] * Q.k0[0] + ccold(c).G134[6 + i] * Q.k0[1] + ccold(c).G134[12 + i] * Q.k0[2] : T(0);
             }
         }
-        if (P.nlim_r > 0) wk = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG));
+        // σ = wκ/(1 + wκ): the slack rows of a joint limit enter the Δκ row (see evaluate) as σ·(∂ slack row / ∂ data)
+        if (P.nlim_r > 0) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
         typedef typename KA::io_type TB;
         if constexpr (QUAD) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
@@ -2167,7 +2166,7 @@ struct LaneProgram {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) rk[i] += GK[c][i][0] * r58[c][0] + GK[c][i][1] * r58[c][1] + GK[c][i][2] * r58[c][2] + GK[c][i][3] * r58[c][3];
             }
-            if (P.nlim_r > 0) { T kap0 = wk * rs0; for (int i = 0; i < 6; ++i) { rk[i] += F.t_b[i] * kap0; upx[i] += F.t_a[i] * kap0; } }
+            if (P.nlim_r > 0) rk[11] += wk * rs0;                   // the Δκ row
             T dk[12], dva[6];
             core_solve(rk, upx, dk, dva);
             for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
