@@ -43,6 +43,9 @@
 #ifndef DJ_LDS_REDUCE
 #define DJ_LDS_REDUCE 1     // quad mapping: environment reductions through LDS (one slot per supernode) instead of shuffle butterflies
 #endif
+#ifndef DJ_TSD
+#define DJ_TSD 0           // 1: the kernels evaluate translational springs / dampers (KernelArgs::tsd); builds of their own
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -637,6 +640,158 @@ template <class T> DJ_HD void spring_impulses(T* sa, T* sb, const NodeP<T>& P, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Translational springs and dampers of joints with free translations (Prismatic, Planar, Cylindrical ...):
+// src/joints/translational/springs.jl:5-76, dampers.jl:5-123, minimal.jl:91-177 in closed form.
+// Their parameters live outside NodeP (KernelArgs::tsd, one entry per supernode) and only the DJ_TSD builds of the
+// kernels evaluate them: the kernels of mechanisms without them keep their code and their register allocation.
+//   e(x, q) = Raᵀ(xb + Rb pb − xa) − pa,  u = e + pa            displacement in the parent frame (minimal.jl:4-12)
+//   spring  f = k Aᵀ(offset − A e2)                              at the current configuration (velocity independent)
+//   damper  f = −(c/Δt) AᵀA (e2 − e1),  e1 = e one step back along the CANDIDATE velocities (minimal.jl:91-110)
+//   both enter the body residuals as Δt·T_a f (parent), Δt·T_b f (child), T = impulse_transform (tra_impulse)
+// ------------------------------------------------------------------------------------------------
+template <class T> struct TraSD { T spring, damper, off[3]; };
+
+template <class T> DJ_HD void tra_AtA(T* M, const NodeP<T>& P) {
+    for (int i = 0; i < 9; ++i) M[i] = T(0);
+    for (int i = 0; i < 3; ++i) if (i < P.nu_t) for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) M[3 * k + j] += P.At[3 * i + k] * P.At[3 * i + j];
+}
+template <class T> DJ_HD void tra_spring_force(T* f, const NodeP<T>& P, const TraSD<T>& sd, const JointCfg<T>& c) {
+    f[0] = f[1] = f[2] = T(0);
+    if (!P.spring_on || sd.spring == T(0)) return;
+    T e[3] = {c.u2[0] - P.pa[0], c.u2[1] - P.pa[1], c.u2[2] - P.pa[2]};
+    for (int i = 0; i < 3; ++i) if (i < P.nu_t) {
+        T dist = sd.off[i] - v3dot(&P.At[3 * i], e);
+        for (int k = 0; k < 3; ++k) f[k] += sd.spring * P.At[3 * i + k] * dist;
+    }
+}
+template <class T>
+struct TraDamperEval {
+    T f[3];                      // damper_force (parent frame)
+    T u1[3];                     // e1 + pa
+    T R1T[9];                    // R(qa1)ᵀ = Xaᵀ Raᵀ
+    T XaT[9], XbT[9];            // R(ξ(−ωa))ᵀ, R(ξ(−ωb))ᵀ  = ∂φ1/∂φ2 of parent / child
+    T Eb1[9];                    // ∂u1/∂φb1 = −2 Xaᵀ Rbaᵀ Xb [pb]x
+    T Pa[9], Pb[9];              // Φ(−ωa), Φ(−ωb):  δφ1 = −Φ(−ω) δω
+};
+template <bool JAC, class T>
+DJ_HD void tra_damper_force(TraDamperEval<T>& D, const NodeP<T>& P, const TraSD<T>& sd, const JointCfg<T>& c,
+                            const T* va, const T* wa, const T* vb, const T* wb, T dt) {
+    T nwa[3] = {-wa[0], -wa[1], -wa[2]}, nwb[3] = {-wb[0], -wb[1], -wb[2]};
+    T xia[4], xib[4], ca, cb, Xa[9], Xb[9];
+    qstep(xia, nwa, dt, &ca); qstep(xib, nwb, dt, &cb);
+    qrot(Xa, xia); qrot(Xb, xib);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { D.XaT[3 * i + j] = Xa[3 * j + i]; D.XbT[3 * i + j] = Xb[3 * j + i]; }
+    T dv[3] = {vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]}, dvw[3], Xbpb[3], t[3], Rt[3], r[3];
+    m3tvec(dvw, c.Ra, dv);
+    m3vec(Xbpb, Xb, P.pb);
+    for (int i = 0; i < 3; ++i) t[i] = Xbpb[i] - P.pb[i];
+    m3tvec(Rt, c.Rba, t);                                   // Raᵀ Rb (Xb pb − pb)
+    for (int i = 0; i < 3; ++i) r[i] = c.u2[i] + Rt[i] - dt * dvw[i];
+    m3vec(D.u1, D.XaT, r);
+    T M[9], du[3], Mdu[3];
+    tra_AtA(M, P);
+    for (int i = 0; i < 3; ++i) du[i] = c.u2[i] - D.u1[i];
+    m3vec(Mdu, M, du);
+    const T g = -sd.damper / dt;
+    for (int i = 0; i < 3; ++i) D.f[i] = g * Mdu[i];
+    if (JAC) {
+        m3mult(D.R1T, D.XaT, c.Ra);
+        phi_of(D.Pa, nwa, ca, dt); phi_of(D.Pb, nwb, cb, dt);
+        T Spb[9], XbS[9], RX[9];
+        m3skew(Spb, P.pb); m3mul(XbS, Xb, Spb); m3tmul(RX, c.Rba, XbS);
+        m3mul(D.Eb1, D.XaT, RX);
+        for (int i = 0; i < 9; ++i) D.Eb1[i] *= T(-2);
+    }
+}
+// residual pieces (+ velocity Jacobian blocks when MAT) of the translational damper, added to what joint_eval left in E / K
+// (damper_jacobian_velocity, translational/dampers.jl:99-123)
+template <bool MAT, class T, class BK>
+DJ_HD void tra_damper_eval(JointEval<T>& E, const NodeP<T>& P, const TraSD<T>& sd, const JointCfg<T>& c,
+                           const T* va, const T* wa, const T* vb, const T* wb, T dt, BK& K) {
+    if (!P.damper_on || sd.damper == T(0) || P.nu_t == 0) return;
+    TraDamperEval<T> D;
+    tra_damper_force<MAT>(D, P, sd, c, va, wa, vb, wb, dt);
+    T p[3] = {dt * D.f[0], dt * D.f[1], dt * D.f[2]}, ia[6], ib[6];
+    tra_impulse(ia, ib, c, P, p);
+    for (int i = 0; i < 6; ++i) { E.imp_a[i] += ia[i]; E.imp_b[i] += ib[i]; }
+    if (MAT) {
+        // ∂f/∂(va, ωa) = (c/Δt) AᵀA [Δt R1ᵀ | −2[u1]x Φa],  ∂f/∂(vb, ωb) = (c/Δt) AᵀA [−Δt R1ᵀ | −Eb1 Φb]
+        T M[9], Su1[9], SP[9], EP[9], FA[18], FB[18];
+        tra_AtA(M, P);
+        m3skew(Su1, D.u1); m3mul(SP, Su1, D.Pa); m3mul(EP, D.Eb1, D.Pb);
+        const T g = sd.damper / dt;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            T a0 = T(0), a1 = T(0), b1 = T(0);
+            for (int m = 0; m < 3; ++m) { a0 += M[3 * i + m] * D.R1T[3 * m + j]; a1 += M[3 * i + m] * SP[3 * m + j]; b1 += M[3 * i + m] * EP[3 * m + j]; }
+            FA[6 * i + j] = g * dt * a0; FA[6 * i + 3 + j] = T(-2) * g * a1;
+            FB[6 * i + j] = -g * dt * a0; FB[6 * i + 3 + j] = -g * b1;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            T ca_[3] = {dt * FA[j], dt * FA[6 + j], dt * FA[12 + j]}, cb_[3] = {dt * FB[j], dt * FB[6 + j], dt * FB[12 + j]};
+            T aa[6], ba[6], ab[6], bb[6];
+            tra_impulse(aa, ba, c, P, ca_);                 // ∂imp_a/∂(vel_a)_j, ∂imp_b/∂(vel_a)_j
+            tra_impulse(ab, bb, c, P, cb_);                 // ∂imp_a/∂(vel_b)_j, ∂imp_b/∂(vel_b)_j
+#pragma unroll
+            for (int r = 0; r < 6; ++r) { K.addD(r, j, -aa[r]); K.addU(r, j, -ba[r]); K.addL(r, j, -ab[r]); K.addS(r, j, -bb[r]); }
+        }
+    }
+}
+// ∂(Δt T f)/∂z2 of the translational spring and damper for the data Jacobian (spring_jacobian_configuration,
+// translational/springs.jl:37-76; damper_jacobian_configuration, dampers.jl:70-97): adds Δt T_x ∂f/∂z_y to the four blocks
+// and returns Δt f, which the caller adds to the joint's translational impulse so that joint_impulse_cfg_jac supplies the
+// impulse_transform_jacobian terms (they are linear in the transported vector).
+template <class T>
+DJ_HD void tra_sd_cfg_jac(T* Jaa, T* Jab, T* Jba, T* Jbb, T* pf, const NodeP<T>& P, const TraSD<T>& sd, const JointCfg<T>& c,
+                          const T* va, const T* wa, const T* vb, const T* wb, T dt) {
+    pf[0] = pf[1] = pf[2] = T(0);
+    const bool sp = P.spring_on && sd.spring != T(0) && P.nu_t > 0, da = P.damper_on && sd.damper != T(0) && P.nu_t > 0;
+    if (!sp && !da) return;
+    T M[9], Su2[9], Spb[9], E2b[9], RaT[9];
+    tra_AtA(M, P);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RaT[3 * i + j] = c.Ra[3 * j + i];
+    m3skew(Su2, c.u2); m3skew(Spb, P.pb); m3tmul(E2b, c.Rba, Spb);       // ∂u2/∂φa = 2[u2]x, ∂u2/∂φb = −2 Rbaᵀ[pb]x
+    T GA[18], GB[18];                                                       // Σ coefficient · ∂u/∂za, ∂u/∂zb  (3x6 each)
+    T ks = T(0), kd = T(0);
+    if (sp) { T f[3]; tra_spring_force(f, P, sd, c); for (int i = 0; i < 3; ++i) pf[i] += dt * f[i]; ks = -sd.spring; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        GA[6 * i + j] = -RaT[3 * i + j]; GA[6 * i + 3 + j] = T(2) * Su2[3 * i + j];
+        GB[6 * i + j] = RaT[3 * i + j]; GB[6 * i + 3 + j] = T(-2) * E2b[3 * i + j];
+    }
+    T HA[18], HB[18];
+    for (int i = 0; i < 18; ++i) HA[i] = HB[i] = T(0);
+    if (da) {
+        TraDamperEval<T> D;
+        tra_damper_force<true>(D, P, sd, c, va, wa, vb, wb, dt);
+        for (int i = 0; i < 3; ++i) pf[i] += dt * D.f[i];
+        kd = -sd.damper / dt;
+        T Su1[9], SX[9], EX[9];
+        m3skew(Su1, D.u1); m3mul(SX, Su1, D.XaT); m3mul(EX, D.Eb1, D.XbT);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            HA[6 * i + j] = -D.R1T[3 * i + j]; HA[6 * i + 3 + j] = T(2) * SX[3 * i + j];
+            HB[6 * i + j] = D.R1T[3 * i + j]; HB[6 * i + 3 + j] = EX[3 * i + j];
+        }
+    }
+    // ∂f/∂z = ks M ∂u2/∂z + kd M (∂u2/∂z − ∂u1/∂z)
+    T FA[18], FB[18];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) {
+        T a = T(0), b = T(0);
+        for (int m = 0; m < 3; ++m) {
+            a += M[3 * i + m] * ((ks + kd) * GA[6 * m + j] - kd * HA[6 * m + j]);
+            b += M[3 * i + m] * ((ks + kd) * GB[6 * m + j] - kd * HB[6 * m + j]);
+        }
+        FA[6 * i + j] = a; FB[6 * i + j] = b;
+    }
+    for (int j = 0; j < 6; ++j) {
+        T ca_[3] = {dt * FA[j], dt * FA[6 + j], dt * FA[12 + j]}, cb_[3] = {dt * FB[j], dt * FB[6 + j], dt * FB[12 + j]};
+        T aa[6], ba[6], ab[6], bb[6];
+        tra_impulse(aa, ba, c, P, ca_);
+        tra_impulse(ab, bb, c, P, cb_);
+        for (int r = 0; r < 6; ++r) { Jaa[6 * r + j] += aa[r]; Jba[6 * r + j] += ba[r]; Jab[6 * r + j] += ab[r]; Jbb[6 * r + j] += bb[r]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // contact evaluation at (x3, q3) of the body: residual rows, impulse, and (JAC) C/G blocks
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -845,6 +1000,9 @@ struct LaneProgram {
     DJ_HD ContactCold<T>& ccold(int c) const { return cpool[pool_by_id ? P.contact[c] : pool_base + c]; }
     JointCfg<T>& cfg;
     T mu;                        // mechanism.μ
+#if DJ_TSD
+    const TraSD<T>* tsd = nullptr;   // translational spring / damper of the parent joint (null: the mechanism has none)
+#endif
 #ifdef DJ_DEBUG
     T* dbg = nullptr; bool dbg_on = false; bool trace = false;
 #endif
@@ -894,6 +1052,9 @@ struct LaneProgram {
         JointEval<T> E;
         if (JAC) K.zero();
         joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, K);
+#if DJ_TSD
+        if (tsd) tra_damper_eval<JAC>(E, P, *tsd, cfg, va, wa, L.v, L.w, dt, K);
+#endif
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
         // body residual: src/integrators/constraint.jl:1-34 in closed form
@@ -1166,12 +1327,14 @@ struct LaneProgram {
                     for (int c = 0; c < 12; ++c) A[i][c] *= ipown[i];
             }
             if (lev > 0) {   // level 0 = the roots of the trees: nothing to pass up (wave-uniform skip)
-            // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero)
+            // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero -- except with a
+            // translational damper, whose force on the child body depends on the parent's velocity: DJ_TSD builds)
             TL Uf[12][6];
+            constexpr int U0 = DJ_TSD ? 0 : 1;
 #pragma unroll
             for (int j = 0; j < 6; ++j) { Uf[0][j] = Uf[1][j] = Uf[2][j] = TL(0); }
 #pragma unroll
-            for (int o = 1; o < 4; ++o)
+            for (int o = U0; o < 4; ++o)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1183,7 +1346,7 @@ struct LaneProgram {
                 for (int j = 0; j < 6; ++j) {
                     TL a_ = TL(0);
 #pragma unroll
-                    for (int m_ = 3; m_ < 12; ++m_) a_ += A[i][m_] * Uf[m_][j];
+                    for (int m_ = 3 * U0; m_ < 12; ++m_) a_ += A[i][m_] * Uf[m_][j];
                     Tq[i][j] = a_;
                 }
 #pragma unroll
@@ -1771,6 +1934,15 @@ struct LaneProgram {
         // springs (velocity independent)
         T sa[6], sb[6];
         spring_impulses(sa, sb, P, cfg, dt);
+#if DJ_TSD
+        if (tsd) {                                             // translational spring: Δt·T f  (translational/springs.jl:21-31)
+            T f[3], ia[6], ib[6];
+            tra_spring_force(f, P, *tsd, cfg);
+            for (int i = 0; i < 3; ++i) f[i] *= dt;
+            tra_impulse(ia, ib, cfg, P, f);
+            for (int i = 0; i < 6; ++i) { sa[i] += ia[i]; sb[i] += ib[i]; }
+        }
+#endif
         for (int i = 0; i < 6; ++i) L.dconst[i] -= sb[i];
         T up[6], acc[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -(ina[i] + sa[i]) : T(0);
@@ -2035,7 +2207,18 @@ struct LaneProgram {
             }
             if (P.nlim_r > 0) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
             T Jaa[36], Jab[36], Jba[36], Jbb[36];
+#if DJ_TSD
+            T Saa[36], Sab[36], Sba[36], Sbb[36], pf[3] = {0, 0, 0};
+            if (tsd) {
+                for (int i = 0; i < 36; ++i) Saa[i] = Sab[i] = Sba[i] = Sbb[i] = T(0);
+                tra_sd_cfg_jac(Saa, Sab, Sba, Sbb, pf, P, *tsd, ce, va, wa, L.v, L.w, dt);
+                for (int i = 0; i < 3; ++i) pt[i] += pf[i];
+            }
+#endif
             joint_impulse_cfg_jac(Jaa, Jab, Jba, Jbb, P, ce, pt, pr, wa, L.w, dt);
+#if DJ_TSD
+            if (tsd) for (int i = 0; i < 36; ++i) { Jaa[i] += Saa[i]; Jab[i] += Sab[i]; Jba[i] += Sba[i]; Jbb[i] += Sbb[i]; }
+#endif
             for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
                 int cj = j < 3 ? j : 3 + j;                       // x2 -> cols 0:3, φ2 -> cols 6:9 of the 12 own-data columns
                 OwnB[i][cj] += Jbb[6 * i + j];
@@ -2408,6 +2591,7 @@ struct KernelArgs {
     TIO* res;                      // [B,6Nb] or null          body residual rows at the solution (for the Storage kernel)
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
+    const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
 #endif
@@ -2475,6 +2659,11 @@ constexpr int FAC_PER_LANE = 72;
 // gradient sweeps must not cost the Newton loop its registers).  The IFT kernel rebuilds the lane
 // program from (z, u), restores the converged solution from the hand-off record and re-linearizes
 // there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
+#if DJ_TSD
+#define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr;
+#else
+#define DJ_TSD_SETUP
+#endif
 #define DJ_LANE_SETUP(GRAD_LAYOUT)                                                                                        \
     const Globals<T>& G = A.G;                                                                                            \
     const int stride = QUAD ? 4 : 1;                                                                                      \
@@ -2505,6 +2694,7 @@ constexpr int FAC_PER_LANE = 72;
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
+    DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
     const bool has_u = A.u != nullptr;                                                                                    \

@@ -28,10 +28,13 @@ DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launc
 DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
 DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
 DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2)
+// the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
+DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
 #define DJ_CDECL(n) int n(const void*, int, void*);
 DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
 DJ_CDECL(dojo_launch_cgrad_double_1_1) DJ_CDECL(dojo_launch_cgrad_double_4_1) DJ_CDECL(dojo_launch_cgrad_double_8_1)
 DJ_CDECL(dojo_launch_cgrad_float_4_2) DJ_CDECL(dojo_launch_cgrad_double_4_2)
+DJ_CDECL(dojo_launch_cgrad_tsd_float_1_1) DJ_CDECL(dojo_launch_cgrad_tsd_float_4_1) DJ_CDECL(dojo_launch_cgrad_tsd_double_1_1) DJ_CDECL(dojo_launch_cgrad_tsd_double_4_1)
 #undef DJ_DECL
 }
 
@@ -51,6 +54,7 @@ struct DojoSim {
     DojoSolverOptions opts;
     int B = 0, dtype = 0, device = 0, grad_mode = DOJO_GRAD_REFERENCE;
     size_t w = 8;                       // bytes per scalar
+    void* d_tsd = nullptr;       // translational springs / dampers per supernode (mechanisms that have them)
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
@@ -284,6 +288,12 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     HIPCHK(hipMalloc(&s->d_contacts, contacts.size() * sizeof(dj::ContactP<T>)));
     HIPCHK(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * sizeof(dj::NodeP<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->d_contacts, contacts.data(), contacts.size() * sizeof(dj::ContactP<T>), hipMemcpyHostToDevice));
+    if (s->M.has_tsd) {
+        std::vector<dj::TraSD<T>> tsd;
+        for (auto& a : s->M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); tsd.push_back(b); }
+        HIPCHK(hipMalloc(&s->d_tsd, tsd.size() * sizeof(dj::TraSD<T>)));
+        HIPCHK(hipMemcpy(s->d_tsd, tsd.data(), tsd.size() * sizeof(dj::TraSD<T>), hipMemcpyHostToDevice));
+    }
     std::vector<int> order;
     for (int lev = 0; lev <= s->M.maxlevel; ++lev) for (int b = 0; b < s->M.Nb; ++b) if (s->M.nodes[b].level == lev) order.push_back(b);
     HIPCHK(hipMalloc((void**)&s->d_order, order.size() * sizeof(int)));
@@ -334,6 +344,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
+    A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
     // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
     // else one lane per supernode
@@ -360,7 +371,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (dc != nullptr) {                   // contact-data columns only: the hand-off of the last differentiable step is re-used
         if (!quad) { g_err = "contact-data gradients need the quad mapping (<= 32 bodies)"; return DOJO_ERR_UNSUPPORTED; }
         typedef int (*claunch_t)(const void*, int, void*);
-        claunch_t cf = NW == 2 ? (f32 ? dojo_launch_cgrad_float_4_2 : dojo_launch_cgrad_double_4_2)
+        claunch_t cf = s->M.has_tsd ? (s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_tsd_float_1_1 : dojo_launch_cgrad_tsd_double_1_1)
+                                                      : (f32 ? dojo_launch_cgrad_tsd_float_4_1 : dojo_launch_cgrad_tsd_double_4_1))
+                     : NW == 2 ? (f32 ? dojo_launch_cgrad_float_4_2 : dojo_launch_cgrad_double_4_2)
                      : s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_float_1_1 : dojo_launch_cgrad_double_1_1)
                      : s->M.maxc <= 4 ? (f32 ? dojo_launch_cgrad_float_4_1 : dojo_launch_cgrad_double_4_1)
                                       : (f32 ? dojo_launch_cgrad_float_8_1 : dojo_launch_cgrad_double_8_1);
@@ -371,7 +384,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         return DOJO_OK;
     }
     launcher_t fn;
-    if (NW == 2) fn = f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2;
+    if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
+                                          : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
+    else if (NW == 2) fn = f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2;
     else if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
                  : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_1 : dojo_launch_double_4_1)
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
@@ -425,6 +440,9 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     DojoSim* s = new DojoSim();
     int rc = dj::build_host_model(*topo, s->M);
     if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
+    if (s->M.has_tsd && (mapping_waves(s->M) != 1 || s->M.maxc > 4)) {
+        g_err = "translational springs/dampers need the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    }
     s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
     s->opts = dj::default_options();
     if (hipSetDevice(device) != hipSuccess) { g_err = "dojo_create: hipSetDevice failed"; delete s; return DOJO_ERR_DEVICE; }
@@ -437,7 +455,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);

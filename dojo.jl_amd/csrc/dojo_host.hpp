@@ -16,6 +16,8 @@ struct HostModel {
     int contact_model = 0;       // 0: NonlinearContact, 1: ImpactContact (one model per mechanism)
     std::vector<NodeP<double>> nodes;
     std::vector<ContactP<double>> contacts;
+    std::vector<TraSD<double>> tsd;   // [Nb + 1] translational springs / dampers per supernode (+ the idle slot's zero entry)
+    bool has_tsd = false;
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
     std::string error;
 };
@@ -27,6 +29,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     if (M.Nb > 64) { M.error = "more than 64 bodies per environment is not supported by the lane=supernode mapping"; return DOJO_ERR_UNSUPPORTED; }
     int S = 1; while (S < M.Nb) S <<= 1; M.S = S;
     M.nodes.assign(M.Nb, NodeP<double>());
+    { TraSD<double> z0; z0.spring = z0.damper = 0; z0.off[0] = z0.off[1] = z0.off[2] = 0; M.tsd.assign(M.Nb + 1, z0); M.has_tsd = false; }
     std::vector<int> pj(M.Nb, -1);
     int uoff = 0, ioff = 0;
     for (int j = 0; j < tp.n_joints; ++j) {
@@ -41,7 +44,11 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         if (J.rot.nlim > 1) { M.error = "joint limits on more than one rotational coordinate are not supported"; return DOJO_ERR_UNSUPPORTED; }
         if (J.rot.nlim == 1 && J.rot.nl != 2) { M.error = "rotational limits need a one-dimensional rotational joint"; return DOJO_ERR_UNSUPPORTED; }
         if (J.tra.nl < 3 && ((J.spring_on && J.tra.spring != 0) || (J.damper_on && J.tra.damper != 0))) {
-            M.error = "translational springs/dampers are not supported yet"; return DOJO_ERR_UNSUPPORTED;
+            // translational spring / damper (joints with free translations): a table of its own next to the nodes, DJ_TSD kernels
+            M.has_tsd = true;
+            TraSD<double>& sd = M.tsd[J.child];
+            sd.spring = J.spring_on ? J.tra.spring : 0.0; sd.damper = J.damper_on ? J.tra.damper : 0.0;
+            for (int i = 0; i < 3 - J.tra.nl; ++i) sd.off[i] = J.tra.spring_offset[i];
         }
         P.spring_on = J.spring_on; P.damper_on = J.damper_on;
         P.nu_t = 3 - J.tra.nl; P.nu_r = 3 - J.rot.nl;

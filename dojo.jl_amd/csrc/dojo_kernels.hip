@@ -134,8 +134,13 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
 
 #define DJ_CAT2(a, b, c, d) a##b##_##c##_##d
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
+#if DJ_TSD      // builds that evaluate translational springs / dampers (KernelArgs::tsd)
+#define DJ_LAUNCHER DJ_CAT(dojo_launch_tsd_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#define DJ_CLAUNCHER DJ_CAT(dojo_launch_cgrad_tsd_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#else
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #define DJ_CLAUNCHER DJ_CAT(dojo_launch_cgrad_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#endif
 
 // mid_event (may be null) is recorded between the two kernels so that each can be timed on its own
 extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, void* mid_event) {

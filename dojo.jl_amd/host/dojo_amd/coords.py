@@ -130,6 +130,14 @@ def nominal_minimal(spec, **kw):
         return minimal_state_dict(spec, c)
     if n == "atlas":                         # initialize_atlas!: z = 0.9385
         return minimal_state_dict(spec, {"floating_base": [0, 0, 0.9385, 0, 0, 0]})
+    if n in ("slider", "nslider"):           # initialize_slider! / initialize_nslider!: zero coordinates (+ optional position / velocity of the first joint)
+        x = np.zeros(2 * spec.nu)
+        x[0] = kw.get("position", 0.0); x[1] = kw.get("velocity", 0.0)
+        return x
+    if n == "raiberthopper":                 # initialize_raiberthopper! (raiberthopper/mechanism.jl:70-82): body above the foot, leg_length = 0.5
+        leg = kw.get("leg_length", 0.5)
+        bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, leg + spec.contacts[0].radius if spec.contacts else leg + 0.05])
+        return minimal_state_dict(spec, {"floating_base": [bp[0], bp[1], bp[2], 0, 0, 0], "leg": [-leg]})
     raise ValueError(n)
 
 

@@ -127,6 +127,67 @@ def get_block(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, edge_l
     return MechanismSpec("block", bodies, joints, contacts, timestep, input_scaling, gravity)
 
 
+def _set_per_joint(spec, springs, dampers):
+    """set_springs!/set_dampers! with one value per joint (DojoEnvironments/src/utilities.jl:11-19,31-39) or a scalar"""
+    if np.ndim(springs) == 0 and np.ndim(dampers) == 0:
+        return set_springs_dampers(spec, float(springs), float(dampers))
+    sp = np.broadcast_to(np.asarray(springs, float), (len(spec.joints),))
+    da = np.broadcast_to(np.asarray(dampers, float), (len(spec.joints),))
+    for j, k, c in zip(spec.joints, sp, da):
+        if j.N == 0:
+            continue
+        if k != 0:
+            j.tra.spring = j.rot.spring = float(k)
+        if c != 0:
+            j.tra.damper = j.rot.damper = float(c)
+
+
+def sphere_inertia(r, m):                                             # src/bodies/shapes.jl (Sphere): 2/5 m r^2
+    return 0.4 * m * r * r * np.eye(3)
+
+
+def get_slider(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dampers=0.0, joint_limits=None):
+    """DojoEnvironments/src/mechanisms/slider/mechanism.jl:1-39: one box on a Prismatic joint along z"""
+    bodies = [BodySpec("pbody", 1.0, box_inertia(0.1, 0.1, 1.0, 1.0))]
+    joints = [Prismatic("joint", -1, 0, Z_AXIS, child_vertex=Z_AXIS / 2)]
+    spec = MechanismSpec("slider", bodies, joints, [], timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    if joint_limits:
+        set_limits(spec, joint_limits)
+    return spec
+
+
+def cylinder_inertia(r, h, m):                                        # src/bodies/shapes.jl:130 (Cylinder, axis z), as the reference has it
+    return 0.5 * m * np.diag([r * r + h * h / 6.0, r * r + h * h / 6.0, r * r])
+
+
+def get_nslider(timestep=0.01, input_scaling=None, gravity=-9.81, num_bodies=5, springs=0.0, dampers=0.0):
+    """DojoEnvironments/src/mechanisms/nslider/mechanism.jl:1-40: cylinders on Prismatic joints along z, each to the previous one"""
+    bodies = [BodySpec("body:%d" % (i + 1), 1.0, cylinder_inertia(0.05, 1.0, 1.0)) for i in range(num_bodies)]
+    joints = [Prismatic("joint:1", -1, 0, Z_AXIS)]
+    for i in range(1, num_bodies):
+        joints.append(Prismatic("joint:%d" % (i + 1), i - 1, i, Z_AXIS, parent_vertex=-0.05 * Y_AXIS, child_vertex=0.05 * Y_AXIS))
+    spec = MechanismSpec("nslider", bodies, joints, [], timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    return spec
+
+
+def get_raiberthopper(timestep=0.05, input_scaling=None, gravity=-9.81, body_mass=4.18, foot_mass=0.52, body_radius=0.1, foot_radius=0.05,
+                      springs=(0.0, 0.0), dampers=(0.0, 0.1), friction_coefficient=0.5, contact_foot=True, contact_body=True,
+                      contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/raiberthopper/mechanism.jl:1-68: a floating sphere with a foot on a damped Prismatic leg"""
+    bodies = [BodySpec("body", body_mass, sphere_inertia(body_radius, body_mass)), BodySpec("foot", foot_mass, sphere_inertia(foot_radius, foot_mass))]
+    joints = [Floating("floating_base", -1, 0), Prismatic("leg", 0, 1, Z_AXIS)]
+    contacts = []
+    if contact_foot:
+        contacts.append(contact_constraint("foot_contact", 1, Z_AXIS, friction_coefficient, contact_radius=foot_radius, contact_type=contact_type))
+    if contact_body:
+        contacts.append(contact_constraint("body_contact", 0, Z_AXIS, friction_coefficient, contact_radius=body_radius, contact_type=contact_type))
+    spec = MechanismSpec("raiberthopper", bodies, joints, contacts, timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    return spec
+
+
 # ----------------------------------------------------------------------------------
 # URDF mechanisms   src/mechanism/urdf.jl, src/mechanism/constructor.jl:89-109
 # ----------------------------------------------------------------------------------
@@ -272,7 +333,8 @@ def get_atlas(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dam
 
 def get_mechanism(name, **kwargs):
     """DojoEnvironments.get_mechanism(:name; kwargs...)  DojoEnvironments/src/mechanisms.jl"""
-    return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas}[name](**kwargs)
+    return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas,
+            "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper}[name](**kwargs)
 
 
 # the five BASELINE.json configurations (BASELINE.md §3)

@@ -5,6 +5,7 @@
 // the CPU-only test tier (-m "not gpu") check the shipped device algorithm against the oracle.
 // It is not a product path: libdojo_hip.so has no CPU fallback.
 #define DJ_DEBUG 1
+#define DJ_TSD 1        // the emulator always carries the translational spring / damper code (KernelArgs::tsd decides)
 #include "../../dojo.jl_amd/csrc/dojo_host.hpp"
 #include <thread>
 #include <mutex>
@@ -101,6 +102,9 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     dj::KernelArgs<TIO, T> A;
     A.G = dj::make_globals<T>(M, opts, grad_mode);
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
+    std::vector<dj::TraSD<T>> tsd;
+    for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); tsd.push_back(b); }
+    A.tsd = M.has_tsd ? tsd.data() : nullptr;
     std::vector<TIO> fet = castv(fext, (size_t)B * 6 * M.Nb); A.fext = fext ? fet.data() : nullptr;
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;

@@ -12,7 +12,19 @@ def _rand_quat(rng, scale):
     q = np.concatenate([[1.0], v]); return q / np.linalg.norm(q)
 
 
-def random_mechanism(seed, contact_type="nonlinear", nb=None):
+def _translational_joint(rng, kind, name, parent, k, pv, cv, qo):
+    """joints with free translations (src/joints/prototypes.jl: Prismatic, Planar, Cylindrical, FixedOrientation) with
+    springs, dampers and spring offsets on the translational half (and on the rotational one where it is free)"""
+    axis = rng.normal(size=3)
+    nl_t, nl_r = {"prismatic": (2, 3), "planar": (1, 3), "cylindrical": (2, 2), "fixed_orientation": (0, 3)}[kind]
+    sp, da = float(rng.choice([0.0, 4.0])), float(rng.choice([0.0, 0.6]))
+    tra = d.JointHalfSpec(nl_t, axis=axis, spring=sp, damper=da, spring_offset=rng.uniform(-0.2, 0.2, size=3 - nl_t))
+    rot = d.JointHalfSpec(nl_r, axis=axis, spring=sp, damper=da, spring_offset=rng.uniform(-0.2, 0.2, size=3 - nl_r))
+    return d.JointSpec(name, parent, k, tra, rot, np.array(pv, float), np.array(cv, float), np.array(qo, float))
+
+
+def random_mechanism(seed, contact_type="nonlinear", nb=None, translational=False):
+    """translational=True mixes in joints with free translations (their own seeds: the other tests' mechanisms do not change)"""
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(2, 8)) if nb is None else int(nb)
     bodies = []; joints = []; contacts = []
@@ -29,6 +41,8 @@ def random_mechanism(seed, contact_type="nonlinear", nb=None):
             cand = [p for p in range(k) if nchild[p] < 4]
             parent = int(rng.choice(cand[-3:] if (nb > 8 and rng.random() < 0.5) else cand)); nchild[parent] += 1
             kind = rng.choice(["revolute", "revolute", "spherical", "fixed"])
+            if translational and rng.random() < 0.6:
+                kind = rng.choice(["prismatic", "prismatic", "planar", "cylindrical", "fixed_orientation"])
         pv, cv = rng.uniform(-0.3, 0.3, size=3), rng.uniform(-0.3, 0.3, size=3)
         qo = _rand_quat(rng, 0.3)
         name = "j%d" % k
@@ -36,6 +50,8 @@ def random_mechanism(seed, contact_type="nonlinear", nb=None):
             joints.append(Floating(name, parent, k))
         elif kind == "fixed":
             joints.append(Fixed(name, parent, k, pv, cv, qo))
+        elif kind in ("prismatic", "planar", "cylindrical", "fixed_orientation"):
+            joints.append(_translational_joint(rng, kind, name, parent, k, pv, cv, qo))
         elif kind == "spherical":
             joints.append(Spherical(name, parent, k, pv, cv, qo, spring=float(rng.choice([0.0, 2.0])), damper=float(rng.choice([0.0, 0.5]))))
         else:

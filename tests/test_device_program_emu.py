@@ -194,3 +194,47 @@ def test_random_tree_mechanisms(seed, quad):
             assert np.abs(r["dz"][0] - dz).max() < 1e-8 * max(1.0, np.abs(dz).max())
             assert np.abs(r["du"][0] - du).max() < 1e-8 * max(1.0, np.abs(du).max())
         z = zo
+
+
+TSD_CASES = [("slider", dict(springs=5.0, dampers=0.7)), ("nslider", dict(num_bodies=3, springs=4.0, dampers=0.5)),
+             ("raiberthopper", dict()), ("raiberthopper", dict(springs=(0.0, 30.0), dampers=(0.0, 2.0)))]
+
+
+@pytest.mark.parametrize("name,kw", TSD_CASES)
+def test_translational_springs_dampers(name, kw):
+    """Translational springs / dampers (translational/springs.jl, dampers.jl; the DJ_TSD path of the lane program) on the
+    reference's slider, nslider and raiberthopper (its default has a damped Prismatic leg): equal Newton iteration counts
+    (the damper's velocity Jacobian is exact), states and IFT Jacobians in both conventions to round-off."""
+    spec = d.get_mechanism(name, **kw)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z, u = Z[0], U[0]
+    for k in range(3):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=k % 2)
+        assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+        dz, du = o.gradients(mode=k % 2)
+        assert np.abs(r["dz"][0] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max())
+        assert np.abs(r["du"][0] - du).max() < 1e-7 * max(1.0, np.abs(du).max())
+        z = zo
+
+
+@pytest.mark.parametrize("seed", [100, 103, 104, 106])
+def test_random_tree_mechanisms_with_translational_joints(seed):
+    """Random trees that mix in Prismatic / Planar / Cylindrical / FixedOrientation joints with springs, dampers and spring
+    offsets on their translational (and free rotational) coordinates."""
+    from random_mechanisms import random_mechanism
+    spec, z, u = random_mechanism(seed, translational=True)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    for k in range(2):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z[None], u[None], opts=opts, quad=True, grad=True, grad_mode=k % 2)
+        assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+        dz, du = o.gradients(mode=k % 2)
+        assert np.abs(r["dz"][0] - dz).max() < 1e-8 * max(1.0, np.abs(dz).max())
+        assert np.abs(r["du"][0] - du).max() < 1e-8 * max(1.0, np.abs(du).max())
+        z = zo

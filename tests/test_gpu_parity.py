@@ -672,8 +672,8 @@ def test_impact_contact_parity_and_properties():
     gm.close()
 
 
-@pytest.mark.parametrize("seed0", [0, 8, 16])
-def test_random_tree_mechanisms_gpu(seed0):
+@pytest.mark.parametrize("seed0,translational", [(0, False), (8, False), (16, False), (100, True), (108, True)])
+def test_random_tree_mechanisms_gpu(seed0, translational):
     """Eight random tree mechanisms per case (tests/random_mechanisms.py; every supported joint type, springs, dampers, limits,
     contacts, up to four children per body), four perturbed copies each: states, iteration counts and the IFT Jacobians in
     both evaluation conventions against the oracle; one of them with ImpactContact (forward only)."""
@@ -683,7 +683,7 @@ def test_random_tree_mechanisms_gpu(seed0):
     nok = 0
     for seed in range(seed0, seed0 + 8):
         impact = seed % 8 == 7
-        spec, z0, u0 = random_mechanism(seed, contact_type="impact" if impact else "nonlinear")
+        spec, z0, u0 = random_mechanism(seed, contact_type="impact" if impact else "nonlinear", translational=translational)
         B = 4
         Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
         gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
@@ -773,4 +773,71 @@ def test_two_wavefront_mapping_is_deterministic_with_a_contact_on_node_zero():
             ref = (zn.copy(), it.copy(), dz.copy())
         else:
             assert np.array_equal(zn, ref[0]) and np.array_equal(it, ref[1]) and np.array_equal(dz, ref[2])
+    gm.close()
+
+
+@pytest.mark.parametrize("name,kw,batch,steps", [("slider", dict(springs=5.0, dampers=0.7), 64, 6), ("nslider", dict(num_bodies=5, springs=4.0, dampers=0.5), 64, 6),
+                                                 ("raiberthopper", dict(), 256, 25), ("raiberthopper", dict(springs=(0.0, 30.0), dampers=(0.0, 2.0)), 64, 25)])
+def test_translational_springs_dampers_gpu(name, kw, batch, steps):
+    """Translational springs / dampers (src/joints/translational/springs.jl, dampers.jl) on the reference's slider, nslider
+    and raiberthopper (damped Prismatic leg, two contacts): states, iteration counts and IFT Jacobians in both conventions
+    against the oracle, fp64; the fp32-ABI mode within 1e-3."""
+    spec = d.get_mechanism(name, **kw)
+    Z, U = d.synthetic_inputs(spec, batch)
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=TIGHT)
+    gm32 = api.BatchedMechanism(spec, batch, dtype="f32", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    z = Z.copy(); nok = 0
+    for k in range(steps):
+        mode = k % 2
+        gm.set_gradient_mode(mode)
+        zg, st, it = gm.step(z, U, with_gradient=True)
+        dzg, dug = gm.gradients()
+        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=mode, nthreads=8)
+        ok = np.nonzero((st == 0) & (st_o == 0))[0]
+        assert len(ok) > 0.9 * batch
+        assert (it[ok] == it_o[ok]).mean() > 0.95
+        assert np.abs(zg[ok] - zo[ok]).max() < 1e-6, (k, np.abs(zg[ok] - zo[ok]).max())
+        ez = np.array([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+        eu = np.array([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
+        assert np.quantile(ez, 0.9) < 1e-6 and np.quantile(eu, 0.9) < 1e-6 and ez.max() < 1e-3, (k, np.quantile(ez, 0.9), ez.max())
+        if k == steps - 1:
+            z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
+            ok32 = np.nonzero((st32 == 0) & (st_o == 0))[0]
+            assert len(ok32) > 0.9 * batch and np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max() < 1e-3
+        nok += len(ok)
+        z = zo
+    gm.close(); gm32.close()
+
+
+def test_raiberthopper_full_batch_gradient_is_the_derivative_of_the_step():
+    """Size-independent property at batch 4096 on the mechanism with a translational damper: the IFT Jacobian of the GPU
+    step equals the central finite difference of the GPU step itself along random (x2, v15, ω15) directions."""
+    spec = d.get_mechanism("raiberthopper", springs=(0.0, 10.0), dampers=(0.0, 1.0))
+    B = 4096
+    Z, _ = d.synthetic_inputs(spec, B)
+    U = np.zeros((B, spec.nu))
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+    gm.set_gradient_mode(api.GRAD_CONSISTENT)
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dz, du = gm.gradients()
+    rng = np.random.default_rng(11)
+    nb = spec.Nb
+    dirs = np.zeros((B, 13 * nb)); tang = np.zeros((B, 12 * nb))
+    for b_ in range(nb):
+        for (zo_, to_) in ((3, 3), (10, 9)):                    # velocities keep the joints closed; positions only of the floating root's subtree as a whole
+            v = rng.standard_normal((B, 3)); dirs[:, 13 * b_ + zo_:13 * b_ + zo_ + 3] = v; tang[:, 12 * b_ + to_:12 * b_ + to_ + 3] = v
+    eps = 1e-6
+    zp, sp, _ = gm.step(Z + eps * dirs, U); zm, sm, _ = gm.step(Z - eps * dirs, U)
+    ok = np.nonzero((st == 0) & (sp == 0) & (sm == 0))[0]
+    assert len(ok) > 0.9 * B
+    fd = (zp - zm) / (2 * eps)
+    jv = np.einsum("bij,bj->bi", dz, tang)
+    err = []
+    for b_ in range(nb):
+        for (zo_, to_) in ((0, 0), (3, 3), (10, 9)):
+            err.append(np.abs(fd[ok][:, 13 * b_ + zo_:13 * b_ + zo_ + 3] - jv[ok][:, 12 * b_ + to_:12 * b_ + to_ + 3]).max(axis=1))
+    err = np.max(np.stack(err), axis=0) / np.maximum(1.0, np.abs(jv[ok]).max(axis=1))
+    assert np.quantile(err, 0.9) < 1e-4, np.quantile(err, 0.9)
     gm.close()

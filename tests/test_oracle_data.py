@@ -49,6 +49,11 @@ CASES = [
     ("quadruped", dict(parse_springs=False, parse_dampers=False, springs=2.0, dampers=0.3), 0.3),
     ("atlas", dict(), 0.1),
     ("atlas", dict(parse_springs=False, parse_dampers=False, springs=2.0, dampers=0.3), 0.1),
+    # translational springs and dampers (spring_jacobian_configuration / damper_jacobian_configuration of translational/*.jl)
+    ("slider", dict(springs=2.0, dampers=0.3), 0.1),
+    ("nslider", dict(num_bodies=3, springs=1.0, dampers=1.0), 0.1),
+    ("raiberthopper", dict(timestep=0.01, springs=(0.0, 5.0), dampers=(0.0, 0.5)), 0.1),
+    ("raiberthopper", dict(timestep=0.01), 0.5),
 ]
 
 

@@ -48,6 +48,10 @@ CASES = [
     ("quadruped", dict(parse_springs=False, parse_dampers=False, springs=1.0, dampers=0.2)),
     ("atlas", dict(parse_dampers=False)),
     ("atlas", dict()),
+    # test/jacobian.jl:86,89,106,109: translational springs and dampers (Prismatic joints)
+    ("slider", dict(springs=1.0, dampers=0.2)),
+    ("nslider", dict(springs=1.0, dampers=0.2)),
+    ("raiberthopper", dict(timestep=0.01)),
 ]
 
 
