@@ -134,6 +134,21 @@ def nominal_minimal(spec, **kw):
         x = np.zeros(2 * spec.nu)
         x[0] = kw.get("position", 0.0); x[1] = kw.get("velocity", 0.0)
         return x
+    if n in ("snake", "twister"):            # initialize_snake! / initialize_twister!: zero coordinates, base pose from the keywords
+        bp = np.array(kw.get("base_position", [0, 0, 0.3]), float)
+        return minimal_state_dict(spec, {"floating_base": np.concatenate([bp, kw.get("base_rotation_vector", np.zeros(3))])},
+                                  {"floating_base": np.concatenate([kw.get("base_linear_velocity", np.zeros(3)), kw.get("base_angular_velocity", np.zeros(3))])})
+    if n == "npendulum":                     # initialize_npendulum!: base angle π/4 on the first joint's rotational coordinates
+        x = np.zeros(2 * spec.nu)
+        j0 = spec.joints[0]
+        if j0.rot.nu > 0:
+            x[j0.tra.nu] = kw.get("base_angle", np.pi / 4)
+        return x
+    if n == "sphere":                        # initialize_sphere!: position [0,0,1] + radius
+        r = spec.contacts[0].radius if spec.contacts else 0.5
+        pos = np.array(kw.get("position", [0, 0, 1.0]), float) + np.array([0, 0, r])
+        return minimal_state_dict(spec, {"floating_base": np.concatenate([pos, np.zeros(3)])},
+                                  {"floating_base": np.concatenate([kw.get("velocity", [1.0, 0, 0]), kw.get("angular_velocity", np.zeros(3))])})
     if n == "raiberthopper":                 # initialize_raiberthopper! (raiberthopper/mechanism.jl:70-82): body above the foot, leg_length = 0.5
         leg = kw.get("leg_length", 0.5)
         bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, leg + spec.contacts[0].radius if spec.contacts else leg + 0.05])

@@ -55,6 +55,27 @@ def Spherical(name, parent, child, parent_vertex=np.zeros(3), child_vertex=np.ze
                      np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
 
 
+# Dojo.Prototype(joint_type, pbody, cbody, axis; ...)  src/joints/prototypes.jl:455-480: (Nλ translational, Nλ rotational)
+PROTOTYPES = {"Fixed": (3, 3), "Prismatic": (2, 3), "Planar": (1, 3), "FixedOrientation": (0, 3), "Revolute": (3, 2), "Cylindrical": (2, 2),
+              "PlanarAxis": (1, 2), "FreeRevolute": (0, 2), "Orbital": (3, 1), "PrismaticOrbital": (2, 1), "PlanarOrbital": (1, 1),
+              "FreeOrbital": (0, 1), "Spherical": (3, 0), "CylindricalFree": (2, 0), "PlanarFree": (1, 0), "Floating": (0, 0)}
+
+
+def Prototype(joint_type, name, parent, child, axis, parent_vertex=np.zeros(3), child_vertex=np.zeros(3),
+              orientation_offset=np.array([1.0, 0, 0, 0]), spring=0.0, damper=0.0, tra_spring_offset=None, rot_spring_offset=None):
+    """Any of the sixteen joint prototypes: Translational{T,Nλt} + Rotational{T,Nλr} about / along `axis` with the same spring and
+    damper value on both halves (prototypes.jl:6-447).  CylindricalFree / PlanarFree take no orientation offset there."""
+    nl_t, nl_r = PROTOTYPES[joint_type]
+    if joint_type in ("CylindricalFree", "PlanarFree", "Floating"):
+        orientation_offset = np.array([1.0, 0, 0, 0])
+    tso = np.zeros(3 - nl_t) if tra_spring_offset is None else np.array(tra_spring_offset, float)
+    rso = np.zeros(3 - nl_r) if rot_spring_offset is None else np.array(rot_spring_offset, float)
+    return JointSpec(name, parent, child,
+                     JointHalfSpec(nl_t, axis=np.array(axis, float), spring=spring, damper=damper, spring_offset=tso),
+                     JointHalfSpec(nl_r, axis=np.array(axis, float), spring=spring, damper=damper, spring_offset=rso),
+                     np.array(parent_vertex, float), np.array(child_vertex, float), np.array(orientation_offset, float))
+
+
 def box_inertia(x, y, z, m):                                          # src/bodies/shapes.jl:90
     return m / 12.0 * np.diag([y * y + z * z, x * x + z * z, x * x + y * y])
 
@@ -170,6 +191,62 @@ def get_nslider(timestep=0.01, input_scaling=None, gravity=-9.81, num_bodies=5, 
     spec = MechanismSpec("nslider", bodies, joints, [], timestep, input_scaling, gravity)
     _set_per_joint(spec, springs, dampers)
     return spec
+
+
+def get_npendulum(timestep=0.01, input_scaling=None, gravity=-9.81, num_bodies=5, mass=1.0, link_length=1.0, springs=0.0, dampers=0.0,
+                  base_joint_type="Revolute", rest_joint_type="Revolute"):
+    """DojoEnvironments/src/mechanisms/npendulum/mechanism.jl:1-43"""
+    bodies = [BodySpec("body:%d" % (i + 1), mass, box_inertia(0.05, 0.05, link_length, mass)) for i in range(num_bodies)]
+    joints = [Prototype(base_joint_type, "joint:1", -1, 0, X_AXIS, parent_vertex=(link_length + 0.1) * Z_AXIS * num_bodies, child_vertex=Z_AXIS * link_length / 2)]
+    for i in range(1, num_bodies):
+        joints.append(Prototype(rest_joint_type, "joint:%d" % (i + 1), i - 1, i, X_AXIS, parent_vertex=-Z_AXIS * link_length / 2, child_vertex=Z_AXIS * link_length / 2))
+    spec = MechanismSpec("npendulum", bodies, joints, [], timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    return spec
+
+
+def get_snake(timestep=0.01, input_scaling=None, gravity=-9.81, num_bodies=2, link_length=1.0, radius=0.05, springs=0.0, dampers=0.0,
+              joint_type="Spherical", friction_coefficient=0.8, contact=True, contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/snake/mechanism.jl:1-66: boxes chained along x by any joint prototype below a floating base,
+    one contact at either end of every link (body order of the contacts: all +x ends, then all −x ends)"""
+    bodies = [BodySpec("body:%d" % (i + 1), link_length, box_inertia(link_length, 3 * radius, 2 * radius, link_length)) for i in range(num_bodies)]
+    joints = [Floating("floating_base", -1, 0)]
+    for i in range(1, num_bodies):
+        joints.append(Prototype(joint_type, "joint:%d" % (i + 1), i - 1, i, X_AXIS, parent_vertex=-X_AXIS * link_length / 2, child_vertex=X_AXIS * link_length / 2))
+    contacts = []
+    if contact:
+        for sgn in (1.0, -1.0):
+            for i in range(num_bodies):
+                contacts.append(contact_constraint("contact:%d" % (len(contacts) + 1), i, Z_AXIS, friction_coefficient, sgn * X_AXIS * link_length / 2,
+                                                   contact_type=contact_type))
+    spec = MechanismSpec("snake", bodies, joints, contacts, timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    return spec
+
+
+def get_twister(timestep=0.01, input_scaling=None, gravity=-9.81, num_bodies=5, height=1.0, radius=0.05, springs=0.0, dampers=0.0,
+                joint_type="Prismatic", friction_coefficient=0.8, contact=True, contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/twister/mechanism.jl:1-68: like the snake with the joint axis cycling through y, z, x"""
+    bodies = [BodySpec("body:%d" % (i + 1), height, box_inertia(height, 3 * radius, 2 * radius, height)) for i in range(num_bodies)]
+    axes = [X_AXIS, Y_AXIS, Z_AXIS]
+    joints = [Floating("floating_base", -1, 0)]
+    for i in range(2, num_bodies + 1):                                  # Julia's i = 2:num_bodies, axes[i % 3 + 1] (1-based)
+        joints.append(Prototype(joint_type, "joint:%d" % i, i - 2, i - 1, axes[i % 3], parent_vertex=-X_AXIS * height / 2, child_vertex=X_AXIS * height / 2))
+    contacts = []
+    if contact:                                                         # [bodies[1]; bodies]: +x end of the first link, −x end of every link
+        origins = [X_AXIS * height / 2] + [-X_AXIS * height / 2] * num_bodies
+        for k, b in enumerate([0] + list(range(num_bodies))):
+            contacts.append(contact_constraint("contact:%d" % (k + 1), b, Z_AXIS, friction_coefficient, origins[k], contact_type=contact_type))
+    spec = MechanismSpec("twister", bodies, joints, contacts, timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    return spec
+
+
+def get_sphere(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, radius=0.5, friction_coefficient=0.8, contact=True, contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/sphere/mechanism.jl:1-45"""
+    bodies = [BodySpec("sphere", mass, sphere_inertia(radius, mass))]
+    contacts = [contact_constraint("contact", 0, Z_AXIS, friction_coefficient, contact_radius=radius, contact_type=contact_type)] if contact else []
+    return MechanismSpec("sphere", bodies, [Floating("floating_base", -1, 0)], contacts, timestep, input_scaling, gravity)
 
 
 def get_raiberthopper(timestep=0.05, input_scaling=None, gravity=-9.81, body_mass=4.18, foot_mass=0.52, body_radius=0.1, foot_radius=0.05,
@@ -334,7 +411,8 @@ def get_atlas(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dam
 def get_mechanism(name, **kwargs):
     """DojoEnvironments.get_mechanism(:name; kwargs...)  DojoEnvironments/src/mechanisms.jl"""
     return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas,
-            "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper}[name](**kwargs)
+            "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper,
+            "npendulum": get_npendulum, "snake": get_snake, "twister": get_twister, "sphere": get_sphere}[name](**kwargs)
 
 
 # the five BASELINE.json configurations (BASELINE.md §3)

@@ -238,3 +238,22 @@ def test_random_tree_mechanisms_with_translational_joints(seed):
         assert np.abs(r["dz"][0] - dz).max() < 1e-8 * max(1.0, np.abs(dz).max())
         assert np.abs(r["du"][0] - du).max() < 1e-8 * max(1.0, np.abs(du).max())
         z = zo
+
+
+@pytest.mark.parametrize("joint_type", ["Prismatic", "Planar", "Cylindrical", "PlanarAxis", "Orbital", "PrismaticOrbital", "FreeOrbital", "CylindricalFree"])
+def test_snake_joint_prototypes(joint_type):
+    """The reference loops its damper / minimal-coordinate tests over every joint prototype on the snake (test/damper.jl:2-25,
+    test/minimal.jl): the same mechanism with springs and dampers on the device program.  (All fifteen prototypes on snake,
+    twister and npendulum run in the GPU tier.)"""
+    spec = d.get_mechanism("snake", num_bodies=2, joint_type=joint_type, springs=1.0, dampers=0.3)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z, u = Z[0], U[0]
+    zo, info = o.step(z, u)
+    r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=1)
+    assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+    assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+    dz, du = o.gradients(mode=1)
+    assert np.abs(r["dz"][0] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max())
+    assert np.abs(r["du"][0] - du).max() < 1e-7 * max(1.0, np.abs(du).max())

@@ -848,3 +848,41 @@ def test_raiberthopper_full_batch_gradient_is_the_derivative_of_the_step():
     err = np.max(np.stack(err), axis=0) / np.maximum(1.0, np.abs(jv[ok]).max(axis=1))
     assert np.quantile(err, 0.9) < 1e-4, np.quantile(err, 0.9)
     gm.close()
+
+
+@pytest.mark.parametrize("joint_type", ["Fixed", "Prismatic", "Planar", "FixedOrientation", "Revolute", "Cylindrical", "PlanarAxis", "FreeRevolute", "Orbital",
+                                        "PrismaticOrbital", "PlanarOrbital", "FreeOrbital", "Spherical", "CylindricalFree", "PlanarFree"])
+def test_joint_prototypes_gpu(joint_type):
+    """Every joint prototype of src/joints/prototypes.jl (the loop of test/damper.jl:2-25 and test/minimal.jl) with springs and
+    dampers on the reference's snake, twister and npendulum: states, iteration counts and the IFT Jacobians in both conventions."""
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    for name, kw in (("snake", dict(num_bodies=3, joint_type=joint_type, springs=1.0, dampers=0.3)),
+                     ("twister", dict(num_bodies=4, joint_type=joint_type, springs=0.5, dampers=0.2)),
+                     ("npendulum", dict(num_bodies=3, base_joint_type=joint_type, rest_joint_type=joint_type, springs=0.5, dampers=0.3))):
+        spec = d.get_mechanism(name, **kw)
+        B = 16
+        Z, U = d.synthetic_inputs(spec, B)
+        gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
+        o = Oracle(spec, opts=opts)
+        z = Z.copy(); ez = []; eu = []; es = []; same = []
+        for k in range(3):
+            gm.set_gradient_mode(k % 2)
+            zg, st, it = gm.step(z, U, with_gradient=True)
+            dzg, dug = gm.gradients()
+            zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=k % 2, nthreads=8)
+            ok = np.nonzero((st == 0) & (st_o == 0))[0]
+            assert len(ok) >= 0.75 * B, (name, k, len(ok))
+            same.append(it[ok] == it_o[ok])
+            es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
+            ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+            if spec.nu:
+                eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
+            z = zo
+        es, ez, same = np.concatenate(es), np.concatenate(ez), np.concatenate(same)
+        assert same.mean() > 0.75, (name, same.mean())          # contacts at the 1e-9 floor: the last iteration may fall either way (DESIGN.md §7)
+        assert np.quantile(es, 0.75) < 1e-9 and np.quantile(es, 0.9) < 1e-7 and es.max() < 1e-5, (name, np.quantile(es, 0.9), es.max())
+        assert np.quantile(ez, 0.9) < 1e-7 and ez.max() < 1e-3, (name, np.quantile(ez, 0.9), ez.max())
+        if eu:
+            eu = np.concatenate(eu)
+            assert np.quantile(eu, 0.9) < 1e-7 and eu.max() < 1e-3, (name, np.quantile(eu, 0.9), eu.max())
+        gm.close()

@@ -54,6 +54,11 @@ CASES = [
     ("nslider", dict(num_bodies=3, springs=1.0, dampers=1.0), 0.1),
     ("raiberthopper", dict(timestep=0.01, springs=(0.0, 5.0), dampers=(0.0, 0.5)), 0.1),
     ("raiberthopper", dict(timestep=0.01), 0.5),
+    # test/data.jl:28-31: snake, 3 bodies, springs = dampers = 1; joint prototypes with free translations and two free rotations
+    ("snake", dict(num_bodies=3, springs=1.0, dampers=1.0), 0.1),
+    ("snake", dict(num_bodies=3, springs=1.0, dampers=1.0, joint_type="PlanarAxis"), 0.1),
+    ("twister", dict(num_bodies=4, springs=1.0, dampers=0.5, joint_type="PrismaticOrbital"), 0.1),
+    ("npendulum", dict(num_bodies=3, springs=1.0, dampers=0.5, rest_joint_type="CylindricalFree"), 0.1),
 ]
 
 

@@ -52,6 +52,11 @@ CASES = [
     ("slider", dict(springs=1.0, dampers=0.2)),
     ("nslider", dict(springs=1.0, dampers=0.2)),
     ("raiberthopper", dict(timestep=0.01)),
+    # test/jacobian.jl:85,88,90 (and 105,108,110): snake, npendulum, twister with springs = 1, dampers = 0.2
+    ("snake", dict(springs=1.0, dampers=0.2)),
+    ("npendulum", dict(springs=1.0, dampers=0.2)),
+    ("twister", dict(springs=1.0, dampers=0.2)),
+    ("sphere", dict()),
 ]
 
 
