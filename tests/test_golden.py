@@ -40,3 +40,41 @@ def test_gpu_matches_golden(cfg):
     if ok[0]:
         ref = G["c%d_dz0" % cfg].astype(np.float64)
         assert np.abs(dz[0] - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+
+
+# ---- mechanisms beyond the five BASELINE configurations (translational springs / dampers, other joint prototypes) ----
+GM = np.load(os.path.join(ROOT, "tests", "golden", "oracle_steps_mechanisms.npz"))
+MECHS = {"raiberthopper": dict(), "nslider": dict(num_bodies=4, springs=1.0, dampers=0.2),
+         "snake_planaraxis": dict(num_bodies=3, joint_type="PlanarAxis", springs=1.0, dampers=0.3),
+         "twister": dict(num_bodies=4, springs=0.5, dampers=0.2),
+         "npendulum_orbital": dict(num_bodies=3, rest_joint_type="Orbital", springs=0.5, dampers=0.3)}
+
+
+@pytest.mark.parametrize("key", sorted(MECHS))
+def test_oracle_reproduces_golden_mechanisms(key):
+    spec = d.get_mechanism(key.split("_")[0], **MECHS[key])
+    o = Oracle(spec, opts=OPTS)
+    Zn, st, it, dz, du = o.step_batch(GM[key + "_z"], GM[key + "_u"], with_grad=True, grad_mode=0, nthreads=4)
+    assert np.array_equal(st, GM[key + "_status"]) and np.array_equal(it, GM[key + "_iters"])
+    assert np.abs(Zn - GM[key + "_zn"]).max() < 1e-12
+    assert np.abs(dz[0] - GM[key + "_dz0"]).max() <= 1e-9 * max(1.0, np.abs(GM[key + "_dz0"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", sorted(MECHS))
+def test_gpu_matches_golden_mechanisms(key):
+    from dojo_amd import api
+    spec = d.get_mechanism(key.split("_")[0], **MECHS[key])
+    Z, U = GM[key + "_z"], GM[key + "_u"]
+    gm = api.BatchedMechanism(spec, len(Z), dtype="f64", opts=OPTS)
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dz, du = gm.gradients()
+    gm.close()
+    ok = (st == 0) & (GM[key + "_status"] == 0)
+    assert ok.any()
+    assert np.abs(zn[ok] - GM[key + "_zn"][ok]).max() < 1e-5            # parity criterion of DESIGN.md §7 (almost-active contacts)
+    if ok[0]:
+        ref = GM[key + "_dz0"]
+        assert np.abs(dz[0] - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+        if spec.nu:
+            assert np.abs(du[0] - GM[key + "_du0"]).max() <= 1e-3 * max(1.0, np.abs(GM[key + "_du0"]).max())

@@ -13,7 +13,8 @@ import dojo_amd as d
 from oracle import Oracle
 
 out = {}
-for cfg, B, pre in ((1, 4, 2), (2, 4, 60), (3, 4, 12), (4, 2, 8), (5, 2, 2)):
+BASE = "--mechanisms-only" not in sys.argv        # python tools/make_golden.py --mechanisms-only leaves oracle_steps.npz as it is
+for cfg, B, pre in (((1, 4, 2), (2, 4, 60), (3, 4, 12), (4, 2, 8), (5, 2, 2)) if BASE else ()):
     spec = d.baseline_config(cfg)
     opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
     o = Oracle(spec, opts=opts)
@@ -25,5 +26,26 @@ for cfg, B, pre in ((1, 4, 2), (2, 4, 60), (3, 4, 12), (4, 2, 8), (5, 2, 2)):
     # Jacobians: keep them small -- the first environment, fp32 is plenty for a 1e-6 relative comparison
     out["c%d_dz0" % cfg] = dz[0].astype(np.float64) if cfg <= 2 else dz[0].astype(np.float32)
     out["c%d_du0" % cfg] = du[0].astype(np.float64) if cfg <= 2 else du[0].astype(np.float32)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps.npz"), **out)
-print("wrote tests/golden/oracle_steps.npz", {k: v.shape for k, v in out.items() if k.endswith("_z")})
+if BASE:
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps.npz"), **out)
+    print("wrote tests/golden/oracle_steps.npz", {k: v.shape for k, v in out.items() if k.endswith("_z")})
+
+
+# Mechanisms beyond the five BASELINE configurations (translational springs / dampers, other joint prototypes):
+# tests/golden/oracle_steps_mechanisms.npz, same conventions.
+MECHS = {"raiberthopper": (dict(), 4, 3), "nslider": (dict(num_bodies=4, springs=1.0, dampers=0.2), 4, 2),
+         "snake_planaraxis": (dict(num_bodies=3, joint_type="PlanarAxis", springs=1.0, dampers=0.3), 4, 4),
+         "twister": (dict(num_bodies=4, springs=0.5, dampers=0.2), 4, 4),
+         "npendulum_orbital": (dict(num_bodies=3, rest_joint_type="Orbital", springs=0.5, dampers=0.3), 4, 3)}
+out = {}
+for key, (kw, B, pre) in MECHS.items():
+    spec = d.get_mechanism(key.split("_")[0], **kw)
+    o = Oracle(spec, opts=d.SolverOptions(rtol=1e-8, btol=1e-8))
+    Z, U = d.synthetic_inputs(spec, B)
+    for _ in range(pre):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    Zn, st, it, dz, du = o.step_batch(Z, U, with_grad=True, grad_mode=0, nthreads=4)
+    out[key + "_z"] = Z; out[key + "_u"] = U; out[key + "_zn"] = Zn; out[key + "_status"] = st; out[key + "_iters"] = it
+    out[key + "_dz0"] = dz[0]; out[key + "_du0"] = du[0]
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps_mechanisms.npz"), **out)
+print("wrote tests/golden/oracle_steps_mechanisms.npz", {k: v.shape for k, v in out.items() if k.endswith("_z")}, {k: v for k, v in out.items() if k.endswith("_status")})
