@@ -114,6 +114,9 @@ struct Factors {
     TL Sq[QUAD ? 3 : 1][12], Uq[QUAD ? 3 : 1][6], Lq[6][QUAD ? 3 : 1];
     // condensation pieces, in the state precision T
     T th_a[3], th_b[3], t_a[6], t_b[6];
+#if DJ_TSD
+    T thv_a[3], thv_b[3];        // translational limit: the linear-velocity part of ∂θ/∂(velocities)
+#endif
 };
 
 template <class T, int MAXC>
@@ -316,6 +319,10 @@ struct JointEval {
     T th_a[3], th_b[3];          // ∂θ/∂ω_a, ∂θ/∂ω_b
     T GaX[18], GaP[18], GbX[18], GbP[18];   // raw rows ∂g/∂x3, ∂g/∂φ3 (6 slots x 3) of parent / child
     T thp_a[3], thp_b[3];        // raw ∂θ/∂φ3
+#if DJ_TSD
+    T thv_a[3], thv_b[3];        // translational limit: ∂θ/∂v_a, ∂θ/∂v_b
+    T thx_a[3], thx_b[3];        // raw ∂θ/∂x3
+#endif
     T t_a[6], t_b[6];            // impulse_transform · Arᵀ (limit impulse direction)
 };
 
@@ -649,7 +656,7 @@ template <class T> DJ_HD void spring_impulses(T* sa, T* sb, const NodeP<T>& P, c
 //   damper  f = −(c/Δt) AᵀA (e2 − e1),  e1 = e one step back along the CANDIDATE velocities (minimal.jl:91-110)
 //   both enter the body residuals as Δt·T_a f (parent), Δt·T_b f (child), T = impulse_transform (tra_impulse)
 // ------------------------------------------------------------------------------------------------
-template <class T> struct TraSD { T spring, damper, off[3]; };
+template <class T> struct TraSD { T spring, damper, off[3], lim_lo, lim_hi; int nlim; };   // nlim = 1: limits on the free translational coordinate (nl_t = 2)
 
 template <class T> DJ_HD void tra_AtA(T* M, const NodeP<T>& P) {
     for (int i = 0; i < 9; ++i) M[i] = T(0);
@@ -790,6 +797,42 @@ DJ_HD void tra_sd_cfg_jac(T* Jaa, T* Jab, T* Jba, T* Jbb, T* pf, const NodeP<T>&
         for (int r = 0; r < 6; ++r) { Jaa[6 * r + j] += aa[r]; Jba[6 * r + j] += ba[r]; Jab[6 * r + j] += ab[r]; Jbb[6 * r + j] += bb[r]; }
     }
 }
+
+#if DJ_TSD
+// Limit on the free translational coordinate of a joint with nl_t = 2 (Prismatic, Cylindrical, PrismaticOrbital,
+// CylindricalFree): src/joints/limits.jl:4-61 with the translational coordinate θ = A·e(x3, q3) (translational/minimal.jl:56-61).
+// Same elimination as the rotational limit (one Δκ row), kept in the free third TRANSLATIONAL slot (row 8).
+template <bool JAC, class T>
+DJ_HD void tra_limit_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>& cfg, const Kin<T>& ka, const Kin<T>& kb, const T* lg, T dt) {
+    T t3[3], wv[3], u[3];
+    m3vec(t3, kb.R3, P.pb);
+    for (int i = 0; i < 3; ++i) wv[i] = kb.x3[i] + t3[i] - ka.x3[i];
+    m3tvec(u, ka.R3, wv);
+    const T* a = P.At;
+    E.theta = a[0] * (u[0] - P.pa[0]) + a[1] * (u[1] - P.pa[1]) + a[2] * (u[2] - P.pa[2]);
+    const T kk = lg[1] - lg[0];                              // projector [0; −A; A; C]ᵀ, joint.jl:92
+    T p[3] = {a[0] * kk, a[1] * kk, a[2] * kk}, ia[6], ib[6];
+    tra_impulse(ia, ib, cfg, P, p);
+    for (int i = 0; i < 6; ++i) { E.imp_a[i] += ia[i]; E.imp_b[i] += ib[i]; }
+    if (JAC) {
+        T RaT_Rb[9], Spb[9], Eb[9], Su[9], SuP[9], EbP[9];
+        m3tmul(RaT_Rb, ka.R3, kb.R3); m3skew(Spb, P.pb); m3mul(Eb, RaT_Rb, Spb);
+        for (int i = 0; i < 9; ++i) Eb[i] *= T(-2);
+        m3skew(Su, u);
+        for (int i = 0; i < 9; ++i) Su[i] *= T(2);
+        m3mul(SuP, Su, ka.Phi); m3mul(EbP, Eb, kb.Phi);
+        for (int j = 0; j < 3; ++j) {
+            const T aRaT = a[0] * ka.R3[3 * j] + a[1] * ka.R3[3 * j + 1] + a[2] * ka.R3[3 * j + 2];
+            E.thx_a[j] = -aRaT; E.thx_b[j] = aRaT; E.thv_a[j] = -dt * aRaT; E.thv_b[j] = dt * aRaT;
+            E.thp_a[j] = a[0] * Su[j] + a[1] * Su[3 + j] + a[2] * Su[6 + j];
+            E.thp_b[j] = a[0] * Eb[j] + a[1] * Eb[3 + j] + a[2] * Eb[6 + j];
+            E.th_a[j] = a[0] * SuP[j] + a[1] * SuP[3 + j] + a[2] * SuP[6 + j];
+            E.th_b[j] = a[0] * EbP[j] + a[1] * EbP[3 + j] + a[2] * EbP[6 + j];
+        }
+        tra_impulse(E.t_a, E.t_b, cfg, P, a);
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // contact evaluation at (x3, q3) of the body: residual rows, impulse, and (JAC) C/G blocks
@@ -1001,7 +1044,16 @@ struct LaneProgram {
     JointCfg<T>& cfg;
     T mu;                        // mechanism.μ
 #if DJ_TSD
-    const TraSD<T>* tsd = nullptr;   // translational spring / damper of the parent joint (null: the mechanism has none)
+    const TraSD<T>* tsd = nullptr;   // translational spring / damper / limit of the parent joint (null: the mechanism has none)
+    bool tlim = false;               // the joint limit of this supernode sits on its translational coordinate (Δκ row = slot 8)
+    DJ_HD bool lim_on() const { return P.nlim_r > 0 || tlim; }
+    DJ_HD T lim_lo() const { return tlim ? tsd->lim_lo : P.lim_lo; }
+    DJ_HD T lim_hi() const { return tlim ? tsd->lim_hi : P.lim_hi; }
+#else
+    static constexpr bool tlim = false;
+    DJ_HD bool lim_on() const { return P.nlim_r > 0; }
+    DJ_HD T lim_lo() const { return P.lim_lo; }
+    DJ_HD T lim_hi() const { return P.lim_hi; }
 #endif
 #ifdef DJ_DEBUG
     T* dbg = nullptr; bool dbg_on = false; bool trace = false;
@@ -1054,6 +1106,7 @@ struct LaneProgram {
         joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, K);
 #if DJ_TSD
         if (tsd) tra_damper_eval<JAC>(E, P, *tsd, cfg, va, wa, L.v, L.w, dt, K);
+        if (tlim) tra_limit_eval<JAC>(E, P, cfg, ka, kb, L.lg, dt);
 #endif
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
@@ -1114,6 +1167,9 @@ struct LaneProgram {
                 }
             }
             for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
+#if DJ_TSD
+            if (tlim) for (int j = 0; j < 3; ++j) { F.thv_a[j] = E.thv_a[j]; F.thv_b[j] = E.thv_b[j]; }
+#endif
             for (int j = 0; j < 6; ++j) { F.t_a[j] = E.t_a[j]; F.t_b[j] = E.t_b[j]; }
         }
     }
@@ -1135,7 +1191,7 @@ struct LaneProgram {
                     b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
                 }
             }
-            if (P.nlim_r > 0) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
+            if (lim_on()) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
         }
         if constexpr (QUAD && DJ_LDS_REDUCE) { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
         else { rvio = env_max(wv, r, envl); bvio = env_max(wv, b, envl); }
@@ -1219,9 +1275,19 @@ struct LaneProgram {
         //     Δκ/(1 + wκ) + σ (θ_a Δω_a + θ_b Δω_b) = κ0/(1 + wκ),   σ = wκ/(1 + wκ);   body rows: −t_x Δκ.
         // Entries stay in [0, 1] whether the limit is inactive (wκ ~ 1e-10: Δκ ≈ 0) or strongly active (wκ ~ 1e11: an equality
         // row with a tiny regularisation); folding wκ t θᵀ into the body blocks instead costs the IFT its digits there.
-        if (P.nlim_r > 0) {
+        if (lim_on()) {
             const T wk = (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG));
             const T c_ = trcp(T(1) + wk), sg_ = wk * c_;
+#if DJ_TSD
+            if (tlim) {                                             // the same row in the third translational slot, θ depends on v and ω
+                K.addS(8, 8, c_ - T(1));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { K.addS(8, 3 + j, sg_ * F.th_b[j]); K.addU(8, 3 + j, sg_ * F.th_a[j]); K.addS(8, j, sg_ * F.thv_b[j]); K.addU(8, j, sg_ * F.thv_a[j]); }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { K.addS(i, 8, -F.t_b[i]); K.addL(i, 8, -F.t_a[i]); }
+                return;
+            }
+#endif
             K.addS(11, 11, c_ - T(1));                              // (the padding put 1 there)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { K.addS(11, 3 + j, sg_ * F.th_b[j]); K.addU(11, 3 + j, sg_ * F.th_a[j]); }
@@ -1459,7 +1525,7 @@ struct LaneProgram {
                 od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
                 rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0); um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
                 // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
-                wkm = (sp.nlim_r > 0 && q == 3 && (mine || par) && typ == 0) ? TG(wk) : TG(0);       // σ on the Δκ row = row 2 of role 3
+                wkm = (sp.nlim_r > 0 && q == ((DJ_TSD && sp.nlim_r == 2) ? 2 : 3) && (mine || par) && typ == 0) ? TG(wk) : TG(0);       // σ on the Δκ row = row 2 of role 3
                 sl_off = mine ? RH::SLO : RH::SLP;
             } else {
                 // contact batch b - nbs = contact index of the environment; cl = its slot on this supernode (or -1)
@@ -1737,20 +1803,24 @@ struct LaneProgram {
             }
         }
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0), isu = T(0), isl = T(0);
-        if (P.nlim_r > 0) {
+        if (lim_on()) {
             su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
             isu = trcp(su); isl = trcp(sl);
             kap0 = (R.lim[1] - gl * rsl) * isl - (R.lim[0] - gu * rsu) * isu;
-            rk[11] = kap0 * trcp(T(1) + gl * isl + gu * isu);      // the Δκ row (see evaluate)
+            const T rkap = kap0 * trcp(T(1) + gl * isl + gu * isu);   // the Δκ row (see evaluate)
+            if (tlim) rk[8] = rkap; else rk[11] = rkap;
         }
         T dk[12], dva[6];
         core_solve(rk, up, dk, dva);
         for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
-        if (P.nlim_r > 0) D.dlam[5] = T(0);                         // slot 11 carried Δκ, not a joint multiplier
+        if (lim_on()) { if (tlim) D.dlam[2] = T(0); else D.dlam[5] = T(0); }   // slot 11 (8) carried Δκ, not a joint multiplier
         // recovery of the condensed variables
-        if (P.nlim_r > 0) {
+        if (lim_on()) {
             T thd = v3dot(F.th_a, dva + 3) + v3dot(F.th_b, D.dw);
+#if DJ_TSD
+            if (tlim) thd += v3dot(F.thv_a, dva) + v3dot(F.thv_b, D.dv);
+#endif
             D.dls[0] = rsu - thd; D.dls[1] = rsl + thd;
             D.dlg[0] = (R.lim[0] - gu * D.dls[0]) * isu;
             D.dlg[1] = (R.lim[1] - gl * D.dls[1]) * isl;
@@ -1818,9 +1888,9 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) { rk[i] = -rb[i]; rk[6 + i] = -rj[i]; }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r58[c][i] = -cres[c][i];
-        if (P.nlim_r > 0) {
-            rs[0] = -(L.ls[0] - (P.lim_hi - theta));       // limits.jl:13-14
-            rs[1] = -(L.ls[1] - (theta - P.lim_lo));
+        if (lim_on()) {
+            rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
+            rs[1] = -(L.ls[1] - (theta - lim_lo()));
         }
         solve_rhs(rk, R, rs, r58, upx, D);
     }
@@ -1836,7 +1906,7 @@ struct LaneProgram {
                 a = tmin(a, soc_step(&L.cs[c][1], &D.dcs[c][1], tsoc));
                 a = tmin(a, soc_step(&L.cg[c][1], &D.dcg[c][1], tsoc));
             }
-            if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) {
+            if (lim_on()) for (int i = 0; i < 2; ++i) {
                 a = tmin(a, ort_step(L.ls[i], D.dls[i], tort));
                 a = tmin(a, ort_step(L.lg[i], D.dlg[i], tort));
             }
@@ -2033,7 +2103,7 @@ struct LaneProgram {
                     for (int i = 0; i < 4; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
                     p2 += G.contact_model == 1 ? T(1) : T(2);
                 }
-                if (P.nlim_r > 0) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
+                if (lim_on()) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
             }
             if constexpr (QUAD && DJ_LDS_REDUCE) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
             else { p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl); }
@@ -2170,6 +2240,9 @@ struct LaneProgram {
         kin_of(ka, xa2e, qa2e, va, wa, dt);
         JointEval<T> E;
         { NullBlocks nk; joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, nk); }
+#if DJ_TSD
+        if (tlim) tra_limit_eval<true>(E, P, ce, ka, kb, L.lg, dt);
+#endif
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -2193,10 +2266,13 @@ struct LaneProgram {
             OwnJ[sl][3 + j] = -pb_; ParJ[sl][3 + j] = -pa_;
         }
         // limit slack rows: up = −∂θ/∂φ2, lo = +∂θ/∂φ2
-        if (P.nlim_r > 0) for (int j = 0; j < 3; ++j) {
+        if (lim_on()) for (int j = 0; j < 3; ++j) {
             T pb_ = T(0), pa_ = T(0);
             for (int m_ = 0; m_ < 3; ++m_) { pb_ += E.thp_b[m_] * kb.Xi[3 * m_ + j]; pa_ += E.thp_a[m_] * ka.Xi[3 * m_ + j]; }
             sl_own[3 + j] = -pb_; sl_par[3 + j] = -pa_;
+#if DJ_TSD
+            if (tlim) { sl_own[j] = -E.thx_b[j]; sl_par[j] = -E.thx_a[j]; }      // translational θ also depends on x2 (∂x3/∂x2 = I)
+#endif
         }
         // body rows <- configurations through the joint impulse map, springs and dampers (data.jl:57-124)
         {
@@ -2206,6 +2282,7 @@ struct LaneProgram {
                 if (i < P.nl_r) for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Cr[3 * i + q_] * L.lam[3 + i];
             }
             if (P.nlim_r > 0) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
+            if (tlim) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pt[q_] += P.At[q_] * kk; }
             T Jaa[36], Jab[36], Jba[36], Jbb[36];
 #if DJ_TSD
             T Saa[36], Sab[36], Sba[36], Sbb[36], pf[3] = {0, 0, 0};
@@ -2279,19 +2356,19 @@ struct LaneProgram {
             }
         }
         // σ = wκ/(1 + wκ): the slack rows of a joint limit enter the Δκ row (see evaluate) as σ·(∂ slack row / ∂ data)
-        if (P.nlim_r > 0) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
+        if (lim_on()) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
         typedef typename KA::io_type TB;
         if constexpr (QUAD) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
             SweepP sp;
             sp.level = P.level; sp.parent = P.parent; sp.pb = has_parent ? base + stride * P.parent : qb; sp.u_off = P.u_off;
-            sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
+            sp.myu = P.nu_t + P.nu_r; sp.nlim_r = tlim ? 2 : P.nlim_r /* 2: translational limit, Δκ row of role 2 */; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
 #pragma unroll
             for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
 #pragma unroll
             for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
-            const bool lim = P.nlim_r > 0;
+            const bool lim = lim_on();
             const int ncon = P.ncontact;
             wv.sync();
             QuadRhs<TB>& R = *(QuadRhs<TB>*)gb_lds;
@@ -2349,7 +2426,7 @@ struct LaneProgram {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) rk[i] += GK[c][i][0] * r58[c][0] + GK[c][i][1] * r58[c][1] + GK[c][i][2] * r58[c][2] + GK[c][i][3] * r58[c][3];
             }
-            if (P.nlim_r > 0) rk[11] += wk * rs0;                   // the Δκ row
+            if (lim_on()) { if (tlim) rk[8] += wk * rs0; else rk[11] += wk * rs0; }   // the Δκ row
             T dk[12], dva[6];
             core_solve(rk, upx, dk, dva);
             for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
@@ -2487,7 +2564,7 @@ struct LaneProgram {
         // cache what the sweeps need from NodeP, then overlay the right-hand sides (one block per supernode) on the dead data
         SweepP sp;
         sp.level = P.level; sp.parent = P.parent; sp.pb = has_parent ? base + stride * P.parent : qb; sp.u_off = P.u_off;
-        sp.myu = P.nu_t + P.nu_r; sp.nlim_r = P.nlim_r; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
+        sp.myu = P.nu_t + P.nu_r; sp.nlim_r = tlim ? 2 : P.nlim_r /* 2: translational limit, Δκ row of role 2 */; sp.nchild = P.nchild; sp.ncontact = P.ncontact;
 #pragma unroll
         for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
 #pragma unroll
@@ -2660,7 +2737,7 @@ constexpr int FAC_PER_LANE = 72;
 // program from (z, u), restores the converged solution from the hand-off record and re-linearizes
 // there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
 #if DJ_TSD
-#define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr;
+#define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr; prog.tlim = prog.tsd != nullptr && prog.tsd->nlim > 0;
 #else
 #define DJ_TSD_SETUP
 #endif
@@ -2805,6 +2882,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
             // get_solution order per joint: [tra: λ_t] [rot: s_up s_lo γ_up γ_lo λ_r]   (translational limits unsupported)
             TIO* jo = A.joint_imp + (size_t)env * G.n_joint_imp + P.imp_off;
             int o2 = 0;
+            if (prog.tlim) { jo[o2++] = TIO(prog.L.ls[0]); jo[o2++] = TIO(prog.L.ls[1]); jo[o2++] = TIO(prog.L.lg[0]); jo[o2++] = TIO(prog.L.lg[1]); }   // [tra: s_up s_lo γ_up γ_lo λ_t]
             for (int i = 0; i < 3; ++i) if (i < P.nl_t) jo[o2++] = TIO(prog.L.lam[i]);
             if (P.nlim_r > 0) { jo[o2++] = TIO(prog.L.ls[0]); jo[o2++] = TIO(prog.L.ls[1]); jo[o2++] = TIO(prog.L.lg[0]); jo[o2++] = TIO(prog.L.lg[1]); }
             for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[3 + i]);

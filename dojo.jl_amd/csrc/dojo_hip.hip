@@ -290,7 +290,7 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     HIPCHK(hipMemcpy(s->d_contacts, contacts.data(), contacts.size() * sizeof(dj::ContactP<T>), hipMemcpyHostToDevice));
     if (s->M.has_tsd) {
         std::vector<dj::TraSD<T>> tsd;
-        for (auto& a : s->M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); tsd.push_back(b); }
+        for (auto& a : s->M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi); b.nlim = a.nlim; tsd.push_back(b); }
         HIPCHK(hipMalloc(&s->d_tsd, tsd.size() * sizeof(dj::TraSD<T>)));
         HIPCHK(hipMemcpy(s->d_tsd, tsd.data(), tsd.size() * sizeof(dj::TraSD<T>), hipMemcpyHostToDevice));
     }

@@ -29,7 +29,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     if (M.Nb > 64) { M.error = "more than 64 bodies per environment is not supported by the lane=supernode mapping"; return DOJO_ERR_UNSUPPORTED; }
     int S = 1; while (S < M.Nb) S <<= 1; M.S = S;
     M.nodes.assign(M.Nb, NodeP<double>());
-    { TraSD<double> z0; z0.spring = z0.damper = 0; z0.off[0] = z0.off[1] = z0.off[2] = 0; M.tsd.assign(M.Nb + 1, z0); M.has_tsd = false; }
+    { TraSD<double> z0; z0.spring = z0.damper = 0; z0.off[0] = z0.off[1] = z0.off[2] = 0; z0.lim_lo = z0.lim_hi = 0; z0.nlim = 0; M.tsd.assign(M.Nb + 1, z0); M.has_tsd = false; }
     std::vector<int> pj(M.Nb, -1);
     int uoff = 0, ioff = 0;
     for (int j = 0; j < tp.n_joints; ++j) {
@@ -40,7 +40,10 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         NodeP<double>& P = M.nodes[J.child];
         P.parent = J.parent;
         P.nl_t = J.tra.nl; P.nl_r = J.rot.nl; P.nlim_r = J.rot.nlim;
-        if (J.tra.nlim != 0) { M.error = "translational joint limits are not supported yet"; return DOJO_ERR_UNSUPPORTED; }
+        if (J.tra.nlim != 0) {            // one limited translational coordinate: joints with nl_t = 2, and no rotational limit on the same joint
+            if (J.tra.nlim > 1 || J.tra.nl != 2) { M.error = "translational limits need a one-dimensional translational joint (Prismatic type)"; return DOJO_ERR_UNSUPPORTED; }
+            if (J.rot.nlim != 0) { M.error = "limits on both halves of one joint are not supported"; return DOJO_ERR_UNSUPPORTED; }
+        }
         if (J.rot.nlim > 1) { M.error = "joint limits on more than one rotational coordinate are not supported"; return DOJO_ERR_UNSUPPORTED; }
         if (J.rot.nlim == 1 && J.rot.nl != 2) { M.error = "rotational limits need a one-dimensional rotational joint"; return DOJO_ERR_UNSUPPORTED; }
         if (J.tra.nl < 3 && ((J.spring_on && J.tra.spring != 0) || (J.damper_on && J.tra.damper != 0))) {
@@ -49,6 +52,11 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
             TraSD<double>& sd = M.tsd[J.child];
             sd.spring = J.spring_on ? J.tra.spring : 0.0; sd.damper = J.damper_on ? J.tra.damper : 0.0;
             for (int i = 0; i < 3 - J.tra.nl; ++i) sd.off[i] = J.tra.spring_offset[i];
+        }
+        if (J.tra.nlim == 1) {
+            M.has_tsd = true;
+            TraSD<double>& sd = M.tsd[J.child];
+            sd.nlim = 1; sd.lim_lo = J.tra.limit_lo[0]; sd.lim_hi = J.tra.limit_hi[0];
         }
         P.spring_on = J.spring_on; P.damper_on = J.damper_on;
         P.nu_t = 3 - J.tra.nl; P.nu_r = 3 - J.rot.nl;

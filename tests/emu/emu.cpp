@@ -103,7 +103,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.G = dj::make_globals<T>(M, opts, grad_mode);
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
     std::vector<dj::TraSD<T>> tsd;
-    for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); tsd.push_back(b); }
+    for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi); b.nlim = a.nlim; tsd.push_back(b); }
     A.tsd = M.has_tsd ? tsd.data() : nullptr;
     std::vector<TIO> fet = castv(fext, (size_t)B * 6 * M.Nb); A.fext = fext ? fet.data() : nullptr;
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;

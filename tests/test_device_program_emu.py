@@ -257,3 +257,43 @@ def test_snake_joint_prototypes(joint_type):
     dz, du = o.gradients(mode=1)
     assert np.abs(r["dz"][0] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max())
     assert np.abs(r["du"][0] - du).max() < 1e-7 * max(1.0, np.abs(du).max())
+
+
+def _limited(name):
+    from dojo_amd.mechanisms import set_limits
+    if name == "slider":
+        return d.get_slider(joint_limits={"joint": [-0.2, 0.3]}, dampers=0.1, springs=0.5), 30, 6, None
+    if name == "raiberthopper":
+        spec = d.get_raiberthopper(timestep=0.01); set_limits(spec, {"leg": [-0.6, -0.4]})
+        return spec, 12, 4, 30.0
+    spec = d.get_twister(num_bodies=3, joint_type="Cylindrical", springs=0.5, dampers=0.2)
+    for j in spec.joints[1:]:
+        j.tra.limits = (np.array([-0.05]), np.array([0.08]))
+    return spec, 9, 3, None
+
+
+@pytest.mark.parametrize("name,quad", [("slider", True), ("slider", False), ("raiberthopper", True), ("twister", True)])
+def test_translational_joint_limits(name, quad):
+    """Limits on the translational coordinate of Prismatic-type joints (the Δκ row in the third translational slot, DJ_TSD
+    builds): free, hitting the stop and resting on it -- iteration counts, states, exported (s, γ) and both gradient conventions."""
+    spec, steps, every, push = _limited(name)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z, u = (d.initialize(spec), np.array([0.3])) if name == "slider" else (Z[0], U[0])
+    if push is not None:
+        u = u.copy(); u[-1] = push                    # drive the leg into its stop
+    nj = spec.n_joint_impulses; active = 0.0
+    for k in range(steps):
+        zo, info = o.step(z, u)
+        if k % every == every - 1:
+            r = emu_step(spec, z, u, opts=opts, quad=quad, grad=True, grad_mode=k % 2)
+            so = o.get_solution()
+            assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-10 and np.abs(r["joint_imp"][0] - so[:nj]).max() < 1e-8
+            dz, du = o.gradients(mode=k % 2)
+            assert np.abs(r["dz"][0] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
+            assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
+            active = max(active, np.abs(so[:nj]).max())
+        z = zo
+    assert active > 1e-3                              # a limit impulse was active at one of the compared steps

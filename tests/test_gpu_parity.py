@@ -886,3 +886,37 @@ def test_joint_prototypes_gpu(joint_type):
             eu = np.concatenate(eu)
             assert np.quantile(eu, 0.9) < 1e-7 and eu.max() < 1e-3, (name, np.quantile(eu, 0.9), eu.max())
         gm.close()
+
+
+@pytest.mark.parametrize("name", ["slider", "raiberthopper", "twister"])
+def test_translational_joint_limits_gpu(name):
+    """Limits on the translational coordinate of Prismatic-type joints: rollouts into the stops (batch 64), states, exported
+    limit variables and IFT Jacobians against the oracle in both conventions."""
+    from test_device_program_emu import _limited
+    spec, steps, every, push = _limited(name)
+    B = 64
+    Z, U = d.synthetic_inputs(spec, B)
+    if push is not None:
+        U[:, -1] = push
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    z = Z.copy(); es = []; ez = []; eu = []; hit = 0
+    for k in range(max(steps, 20)):
+        gm.set_gradient_mode(k % 2)
+        zg, st, it = gm.step(z, U, with_gradient=True)
+        dzg, dug = gm.gradients()
+        vel, ji, cs = gm.get_solution()
+        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=k % 2, nthreads=8)
+        ok = np.nonzero((st == 0) & (st_o == 0))[0]
+        assert len(ok) > 0.8 * B
+        es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
+        ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+        eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
+        hit += int((np.abs(ji[ok]).max(axis=1) > 1e-3).sum())
+        z = zo
+    es, ez, eu = np.concatenate(es), np.concatenate(ez), np.concatenate(eu)
+    assert hit > 0
+    assert np.quantile(es, 0.9) < 1e-6 and es.max() < 1e-3, (np.quantile(es, 0.9), es.max())
+    assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(ez, 0.99) < 1e-3, (np.quantile(ez, 0.75), np.quantile(ez, 0.99))
+    assert np.quantile(eu, 0.75) < 1e-6 and np.quantile(eu, 0.99) < 1e-3, (np.quantile(eu, 0.75), np.quantile(eu, 0.99))
+    gm.close()

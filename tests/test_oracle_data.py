@@ -66,3 +66,8 @@ CASES = [
 def test_data_jacobian(name, kw, tsim):
     err = run_data(d.get_mechanism(name, **kw), tsim)
     assert err < 1.0e-6, err
+
+
+def test_data_jacobian_translational_limits():
+    spec = d.get_slider(joint_limits={"joint": [-0.2, 0.3]}, dampers=0.1, springs=0.5)
+    assert run_data(spec, 0.05) < 1.0e-6 and run_data(spec, 0.4) < 1.0e-6        # free, and resting on the lower stop

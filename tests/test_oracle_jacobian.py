@@ -76,3 +76,15 @@ def test_solmat_pendulum_with_limits():
     spec = d.get_pendulum(joint_limits={"joint": [-0.3, 0.25 * np.pi]}, dampers=0.1)
     err, _ = run_solmat(spec, 0.4)
     assert err < EPS, err
+
+
+def test_solmat_translational_limits():
+    """Limits on a translational coordinate (src/joints/limits.jl with the Prismatic coordinate): the slider resting on its
+    lower limit, and the raiberthopper with its leg pushed against the stop."""
+    spec = d.get_slider(joint_limits={"joint": [-0.2, 0.3]}, dampers=0.1, springs=0.5)
+    err, traj = run_solmat(spec, 0.4)
+    assert err < EPS and abs(traj[-1][2] + 0.7) < 1e-6, err          # z = −(0.5 + 0.2): on the lower stop
+    from dojo_amd.mechanisms import set_limits
+    spec = d.get_raiberthopper(timestep=0.01); set_limits(spec, {"leg": [-0.6, -0.4]})
+    err, _ = run_solmat(spec, 0.3)
+    assert err < EPS, err
