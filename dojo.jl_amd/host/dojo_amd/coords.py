@@ -149,6 +149,22 @@ def nominal_minimal(spec, **kw):
         pos = np.array(kw.get("position", [0, 0, 1.0]), float) + np.array([0, 0, r])
         return minimal_state_dict(spec, {"floating_base": np.concatenate([pos, np.zeros(3)])},
                                   {"floating_base": np.concatenate([kw.get("velocity", [1.0, 0, 0]), kw.get("angular_velocity", np.zeros(3))])})
+    if n == "cartpole":                      # initialize_cartpole!: position 0, pole at π/4
+        return minimal_state_dict(spec, {"cart_joint": [kw.get("position", 0.0)], "pole_joint": [kw.get("orientation", np.pi / 4)]})
+    if n == "block2d":                       # initialize_block2d!: (y, z) = position + half the edge, rotation about x
+        edge = (12.0 * spec.bodies[0].inertia[0, 0] / spec.bodies[0].mass / 2.0) ** 0.5
+        off = spec.contacts[0].radius if spec.contacts else 0.0
+        pos = np.array(kw.get("position", [0.0, 1.0]), float)
+        x = np.zeros(2 * spec.nu)
+        x[0:3] = [pos[0], pos[1] + edge / 2 + off, kw.get("orientation", 0.0)]
+        x[3:6] = list(kw.get("velocity", [0.0, 0.0])) + [kw.get("angular_velocity", 0.5)]
+        return x
+    if n == "dzhanibekov":                   # initialize_dzhanibekov!: at z = 1 spinning about x with a small perturbation
+        return minimal_state_dict(spec, {"floating": [0, 0, 1.0, 0, 0, 0]}, {"floating": list(kw.get("linear_velocity", [0, 0, 0])) + list(kw.get("angular_velocity", [10.0, 0.01, 0.0]))})
+    if n == "tippetop":                      # initialize_tippetop!: resting height, spinning about z
+        r = spec.contacts[0].radius if spec.contacts else 0.5
+        return minimal_state_dict(spec, {"floating_joint": [0, 0, r + kw.get("height", 0.0), 0, 0, 0]},
+                                  {"floating_joint": list(kw.get("body_linear_velocity", [0, 0.1, 0])) + list(kw.get("body_angular_velocity", [0.1, 0.1, 50.0]))})
     if n == "raiberthopper":                 # initialize_raiberthopper! (raiberthopper/mechanism.jl:70-82): body above the foot, leg_length = 0.5
         leg = kw.get("leg_length", 0.5)
         bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, leg + spec.contacts[0].radius if spec.contacts else leg + 0.05])

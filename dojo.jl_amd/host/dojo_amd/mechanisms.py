@@ -249,6 +249,55 @@ def get_sphere(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, radiu
     return MechanismSpec("sphere", bodies, [Floating("floating_base", -1, 0)], contacts, timestep, input_scaling, gravity)
 
 
+def capsule_inertia(r, h, m):                                         # src/bodies/shapes.jl:157-180 (Capsule, axis z)
+    vc, vh = np.pi * h * r ** 2, np.pi * 4.0 / 3.0 * r ** 3 / 2.0
+    mc, mh = m * vc / (vc + 2 * vh), m * vh / (vc + 2 * vh)
+    dd = 3.0 / 8.0 * r + 0.5 * h
+    ixx = mc * (h * h / 12.0 + r * r / 4.0) + 2.0 * (83.0 / 320 * mh * r * r + mh * dd * dd)
+    izz = mc * 0.5 * r * r + 2.0 * (mh * 0.4 * r * r / 2.0)
+    return np.diag([ixx, ixx, izz])
+
+
+def get_cartpole(timestep=0.01, input_scaling=None, gravity=-9.81, slider_mass=1.0, pendulum_mass=1.0, link_length=1.0, radius=0.075,
+                 springs=0.0, dampers=0.0, joint_limits=None):
+    """DojoEnvironments/src/mechanisms/cartpole/mechanism.jl:1-48"""
+    bodies = [BodySpec("cart", slider_mass, capsule_inertia(1.5 * radius, 1.0, slider_mass)), BodySpec("pole", pendulum_mass, capsule_inertia(radius, link_length, pendulum_mass))]
+    joints = [Prismatic("cart_joint", -1, 0, Y_AXIS), Revolute("pole_joint", 0, 1, X_AXIS, child_vertex=-0.5 * link_length * Z_AXIS)]
+    spec = MechanismSpec("cartpole", bodies, joints, [], timestep, input_scaling, gravity)
+    _set_per_joint(spec, springs, dampers)
+    if joint_limits:
+        set_limits(spec, joint_limits)
+    return spec
+
+
+def get_block2d(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, edge_length=0.5, friction_coefficient=0.8, contact=True,
+                contact_radius=0.0, contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/block2d/mechanism.jl:1-54: a box on a PlanarAxis joint (y-z plane) with its four corners as contacts"""
+    bodies = [BodySpec("block", mass, box_inertia(edge_length, edge_length, edge_length, mass))]
+    joints = [Prototype("PlanarAxis", "joint", -1, 0, X_AXIS)]
+    h = edge_length / 2
+    contacts = [contact_constraint("contact%d" % (i + 1), 0, Z_AXIS, friction_coefficient, o, contact_radius, contact_type=contact_type)
+                for i, o in enumerate([[0, h, h], [0, h, -h], [0, -h, h], [0, -h, -h]])] if contact else []
+    return MechanismSpec("block2d", bodies, joints, contacts, timestep, input_scaling, gravity)
+
+
+def get_dzhanibekov(timestep=0.01, input_scaling=None, gravity=-9.81):
+    """DojoEnvironments/src/mechanisms/dzhanibekov/mechanism.jl:1-36: two capsules fixed to each other, floating"""
+    bodies = [BodySpec("main", 1.0, capsule_inertia(0.1, 1.0, 1.0)), BodySpec("side", 0.5, capsule_inertia(0.05, 0.35, 0.5))]
+    joints = [Floating("floating", -1, 0), Fixed("fixed", 0, 1, child_vertex=[-0.25, 0, 0])]
+    return MechanismSpec("dzhanibekov", bodies, joints, [], timestep, input_scaling, gravity)
+
+
+def get_tippetop(timestep=0.01, input_scaling=None, gravity=-9.81, mass=1.0, radius=0.5, scale=0.2, friction_coefficient=0.4, contact=True,
+                 contact_type="nonlinear"):
+    """DojoEnvironments/src/mechanisms/tippetop/mechanism.jl:1-54: two spheres fixed to each other, one contact each"""
+    bodies = [BodySpec("sphere1", mass, sphere_inertia(radius, mass)), BodySpec("sphere2", mass * scale ** 3, sphere_inertia(radius * scale, mass * scale ** 3))]
+    joints = [Floating("floating_joint", -1, 0), Fixed("fixed_joint", 0, 1, parent_vertex=[0, 0, radius])]
+    contacts = [contact_constraint("contact%d" % (i + 1), i, Z_AXIS, friction_coefficient, contact_radius=r, contact_type=contact_type)
+                for i, r in enumerate([radius, radius * scale])] if contact else []
+    return MechanismSpec("tippetop", bodies, joints, contacts, timestep, input_scaling, gravity)
+
+
 def get_raiberthopper(timestep=0.05, input_scaling=None, gravity=-9.81, body_mass=4.18, foot_mass=0.52, body_radius=0.1, foot_radius=0.05,
                       springs=(0.0, 0.0), dampers=(0.0, 0.1), friction_coefficient=0.5, contact_foot=True, contact_body=True,
                       contact_type="nonlinear"):
@@ -412,7 +461,8 @@ def get_mechanism(name, **kwargs):
     """DojoEnvironments.get_mechanism(:name; kwargs...)  DojoEnvironments/src/mechanisms.jl"""
     return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas,
             "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper,
-            "npendulum": get_npendulum, "snake": get_snake, "twister": get_twister, "sphere": get_sphere}[name](**kwargs)
+            "npendulum": get_npendulum, "snake": get_snake, "twister": get_twister, "sphere": get_sphere,
+            "cartpole": get_cartpole, "block2d": get_block2d, "dzhanibekov": get_dzhanibekov, "tippetop": get_tippetop}[name](**kwargs)
 
 
 # the five BASELINE.json configurations (BASELINE.md §3)

@@ -297,3 +297,25 @@ def test_translational_joint_limits(name, quad):
             active = max(active, np.abs(so[:nj]).max())
         z = zo
     assert active > 1e-3                              # a limit impulse was active at one of the compared steps
+
+
+@pytest.mark.parametrize("name,kw,pre", [("cartpole", dict(joint_limits={"cart_joint": [-0.3, 0.3]}, dampers=0.1), 0), ("block2d", dict(), 50),
+                                         ("dzhanibekov", dict(), 5), ("tippetop", dict(), 10), ("sphere", dict(), 45)])
+def test_more_reference_mechanisms(name, kw, pre):
+    """cartpole (Prismatic cart with limits + Revolute pole), block2d (PlanarAxis root, four contacts), dzhanibekov, tippetop,
+    sphere: the reference's builders from their nominal states, after `pre` oracle steps (contacts active where there are any)."""
+    spec = d.get_mechanism(name, **kw)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    z = d.initialize(spec); u = 0.3 * np.ones(spec.nu)
+    if spec.joints[0].nu == 6:
+        u[:6] = 0
+    for _ in range(pre):
+        z, _ = o.step(z, u)
+    zo, info = o.step(z, u)
+    r = emu_step(spec, z, u, opts=opts, quad=True, grad=True, grad_mode=1)
+    assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+    assert np.abs(r["z_next"][0] - zo).max() < 1e-10
+    dz, du = o.gradients(mode=1)
+    assert np.abs(r["dz"][0] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
+    assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())

@@ -920,3 +920,42 @@ def test_translational_joint_limits_gpu(name):
     assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(ez, 0.99) < 1e-3, (np.quantile(ez, 0.75), np.quantile(ez, 0.99))
     assert np.quantile(eu, 0.75) < 1e-6 and np.quantile(eu, 0.99) < 1e-3, (np.quantile(eu, 0.75), np.quantile(eu, 0.99))
     gm.close()
+
+
+REFERENCE_MECHANISMS = [("pendulum", dict(springs=1.0, dampers=0.2)), ("block", dict()), ("block2d", dict()), ("sphere", dict()), ("cartpole", dict(dampers=0.1)),
+                        ("slider", dict(springs=1.0, dampers=0.2)), ("nslider", dict(springs=1.0, dampers=0.2)), ("npendulum", dict(springs=1.0, dampers=0.2)),
+                        ("snake", dict(num_bodies=4, springs=1.0, dampers=0.2)), ("twister", dict(springs=1.0, dampers=0.2)), ("dzhanibekov", dict()),
+                        ("tippetop", dict()), ("raiberthopper", dict()), ("ant", dict()), ("quadruped", dict()), ("atlas", dict())]
+
+
+@pytest.mark.parametrize("name,kw", REFERENCE_MECHANISMS)
+def test_reference_mechanisms_rollout_gpu(name, kw):
+    """Every mechanism of DojoEnvironments/src/mechanisms that the host builders restate (16 of 26), from perturbed nominal states
+    with random inputs: a 12-step rollout, every step compared with the oracle started from the same state (states; gradients at
+    the last step), and the fp32-ABI mode within 1e-3."""
+    spec = d.get_mechanism(name, **kw)
+    B = 32 if spec.Nb <= 16 else 8
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    z = Z.copy(); es = []
+    for k in range(12):
+        last = k == 11
+        zg, st, it = gm.step(z, U, with_gradient=last)
+        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=last, grad_mode=0, nthreads=8)
+        ok = np.nonzero((st == 0) & (st_o == 0))[0]
+        assert len(ok) >= 0.7 * B, (k, len(ok))
+        es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
+        if last:
+            dzg, dug = gm.gradients()
+            ez = np.array([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+            assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(ez, 0.95) < 1e-3, (np.quantile(ez, 0.75), ez.max())
+            gm32 = api.BatchedMechanism(spec, B, dtype="f32", opts=TIGHT)
+            z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
+            ok32 = np.nonzero((st32 == 0) & (st_o == 0))[0]
+            assert len(ok32) >= 0.7 * B and np.quantile(np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max(axis=1), 0.9) < 1e-3
+            gm32.close()
+        z = zo
+    es = np.concatenate(es)
+    assert np.quantile(es, 0.9) < 1e-6 and es.max() < 1e-3, (np.quantile(es, 0.9), es.max())
+    gm.close()

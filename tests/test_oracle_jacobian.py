@@ -57,6 +57,10 @@ CASES = [
     ("npendulum", dict(springs=1.0, dampers=0.2)),
     ("twister", dict(springs=1.0, dampers=0.2)),
     ("sphere", dict()),
+    ("cartpole", dict(dampers=0.1)),
+    ("block2d", dict()),
+    ("dzhanibekov", dict()),
+    ("tippetop", dict()),
 ]
 
 
