@@ -12,7 +12,7 @@ def _rand_quat(rng, scale):
     q = np.concatenate([[1.0], v]); return q / np.linalg.norm(q)
 
 
-def _translational_joint(rng, kind, name, parent, k, pv, cv, qo):
+def _translational_joint(rng, kind, name, parent, k, pv, cv, qo, tra_limits=False):
     """joints with free translations (src/joints/prototypes.jl: Prismatic, Planar, Cylindrical, FixedOrientation) with
     springs, dampers and spring offsets on the translational half (and on the rotational one where it is free)"""
     axis = rng.normal(size=3)
@@ -20,10 +20,12 @@ def _translational_joint(rng, kind, name, parent, k, pv, cv, qo):
     sp, da = float(rng.choice([0.0, 4.0])), float(rng.choice([0.0, 0.6]))
     tra = d.JointHalfSpec(nl_t, axis=axis, spring=sp, damper=da, spring_offset=rng.uniform(-0.2, 0.2, size=3 - nl_t))
     rot = d.JointHalfSpec(nl_r, axis=axis, spring=sp, damper=da, spring_offset=rng.uniform(-0.2, 0.2, size=3 - nl_r))
+    if tra_limits and nl_t == 2 and rng.random() < 0.6:              # limits on the free translational coordinate (Prismatic-type joints)
+        tra.limits = (np.array([rng.uniform(-0.3, -0.05)]), np.array([rng.uniform(0.05, 0.3)]))
     return d.JointSpec(name, parent, k, tra, rot, np.array(pv, float), np.array(cv, float), np.array(qo, float))
 
 
-def random_mechanism(seed, contact_type="nonlinear", nb=None, translational=False):
+def random_mechanism(seed, contact_type="nonlinear", nb=None, translational=False, tra_limits=False):
     """translational=True mixes in joints with free translations (their own seeds: the other tests' mechanisms do not change)"""
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(2, 8)) if nb is None else int(nb)
@@ -51,7 +53,7 @@ def random_mechanism(seed, contact_type="nonlinear", nb=None, translational=Fals
         elif kind == "fixed":
             joints.append(Fixed(name, parent, k, pv, cv, qo))
         elif kind in ("prismatic", "planar", "cylindrical", "fixed_orientation"):
-            joints.append(_translational_joint(rng, kind, name, parent, k, pv, cv, qo))
+            joints.append(_translational_joint(rng, kind, name, parent, k, pv, cv, qo, tra_limits))
         elif kind == "spherical":
             joints.append(Spherical(name, parent, k, pv, cv, qo, spring=float(rng.choice([0.0, 2.0])), damper=float(rng.choice([0.0, 0.5]))))
         else:
