@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=16, help="the per-GPU batch is stepped as this many independent groups of environments, "
                     "each on its own HIP stream, so that the few environments that run into max_iter do not idle the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine", type=float, default=None, help="stiffness threshold of the solve refinement (dojo_set_refinement); default: the library's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1: nccl (= RCCL, production) or gloo "
                     "(plumbing check of the N > 1 path on a box with fewer GPUs than ranks: ranks share devices, the gather goes through the host)")
     args = ap.parse_args()
@@ -83,6 +84,8 @@ def main():
         lo, hi = bounds[c], bounds[c + 1]
         groups.append({"lo": lo, "hi": hi, "gm": api.BatchedMechanism(spec, hi - lo, dtype=args.io_dtype, device=local),
                        "stream": torch.cuda.Stream(device=dev)})
+        if args.refine is not None:
+            groups[-1]["gm"].set_refinement(args.refine)
 
     def ptr(t):
         return C.c_void_p(0 if t is None else t.data_ptr())

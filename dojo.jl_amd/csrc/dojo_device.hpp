@@ -46,6 +46,14 @@
 #ifndef DJ_TSD
 #define DJ_TSD 0           // 1: the kernels evaluate translational springs / dampers (KernelArgs::tsd); builds of their own
 #endif
+#ifndef DJ_REFINE
+#define DJ_REFINE 1        // quad mapping: iterative refinement of the Newton / IFT solves against the UNCONDENSED system for environments whose
+                           // cone variables have become stiff (max γ/s > Globals::refine_w): the condensed body blocks D + (γ/s) g cᵀ lose the
+                           // low bits of D there, which the dense pivoted LU of the reference-level oracle does not
+#endif
+#ifndef DJ_REFINE_STEPS
+#define DJ_REFINE_STEPS 2  // rounds per solve (the contraction per round is ~ε·γ/s·cond of the un-stiff part; nearly redundant joint / contact rows need two)
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -58,11 +66,13 @@ constexpr double REG = 1e-10;     // src/Dojo.jl:4
 #define DJ_STATUS_SUCCESS 0
 #define DJ_STATUS_FAILED 1
 #define DJ_STATUS_EXCESSIVE_W 2
+#define DJ_STATUS_DEFERRED 3      // internal: the environment's cones became stiff; the refining kernels re-solve it (never reaches the caller)
 
 template <class T>
 struct Globals {
     T dt, idt2 /* 1/dt² */, input_scaling, g[3];
     T rtol, btol, undercut, no_progress_undercut;
+    T refine_w;                  // refine the linear solves of an environment once max γ/s over its cones exceeds this (inf: never, 0: always)
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
@@ -1068,6 +1078,20 @@ struct LaneProgram {
 #endif
     // residual pieces of the last evaluation
     T rb[6], rj[6], theta, cres[MAXC][4];
+    // Iterative refinement of the linear solves (DJ_REFINE, quad mapping).  `refine` is a per-environment flag (sticky once the
+    // cones are stiff); the un-factored, contact-UNcondensed supernode rows of the last linearization live in global memory
+    // (KernelArgs::blk, [workgroup][BLK_PER_LANE][lanes]: lane index fastest), written only while some environment of the
+    // workgroup refines.
+    // Two builds of the kernels share this program: the plain one only TRACKS the stiffness and hands stiff environments over
+    // (DJ_STATUS_DEFERRED); the refining one (Wave::kRefine) re-solves exactly those -- so the plain kernels' register
+    // allocation never sees the refinement code.
+    static constexpr bool kTrack = DJ_REFINE && QUAD;
+    static constexpr bool kRefine = kTrack && Wave::kRefine;
+    enum { BLK_PER_LANE = 90 };        // S rows 3x12, U rows 3x6, L columns 6x3, Dup rows 3x6
+    T* blk = nullptr; int blk_stride = 0;
+    bool refine = false;
+    T wstiff = T(0);                   // max γ/s over the cones of the environment at the last evaluated iterate
+    T dk_lim = T(0);                   // Δκ of the last solve (the multiplier slot that carries the net limit impulse)
 
     DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, int q_, bool act, Lane<T, MAXC>& lane_, Cold<T, MAXC>& cold_)
         : wv(w), G(g), P(p), CP(cp), base(base_), k(k_), active(act), L(lane_), cold(cold_), cfg(cold_.cfg) {
@@ -1175,8 +1199,9 @@ struct LaneProgram {
     }
 
     // ---------------------------------------------------------------- violations (src/solver/violations.jl)
+    // Also reduces the stiffness of the evaluated iterate, wstiff = max γ/s over the cones of the environment (DJ_REFINE).
     DJ_HD void violations(T& rvio, T& bvio) {
-        T r = T(0), b = T(0);
+        T r = T(0), b = T(0), wq = T(0);
         if (active) {
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rb[i]));
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rj[i]));          // only the Nλ equality rows (padded slots are 0)
@@ -1190,11 +1215,21 @@ struct LaneProgram {
                     b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
                     b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
                 }
+                if constexpr (kTrack) {
+                    wq = tmax(wq, (g[0] + T(REG)) * trcp(s[0] + T(REG)));
+                    if (G.contact_model == 0) wq = tmax(wq, (g[1] + T(REG)) * trcp(s[1] + T(REG)));
+                }
             }
-            if (lim_on()) { b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1])); }
+            if (lim_on()) {
+                b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1]));
+                if constexpr (kTrack) { wq = tmax(wq, (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG))); wq = tmax(wq, (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG))); }
+            }
         }
-        if constexpr (QUAD && DJ_LDS_REDUCE) { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
-        else { rvio = env_max(wv, r, envl); bvio = env_max(wv, b, envl); }
+        if constexpr (QUAD && DJ_LDS_REDUCE) {
+            if constexpr (kTrack) { T v3[3] = {r, b, wq}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v3[0]; bvio = v3[1]; wstiff = v3[2]; }
+            else { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
+        }
+        else { rvio = env_max(wv, r, envl); bvio = env_max(wv, b, envl); if constexpr (kTrack) wstiff = env_max(wv, wq, envl); }
     }
 
     // ---------------------------------------------------------------- condensation of cone rows
@@ -1248,7 +1283,9 @@ struct LaneProgram {
     // ---------------------------------------------------------------- condensation of the cone rows
     // Contacts and joint limits are eliminated analytically onto the body rows.
     template <class BK>
-    DJ_HD void condense(BK& K) {
+    DJ_HD void condense(BK& K) { condense_contacts(K); condense_limits(K); }
+    template <class BK>
+    DJ_HD void condense_contacts(BK& K) {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
@@ -1269,6 +1306,9 @@ struct LaneProgram {
                     }
             }
         }
+    }
+    template <class BK>
+    DJ_HD void condense_limits(BK& K) {
         // joint limit: the pair (s, γ) of both sides is eliminated down to ONE unknown, the net limit impulse Δκ = Δγ_lo − Δγ_up
         // = κ0 − wκ (θ_a Δω_a + θ_b Δω_b), wκ = γ_up/s_up + γ_lo/s_lo, which keeps its own row -- the third rotational multiplier
         // slot, free for the one-dimensional rotational joints that may carry limits -- scaled by 1/(1 + wκ):
@@ -1790,7 +1830,7 @@ struct LaneProgram {
     // Generic right-hand side: rk0 = rhs of the body (6) and joint-equality (6) rows, R = rhs of the
     // cone (complementarity) rows, rs = rhs of the two limit slack rows, r58 = rhs of the contact
     // constraint rows, upx = direct rhs contribution to the parent's body rows.
-    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D) {
+    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D, T* dva_out = nullptr) {
         T rk[12], up[6];
         for (int i = 0; i < 12; ++i) rk[i] = rk0[i];
         for (int i = 0; i < 6; ++i) up[i] = upx[i];
@@ -1814,6 +1854,7 @@ struct LaneProgram {
         core_solve(rk, up, dk, dva);
         for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
+        if (dva_out != nullptr) for (int i = 0; i < 6; ++i) dva_out[i] = dva[i];
         if (lim_on()) { if (tlim) D.dlam[2] = T(0); else D.dlam[5] = T(0); }   // slot 11 (8) carried Δκ, not a joint multiplier
         // recovery of the condensed variables
         if (lim_on()) {
@@ -1892,7 +1933,132 @@ struct LaneProgram {
             rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
             rs[1] = -(L.ls[1] - (theta - lim_lo()));
         }
-        solve_rhs(rk, R, rs, r58, upx, D);
+        if constexpr (kRefine) {
+            T dva[6];
+            solve_rhs(rk, R, rs, r58, upx, D, dva);
+            if (blk != nullptr && wv.any(refine)) {
+#pragma unroll 1
+                for (int rstep = 0; rstep < DJ_REFINE_STEPS; ++rstep) refine_solution(rk, R, rs, r58, upx, D, dva);
+            }
+        } else solve_rhs(rk, R, rs, r58, upx, D);
+    }
+
+    // ---------------------------------------------------------------- iterative refinement (DJ_REFINE)
+    // The condensed body block D + Σ (γ/s) g cᵀ is formed in fp64, so with γ/s ~ 1e8 .. 1e12 (tight tolerances, strongly active
+    // contacts and limits) the solve loses that many digits of D and the recovered Δγ = (γ/s)(k − cᵀΔw) inherits ε·γ/s·|cᵀΔw|.
+    // One step of refinement against the UNCONDENSED equations restores them: every term of
+    //     body rows      S⁰ [Δw; Δλ] + U⁰ Δw_a + Σ_children (L⁰ [Δw_c; Δλ_c] + Dup⁰ Δw) − Σ_contacts G Δγ₁₃₄  = r_body (+ Σ upx_c)
+    //     joint rows     S⁰ [Δw; Δλ] + U⁰ Δw_a = r_joint
+    //     cone rows      γ̃ Δs + s̃ Δγ = r_c   (orthant and arrow products, contacts and joint limits)
+    // is O(1), so the residual is exact to ε, and the correction is one more condensed solve with that residual as its
+    // right-hand side (solve_rhs is linear in rk0, R, rs, r58, upx).  The rows that define Δs₁, Δs₃, Δs₄, Δγ₂ and the limit
+    // slacks are satisfied by construction.  S⁰ U⁰ L⁰ Dup⁰ = the rows store_blocks() parked in global memory.
+    template <class BK>
+    DJ_HD void store_blocks(const BK& K) {
+        T* o = blk;
+        const size_t W = (size_t)blk_stride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) o[(size_t)(12 * i + j) * W] = T(K.S[i][j]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { o[(size_t)(36 + 6 * i + j) * W] = T(K.U[i][j]); o[(size_t)(54 + 6 * i + j) * W] = T(K.L[j][i]); o[(size_t)(72 + 6 * i + j) * W] = T(K.D[i][j]); }
+        }
+    }
+    DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D, T* dva) {
+        const T* bl = blk;
+        const size_t W = (size_t)blk_stride;
+        T xk[12];
+        for (int i = 0; i < 3; ++i) { xk[i] = D.dv[i]; xk[3 + i] = D.dw[i]; }
+        for (int i = 0; i < 6; ++i) xk[6 + i] = D.dlam[i];
+        if (lim_on()) { const T dkap = D.dlg[1] - D.dlg[0]; if (tlim) xk[8] = dkap; else xk[11] = dkap; }   // net limit impulse Δκ = Δγ_lo − Δγ_up
+        // own rows 3q .. 3q+2
+        T rho[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T a_ = T(0);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) a_ += bl[(size_t)(12 * i + j) * W] * xk[j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a_ += bl[(size_t)(36 + 6 * i + j) * W] * dva[j];
+            rho[i] = a_;
+        }
+        // what this supernode puts on its parent's body rows: L⁰ x (this lane: columns 3q .. 3q+2) + Dup⁰ Δw_a (roles 0, 1: rows 3q ..)
+        T xq[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const T a_ = xk[j], b_ = xk[3 + j], c_ = xk[6 + j], d_ = xk[9 + j]; xq[j] = q == 0 ? a_ : q == 1 ? b_ : q == 2 ? c_ : d_; }
+        T m6[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m6[r] = bl[(size_t)(54 + r) * W] * xq[0] + bl[(size_t)(54 + 6 + r) * W] * xq[1] + bl[(size_t)(54 + 12 + r) * W] * xq[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T a_ = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a_ += bl[(size_t)(72 + 6 * i + j) * W] * dva[j];
+            m6[i] += q == 0 ? a_ : T(0); m6[3 + i] += q == 1 ? a_ : T(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m6[r] += wv.quad_xor(m6[r], 1);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m6[r] += wv.quad_xor(m6[r], 2);
+        T msg[6], acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < 6; ++r) msg[r] = has_parent ? upx[r] - m6[r] : T(0);
+        mail_post_node<6>(msg); mail_add_children_node<6>(acc, active, G.maxch);
+        // contacts: −G Δγ₁₃₄ on the body rows; cone rows
+        ConeRhs R2;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < P.ncontact) {
+                const T* gam = L.cg[c]; const T* s = L.cs[c]; const T* ds = D.dcs[c]; const T* dg = D.dcg[c];
+                const ContactCold<T>& cc_ = ccold(c);
+                for (int i = 0; i < 6; ++i) acc[i] += cc_.G134[i] * dg[0] + cc_.G134[6 + i] * dg[2] + cc_.G134[12 + i] * dg[3];
+                const T g1t = gam[0] + T(REG), s1t = s[0] + T(REG), g0 = gam[1] + T(REG), h0 = s[1] + T(REG);
+                R2.cc[c][0] = R.cc[c][0] - (g1t * ds[0] + s1t * dg[0]);
+                if (G.contact_model == 0) {
+                    R2.cc[c][1] = R.cc[c][1] - (g0 * ds[1] + gam[2] * ds[2] + gam[3] * ds[3] + h0 * dg[1] + s[2] * dg[2] + s[3] * dg[3]);
+                    R2.cc[c][2] = R.cc[c][2] - (gam[2] * ds[1] + g0 * ds[2] + s[2] * dg[1] + h0 * dg[2]);
+                    R2.cc[c][3] = R.cc[c][3] - (gam[3] * ds[1] + g0 * ds[3] + s[3] * dg[1] + h0 * dg[3]);
+                } else { R2.cc[c][1] = R2.cc[c][2] = R2.cc[c][3] = T(0); }
+            } else { for (int i = 0; i < 4; ++i) R2.cc[c][i] = T(0); }
+        }
+        R2.lim[0] = R2.lim[1] = T(0);
+        if (lim_on()) {
+            R2.lim[0] = R.lim[0] - ((L.lg[0] + T(REG)) * D.dls[0] + (L.ls[0] + T(REG)) * D.dlg[0]);
+            R2.lim[1] = R.lim[1] - ((L.lg[1] + T(REG)) * D.dls[1] + (L.ls[1] + T(REG)) * D.dlg[1]);
+        }
+        // residual rows of this lane's role (the solve reads rows 3q .. 3q+2 of rk only)
+        T rk2[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T b0_ = rk0[i] + acc[i] - rho[i], b1_ = rk0[3 + i] + acc[3 + i] - rho[i], j0_ = rk0[6 + i] - rho[i], j1_ = rk0[9 + i] - rho[i];
+            rk2[i] = q == 0 ? b0_ : T(0); rk2[3 + i] = q == 1 ? b1_ : T(0); rk2[6 + i] = q == 2 ? j0_ : T(0); rk2[9 + i] = q == 3 ? j1_ : T(0);
+        }
+        const T rs2[2] = {T(0), T(0)}, up2[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        T r582[MAXC][4];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r582[c][i] = T(0);
+        (void)rs; (void)r58;
+        Step<T, MAXC> D2;
+        T dva2[6];
+        solve_rhs(rk2, R2, rs2, r582, up2, D2, dva2);
+        for (int i = 0; i < 6; ++i) dva[i] += dva2[i];
+#ifdef DJ_DEBUG
+        if (trace && active && q == 0) {
+            T m1 = 0, m2 = 0, mr = 0, mc = 0;
+            for (int i = 0; i < 3; ++i) { m1 = tmax(m1, tmax(tabs(D.dv[i]), tabs(D.dw[i]))); m2 = tmax(m2, tmax(tabs(D2.dv[i]), tabs(D2.dw[i]))); }
+            for (int i = 0; i < 12; ++i) mr = tmax(mr, tabs(rk2[i]));
+            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(R2.cc[c][i]));
+            if (P.level == 1) std::printf("   node %d: m6 %.3e %.3e %.3e xk9-11 %.3e %.3e %.3e dls %.3e %.3e dlg %.3e %.3e ls %.3e %.3e lg %.3e %.3e Rlim %.3e %.3e\n", k, (double)m6[0], (double)m6[1], (double)m6[2], (double)xk[9], (double)xk[10], (double)xk[11],
+                                         (double)D.dls[0], (double)D.dls[1], (double)D.dlg[0], (double)D.dlg[1], (double)L.ls[0], (double)L.ls[1], (double)L.lg[0], (double)L.lg[1], (double)R.lim[0], (double)R.lim[1]);
+            if (k == 0) std::printf("   root: rk0 %.3e %.3e %.3e acc %.3e %.3e %.3e rho %.3e %.3e %.3e  dv %.3e %.3e %.3e\n", (double)rk0[0], (double)rk0[1], (double)rk0[2], (double)acc[0], (double)acc[1], (double)acc[2], (double)rho[0], (double)rho[1], (double)rho[2], (double)D.dv[0], (double)D.dv[1], (double)D.dv[2]);
+            std::printf("   refine k=%d |dw| %.2e |corr| %.2e  |res own rows| %.2e |res cone| %.2e lim %.2e %.2e\n", k, (double)m1, (double)m2, (double)mr, (double)mc, (double)R2.lim[0], (double)R2.lim[1]);
+        }
+#endif
+        for (int i = 0; i < 3; ++i) { D.dv[i] += D2.dv[i]; D.dw[i] += D2.dw[i]; }
+        for (int i = 0; i < 6; ++i) D.dlam[i] += D2.dlam[i];
+        for (int i = 0; i < 2; ++i) { D.dls[i] += D2.dls[i]; D.dlg[i] += D2.dlg[i]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { D.dcs[c][i] += D2.dcs[c][i]; D.dcg[c][i] += D2.dcg[c][i]; }
     }
 
     // cone_line_search!  src/solver/line_search.jl:36-96
@@ -2034,7 +2200,9 @@ struct LaneProgram {
             QuadBlocks<TL> K(F.Sq, F.Uq, F.Lq, q);
             DJ_PB();
             evaluate<true>(K);
-            condense(K);
+            condense_limits(K);
+            if constexpr (kRefine) { if (blk != nullptr && wv.any(refine)) store_blocks(K); }   // the rows before the contacts are folded in
+            condense_contacts(K);
             DJ_PE(0); DJ_PB();
             factorize_quad(K);
             DJ_PE(1);
@@ -2066,6 +2234,7 @@ struct LaneProgram {
         T mutarget = T(0), undercut = G.undercut;
         int no_progress = 0;
         mu = T(0);
+        if constexpr (kTrack) refine = T(1) > G.refine_w;        // reset! / initialize! leave every cone at γ/s = 1
         linearize();
         typename QuadKType<TL, QUAD>::type Kq(F.Sq, F.Uq, F.Lq, q);   // quad mapping: the lane's rows, assembled in place in the factor storage
 #ifdef DJ_DEBUG
@@ -2080,6 +2249,7 @@ struct LaneProgram {
             if (trace && wv.lane() == 0) std::printf("%3d  bvio %.3e  rvio %.3e  mu %.3e\n", n, (double)bvio, (double)rvio, (double)mu);
 #endif
             if (!done && rvio < G.rtol && bvio < G.btol) { status = DJ_STATUS_SUCCESS; done = true; }
+            if constexpr (kTrack && !kRefine) { if (!done && refine) { status = DJ_STATUS_DEFERRED; done = true; } }   // left to the refining kernel
             if (!wv.any(active && !done)) break;
             // Lanes of finished environments keep executing (wave-uniform control flow, all lanes must
             // take part in the shuffles) but never change their state: their step factor is 0.
@@ -2147,6 +2317,14 @@ struct LaneProgram {
                     if constexpr (decltype(with_jac)::value) evaluate<true>(Kq); else { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
+#ifdef DJ_DEBUG
+                    if (trace && active && q == 0) {
+                        T mb = 0, mj = 0, mc = 0;
+                        for (int i = 0; i < 6; ++i) { mb = tmax(mb, tabs(rb[i])); mj = tmax(mj, tabs(rj[i])); }
+                        for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(cres[c][i]));
+                        if (tmax(mb, tmax(mj, mc)) > T(0.3) * r2) std::printf("   trial %d f %.3e node %d: body %.2e joint %.2e contact %.2e (rvio %.2e)\n", ls, (double)f, k, (double)mb, (double)mj, (double)mc, (double)r2);
+                    }
+#endif
                     int anybad;
                     if constexpr (QUAD && DJ_LDS_REDUCE) { T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)}; env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); anybad = vb[0] > T(0.5) ? 1 : 0; }
                     else anybad = env_or(wv, (active && searching) ? bad : 0, envl);
@@ -2180,6 +2358,7 @@ struct LaneProgram {
                     rvio = rc; bvio = bc;
                     if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
                     mu = mutarget;
+                    if constexpr (kTrack) refine = refine || (wstiff > G.refine_w);    // (wstiff: from the accepted trial's violations)
                 }
                 // Forward-only launch, every environment of the workgroup converged with this step: the next iteration would only
                 // flag success (mehrotra.jl:23-27) -- do that here and skip the linearization nobody will use.
@@ -2194,7 +2373,7 @@ struct LaneProgram {
                 } else linearize();
             }
         }
-        if (excessive) status = DJ_STATUS_EXCESSIVE_W;
+        if (excessive && status != DJ_STATUS_DEFERRED) status = DJ_STATUS_EXCESSIVE_W;
         iters_out = iters;
         return status;
     }
@@ -2208,8 +2387,11 @@ struct LaneProgram {
     // G.grad_mode: DOJO_GRAD_REFERENCE = post-update_state! states (literal
     // reference behaviour), DOJO_GRAD_CONSISTENT = pre-update states.
     // Output layout: column-major per environment (Julia-native): dz[env][col][row], du[env][ucol][row].
-    template <class KA>
-    DJ_HD void gradients(const KA& A, int env) {
+    // PRECISE (quad mapping, DJ_REFINE): the column-by-column path below with every column solved through solve_rhs and
+    // refined against the uncondensed system -- for the environments whose cones were stiff at the solution (`write_out`
+    // selects them inside a workgroup); the pipelined sweeps serve everything else.
+    template <bool PRECISE = false, class KA>
+    DJ_HD void gradients(const KA& A, int env, bool write_out = true) {
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
         DJ_PB();
@@ -2358,7 +2540,7 @@ struct LaneProgram {
         // σ = wκ/(1 + wκ): the slack rows of a joint limit enter the Δκ row (see evaluate) as σ·(∂ slack row / ∂ data)
         if (lim_on()) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
         typedef typename KA::io_type TB;
-        if constexpr (QUAD) {
+        if constexpr (QUAD && !PRECISE) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
             SweepP sp;
@@ -2421,6 +2603,20 @@ struct LaneProgram {
         // ---- column loop (lane = supernode mapping) ----
         struct { T dv[3], dw[3]; } D;
         auto grad_solve = [&](T* rk, T rs0, const T (*r58)[4], T* upx) {
+            if constexpr (PRECISE) {
+                // the same column through the general solve (cone right-hand sides zero, slack rows (rs, −rs)) and refined
+                ConeRhs R0;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) R0.cc[c][i] = T(0);
+                R0.lim[0] = R0.lim[1] = T(0);
+                const T rs2[2] = {rs0, -rs0};
+                Step<T, MAXC> Dp; T dva[6];
+                solve_rhs(rk, R0, rs2, r58, upx, Dp, dva);
+#pragma unroll 1
+                for (int rstep = 0; rstep < DJ_REFINE_STEPS; ++rstep) refine_solution(rk, R0, rs2, r58, upx, Dp, dva);
+                for (int i = 0; i < 3; ++i) { D.dv[i] = Dp.dv[i]; D.dw[i] = Dp.dw[i]; }
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
 #pragma unroll
@@ -2454,7 +2650,7 @@ struct LaneProgram {
                     rs[0] = T(gb.sl_par[cc]); rs[1] = -rs[0];
                 }
                 grad_solve(rk, rs[0], r58, upx);
-                if (active && q == 0 && A.dz) {
+                if (active && q == 0 && A.dz && write_out) {
                     OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k;
                     T pw[3];
                     m3vec(pw, kb0.Phi, D.dw);
@@ -2479,7 +2675,7 @@ struct LaneProgram {
                 for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
                 if (mine) for (int i = 0; i < 6; ++i) { rk[i] = T(gb.UB[i][c]); upx[i] = T(gb.UA[i][c]); }
                 grad_solve(rk, rs[0], r58, upx);
-                if (active && q == 0 && A.du) {
+                if (active && q == 0 && A.du && write_out) {
                     OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + c)) * nx + 12 * k;
                     T pw[3];
                     m3vec(pw, kb0.Phi, D.dw);
@@ -2668,6 +2864,8 @@ struct KernelArgs {
     TIO* res;                      // [B,6Nb] or null          body residual rows at the solution (for the Storage kernel)
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
+    T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
+    int* flag = nullptr;           // [B] 1: the plain step kernel deferred this environment to the refining kernels (DJ_REFINE; or null)
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
@@ -2728,7 +2926,8 @@ constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKST
 
 // doubles per supernode in the step -> IFT hand-off record: v ω λ(6), s,γ of the joint limit, s,γ of the contacts, μ,
 // and the pieces of the final linearization the IFT needs besides the factors: t_a, t_b (limit condensation), G134
-template <int MAXC> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC; }
+template <int MAXC> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
+template <int MAXC> constexpr int sol_flag_off() { return sol_record<MAXC>() - 1; }
 // quad mapping: the factors themselves travel too (72 values per lane, stored [wave][72][64 lanes]: coalesced)
 constexpr int FAC_PER_LANE = 72;
 
@@ -2741,14 +2940,14 @@ constexpr int FAC_PER_LANE = 72;
 #else
 #define DJ_TSD_SETUP
 #endif
-#define DJ_LANE_SETUP(GRAD_LAYOUT)                                                                                        \
+#define DJ_LANE_SETUP(GRAD_LAYOUT, ENV_OK)                                                                                \
     const Globals<T>& G = A.G;                                                                                            \
     const int stride = QUAD ? 4 : 1;                                                                                      \
     const int envl = stride * G.S, E = wv.width() / envl;        /* lanes per environment, environments per workgroup */  \
     const int lane = wv.lane();                                                                                           \
     const int slot = lane / envl, k = (lane % envl) / stride, q = lane % stride;                                          \
     const int env = wave_index * E + slot;                                                                                \
-    const bool active = (env < A.B) && (k < G.Nb);                                                                        \
+    const bool active = (env < A.B) && (k < G.Nb) && (ENV_OK);                                                            \
     const int base = slot * envl;                                                                                         \
     typedef StepLds<TIO, T, MAXC, (GRAD_LAYOUT), QUAD, Wave::kLockstep, Wave::kWaves> LY;                                   \
     constexpr bool SHARE = QUAD && Wave::kLockstep;                                                                       \
@@ -2770,6 +2969,7 @@ constexpr int FAC_PER_LANE = 72;
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
+        if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
@@ -2782,12 +2982,27 @@ constexpr int FAC_PER_LANE = 72;
     prog.begin_step(zb, has_u ? ue : nullptr, has_f ? fe : nullptr);
 
 // IFT kernel entry: one call per lane
+// MODE 0: state + control columns, pipelined sweeps; 1: contact-data columns; 2: state + control columns of the environments
+// whose solves were being refined, column by column through the refined general solve (LDS layout of the step kernel:
+// NodeP / Lane / Cold stay alive)
 template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, int MODE = 0>
 DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
-    DJ_LANE_SETUP(MODE == 0 ? 1 : 2)
+    if constexpr (QUAD && DJ_REFINE && (MODE == 0 || MODE == 2)) {
+        // refined environments belong to the MODE 2 kernel; a workgroup without work for this kernel leaves at once (uniform)
+        const int stride_ = 4, envl_ = stride_ * A.G.S, E_ = wv.width() / envl_, lane_ = wv.lane();
+        const int env_ = wave_index * E_ + lane_ / envl_, k_ = (lane_ % envl_) / stride_;
+        const bool act_ = (env_ < A.B) && (k_ < A.G.Nb);
+        const bool fl_ = act_ && A.sol[((size_t)env_ * A.G.S + (size_t)k_) * sol_record<MAXC>() + sol_flag_off<MAXC>()] != T(0);
+        if (MODE == 0 ? !wv.any(act_ && !fl_) : !wv.any(fl_)) return;
+    }
+    static_assert(MODE != 2 || Wave::kRefine || !(QUAD && DJ_REFINE), "the MODE 2 IFT kernel needs a refining Wave");
+    DJ_LANE_SETUP(MODE == 0 ? 1 : MODE == 1 ? 2 : 0,
+                  MODE != 2 || A.sol[(size_t)env * G.S * sol_record<MAXC>() + sol_flag_off<MAXC>()] != T(0))
+    bool flagged = false;
     {   // restore the converged solution (identical on the four lanes of a quad)
         const T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
         if (active) {
+            flagged = r[sol_flag_off<MAXC>()] != T(0);
             for (int i = 0; i < 3; ++i) { prog.L.v[i] = r[i]; prog.L.w[i] = r[3 + i]; }
             for (int i = 0; i < 6; ++i) prog.L.lam[i] = r[6 + i];
             prog.L.ls[0] = r[12]; prog.L.ls[1] = r[13]; prog.L.lg[0] = r[14]; prog.L.lg[1] = r[15];
@@ -2819,6 +3034,19 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         prog.linearize();                                     // lane mapping: rebuild the final linearization instead
     }
     if constexpr (MODE == 0) prog.gradients(A, env);
+    else if constexpr (MODE == 2) {
+        if constexpr (QUAD && DJ_REFINE) {
+            // the un-factored rows of the final linearization (the step kernel's copy may be older than its last iterate's):
+            // set_entries! once more into scratch rows; this also restores C134 / G134 and the limit rows of F
+            TL S2[3][12], U2[3][6], L2[6][3];
+            QuadBlocks<TL> K2(S2, U2, L2, q);
+            prog.refine = flagged;
+            prog.template evaluate<true>(K2);
+            prog.condense_limits(K2);
+            prog.store_blocks(K2);
+            prog.template gradients<true>(A, env, flagged);
+        }
+    }
     else if constexpr (QUAD) prog.gradients_contact(A, env);
 #ifdef DJ_PROF
     if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); }
@@ -2827,7 +3055,12 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 
 template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
-    DJ_LANE_SETUP(0)
+    constexpr bool RF = QUAD && DJ_REFINE && Wave::kRefine;      // the refining build: re-solves the environments the plain kernel deferred
+    if constexpr (RF) {
+        const int envl_ = 4 * A.G.S, E_ = wv.width() / envl_, env_ = wave_index * E_ + wv.lane() / envl_;
+        if (A.flag == nullptr || !wv.any(env_ < A.B && A.flag[env_] != 0)) return;          // nothing deferred in this workgroup (uniform)
+    }
+    DJ_LANE_SETUP(0, !RF || A.flag[env] != 0)
 #ifdef DJ_DEBUG
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
     if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
@@ -2854,8 +3087,10 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) for (int i = 0; i < 18; ++i) r2[12 + 18 * c + i] = prog.ccold(c).G134[i];
         }
+        r[sol_flag_off<MAXC>()] = (RF || status == DJ_STATUS_DEFERRED) ? T(1) : T(0);
     }
-    if (QUAD && A.fac) {
+    if (!RF && A.flag && active && q == 0 && k == 0) A.flag[env] = status == DJ_STATUS_DEFERRED ? 1 : 0;
+    if (QUAD && A.fac && (!RF || active)) {
         T* f = A.fac + (size_t)wave_index * FAC_PER_LANE * wv.width() + lane;
         const int W = wv.width();
 #pragma unroll

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include "dojo_host.hpp"
 #include "dojo_coords.hpp"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,9 @@ struct DojoSim {
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
+    void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
+    int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
+    double refine_w = -1.0;             // refine once max γ/s of an environment exceeds this (dojo_set_refinement); < 0: chosen from the tolerances
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false, have_u = false;
     hipStream_t stream = nullptr;
@@ -337,7 +341,10 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
     auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
     dj::KernelArgs<TIO, T> A;
-    A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode);
+    // Refinement threshold: explicit (dojo_set_refinement) or tied to the requested tolerances -- the reference's defaults
+    // (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
+    const double rw_ = s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol < 1e-7 || s->opts.btol < 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
+    A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode, rw_);
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
@@ -366,6 +373,13 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
     }
     A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
+    A.blk = nullptr; A.flag = nullptr;
+    if (quad && A.G.refine_w < INFINITY) {                  // the refining kernels follow the plain ones (dojo_kernels.hip)
+        if (!s->d_blk) HIPCHK(hipMalloc(&s->d_blk, waves_total * 90 * 64 * NW * sizeof(T)));
+        if (!s->d_flag) HIPCHK(hipMalloc((void**)&s->d_flag, (size_t)s->B * sizeof(int)));
+        A.blk = (T*)s->d_blk + wave0 * 90 * 64 * NW;
+        A.flag = s->d_flag + env0;
+    }
     typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
     if (dc != nullptr) {                   // contact-data columns only: the hand-off of the last differentiable step is re-used
@@ -455,7 +469,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
@@ -495,6 +509,14 @@ int dojo_set_external_force(DojoHandle s, const void* fext) {
     HIPCHK(hipMemcpy(s->d_fext, fext, bytes, hipMemcpyHostToDevice));
     s->fext = s->d_fext;
     return DOJO_OK;
+}
+
+// Accuracy of the linear solves (no counterpart in the reference, whose LDU has no such knob): environments whose cone
+// variables reach max γ/s > stiffness get their Newton and IFT solves refined against the uncondensed KKT system.
+// INFINITY switches the refinement off, 0 refines every solve.
+int dojo_set_refinement(DojoHandle s, double stiffness) {
+    if (!s || stiffness != stiffness) { g_err = "dojo_set_refinement: bad argument"; return DOJO_ERR_INVALID; }   // negative: back to the tolerance-based default
+    s->refine_w = stiffness; return DOJO_OK;
 }
 
 int dojo_set_gradient_mode(DojoHandle s, int32_t mode) {

@@ -142,8 +142,11 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
     b.r = T(a.r); b.mu = T(a.mu);
     return b;
 }
-template <class T> inline Globals<T> make_globals(const HostModel& M, const DojoSolverOptions& o, int grad_mode) {
+// refine_w: stiffness (max γ/s over the cones of an environment) beyond which the device refines its linear solves against
+// the uncondensed system (DJ_REFINE, dojo_device.hpp); INFINITY = never
+template <class T> inline Globals<T> make_globals(const HostModel& M, const DojoSolverOptions& o, int grad_mode, double refine_w = INFINITY) {
     Globals<T> G;
+    G.refine_w = T(refine_w);
     G.dt = T(M.dt); G.idt2 = T(1.0 / (M.dt * M.dt)); G.input_scaling = T(M.input_scaling);
     for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
     G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);

@@ -22,8 +22,10 @@ namespace {
 // NW = wavefronts per workgroup.  NW = 1: the workgroup is one wavefront (<= 16 supernodes x 4 roles).  NW = 2: one
 // environment of 17..32 bodies spans two wavefronts; quads never straddle a wave, so everything quad-local is unchanged,
 // and the exchanges between quads (LDS mailbox, reductions, votes) go through LDS with real barriers.
-template <int NW>
+// RF = the refining build of the kernels (DJ_REFINE, dojo_device.hpp): re-solves the environments the plain kernels deferred
+template <int NW, bool RF = false>
 struct GpuWave {
+    static constexpr bool kRefine = RF;
     static constexpr bool kLockstep = true;     // the 64 lanes of a wave (so the 4 lanes of a quad) execute every instruction together
     static constexpr int kWaves = NW;
     void* lds_;
@@ -111,6 +113,16 @@ dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
+// the Newton loop once more, with every linear solve refined once the cones are stiff, for the environments the plain kernel
+// deferred (DJ_STATUS_DEFERRED); workgroups without one leave at once
+template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
+__global__ void __launch_bounds__(64 * NW) dojo_stepp_kernel(dj::KernelArgs<TIO, TS> A) {
+    typedef dj::StepLds<TIO, TS, MAXC, 0, QUAD, true, NW> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<NW, true> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW, true>>(w, A, (int)blockIdx.x);
+}
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
 dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
@@ -119,6 +131,17 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
+}
+// the IFT kernel of the environments whose linear solves were being refined (DJ_REFINE: stiff cones, max γ/s beyond
+// Globals::refine_w): column by column through the refined general solve; workgroups without such an environment leave
+// at once.  LDS layout of the step kernel (the lane program's state stays alive).  Quad mappings only.
+template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
+__global__ void __launch_bounds__(64 * NW) dojo_gradp_kernel(dj::KernelArgs<TIO, TS> A) {
+    typedef dj::StepLds<TIO, TS, MAXC, 0, QUAD, true, NW> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<NW, true> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW, true>, 2>(w, A, (int)blockIdx.x);
 }
 // the IFT kernel for the contact-data columns (get_contact_gradients); quad mappings only
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
@@ -147,8 +170,14 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, v
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
     constexpr int NW = DJ_QUAD == 2 ? 2 : 1;
     hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#if DJ_QUAD != 0 && DJ_REFINE
+    if (A.flag != nullptr) hipLaunchKernelGGL((dojo_stepp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#endif
     if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
     if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#if DJ_QUAD != 0 && DJ_REFINE
+    if (grad && A.flag != nullptr) hipLaunchKernelGGL((dojo_gradp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#endif
     return (int)hipGetLastError();
 }
 

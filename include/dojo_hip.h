@@ -168,6 +168,14 @@ void dojo_destroy(DojoHandle h);
 int  dojo_get_dims(DojoHandle h, DojoDims* dims);
 int  dojo_set_options(DojoHandle h, const DojoSolverOptions* opts);
 int  dojo_set_gradient_mode(DojoHandle h, int32_t mode);
+/* Accuracy of the device's linear solves.  The reference's block LDU (GraphBasedSystems, call sites
+ * src/solver/mehrotra.jl:36-37,49 and the dense `\` of src/gradients/state.jl:99) is an exact direct method; the device
+ * eliminates contacts and limits first, which in fp64 costs log10(gamma/s) digits of the body blocks.  Environments whose
+ * cones reach max gamma/s > stiffness therefore get every Newton and IFT solve refined against the un-eliminated KKT system
+ * (DESIGN.md section 4.5).  INFINITY = never, 0 = always, negative = the default policy: DOJO_DEFAULT_REFINE_STIFFNESS when the
+ * solver tolerances are tighter than rtol 1e-7 / btol 1e-6, never at the reference's default tolerances. */
+#define DOJO_DEFAULT_REFINE_STIFFNESS 1.0e4
+int  dojo_set_refinement(DojoHandle h, double stiffness);
 
 /* step!: z [B,13Nb], u [B,nu] (NULL = zeros) -> z_next [B,13Nb] = the mechanism's internal
  * state after update_state! (x3,v25,q3,w25; SURVEY §8a note Q1), status [B], iters [B]

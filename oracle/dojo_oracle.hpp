@@ -135,6 +135,7 @@ struct Mechanism {
     std::vector<T> A_solved;                 // matrix of the last set_entries! before any factorization (kept for gradients)
     int last_iters = 0;
     bool verbose = false; T last_alpha = 1;
+    int refine_steps = 2;         // rounds of iterative refinement of every linear solve (DenseLU::solve_refined); 0 = plain LU, as timed by bench.py's cpu_baseline
     bool excessive_w = false;
 
     // ---------------- construction from the C-POD topology ----------------
@@ -175,6 +176,7 @@ struct Mechanism {
             contacts.push_back(c);
         }
         verbose = std::getenv("ORC_VERBOSE") != nullptr;
+        if (const char* rs_ = std::getenv("ORC_REFINE")) refine_steps = std::atoi(rs_);
         int off = 0;
         for (auto& J : joints) { joff.push_back(off); off += J.N(); }
         for (size_t i = 0; i < bodies.size(); ++i) { boff.push_back(off); off += 6; }
@@ -1050,7 +1052,7 @@ struct Mechanism {
             if (rvio < T(opts.rtol) && bvio < T(opts.btol)) { status = DOJO_STATUS_SUCCESS; break; }
             rcache = b;                                   // pull_residual!
             lu.factor(A, n);                              // ldu_factorization!
-            lu.solve(b.data(), 1);                        // ldu_backsubstitution!  -> Δaff in b
+            lu.solve_refined(b.data(), 1, refine_steps);  // ldu_backsubstitution!  -> Δaff in b
             T aaff = cone_line_search(T(0.95), T(0.95));
             T nu_, nuaff; centering(aaff, nu_, nuaff);
             T ratio = nuaff / (nu_ + T(1e-20));
@@ -1061,7 +1063,7 @@ struct Mechanism {
             mu = mutarget;
             correction();
             b = rcache;                                   // push_residual!
-            lu.solve(b.data(), 1);
+            lu.solve_refined(b.data(), 1, refine_steps);
             T tau = std::fmax(T(0.95), T(1) - std::fmax(rvio, bvio) * std::fmax(rvio, bvio));
             T alpha = cone_line_search(tau, std::fmin(tau, T(0.95)));
             last_alpha = alpha;
@@ -1421,7 +1423,7 @@ struct Mechanism {
         int nc = (int)cols.size();
         std::vector<T> R((size_t)n * nc);
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + cols[c]];
-        DenseLU<T> lu; lu.factor(solmat, n); lu.solve(R.data(), nc);   // data_jacobian = solmat \ datamat
+        DenseLU<T> lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps);   // data_jacobian = solmat \ datamat
         std::fill(jac_state, jac_state + (size_t)nx * nx, T(0));
         std::fill(jac_control, jac_control + (size_t)nx * nu_, T(0));
         auto out = [&](int row, int c) -> T& { return c < nx ? jac_state[(size_t)row * nx + c] : jac_control[(size_t)row * nu_ + (c - nx)]; };
@@ -1454,7 +1456,7 @@ struct Mechanism {
         int nc = 5 * (int)contacts.size();
         std::vector<T> R((size_t)n * std::max(nc, 1));
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + o + c];
-        DenseLU<T> lu; lu.factor(solmat, n); if (nc > 0) lu.solve(R.data(), nc);
+        DenseLU<T> lu; lu.factor(solmat, n); if (nc > 0) lu.solve_refined(R.data(), nc, refine_steps);
         std::fill(jac_contact, jac_contact + (size_t)nx * nc, T(0));
         for (int i = 0; i < Nb; ++i) {
             const State<T>& s = bodies[i].st;

@@ -246,8 +246,9 @@ template <class T> Quat<T> axis_angle_to_quaternion(const SM<T>& x) {
 template <class T>
 struct DenseLU {
     int n = 0; std::vector<T> lu; std::vector<int> piv;
+    std::vector<T> a0;            // the matrix itself, kept for solve_refined
     bool factor(const std::vector<T>& A, int n_) {
-        n = n_; lu = A; piv.resize(n);
+        n = n_; lu = A; a0 = A; piv.resize(n);
         for (int k = 0; k < n; ++k) {
             int p = k; T best = std::fabs(lu[k * n + k]);
             for (int i = k + 1; i < n; ++i) { T v = std::fabs(lu[i * n + k]); if (v > best) { best = v; p = i; } }
@@ -268,6 +269,26 @@ struct DenseLU {
         for (int i = n - 1; i >= 0; --i) {
             for (int k = i + 1; k < n; ++k) { T f = lu[i * n + k]; if (f != T(0)) for (int j = 0; j < nrhs; ++j) B[i * nrhs + j] -= f * B[k * nrhs + j]; }
             T d = lu[i * n + i]; for (int j = 0; j < nrhs; ++j) B[i * nrhs + j] /= d;
+        }
+    }
+    // The same solve followed by `steps` rounds of iterative refinement with the residual accumulated in long double: the
+    // checker's stand-in for exact arithmetic.  (The reference's LDU is an exact direct method; what the GPU path is compared
+    // with should not carry the cond(A)·ε ~ 1e-6 forward error a single fp64 LU solve has on contact-rich steps, where
+    // cond(A) reaches 1e10 -- the iterate path of a 20..40-iteration solve amplifies it to the parity bound.)
+    void solve_refined(T* B, int nrhs, int steps) const {
+        if (steps <= 0) { solve(B, nrhs); return; }
+        std::vector<T> rhs(B, B + (size_t)n * nrhs), r((size_t)n * nrhs);
+        solve(B, nrhs);
+        std::vector<long double> acc(nrhs);
+        for (int s = 0; s < steps; ++s) {
+            for (int i = 0; i < n; ++i) {
+                for (int j = 0; j < nrhs; ++j) acc[j] = (long double)rhs[(size_t)i * nrhs + j];
+                const T* ai = &a0[(size_t)i * n];
+                for (int k = 0; k < n; ++k) { const long double a = (long double)ai[k]; if (a != 0.0L) { const T* bk = &B[(size_t)k * nrhs]; for (int j = 0; j < nrhs; ++j) acc[j] -= a * (long double)bk[j]; } }
+                for (int j = 0; j < nrhs; ++j) r[(size_t)i * nrhs + j] = (T)acc[j];
+            }
+            solve(r.data(), nrhs);
+            for (size_t i = 0; i < r.size(); ++i) B[i] += r[i];
         }
     }
 };

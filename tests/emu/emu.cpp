@@ -37,8 +37,9 @@ struct Shared {
     explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(160 * 1024 / 8) {}
 };
 
-template <int NW>
+template <int NW, bool RF = false>
 struct EmuWaveT {
+    static constexpr bool kRefine = RF;         // the refining build of the kernels (DJ_REFINE)
     static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
     static constexpr int kWaves = NW;           // selects the LDS layout and the workgroup-reduction code paths of the multi-wave kernels
     Shared* sh; int l;
@@ -100,7 +101,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<TIO> zn((size_t)B * nz), velt(vel ? (size_t)B * 6 * M.Nb : 0), jt(jimp ? (size_t)B * std::max(M.n_joint_imp, 1) : 0),
         ct(csg ? (size_t)B * 8 * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
     dj::KernelArgs<TIO, T> A;
-    A.G = dj::make_globals<T>(M, opts, grad_mode);
+    { const char* rw = std::getenv("EMU_REFINE_W"); A.G = dj::make_globals<T>(M, opts, grad_mode, rw ? std::atof(rw) : INFINITY); }
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
     std::vector<dj::TraSD<T>> tsd;
     for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi); b.nlim = a.nlim; tsd.push_back(b); }
@@ -115,16 +116,27 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
     std::vector<T> facbuf((dz && QUAD) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
+    std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
     // the same two launches as the product: step kernel, then (when gradients are wanted) the IFT kernel
-    for (int pass = 0; pass < ((dz && !dbg) ? 2 : 1); ++pass)
-    for (int wi = 0; wi < nwaves; ++wi) {
-        Shared sh(W);
-        std::vector<std::thread> th;
-        for (int l = 0; l < W; ++l) th.emplace_back([&, l, pass]() {
-            EmuWaveT<NW> w{&sh, l};
-            if (pass == 0) dj::step_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi); else dj::grad_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi);
-        });
-        for (auto& t : th) t.join();
+    // the product's launches: step kernel, refining step kernel (quad mapping; re-solves what the first deferred), IFT kernel,
+    // refining IFT kernel
+    std::vector<int> flagbuf(B, 0); A.flag = (QUAD && A.G.refine_w < INFINITY) ? flagbuf.data() : nullptr;
+    if (!A.flag) A.blk = nullptr;
+    for (int pass = 0; pass < 4; ++pass) {
+        if ((pass == 1 || pass == 3) && !A.flag) continue;
+        if (pass >= 2 && !(dz && !dbg)) continue;
+        for (int wi = 0; wi < nwaves; ++wi) {
+            Shared sh(W);
+            std::vector<std::thread> th;
+            for (int l = 0; l < W; ++l) th.emplace_back([&, l, pass]() {
+                EmuWaveT<NW> w{&sh, l}; EmuWaveT<NW, true> wr{&sh, l};
+                if (pass == 0) dj::step_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi);
+                else if (pass == 1) { if constexpr (QUAD) dj::step_entry<TIO, T, TL, MAXC, QUAD>(wr, A, wi); }
+                else if (pass == 2) dj::grad_entry<TIO, T, TL, MAXC, QUAD>(w, A, wi);
+                else { if constexpr (QUAD) dj::grad_entry<TIO, T, TL, MAXC, QUAD, EmuWaveT<NW, true>, 2>(wr, A, wi); }
+            });
+            for (auto& t : th) t.join();
+        }
     }
     if constexpr (QUAD) if (dz && dc && !dbg && M.Nc > 0) {          // third launch: the contact-data columns (re-uses the hand-off)
         A.dc = dct.data(); A.dz = nullptr; A.du = nullptr;
