@@ -46,6 +46,12 @@
 #ifndef DJ_TSD
 #define DJ_TSD 0           // 1: the kernels evaluate translational springs / dampers (KernelArgs::tsd); builds of their own
 #endif
+#ifndef DJ_SPLIT_Y
+#define DJ_SPLIT_Y 0       // IFT sweeps, fp32 ABI: 1 = park the forward-substituted right-hand sides as two floats (measured: IFT kernel +33 %, while the f32-ABI and f64-ABI gradients already agree to 2e-7 relative without it)
+#endif
+#ifndef DJ_RHS_T
+#define DJ_RHS_T TIO       // quad mapping: type of the IFT right-hand-side blocks in LDS (the ABI type; double was measured: +25 % IFT kernel time, same error)
+#endif
 #ifndef DJ_REFINE
 #define DJ_REFINE 1        // quad mapping: iterative refinement of the Newton / IFT solves against the UNCONDENSED system for environments whose
                            // cone variables have become stiff (max γ/s > Globals::refine_w): the condensed body blocks D + (γ/s) g cᵀ lose the
@@ -1491,6 +1497,7 @@ struct LaneProgram {
     DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0, const SweepP& sp) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
+        constexpr bool kSplitY = DJ_SPLIT_Y && sizeof(TIO) < sizeof(TG);      // park y as (high, low) halves when the ABI type is narrower
         constexpr int NC = 6;
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
@@ -1646,7 +1653,12 @@ struct LaneProgram {
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? p0_ : p1_) : TG(0); }
-                    if (q < 2 && col_ok(b, cI)) { TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
+                    if (q < 2 && col_ok(b, cI)) {
+                        TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]);
+                        // fp32 ABI: the parked y keeps its low half in the x3 / φ3 slots of the same column (free until the down-sweep writes
+                        // them): y − S⁻¹(U Δ_parent) cancels, and an fp32 y costs stiff environments their gradient (measured: 0.1 relative)
+                        if constexpr (kSplitY) { o[0] = TIO(yy[0] - TG(TIO(yy[0]))); o[1] = TIO(yy[1] - TG(TIO(yy[1]))); o[2] = TIO(yy[2] - TG(TIO(yy[2]))); }
+                    }
                 }
             }
         }
@@ -1662,7 +1674,8 @@ struct LaneProgram {
         T Mq[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Mq[i] = q == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
-        TIO ynext[NC][3];
+        typedef typename std::conditional<kSplitY, TG, TIO>::type TY;
+        TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
             const bool v_ = active && q < 2 && b_ >= 0 && b_ < NB;
             TIO* const cbn = colbase(v_ ? b_ : 0);
@@ -1672,14 +1685,14 @@ struct LaneProgram {
                 const bool ok_ = v_ && col_ok(b_, n);
                 const TIO* o_ = cbn + (size_t)((isS_ && n >= 3) ? n + 3 : n) * nx;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? o_[3 + i] : TIO(0);
+                for (int i = 0; i < 3; ++i) { if constexpr (kSplitY) ynext[n][i] = ok_ ? TG(o_[3 + i]) + TG(o_[i]) : TG(0); else ynext[n][i] = ok_ ? o_[3 + i] : TIO(0); }
             }
         };
         fetch_y(0 - lvl);
         for (int t = 0; t < NB + G.maxlevel; ++t) {
             const int b = t - lvl;
             const bool valid = active && b >= 0 && b < NB;
-            TIO ycur[NC][3];
+            TY ycur[NC][3];
 #pragma unroll
             for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ycur[n][i] = ynext[n][i];
             fetch_y(b + 1);
@@ -2539,7 +2552,8 @@ struct LaneProgram {
         }
         // σ = wκ/(1 + wκ): the slack rows of a joint limit enter the Δκ row (see evaluate) as σ·(∂ slack row / ∂ data)
         if (lim_on()) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
-        typedef typename KA::io_type TB;
+        // precision the IFT right-hand sides are kept in (DJ_RHS_T)
+        typedef typename KA::io_type TIO; typedef typename std::conditional<QUAD, DJ_RHS_T, TIO>::type TB;
         if constexpr (QUAD && !PRECISE) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
@@ -2911,7 +2925,7 @@ struct StepLds {
     static constexpr bool ls_in_lds = DJ_LS_IN_LDS && share && !GRAD && NW == 1 && MAXC == 1;                 // (must match LaneProgram::kLsInLds)
     static constexpr int ls_off = pool_off + pool_bytes;
     static constexpr int a_end = ls_off + (ls_in_lds ? ls_slot * NSN : 0);
-    static constexpr int rhs_bytes = !QUAD ? 0 : GRAD == 1 ? (int)sizeof(QuadRhs<TIO>) * NSN : GRAD == 2 ? (int)sizeof(ConRhs<MAXC>) * NSN : 0;
+    static constexpr int rhs_bytes = !QUAD ? 0 : GRAD == 1 ? (int)sizeof(QuadRhs<DJ_RHS_T>) * NSN : GRAD == 2 ? (int)sizeof(ConRhs<MAXC>) * NSN : 0;
     static constexpr int mail_need = QUAD ? 2 * NSN * 20 * 8 : 0;
     static constexpr int rhs_off = 0;
     // (contact-data kernel: the mailbox keeps its own room behind the phase-A data; packed right behind the ConRhs blocks
@@ -2964,7 +2978,7 @@ constexpr int FAC_PER_LANE = 72;
     if (QUAD) {                                                                                                           \
         prog.cpool = (ContactCold<T>*)(lds + LY::pool_off); prog.pool_by_id = LY::pool_by_id;                             \
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
-        prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
+        prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<DJ_RHS_T>*)lds) + lane / 4); \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \

@@ -62,7 +62,9 @@ struct DojoSim {
     // internal device buffers used by the host-pointer entry points
     const void* fext = nullptr;                     // device [B,6Nb] external forces applied by every step, or null (dojo_set_external_force)
     void *d_fext = nullptr, *d_res = nullptr, *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
-    std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // rollout: environment groups
+    std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // environment groups (rollouts, dojo_step_dev)
+    int groups = -1;                    // environment groups of dojo_step_dev: -1 = chosen from the batch size, 1 = one launch on the caller's stream
+    bool async = false, pending = false;   // dojo_set_async: dojo_step_dev returns without joining the groups into the caller's stream
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
     void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
@@ -332,6 +334,34 @@ int acquire_slot(DojoSim* s, int* idx) {
     return drain_slot(s, s->ring[*idx]);
 }
 
+// Environments are independent, so a batch is stepped as NG groups on internal streams: a group that contains an
+// environment running into max_iter (one wavefront, ~5x the mean step time) delays only itself while the other groups'
+// launches keep the GPU busy.  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+// streams that share a queue serialize, so the count stays below that.
+size_t group_count(const DojoSim* s, bool want) {
+    const size_t B = (size_t)s->B;
+    size_t NG = (want && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
+    if (s->groups > 0) NG = std::min<size_t>((size_t)s->groups, std::max<size_t>(1, B / 64));
+    const char* hq = getenv("GPU_MAX_HW_QUEUES");
+    const int nq = hq ? atoi(hq) : 4;
+    return std::min<size_t>(NG, (size_t)std::max(1, nq - 1));
+}
+int ensure_groups(DojoSim* s, size_t NG) {
+    while (s->gstreams.size() < NG) {
+        hipStream_t g_; HIPCHK(hipStreamCreateWithFlags(&g_, hipStreamNonBlocking)); s->gstreams.push_back(g_);
+        hipEvent_t gev_; HIPCHK(hipEventCreateWithFlags(&gev_, hipEventDisableTiming)); s->gevents.push_back(gev_);
+    }
+    if (!s->fork_event) HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+    return DOJO_OK;
+}
+// the caller's stream waits for everything the environment groups have in flight
+int join_groups(DojoSim* s, hipStream_t st) {
+    if (!s->pending) return DOJO_OK;
+    for (size_t gi = 0; gi < s->gstreams.size(); ++gi) { HIPCHK(hipEventRecord(s->gevents[gi], s->gstreams[gi])); HIPCHK(hipStreamWaitEvent(st, s->gevents[gi], 0)); }
+    s->pending = false;
+    return DOJO_OK;
+}
+
 // Launches the step (and IFT) kernels for the environments [env0, env0 + nenv) of the batch; all pointers are the
 // batch-level buffers.  env0 must be a multiple of the environments per wavefront.
 template <class TIO, class T, class TL>
@@ -533,9 +563,50 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
     if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
-    rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, (hipStream_t)stream, true);
-    if (rc == DOJO_OK) { s->stream = (hipStream_t)stream; s->have_solution = true; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t NG = group_count(s, true);
+    if (NG <= 1) {
+        if ((rc = join_groups(s, st))) return rc;
+        rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, st, true);
+    } else {
+        // fork: every group waits for what the caller's stream holds (the inputs); group g of this call runs behind group g of
+        // the previous call on the same internal stream.  join: the caller's stream waits for all groups -- unless the handle
+        // is asynchronous (dojo_set_async), where consecutive calls chain per group and dojo_join() does it once.
+        if ((rc = ensure_groups(s, NG))) return rc;
+        HIPCHK(hipEventRecord(s->fork_event, st));
+        const size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;       // multiple of 64: whole wavefronts for every mapping
+        for (size_t gi = 0; gi < NG; ++gi) {
+            const size_t env0 = gi * per;
+            if (env0 >= B) break;
+            HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->fork_event, 0));
+            rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0));
+            if (rc != DOJO_OK) return rc;
+        }
+        s->pending = true;
+        if (!s->async && (rc = join_groups(s, st))) return rc;
+    }
+    if (rc == DOJO_OK) { s->stream = st; s->have_solution = true; }
     return rc;
+}
+
+// dojo_set_async(h, 1): dojo_step_dev no longer makes the caller's stream wait for the environment groups, so that
+// consecutive steps of one group never wait for another group's straggler; dojo_join(h, stream) orders `stream` behind
+// everything in flight (every host-pointer entry point does that implicitly).  dojo_set_groups: number of environment
+// groups of dojo_step_dev (0 / negative: chosen from the batch size; 1: a single launch on the caller's stream).
+int dojo_set_async(DojoHandle s, int32_t on) {
+    if (!s) { g_err = "dojo_set_async: bad argument"; return DOJO_ERR_INVALID; }
+    s->async = on != 0; return DOJO_OK;
+}
+int dojo_set_groups(DojoHandle s, int32_t n) {
+    if (!s) { g_err = "dojo_set_groups: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    s->pending = false; s->groups = n > 0 ? n : -1; return DOJO_OK;
+}
+int dojo_join(DojoHandle s, void* stream) {
+    if (!s) { g_err = "dojo_join: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    return join_groups(s, (hipStream_t)stream);
 }
 
 int dojo_step(DojoHandle s, const void* z, const void* u, void* z_next, int32_t* status, int32_t* iters, int32_t with_gradient) {
@@ -617,19 +688,11 @@ static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, 
     // Environments are independent, so the batch is rolled out as NG groups on internal streams: a group whose step
     // contains an environment that runs into max_iter (one wavefront, ~5x the mean step time) delays only itself while
     // the other groups' launches keep the GPU busy.  (ROCm runs at most GPU_MAX_HW_QUEUES streams concurrently.)
-    const int NW_ = mapping_waves(s->M);
-    const size_t E_ = 64 * (NW_ > 0 ? NW_ : 1) / (s->M.S * (NW_ > 0 ? 4 : 1));
-    size_t NG = (H >= 2 && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
-    {   // streams beyond the hardware queues serialize behind each other: stay below GPU_MAX_HW_QUEUES (ROCm default 4)
-        const char* hq = getenv("GPU_MAX_HW_QUEUES");
-        int nq = hq ? atoi(hq) : 4;
-        NG = std::min<size_t>(NG, (size_t)std::max(1, nq - 1));
-    }
+    if ((rc = join_groups(s, st))) return rc;                  // (asynchronous steps still in flight)
+    const size_t NG = group_count(s, H >= 2);
     size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;            // group size: multiple of 64 (and so of the environments per wave)
-    (void)E_;
     if (NG > 1) {
-        while (s->gstreams.size() < NG) { hipStream_t g_; HIPCHK(hipStreamCreateWithFlags(&g_, hipStreamNonBlocking)); s->gstreams.push_back(g_); hipEvent_t gev_; HIPCHK(hipEventCreateWithFlags(&gev_, hipEventDisableTiming)); s->gevents.push_back(gev_); }
-        if (!s->fork_event) HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+        if ((rc = ensure_groups(s, NG))) return rc;
         HIPCHK(hipEventRecord(s->fork_event, st));
     }
     const char* last = cur;
@@ -714,6 +777,7 @@ int dojo_contact_gradients_dev(DojoHandle s, const void* z, const void* u, void*
     if (!s->d_sol) { g_err = "dojo_contact_gradients_dev: no differentiable step (dz/du requested) has been run on this handle"; return DOJO_ERR_INVALID; }
     if (s->M.Nc == 0) return DOJO_OK;
     HIPCHK(hipSetDevice(s->device));
+    { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }
     return launch_any(s, z, u, s->d_zn ? s->d_zn : (void*)z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, true, 0, -1, dc);
 }
 int dojo_contact_gradients(DojoHandle s, void* dc) {
@@ -763,6 +827,7 @@ int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_for
     if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
     if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
+    { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }
     const int Nc = contact_forces ? s->M.Nc : 0, ld = 2 * s->M.nu + Nc;
     const long long n = (long long)s->B * s->M.Nb, nc = (long long)s->B * Nc; const int T_ = 256;
     if (s->dtype == DOJO_DTYPE_F32) {

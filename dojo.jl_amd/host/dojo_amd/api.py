@@ -34,7 +34,7 @@ def lib():
             raise DojoError("libdojo_hip.so not built (run __graft_entry__.build()); there is no CPU fallback")
         L = C.CDLL(_LIB_PATH)
         L.dojo_last_error.restype = C.c_char_p
-        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_step",
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -47,7 +47,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
-                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
+                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
@@ -109,6 +109,16 @@ class BatchedMechanism:
 
     def set_gradient_mode(self, mode):
         _chk(lib().dojo_set_gradient_mode(self.h, int(mode)))
+
+    def set_async(self, on=True):
+        """dojo_step_dev no longer joins its environment groups into the caller's stream; join() does it once."""
+        _chk(lib().dojo_set_async(self.h, int(bool(on))))
+
+    def set_groups(self, n):
+        _chk(lib().dojo_set_groups(self.h, int(n)))
+
+    def join(self, stream=None):
+        _chk(lib().dojo_join(self.h, C.c_void_p(stream or 0)))
 
     def set_refinement(self, stiffness):
         """Refine the linear solves of environments whose cones reach max gamma/s > stiffness (inf: never, 0: always)."""

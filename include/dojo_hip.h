@@ -205,6 +205,18 @@ int  dojo_get_state(DojoHandle h, void* z);
  * synchronized; outputs are valid after the stream is synchronized. */
 int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
                    int32_t* status, int32_t* iters, void* dz, void* du, void* stream);
+/* Environment groups.  Environments are independent, so dojo_step_dev steps a batch of >= 512 environments as up to 16
+ * groups on internal HIP streams: a group that holds an environment running into max_iter (~5x the mean step time for
+ * its wavefront) delays only itself.  By default the call forks from and joins into `stream`, i.e. it behaves like one
+ * launch on `stream`.  dojo_set_async(h, 1) drops the join: consecutive dojo_step_dev calls then chain per group (group g
+ * of call k+1 runs behind group g of call k and behind what `stream` held at call time), and dojo_join(h, stream)
+ * -- or any host-pointer entry point -- orders `stream` behind everything in flight.  The caller must not touch the
+ * outputs, nor overwrite the inputs, of un-joined calls.  dojo_set_groups(h, n): n groups (n <= 0: automatic; 1: a
+ * single launch on the caller's stream).  ROCm runs at most GPU_MAX_HW_QUEUES (default 4) streams concurrently: set it
+ * to >= groups + 1 before the HIP runtime starts.  (No counterpart in the reference, which is single-threaded.) */
+int  dojo_set_async(DojoHandle h, int32_t on);
+int  dojo_set_groups(DojoHandle h, int32_t n);
+int  dojo_join(DojoHandle h, void* stream);
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
 

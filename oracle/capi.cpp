@@ -4,6 +4,8 @@
 // oracle computes in (0 = fp64, 1 = fp32).
 #include "dojo_oracle.hpp"
 #include <thread>
+#include <atomic>
+#include <chrono>
 #include <memory>
 #include <algorithm>
 
@@ -36,6 +38,7 @@ struct IOracle {
     virtual void debug_assemble(const double* z, const double* u, double* A, double* b) = 0;
     virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
+    virtual void set_refine_steps(int n) = 0;
 };
 
 template <class T>
@@ -48,6 +51,7 @@ struct OracleT : IOracle {
         m.opts.rtol = o.rtol; m.opts.btol = o.btol; m.opts.undercut = o.undercut; m.opts.no_progress_undercut = o.no_progress_undercut;
         m.opts.max_iter = o.max_iter; m.opts.max_ls = o.max_ls; m.opts.no_progress_max = o.no_progress_max;
     }
+    void set_refine_steps(int n) override { m.refine_steps = n; }
     void dims(int* out) override {
         out[0] = m.n; out[1] = m.nu(); out[2] = m.data_dim(false); out[3] = m.data_dim(true);
         out[4] = (int)m.bodies.size(); out[5] = (int)m.joints.size(); out[6] = (int)m.contacts.size();
@@ -222,6 +226,38 @@ void orc_step_batch(void* h, int B, const double* z, const double* u, double* z_
         });
     }
     for (auto& x : th) x.join();
+}
+
+// rounds of iterative refinement of every linear solve (default 2: the checker; 0: a plain LU solve like the reference's)
+void orc_set_refine_steps(void* h, int n) { ((IOracle*)h)->set_refine_steps(n); }
+
+// bench.py's cpu_baseline leg: every thread owns a clone of the mechanism and walks its share of the B environments `rounds`
+// times (results discarded); the clock starts once all threads stand at the barrier.  Returns the wall-clock seconds.
+double orc_time_batch(void* h, int B, const double* z, const double* u, int with_grad, int grad_mode, int nthreads, int rounds) {
+    IOracle* base = (IOracle*)h; int d[7]; base->dims(d);
+    const int nz = 13 * d[4], nu = d[1], nx = 12 * d[4];
+    nthreads = std::max(1, std::min(nthreads, B));
+    std::atomic<int> ready{0}; std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+        th.emplace_back([&, t]() {
+            std::unique_ptr<IOracle> o(base->clone());
+            std::vector<double> zs(nz), dz(with_grad ? (size_t)nx * nx : 0), du(with_grad ? (size_t)nx * std::max(nu, 1) : 0);
+            ready.fetch_add(1);
+            while (!go.load()) std::this_thread::yield();
+            for (int r = 0; r < rounds; ++r)
+                for (int e = t; e < B; e += nthreads) {
+                    int it = 0;
+                    o->step(z + (size_t)e * nz, u ? u + (size_t)e * nu : nullptr, zs.data(), nullptr, &it);
+                    if (with_grad) o->gradients(grad_mode, dz.data(), du.data());
+                }
+        });
+    }
+    while (ready.load() < nthreads) std::this_thread::yield();
+    auto t0 = std::chrono::steady_clock::now();
+    go.store(true);
+    for (auto& x : th) x.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 } // extern "C"

@@ -36,6 +36,8 @@ def lib():
                      "orc_data_attjac", "orc_set_state", "orc_get_state", "orc_set_external_force",
                      "orc_body_velocity_solution", "orc_save_to_storage", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
             getattr(_lib, name).restype = None
+        _lib.orc_time_batch.restype = C.c_double
+        _lib.orc_set_refine_steps.restype = None
         _lib.orc_step.restype = C.c_int
         _lib.orc_simulate_step.restype = C.c_int
         _lib.orc_simulate_step_record.restype = C.c_int
@@ -171,6 +173,15 @@ class Oracle:
             status.append(lib().orc_simulate_step_record(self.h, _p(np.ascontiguousarray(U[k], dtype=np.float64)), int(k == H - 1), _p(row := np.zeros((self.Nb, 25)))))
             rows.append(row)
         return np.stack(rows), status
+
+    def set_refine_steps(self, n):
+        """rounds of iterative refinement of every linear solve: 2 (default) = the checker, 0 = plain LU like the reference's direct solve"""
+        lib().orc_set_refine_steps(self.h, int(n))
+
+    def time_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1, rounds=1):
+        """wall-clock seconds for `rounds` passes over the batch on `nthreads` persistent threads (results discarded)"""
+        Z = np.ascontiguousarray(Z, dtype=np.float64); U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
+        return float(lib().orc_time_batch(self.h, Z.shape[0], _p(Z), _p(U), int(with_grad), int(grad_mode), int(nthreads), int(rounds)))
 
     def step_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1):
         Z = np.ascontiguousarray(Z, dtype=np.float64); B = Z.shape[0]
