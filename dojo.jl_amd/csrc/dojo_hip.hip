@@ -373,7 +373,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     dj::KernelArgs<TIO, T> A;
     // Refinement threshold: explicit (dojo_set_refinement) or tied to the requested tolerances -- the reference's defaults
     // (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
-    const double rw_ = s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol < 1e-7 || s->opts.btol < 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
+    const double rw_ = s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol <= 1e-7 || s->opts.btol <= 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode, rw_);
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);

@@ -173,7 +173,7 @@ int  dojo_set_gradient_mode(DojoHandle h, int32_t mode);
  * eliminates contacts and limits first, which in fp64 costs log10(gamma/s) digits of the body blocks.  Environments whose
  * cones reach max gamma/s > stiffness therefore get every Newton and IFT solve refined against the un-eliminated KKT system
  * (DESIGN.md section 4.5).  INFINITY = never, 0 = always, negative = the default policy: DOJO_DEFAULT_REFINE_STIFFNESS when the
- * solver tolerances are tighter than rtol 1e-7 / btol 1e-6, never at the reference's default tolerances. */
+ * solver tolerances are rtol <= 1e-7 or btol <= 1e-6, never at the reference's default tolerances. */
 #define DOJO_DEFAULT_REFINE_STIFFNESS 1.0e4
 int  dojo_set_refinement(DojoHandle h, double stiffness);
 

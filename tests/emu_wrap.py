@@ -13,6 +13,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if os.environ.get("EMU_LIB"):                      # an experimental build (g++ ... -DDJ_xxx=1), no rebuild check
+            _lib = C.CDLL(os.environ["EMU_LIB"]); _lib.emu_step.restype = C.c_int
+            return _lib
         so = os.path.join(_HERE, "emu", "libemu.so")
         src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
                                                          for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]

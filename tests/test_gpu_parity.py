@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI of libdojo_hip.so, against
 the CPU oracle on the same seeded inputs.  Tolerances: state/solution inf-norm <= 1e-6 in fp64
 (tight solver tolerances) and <= 1e-3 in fp32 (BASELINE.json north_star)."""
+import os
 import numpy as np
 import pytest
 import dojo_amd as d
@@ -8,26 +9,27 @@ from dojo_amd import api
 from oracle import Oracle
 
 pytestmark = pytest.mark.gpu
-# 1e-8: tight enough for 1e-6 parity; below ~1e-9 the condensed KKT (entries ~γ/s) loses accuracy in fp64
+# 1e-8: tight enough for 1e-6 parity; the library refines its linear solves at such tolerances (dojo_set_refinement)
 TIGHT = d.SolverOptions(rtol=1e-8, btol=1e-8)
 
 
 def _rollout_compare(cfg, batch, steps, dtype, opts, check_residual=True):
-    """Step GPU and oracle from the same states; returns per-env-step state errors of the environments both
-    solvers converged on.  When check_residual, every GPU solution is also plugged into the ORACLE's
+    """Step GPU and oracle from the same states; returns per-env-step (state error, GPU iterations, oracle iterations) of
+    the environments both solvers converged on.  When check_residual, every GPU solution is also plugged into the ORACLE's
     residual functions (src/solver/violations.jl) and must satisfy the solver tolerances there."""
     spec = d.baseline_config(cfg)
     Z, U = d.synthetic_inputs(spec, batch)
     gm = api.BatchedMechanism(spec, batch, dtype=dtype, opts=opts)
     o = Oracle(spec, opts=opts)
     z_o = Z.copy()
-    errs = []; conv = []
+    errs = []; conv = []; itg = []; ito = []; nstat = 0
     for k in range(steps):
         zn_g, st, it = gm.step(z_o.astype(gm.np_dtype), U)
         zn_o, st_o, it_o, _, _ = o.step_batch(z_o, U, nthreads=16)
         ok = (st == 0) & (st_o == 0)
+        nstat += int((st != st_o).sum())
         conv.append((st == 0).mean())
-        errs.append(np.abs(zn_g[ok].astype(np.float64) - zn_o[ok]).max(axis=1))
+        errs.append(np.abs(zn_g[ok].astype(np.float64) - zn_o[ok]).max(axis=1)); itg.append(it[ok]); ito.append(it_o[ok])
         if check_residual and dtype == "f64":
             vel, ji, cs = gm.get_solution()
             for b in np.nonzero(st == 0)[0][:16]:
@@ -35,29 +37,60 @@ def _rollout_compare(cfg, batch, steps, dtype, opts, check_residual=True):
                 assert rv < 2 * opts.rtol and bv < 2 * opts.btol, (k, b, rv, bv)
         z_o = zn_o                                    # both start every step from the oracle's state
     gm.close()
-    return np.concatenate(errs), float(np.mean(conv))
+    return np.concatenate(errs), float(np.mean(conv)), np.concatenate(itg), np.concatenate(ito), nstat
 
 
-# Parity criterion: a converged interior-point solution is only defined up to the
-# solver tolerance -- an almost-active contact may carry any impulse γ <= btol / s, which moves a
-# 0.06 kg Ant foot by ~btol/(s m).  With rtol = btol = 1e-8 the two solvers therefore agree to
-# <= 1e-6 on almost all environment-steps and to ~1e-5 on the few with such a contact; mechanisms
-# without (near-)active cones agree to ~1e-12.  (Ant, 766 converged env-steps: q50 1e-14, q90 6e-14, q99 4e-7, one at 1.1e-4.)
-@pytest.mark.parametrize("cfg,batch,steps,q90,qmax", [(1, 64, 5, 1e-9, 1e-9), (2, 128, 40, 1e-6, 1e-6), (3, 64, 12, 1e-6, 3e-4),
-                                                    (4, 32, 12, 1e-6, 1e-4), (5, 8, 6, 1e-6, 1e-4)])
-def test_forward_parity_fp64(cfg, batch, steps, q90, qmax):
-    errs, conv = _rollout_compare(cfg, batch, steps, "f64", TIGHT)
+# Parity criterion.  With the refined linear solves the device follows the oracle's Newton iterate path: equal
+# iteration counts, equal status, and the north-star bound 1e-6 holds as a MAXIMUM over every converged environment-step whose
+# solve is regular (<= REGULAR_ITERS Newton iterations, twice the typical count).  A solve that stalls beyond that wanders at
+# mu <= 1e-12, where cond(KKT) eps > 1e-4: no two fp64 implementations agree there better than ~1e-5 (measured on 28 672
+# Ant environment-steps at rtol = btol = 1e-8: one such step, 1.8e-6).
+REGULAR_ITERS = 20
+
+
+@pytest.mark.parametrize("cfg,batch,steps", [(1, 64, 5), (2, 128, 40), (3, 64, 12), (4, 32, 12), (5, 8, 6)])
+def test_forward_parity_fp64(cfg, batch, steps):
+    errs, conv, itg, ito, nstat = _rollout_compare(cfg, batch, steps, "f64", TIGHT)
     assert conv > 0.9, conv
-    assert np.quantile(errs, 0.9) <= q90, np.quantile(errs, 0.9)
-    assert errs.max() <= qmax, errs.max()
+    assert nstat == 0, nstat
+    reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
+    assert np.array_equal(itg[reg], ito[reg]), int((itg[reg] != ito[reg]).sum())
+    assert errs[reg].max() <= 1e-6, errs[reg].max()
+    assert errs.max() <= 1e-5, errs.max()
+
+
+def test_forward_parity_fp64_default_options():
+    """The reference's default tolerances (rtol 1e-6, btol 1e-4): no refinement needed, the plain kernels already follow
+    the oracle's iterate path (measured at batch 4096: 0 iteration mismatches, state max 5e-11)."""
+    errs, conv, itg, ito, nstat = _rollout_compare(3, 128, 10, "f64", d.SolverOptions(), check_residual=False)
+    assert nstat == 0 and np.array_equal(itg, ito)
+    assert errs.max() <= 1e-6, errs.max()
 
 
 @pytest.mark.parametrize("cfg,batch,steps", [(2, 128, 40), (3, 64, 12), (4, 32, 12)])
 def test_forward_parity_f32_io(cfg, batch, steps):
     """fp32 buffers at the ABI, reference-default solver options: state inf-norm <= 1e-3 (north_star)."""
-    errs, conv = _rollout_compare(cfg, batch, steps, "f32", d.SolverOptions(), check_residual=False)
+    errs, conv, itg, ito, nstat = _rollout_compare(cfg, batch, steps, "f32", d.SolverOptions(), check_residual=False)
     assert conv > 0.95
     assert errs.max() <= 1e-3, errs.max()
+
+
+def _grad_errors(spec, Z, U, opts, mode=0, dtype="f64"):
+    """one differentiable step on the device and on the oracle from the same states -> per-environment relative inf-norm
+    errors of jacobian_state / jacobian_control, state errors, iteration counts (converged environments only)"""
+    B = len(Z)
+    gm = api.BatchedMechanism(spec, B, dtype=dtype, opts=opts)
+    gm.set_gradient_mode(mode)
+    zn, st, it = gm.step(Z.astype(gm.np_dtype), U.astype(gm.np_dtype), with_gradient=True)
+    dz, du = gm.gradients()
+    gm.close()
+    o = Oracle(spec, opts=opts)
+    Zo, st_o, it_o, dz_o, du_o = o.step_batch(Z, U, with_grad=True, grad_mode=mode, nthreads=os.cpu_count() or 8)
+    ok = np.nonzero((st == 0) & (st_o == 0))[0]
+    ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+    eu = np.array([np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok]) if spec.nu else np.zeros(len(ok))
+    es = np.abs(zn[ok].astype(np.float64) - Zo[ok]).max(axis=1)
+    return ok, ez, eu, es, it[ok], it_o[ok], int((st != st_o).sum())
 
 
 def test_solution_export_matches_oracle():
@@ -75,33 +108,53 @@ def test_solution_export_matches_oracle():
     gm.close()
 
 
-# Gradient parity.  The device factorization works on the condensed KKT system (like the
-# reference's block LDU), whose body blocks hold entries ~γ/s; its fp64 round-off therefore grows like
-# 1/tol² with the solver tolerance, while the oracle (dense pivoted LU on the uncondensed system) does not.
-# Measured on MI355X (tools/gpu_probe.py grad, Ant in contact, relative inf-norm error of jacobian_state):
-#   tol 1e-5: max 2e-7 | tol 1e-6: q90 1e-7, max 2e-5 | tol 1e-7: q90 8e-5, max 7e-3.
-# At the reference's default tolerances (btol 1e-4) the Jacobians agree to ~1e-9.  The test uses tol 1e-6.
+# Gradient parity.  At tight tolerances the refining kernels (dojo_set_refinement, default policy) solve every
+# IFT column against the uncondensed system: the Jacobians agree with the oracle's to ~1e-9; what remains are environments
+# whose Jacobian itself has entries ~1e4..1e5 (a contact about to switch), where the 1e-9 state agreement is amplified.
+# Measured on 28 672 Ant environment-steps at 1e-8: 10 above 1e-6 (nine <= 4e-5, one 1.3e-3 in a 25-iteration solve).
 @pytest.mark.parametrize("cfg,batch,pre_steps,mode", [(1, 8, 3, 0), (2, 16, 120, 0), (3, 16, 0, 0), (3, 32, 12, 0), (3, 32, 12, 1), (4, 16, 10, 0), (5, 4, 3, 0)])
-def test_gradient_parity_fp64(cfg, batch, pre_steps, mode):
+@pytest.mark.parametrize("tol", [1e-6, 1e-8])
+def test_gradient_parity_fp64(cfg, batch, pre_steps, mode, tol):
     """IFT Jacobians (get_maximal_gradients!) vs the oracle; mode 0 = literal reference, 1 = consistent."""
     spec = d.baseline_config(cfg)
-    opts = d.SolverOptions(rtol=1e-6, btol=1e-6)
+    opts = d.SolverOptions(rtol=tol, btol=tol)
     Z, U = d.synthetic_inputs(spec, batch)
     o = Oracle(spec, opts=opts)
     for _ in range(pre_steps):
         Z, st, it, _, _ = o.step_batch(Z, U, nthreads=16)
-    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=opts)
-    gm.set_gradient_mode(mode)
-    zn, st, it = gm.step(Z, U, with_gradient=True)
-    dz, du = gm.gradients()
-    Zo, st_o, it_o, dz_o, du_o = o.step_batch(Z, U, with_grad=True, grad_mode=mode, nthreads=16)
-    ok = np.nonzero((st == 0) & (st_o == 0))[0]
-    assert len(ok) > 0.8 * batch
-    ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
-    eu = np.array([np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
-    assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(eu, 0.75) < 1e-6, (np.quantile(ez, 0.75), np.quantile(eu, 0.75))
-    assert ez.max() < 1e-3 and eu.max() < 1e-3, (ez.max(), eu.max())
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, opts, mode)
+    assert len(ok) > 0.8 * batch and nstat == 0
+    reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
+    assert np.array_equal(itg[reg], ito[reg])
+    assert es[reg].max() <= 1e-6, es[reg].max()
+    assert ez[reg].max() <= 1e-6 and eu[reg].max() <= 1e-6, (ez[reg].max(), eu[reg].max())
+
+
+def test_parity_at_the_baseline_batch_distinct_seeds():
+    """BASELINE configs[2] at its full batch: 4096 DISTINCT seeded Ant environments after 8 closed-loop steps, one
+    differentiable step on the device against the oracle on all host cores.
+    Reference-default options (what bench.py times; plain kernels): equal iterate paths, state max <= 1e-6, gradient
+    q99 <= 1e-6 and max <= 1e-4 (the plain IFT re-uses explicitly inverted supernode blocks; bench.py reports the figures).
+    rtol = btol = 1e-8 (refining kernels): state max <= 1e-6 and gradient max <= 1e-6 over the regular solves, at most
+    0.1 % of them above (environments whose Jacobian has entries >= 1e4, see above)."""
+    spec = d.baseline_config(3)
+    B = 4096
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    for _ in range(8):
+        Z, st, it = gm.step(Z, U)
     gm.close()
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions())
+    assert len(ok) > 0.99 * B and nstat == 0 and np.array_equal(itg, ito)
+    assert es.max() <= 1e-6, es.max()
+    eg = np.maximum(ez, eu)
+    assert np.quantile(eg, 0.99) <= 1e-6 and eg.max() <= 1e-4, (np.quantile(eg, 0.99), eg.max())
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, TIGHT)
+    reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
+    assert len(ok) > 0.99 * B and nstat == 0 and np.array_equal(itg[reg], ito[reg])
+    assert es[reg].max() <= 1e-6, es[reg].max()
+    eg = np.maximum(ez, eu)[reg]
+    assert (eg > 1e-6).mean() <= 1e-3 and eg.max() <= 1e-4, ((eg > 1e-6).sum(), eg.max())
 
 
 def test_gradient_parity_f32_io():
@@ -203,7 +256,7 @@ def test_pendulum_springs_dampers_limits_and_no_input():
     Zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, nthreads=8)
     ok = np.nonzero((st == 0) & (st_o == 0))[0]
     ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
-    assert np.quantile(ez, 0.75) < 1e-6 and ez.max() < 1e-3, (np.quantile(ez, 0.75), ez.max())
+    assert ez.max() <= 1e-6, (ez.max(),)
     gm.close()
 
 
@@ -302,7 +355,7 @@ def test_contact_gradient_parity(cfg, batch, pre_steps):
         errs.append(np.abs(dc[b] - dco).max() / max(1.0, np.abs(dco).max()))
     errs = np.array(errs)
     assert len(errs) > 0.7 * batch
-    assert np.quantile(errs, 0.75) < 1e-6 and errs.max() < 1e-3, (np.quantile(errs, 0.75), errs.max())
+    assert errs.max() <= 1e-6, (errs.max(),)
     gm.close()
 
 
@@ -477,8 +530,8 @@ def test_simulate_storage_matches_oracle(cfg, batch, H, pre):
         nchecked += good
     assert nchecked >= batch * H // 2
     errs0, errs = np.array(errs0), np.array(errs)
-    assert np.quantile(errs0, 0.9) < 1e-6 and errs0.max() < 1e-4, (np.quantile(errs0, 0.9), errs0.max())
-    assert np.quantile(errs, 0.8) < 1e-5 and errs.max() < 1e-3, (np.quantile(errs, 0.8), errs.max())
+    assert errs0.max() <= 1e-6, (errs0.max(),)
+    assert errs.max() <= 1e-6, (errs.max(),)
     # row k holds the state step k was solved at: x2/q2/v15/w15 of row k+1 = z after step k (simulate.jl:32 updates after saving)
     zt = Zt.reshape(H, batch, spec.Nb, 13)
     assert np.array_equal(S[1:, :, :, 0:3], zt[:-1, :, :, 0:3]) and np.array_equal(S[1:, :, :, 3:7], zt[:-1, :, :, 6:10])
@@ -631,7 +684,7 @@ def test_external_force_behaviour_and_parity():
         if s_o == 0 and st[0, b] == 0:
             errs.append(max(np.abs(S[0, b] - row).max() / max(1.0, np.abs(row).max()), np.abs(Zt[0, b, 3:6] - o.velocity_solution()[0:3]).max()))
     errs = np.array(errs)
-    assert len(errs) >= B // 2 and np.quantile(errs, 0.9) < 1e-6 and errs.max() < 1e-4, (len(errs), errs.max())
+    assert len(errs) >= B // 2 and errs.max() <= 1e-6, (errs.max(),)
     gm.close()
 
 
@@ -796,15 +849,13 @@ def test_translational_springs_dampers_gpu(name, kw, batch, steps):
         zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=mode, nthreads=8)
         ok = np.nonzero((st == 0) & (st_o == 0))[0]
         assert len(ok) > 0.9 * batch
-        assert (it[ok] == it_o[ok]).mean() > 0.8, (k, (it[ok] == it_o[ok]).mean())   # borderline convergence checks may fall either way in contact
+        reg_ = (it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)                   # (stalled solves: see test_forward_parity_fp64)
+        assert np.array_equal(it[ok][reg_], it_o[ok][reg_]), (k, int((it[ok] != it_o[ok]).sum()))   # the same Newton iterate path
         es = np.abs(zg[ok] - zo[ok]).max(axis=1)             # parity criterion of DESIGN.md §7: almost-active contacts are defined up to the tolerance
-        assert np.quantile(es, 0.9) < 1e-6 and es.max() < 1e-3, (k, np.quantile(es, 0.9), es.max())
+        assert es.max() <= 1e-6, (es.max(),)
         ez = np.array([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
         eu = np.array([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
-        # the criterion of test_gradient_parity_fp64 (active cones: the IFT system amplifies the solver tolerance)
-        assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(eu, 0.75) < 1e-6, (k, np.quantile(ez, 0.75), np.quantile(eu, 0.75))
-        # worst case: at a contact transition the Jacobian depends on where on the central path each solver stopped (both inside
-        # the tolerance, iteration counts differ by 2-3 there); bounded over all steps below
+        assert ez.max() <= 1e-6 and eu.max() <= 1e-6, (k, ez.max(), eu.max())   # the criterion of test_gradient_parity_fp64
         allz.append(ez); allu.append(eu)
         if k == steps - 1:
             z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
@@ -813,7 +864,6 @@ def test_translational_springs_dampers_gpu(name, kw, batch, steps):
         nok += len(ok)
         z = zo
     allz, allu = np.concatenate(allz), np.concatenate(allu)
-    assert np.quantile(allz, 0.99) < 1e-3 and np.quantile(allu, 0.99) < 1e-3, (np.quantile(allz, 0.99), allz.max())
     gm.close(); gm32.close()
 
 
@@ -880,11 +930,11 @@ def test_joint_prototypes_gpu(joint_type):
             z = zo
         es, ez, same = np.concatenate(es), np.concatenate(ez), np.concatenate(same)
         assert same.mean() > 0.75, (name, same.mean())          # contacts at the 1e-9 floor: the last iteration may fall either way
-        assert np.quantile(es, 0.75) < 1e-9 and np.quantile(es, 0.9) < 1e-7 and es.max() < 1e-5, (name, np.quantile(es, 0.9), es.max())
-        assert np.quantile(ez, 0.9) < 1e-7 and ez.max() < 1e-3, (name, np.quantile(ez, 0.9), ez.max())
+        assert es.max() <= 1e-6, (es.max(),)
+        assert ez.max() <= 1e-6, (ez.max(),)
         if eu:
             eu = np.concatenate(eu)
-            assert np.quantile(eu, 0.9) < 1e-7 and eu.max() < 1e-3, (name, np.quantile(eu, 0.9), eu.max())
+            assert eu.max() <= 1e-6, (eu.max(),)
         gm.close()
 
 
@@ -916,9 +966,9 @@ def test_translational_joint_limits_gpu(name):
         z = zo
     es, ez, eu = np.concatenate(es), np.concatenate(ez), np.concatenate(eu)
     assert hit > 0
-    assert np.quantile(es, 0.9) < 1e-6 and es.max() < 1e-3, (np.quantile(es, 0.9), es.max())
-    assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(ez, 0.99) < 1e-3, (np.quantile(ez, 0.75), np.quantile(ez, 0.99))
-    assert np.quantile(eu, 0.75) < 1e-6 and np.quantile(eu, 0.99) < 1e-3, (np.quantile(eu, 0.75), np.quantile(eu, 0.99))
+    assert es.max() <= 1e-6, (es.max(),)
+    assert ez.max() <= 1e-6, (ez.max(),)
+    assert eu.max() <= 1e-6, (eu.max(),)
     gm.close()
 
 
@@ -949,13 +999,13 @@ def test_reference_mechanisms_rollout_gpu(name, kw):
         if last:
             dzg, dug = gm.gradients()
             ez = np.array([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
-            assert np.quantile(ez, 0.75) < 1e-6 and np.quantile(ez, 0.95) < 1e-3, (np.quantile(ez, 0.75), ez.max())
+            assert ez.max() <= 1e-6, (ez.max(),)
             gm32 = api.BatchedMechanism(spec, B, dtype="f32", opts=TIGHT)
             z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
             ok32 = np.nonzero((st32 == 0) & (st_o == 0))[0]
-            assert len(ok32) >= 0.7 * B and np.quantile(np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max(axis=1), 0.9) < 1e-3
+            assert len(ok32) >= len(ok) - 1 and np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max() < 1e-3
             gm32.close()
         z = zo
     es = np.concatenate(es)
-    assert np.quantile(es, 0.9) < 1e-6 and es.max() < 1e-3, (np.quantile(es, 0.9), es.max())
+    assert es.max() <= 1e-6, (es.max(),)
     gm.close()
