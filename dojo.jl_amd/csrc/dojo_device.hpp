@@ -2880,6 +2880,7 @@ struct KernelArgs {
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
     T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
     int* flag = nullptr;           // [B] 1: the plain step kernel deferred this environment to the refining kernels (DJ_REFINE; or null)
+    T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
@@ -3120,7 +3121,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         prog.next_state(zn);
         TIO* o = A.z_next + (size_t)env * 13 * G.Nb + 13 * k;
         for (int i = 0; i < 13; ++i) o[i] = TIO(zn[i]);
-        if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; }
+        if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; if (A.mu_out) A.mu_out[env] = prog.mu; }
         if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[i]); vo[3 + i] = TIO(prog.L.w[i]); } }
         if (A.res) { TIO* ro = A.res + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 6; ++i) ro[i] = TIO(prog.rb[i]); }
 #ifdef DJ_PROF

@@ -18,9 +18,21 @@
 #include <algorithm>
 #include <mutex>
 
+struct DojoSim;
 namespace {
 
-thread_local std::string g_err;
+// Error text: one process-wide string behind a mutex (dojo_last_error: what the last failing call on ANY thread said -- a
+// Julia task may migrate between the failing @ccall and the query, so it must not be thread-local) and a copy on the handle
+// the failing entry point was called with (dojo_handle_error: per handle).
+void handle_set_error(::DojoSim* s, const std::string& m);
+thread_local ::DojoSim* t_handle = nullptr;            // handle of the entry point running on this thread
+struct ErrSink {
+    std::mutex m; std::string last; std::string ret;
+    ErrSink& operator=(const std::string& v) { { std::lock_guard<std::mutex> g(m); last = v; } if (t_handle) handle_set_error(t_handle, v); return *this; }
+    ErrSink& operator=(const char* v) { return *this = std::string(v); }
+    const char* c_str() { std::lock_guard<std::mutex> g(m); ret = last; return ret.c_str(); }
+} g_err;
+struct Enter { ::DojoSim* prev; explicit Enter(::DojoSim* s) : prev(t_handle) { t_handle = s; } ~Enter() { t_handle = prev; } };
 
 // kernel launchers, one per object file of dojo_kernels.hip: dojo_launch_<abi type>_<max contacts per body>_<quad>
 extern "C" {
@@ -58,6 +70,9 @@ struct DojoSim {
     void* d_tsd = nullptr;       // translational springs / dampers per supernode (mechanisms that have them)
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
+    void *d_cz = nullptr;                   // maximal-state scratch of dojo_minimal_to_maximal / dojo_maximal_to_minimal (d_z stays the state of the last step)
+    void *d_jf = nullptr;                   // dojo_step_impulses: body impulses folded into the external-force slot
+    double *d_mu = nullptr;                 // [B] mechanism.μ at the end of the last step (dojo_get_mu)
     void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
     // internal device buffers used by the host-pointer entry points
     const void* fext = nullptr;                     // device [B,6Nb] external forces applied by every step, or null (dojo_set_external_force)
@@ -72,6 +87,7 @@ struct DojoSim {
     double refine_w = -1.0;             // refine once max γ/s of an environment exceeds this (dojo_set_refinement); < 0: chosen from the tolerances
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false, have_u = false;
+    std::string err; std::mutex err_m;  // text of the last failure of a call on this handle (dojo_handle_error)
     hipStream_t stream = nullptr;
     // kernel timing: a ring of event triples (launch begin / between the step and the IFT kernel / end), so that
     // timed launches never make the host wait; totals are accumulated when a slot is reused or queried
@@ -81,7 +97,7 @@ struct DojoSim {
 };
 
 namespace {
-
+void handle_set_error(::DojoSim* s, const std::string& m) { std::lock_guard<std::mutex> g(s->err_m); s->err = m; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Minimal <-> maximal coordinates: HBM-bound helper kernels around the step; every DojoEnvironments
@@ -280,6 +296,11 @@ __global__ void chain_out_kernel(const NodeP<double>* nodes, int Nb, int nu, int
         if (j < nm) jx[((size_t)env * nm + i) * nm + j] = (TIO)acc; else if (ju) ju[((size_t)env * nm + i) * nu + (j - nm)] = (TIO)acc;
     }
 }
+// dojo_step_impulses: external force + body impulses / dt
+template <class TIO> __global__ void fold_impulses_kernel(long long n, const TIO* fext, const TIO* jf, double inv_dt, TIO* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (TIO)((fext ? (double)fext[i] : 0.0) + (double)jf[i] * inv_dt);
+}
 } // namespace ckern
 
 template <class T>
@@ -382,6 +403,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
+    A.mu_out = s->d_mu ? (T*)s->d_mu + env0 : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
     // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
     // else one lane per supernode
@@ -467,6 +489,8 @@ int ensure(void** p, size_t bytes) {
 extern "C" {
 
 const char* dojo_last_error(void) { return g_err.c_str(); }
+// text of the last failure of a call on THIS handle ("" if none); the pointer stays valid until the next failing call on it
+const char* dojo_handle_error(DojoHandle s) { if (!s) return ""; std::lock_guard<std::mutex> g(s->err_m); return s->err.c_str(); }
 
 int dojo_device_count(void) {
     int n = 0;
@@ -499,7 +523,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
@@ -509,6 +533,7 @@ void dojo_destroy(DojoHandle s) {
 }
 
 int dojo_get_dims(DojoHandle s, DojoDims* d) {
+    Enter enter_(s);
     if (!s || !d) { g_err = "dojo_get_dims: bad argument"; return DOJO_ERR_INVALID; }
     d->n_bodies = s->M.Nb; d->n_joints = (int)s->M.nodes.size(); d->n_contacts = s->M.Nc;
     d->nz = 13 * s->M.Nb; d->nx = 12 * s->M.Nb; d->nu = s->M.nu; d->n_joint_impulses = s->M.n_joint_imp;
@@ -517,6 +542,7 @@ int dojo_get_dims(DojoHandle s, DojoDims* d) {
 }
 
 int dojo_set_options(DojoHandle s, const DojoSolverOptions* o) {
+    Enter enter_(s);
     if (!s || !o || o->max_iter < 1 || o->max_ls < 1) { g_err = "dojo_set_options: bad argument"; return DOJO_ERR_INVALID; }
     s->opts = *o; return DOJO_OK;
 }
@@ -524,11 +550,13 @@ int dojo_set_options(DojoHandle s, const DojoSolverOptions* o) {
 // set_external_force!(body; force, torque, vertex) (src/bodies/set.jl:110-115) for every body of every environment: state.Fext
 // (world frame) and state.τext (body frame) as they enter the body residual (integrators/constraint.jl:15-18)
 int dojo_set_external_force_dev(DojoHandle s, const void* fext) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_set_external_force_dev: bad argument"; return DOJO_ERR_INVALID; }
     s->fext = fext;
     return DOJO_OK;
 }
 int dojo_set_external_force(DojoHandle s, const void* fext) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_set_external_force: bad argument"; return DOJO_ERR_INVALID; }
     if (!fext) { s->fext = nullptr; return DOJO_OK; }
     HIPCHK(hipSetDevice(s->device));
@@ -545,16 +573,19 @@ int dojo_set_external_force(DojoHandle s, const void* fext) {
 // variables reach max γ/s > stiffness get their Newton and IFT solves refined against the uncondensed KKT system.
 // INFINITY switches the refinement off, 0 refines every solve.
 int dojo_set_refinement(DojoHandle s, double stiffness) {
+    Enter enter_(s);
     if (!s || stiffness != stiffness) { g_err = "dojo_set_refinement: bad argument"; return DOJO_ERR_INVALID; }   // negative: back to the tolerance-based default
     s->refine_w = stiffness; return DOJO_OK;
 }
 
 int dojo_set_gradient_mode(DojoHandle s, int32_t mode) {
+    Enter enter_(s);
     if (!s || (mode != DOJO_GRAD_REFERENCE && mode != DOJO_GRAD_CONSISTENT)) { g_err = "dojo_set_gradient_mode: bad argument"; return DOJO_ERR_INVALID; }
     s->grad_mode = mode; return DOJO_OK;
 }
 
 int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int32_t* status, int32_t* iters, void* dz, void* du, void* stream) {
+    Enter enter_(s);
     if (!s || !z || !z_next) { g_err = "dojo_step_dev: bad argument"; return DOJO_ERR_INVALID; }
     if ((dz == nullptr) != (du == nullptr) && s->M.nu > 0) { g_err = "dojo_step_dev: dz and du must both be given or both be NULL"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
@@ -563,6 +594,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
     if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    if ((rc = ensure((void**)&s->d_mu, B * sizeof(double)))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t NG = group_count(s, true);
     if (NG <= 1) {
@@ -594,22 +626,26 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
 // everything in flight (every host-pointer entry point does that implicitly).  dojo_set_groups: number of environment
 // groups of dojo_step_dev (0 / negative: chosen from the batch size; 1: a single launch on the caller's stream).
 int dojo_set_async(DojoHandle s, int32_t on) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_set_async: bad argument"; return DOJO_ERR_INVALID; }
     s->async = on != 0; return DOJO_OK;
 }
 int dojo_set_groups(DojoHandle s, int32_t n) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_set_groups: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
     s->pending = false; s->groups = n > 0 ? n : -1; return DOJO_OK;
 }
 int dojo_join(DojoHandle s, void* stream) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_join: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     return join_groups(s, (hipStream_t)stream);
 }
 
 int dojo_step(DojoHandle s, const void* z, const void* u, void* z_next, int32_t* status, int32_t* iters, int32_t with_gradient) {
+    Enter enter_(s);
     if (!s || !z || !z_next) { g_err = "dojo_step: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nx = 12 * s->M.Nb, nu = s->M.nu;
@@ -636,7 +672,45 @@ int dojo_step(DojoHandle s, const void* z, const void* u, void* z_next, int32_t*
     return DOJO_OK;
 }
 
+// The mehrotra!(mechanism) seam (src/solver/mehrotra.jl:9): at that point set_input!/input_impulse! (src/mechanism/set.jl:40-53,
+// src/joints/*/input.jl) have already folded the controls into every body's state.JF2 / state.Jτ2 and cleared the joints'
+// inputs, so the drop-in hands over body impulses, not u.  jf [B, 6Nb] = [JF2 (world frame); Jτ2 (body frame)] per body, as
+// they enter the body residual (src/integrators/constraint.jl:20-21: d -= [JF2; Jτ2]).  They share the external-force slot:
+// -Δt·[Fext; τext] and -[JF2; Jτ2] are the same term (constraint.jl:15-18), so the kernels read fext + jf/Δt.
+int dojo_step_impulses(DojoHandle s, const void* z, const void* jf, void* z_next, int32_t* status, int32_t* iters) {
+    Enter enter_(s);
+    if (!s || !z || !jf || !z_next) { g_err = "dojo_step_impulses: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nf = 6 * s->M.Nb;
+    int rc;
+    if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    if ((rc = ensure(&s->d_jf, 2 * B * nf * w))) return rc;               // [raw impulses | folded forces]
+    if ((rc = ensure((void**)&s->d_status, B * sizeof(int)))) return rc;
+    if ((rc = ensure((void**)&s->d_iters, B * sizeof(int)))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(s->d_z, z, B * nz * w, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_jf, jf, B * nf * w, hipMemcpyHostToDevice));
+    void* folded = (char*)s->d_jf + B * nf * w;
+    const long long n = (long long)(B * nf); const int T_ = 256;
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::fold_impulses_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, nullptr, n, (const float*)s->fext, (const float*)s->d_jf, 1.0 / s->M.dt, (float*)folded);
+    else hipLaunchKernelGGL((ckern::fold_impulses_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, nullptr, n, (const double*)s->fext, (const double*)s->d_jf, 1.0 / s->M.dt, (double*)folded);
+    HIPCHK(hipGetLastError());
+    const void* user_fext = s->fext;
+    s->fext = folded;
+    rc = dojo_step_dev(s, s->d_z, nullptr, s->d_zn, s->d_status, s->d_iters, nullptr, nullptr, nullptr);
+    s->fext = user_fext;
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(z_next, s->d_zn, B * nz * w, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, s->d_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    s->have_grad = false; s->have_u = false;
+    return DOJO_OK;
+}
+
 int dojo_get_solution(DojoHandle s, void* vel, void* joint_imp, void* contact_sg) {
+    Enter enter_(s);
     if (!s || !s->have_solution) { g_err = "dojo_get_solution: no step has been taken"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
@@ -647,7 +721,19 @@ int dojo_get_solution(DojoHandle s, void* vel, void* joint_imp, void* contact_sg
     return DOJO_OK;
 }
 
+// mechanism.μ (the central-path parameter, src/solver/mehrotra.jl:45) of every environment when the last step's solve
+// returned: what a mehrotra! drop-in writes back before it calls set_entries! to leave mechanism.system as the reference does
+int dojo_get_mu(DojoHandle s, double* mu) {
+    Enter enter_(s);
+    if (!s || !mu || !s->have_solution || !s->d_mu) { g_err = "dojo_get_mu: no step has been taken"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(mu, s->d_mu, (size_t)s->B * sizeof(double), hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
 int dojo_gradients(DojoHandle s, void* dz, void* du) {
+    Enter enter_(s);
     if (!s || !s->have_grad) { g_err = "dojo_gradients: the last dojo_step was not run with with_gradient=1"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nx = 12 * s->M.Nb, nu = s->M.nu;
@@ -722,10 +808,12 @@ static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, 
 }
 
 int dojo_rollout_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* stream) {
+    Enter enter_(s);
     return rollout_core(s, z0, U, H, Z, status, nullptr, stream);
 }
 
 int dojo_simulate_dev(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status, void* stream) {
+    Enter enter_(s);
     if (!storage) { g_err = "dojo_simulate_dev: storage must not be NULL (use dojo_rollout_dev for record = false)"; return DOJO_ERR_INVALID; }
     return rollout_core(s, z0, U, H, Z, status, storage, stream);
 }
@@ -733,10 +821,12 @@ int dojo_simulate_dev(DojoHandle s, const void* z0, const void* U, int32_t H, vo
 static int rollout_host(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status);
 
 int dojo_rollout(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status) {
+    Enter enter_(s);
     return rollout_host(s, z0, U, H, Z, nullptr, status);
 }
 
 int dojo_simulate(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, void* storage, int32_t* status) {
+    Enter enter_(s);
     if (!storage) { g_err = "dojo_simulate: storage must not be NULL (use dojo_rollout for record = false)"; return DOJO_ERR_INVALID; }
     return rollout_host(s, z0, U, H, Z, storage, status);
 }
@@ -764,6 +854,7 @@ static int rollout_host(DojoHandle s, const void* z0, const void* U, int32_t H, 
 }
 
 int dojo_get_state(DojoHandle s, void* z) {
+    Enter enter_(s);
     if (!s || !z || !s->d_zn) { g_err = "dojo_get_state: no state"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
@@ -773,6 +864,7 @@ int dojo_get_state(DojoHandle s, void* z) {
 
 // ---- contact-data gradients: get_contact_gradients, src/gradients/contact.jl:1-55 ----
 int dojo_contact_gradients_dev(DojoHandle s, const void* z, const void* u, void* dc, void* stream) {
+    Enter enter_(s);
     if (!s || !z || !dc) { g_err = "dojo_contact_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
     if (!s->d_sol) { g_err = "dojo_contact_gradients_dev: no differentiable step (dz/du requested) has been run on this handle"; return DOJO_ERR_INVALID; }
     if (s->M.Nc == 0) return DOJO_OK;
@@ -781,6 +873,7 @@ int dojo_contact_gradients_dev(DojoHandle s, const void* z, const void* u, void*
     return launch_any(s, z, u, s->d_zn ? s->d_zn : (void*)z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, true, 0, -1, dc);
 }
 int dojo_contact_gradients(DojoHandle s, void* dc) {
+    Enter enter_(s);
     if (!s || !dc) { g_err = "dojo_contact_gradients: bad argument"; return DOJO_ERR_INVALID; }
     if (!s->have_grad || !s->d_z) { g_err = "dojo_contact_gradients: call dojo_step(..., with_gradient = 1) first"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
@@ -801,6 +894,7 @@ int dojo_contact_gradients(DojoHandle s, void* dc) {
 
 // ---- minimal <-> maximal coordinates ----
 int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stream) {
+    Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const int B = s->B, T_ = 64;
@@ -810,6 +904,7 @@ int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stre
     return DOJO_OK;
 }
 int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stream) {
+    Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
@@ -822,6 +917,7 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
 // and, with contact_forces != 0, the clamped normal impulses of the last step behind it (ant_ars.jl:72-80).
 // obs [B, 2nu (+ Nc)]
 int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_forces, void* stream) {
+    Enter enter_(s);
     if (!s || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
     if (!z) z = s->d_zn;                   // the state the last host-buffer / minimal-coordinate step left on the handle
     if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
@@ -841,12 +937,14 @@ int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_for
     return DOJO_OK;
 }
 int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
+    Enter enter_(s);
     if (!s || !obs || !s->d_zn || !s->have_solution) { g_err = "dojo_observe: no step has been taken on this handle"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const size_t ld = 2 * s->M.nu + (contact_forces ? s->M.Nc : 0), bytes = (size_t)s->B * ld * s->w;
     DevBuf d;
     HIPCHK(d.alloc(bytes));
-    int rc = dojo_observe_dev(s, s->d_zn, d.p, contact_forces, s->stream);
+    HIPCHK(hipDeviceSynchronize());                          // (not the cached stream of the last step: the caller may have destroyed it)
+    int rc = dojo_observe_dev(s, s->d_zn, d.p, contact_forces, nullptr);
     if (rc != DOJO_OK) return rc;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(obs, d.p, bytes, hipMemcpyDeviceToHost));
@@ -854,6 +952,7 @@ int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
 }
 // step_minimal_coordinates!  src/simulation/step.jl:42-60: x -> z -> step! -> z' -> x'
 int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {
+    Enter enter_(s);
     if (!s || !x || !x_next) { g_err = "dojo_step_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb;
@@ -862,6 +961,7 @@ int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_ne
     if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
     if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
     if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, nullptr, nullptr, stream))) return rc;
+    s->have_grad = false;
     return dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream);
 }
 // get_minimal_gradients!(mechanism, y, u; opts)  src/gradients/state.jl:183-217: steps in minimal coordinates and chains
@@ -872,6 +972,7 @@ int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_ne
 // jx [B][2nu][2nu], ju [B][2nu][nu] row-major per environment.
 int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters,
                                void* jx, void* ju, void* stream) {
+    Enter enter_(s);
     if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     const size_t B = s->B, w = s->w, Nb = s->M.Nb, nz = 13 * Nb, nx = 12 * Nb, nu = s->M.nu, nm = 2 * nu;
@@ -886,6 +987,7 @@ int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void*
     if ((rc = ensure(&s->d_jb, B * Nb * 12 * 24 * sizeof(double)))) return rc;
     if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
     if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, s->d_dz, s->d_du, stream))) return rc;
+    s->have_grad = false;          // the hand-off belongs to (d_z, the CALLER's u): the host variant below re-arms the flag with its own copy of u
     if ((rc = dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream))) return rc;
     const bool literal = s->grad_mode == DOJO_GRAD_REFERENCE;
     const void* xj = literal ? (const void*)x_next : x;                // where the min -> max Jacobian is evaluated ...
@@ -907,6 +1009,7 @@ int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void*
     return DOJO_OK;
 }
 int dojo_minimal_gradients(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* jx, void* ju) {
+    Enter enter_(s);
     if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nu = s->M.nu, nm = 2 * nu;
@@ -922,6 +1025,7 @@ int dojo_minimal_gradients(DojoHandle s, const void* x, const void* u, void* x_n
     HIPCHK(hipMemcpy(s->d_x, x, B * nm * w, hipMemcpyHostToDevice));
     if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
     rc = dojo_minimal_gradients_dev(s, s->d_x, (u && nu) ? s->d_u : nullptr, s->d_xn, s->d_status, s->d_iters, d_jx, d_ju, nullptr);
+    if (rc == DOJO_OK) { s->have_grad = true; s->have_u = (u && nu); }   // d_z, d_u, d_dz, d_du and the hand-off all belong to this step
     if (rc == DOJO_OK) {
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(x_next, s->d_xn, B * nm * w, hipMemcpyDeviceToHost));
@@ -938,8 +1042,8 @@ static int coords_host(DojoHandle s, const void* in, void* out, size_t n_in, siz
     size_t B = s->B, w = s->w;
     int rc;
     if ((rc = ensure(&s->d_x, B * (2 * s->M.nu + 1) * w))) return rc;
-    if ((rc = ensure(&s->d_z, B * 13 * s->M.Nb * w))) return rc;
-    void* din = to_max ? s->d_x : s->d_z; void* dout = to_max ? s->d_z : s->d_x;
+    if ((rc = ensure(&s->d_cz, B * 13 * s->M.Nb * w))) return rc;       // not d_z: that is the state dojo_contact_gradients re-linearizes at
+    void* din = to_max ? s->d_x : s->d_cz; void* dout = to_max ? s->d_cz : s->d_x;
     HIPCHK(hipMemcpy(din, in, B * n_in * w, hipMemcpyHostToDevice));
     rc = to_max ? dojo_minimal_to_maximal_dev(s, din, dout, nullptr) : dojo_maximal_to_minimal_dev(s, din, dout, nullptr);
     if (rc != DOJO_OK) return rc;
@@ -948,14 +1052,17 @@ static int coords_host(DojoHandle s, const void* in, void* out, size_t n_in, siz
     return DOJO_OK;
 }
 int dojo_minimal_to_maximal(DojoHandle s, const void* x, void* z) {
+    Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal: bad argument"; return DOJO_ERR_INVALID; }
     return coords_host(s, x, z, 2 * s->M.nu, 13 * s->M.Nb, true);
 }
 int dojo_maximal_to_minimal(DojoHandle s, const void* z, void* x) {
+    Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal: bad argument"; return DOJO_ERR_INVALID; }
     return coords_host(s, z, x, 13 * s->M.Nb, 2 * s->M.nu, false);
 }
 int dojo_step_minimal(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters) {
+    Enter enter_(s);
     if (!s || !x || !x_next) { g_err = "dojo_step_minimal: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nm = 2 * s->M.nu, nu = s->M.nu;
@@ -969,6 +1076,7 @@ int dojo_step_minimal(DojoHandle s, const void* x, const void* u, void* x_next, 
     if (u && nu) HIPCHK(hipMemcpy(s->d_u, u, B * nu * w, hipMemcpyHostToDevice));
     rc = dojo_step_minimal_dev(s, s->d_x, (u && nu) ? s->d_u : nullptr, s->d_xn, s->d_status, s->d_iters, nullptr);
     if (rc != DOJO_OK) return rc;
+    s->have_grad = false;                                   // d_z / d_u now hold this (forward-only) step's inputs
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(x_next, s->d_xn, B * nm * w, hipMemcpyDeviceToHost));
     if (status) HIPCHK(hipMemcpy(status, s->d_status, B * sizeof(int), hipMemcpyDeviceToHost));
@@ -977,6 +1085,7 @@ int dojo_step_minimal(DojoHandle s, const void* x, const void* u, void* x_next, 
 }
 
 int dojo_last_kernel_ms(DojoHandle s, double* ms) {
+    Enter enter_(s);
     double a = 0, b = 0;
     int rc = dojo_last_kernel_times(s, &a, &b);
     if (rc == DOJO_OK && ms) *ms = a + b;
@@ -984,6 +1093,7 @@ int dojo_last_kernel_ms(DojoHandle s, double* ms) {
 }
 
 int dojo_last_kernel_times(DojoHandle s, double* step_ms, double* ift_ms) {
+    Enter enter_(s);
     if (!s || !step_ms || !ift_ms || s->last_slot < 0) { g_err = "dojo_last_kernel_times: nothing was launched"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     DojoSim::Ev3& e = s->ring[s->last_slot];
@@ -996,6 +1106,7 @@ int dojo_last_kernel_times(DojoHandle s, double* step_ms, double* ift_ms) {
 }
 
 int dojo_kernel_time_totals(DojoHandle s, double* step_ms, double* ift_ms, int64_t* launches, int32_t reset) {
+    Enter enter_(s);
     if (!s) { g_err = "dojo_kernel_time_totals: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     for (auto& e : s->ring) { int rc = drain_slot(s, e); if (rc != DOJO_OK) return rc; }

@@ -34,7 +34,8 @@ def lib():
             raise DojoError("libdojo_hip.so not built (run __graft_entry__.build()); there is no CPU fallback")
         L = C.CDLL(_LIB_PATH)
         L.dojo_last_error.restype = C.c_char_p
-        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step",
+        L.dojo_handle_error.restype = C.c_char_p; L.dojo_handle_error.argtypes = [C.c_void_p]
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step", "dojo_step_impulses", "dojo_get_mu",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -46,7 +47,7 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
+EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
                     "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -137,6 +138,24 @@ class BatchedMechanism:
         zn = np.empty_like(z); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
         _chk(lib().dojo_step(self.h, _p(z), _p(u), _p(zn), _p(st), _p(it), int(with_gradient)))
         return zn, st, it
+
+    def step_impulses(self, z, jf):
+        """The mehrotra!(mechanism) seam: one step with the controls already folded into the bodies' impulses,
+        jf [B, Nb, 6] = [state.JF2 (world); state.Jtau2 (body frame)] (src/integrators/constraint.jl:20-21)."""
+        B, s = self.batch, self.spec
+        z = self._arr(z, (B, s.nz))
+        jf = self._arr(np.asarray(jf).reshape(B, 6 * s.Nb), (B, 6 * s.Nb))
+        zn = np.empty_like(z); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        _chk(lib().dojo_step_impulses(self.h, _p(z), _p(jf), _p(zn), _p(st), _p(it)))
+        return zn, st, it
+
+    def get_mu(self):
+        mu = np.empty(self.batch, np.float64)
+        _chk(lib().dojo_get_mu(self.h, _p(mu)))
+        return mu
+
+    def last_error(self):
+        return lib().dojo_handle_error(self.h).decode()
 
     def get_solution(self):
         B, s = self.batch, self.spec

@@ -2,20 +2,29 @@
 #
 # NOT EXECUTED IN THE BUILD CONTAINER (no Julia toolchain there); kept deliberately thin: it only
 # (a) walks a live Dojo `Mechanism` and fills the C-POD topology, (b) owns a handle, (c) forwards
-# step! / simulate! / get_maximal_gradients! for a batch, and (d) offers an opt-in override of
-# Dojo.mehrotra! that round-trips one Mechanism through the library (B = 1) and writes the
-# solution back so that DojoEnvironments works unmodified.  The same calls are exercised from
+# step! / simulate! / get_maximal_gradients! for a batch, and (d) installs, on enable!(mechanism), a
+# Dojo.mehrotra! method that round-trips that Mechanism through the library (B = 1, body impulses
+# JF2/Jτ2 in, solution + μ out) and writes everything mehrotra! mutates back, so that DojoEnvironments
+# works unmodified.  The exact call sequence of (d) is replayed from C by tests/c_driver/shim_driver.c.  The same calls are exercised from
 # Python by dojo.jl_amd/host/dojo_amd/api.py, which the parity tests drive.
 module DojoHIP
 
 using Dojo
 using StaticArrays
+using Libdl
 
-# one hardware queue per environment group of dojo_rollout (INTEGRATION.md "Streams and hardware queues");
-# has to be in the environment before the HIP runtime starts
-get!(ENV, "GPU_MAX_HW_QUEUES", "24")
-
-const LIB = get(ENV, "DOJO_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdojo_hip.so"))
+# The library is opened when the module is LOADED (not when it is precompiled): __init__ puts GPU_MAX_HW_QUEUES into the
+# environment before the HIP runtime starts (one hardware queue per environment group of dojo_step_dev / dojo_rollout,
+# INTEGRATION.md "Streams and hardware queues"), resolves DOJO_HIP_LIB and dlopens it; every @ccall below goes through a
+# dlsym'ed function pointer.
+const LIBH = Ref{Ptr{Cvoid}}(C_NULL)
+const SYMS = Dict{Symbol,Ptr{Cvoid}}()
+function __init__()
+    get!(ENV, "GPU_MAX_HW_QUEUES", "24")
+    LIBH[] = Libdl.dlopen(get(ENV, "DOJO_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdojo_hip.so")))
+    empty!(SYMS)
+end
+fn(name::Symbol) = get!(() -> Libdl.dlsym(LIBH[], name), SYMS, name)
 
 # ---- C PODs (layout identical to include/dojo_hip.h) -------------------------------------------
 struct CBody;      mass::Cdouble; inertia::NTuple{9,Cdouble}; end
@@ -81,7 +90,9 @@ mutable struct BatchedMechanism{T}
     nz::Int; nx::Int; nu::Int
 end
 
-check(rc) = rc == 0 || error("libdojo_hip: " * unsafe_string(@ccall LIB.dojo_last_error()::Cstring))
+check(rc) = rc == 0 || error("libdojo_hip: " * unsafe_string(@ccall $(fn(:dojo_last_error))()::Cstring))
+"the text of the last failure on this handle (per handle; dojo_last_error is process-wide)"
+last_error(bm) = unsafe_string(@ccall $(fn(:dojo_handle_error))(bm.handle::Ptr{Cvoid})::Cstring)
 
 function BatchedMechanism(m::Dojo.Mechanism, batch::Int; T=Float32, device::Int=0)
     bodies, joints, contacts = export_topology(m)
@@ -89,16 +100,16 @@ function BatchedMechanism(m::Dojo.Mechanism, batch::Int; T=Float32, device::Int=
     GC.@preserve bodies joints contacts begin
         topo = CTopology(length(bodies), length(joints), length(contacts), 0, m.timestep, m.input_scaling,
                          pad(m.gravity, 3), pointer(bodies), pointer(joints), pointer(contacts))
-        check(@ccall LIB.dojo_create(Ref(topo)::Ref{CTopology}, batch::Int32, (T == Float32 ? 1 : 0)::Int32, device::Int32, h::Ref{Ptr{Cvoid}})::Cint)
+        check(@ccall $(fn(:dojo_create))(Ref(topo)::Ref{CTopology}, batch::Int32, (T == Float32 ? 1 : 0)::Int32, device::Int32, h::Ref{Ptr{Cvoid}})::Cint)
     end
     bm = BatchedMechanism{T}(h[], m, batch, 13length(m.bodies), 12length(m.bodies), Dojo.input_dimension(m))
-    finalizer(b -> (@ccall LIB.dojo_destroy(b.handle::Ptr{Cvoid})::Cvoid), bm)
+    finalizer(b -> (@ccall $(fn(:dojo_destroy))(b.handle::Ptr{Cvoid})::Cvoid), bm)
     return bm
 end
 
 function set_options!(bm::BatchedMechanism, o::Dojo.SolverOptions)
     c = CSolverOptions(o.rtol, o.btol, o.undercut, o.no_progress_undercut, o.max_iter, o.max_ls, o.no_progress_max, 0)
-    check(@ccall LIB.dojo_set_options(bm.handle::Ptr{Cvoid}, Ref(c)::Ref{CSolverOptions})::Cint)
+    check(@ccall $(fn(:dojo_set_options))(bm.handle::Ptr{Cvoid}, Ref(c)::Ref{CSolverOptions})::Cint)
 end
 
 # z: nz x B and u: nu x B column-major Julia matrices == the row-major [B, nz] / [B, nu] of the ABI
@@ -106,7 +117,7 @@ end
 function Dojo.step!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}(), with_gradient::Bool=false) where T
     set_options!(bm, opts)
     zn = similar(z); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
-    check(@ccall LIB.dojo_step(bm.handle::Ptr{Cvoid}, z::Ptr{T}, u::Ptr{T}, zn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, with_gradient::Int32)::Cint)
+    check(@ccall $(fn(:dojo_step))(bm.handle::Ptr{Cvoid}, z::Ptr{T}, u::Ptr{T}, zn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, with_gradient::Int32)::Cint)
     return zn, status
 end
 
@@ -114,7 +125,7 @@ end
 function Dojo.get_maximal_gradients!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
     Dojo.step!(bm, z, u; opts, with_gradient=true)
     dz = Array{T}(undef, bm.nx, bm.nx, bm.batch); du = Array{T}(undef, bm.nu, bm.nx, bm.batch)      # ABI is row-major [B,nx,nx]/[B,nx,nu]
-    check(@ccall LIB.dojo_gradients(bm.handle::Ptr{Cvoid}, dz::Ptr{T}, du::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_gradients))(bm.handle::Ptr{Cvoid}, dz::Ptr{T}, du::Ptr{T})::Cint)
     return permutedims(dz, (2, 1, 3)), permutedims(du, (2, 1, 3))
 end
 
@@ -123,16 +134,16 @@ function Dojo.simulate!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}; o
     set_options!(bm, opts)
     H = size(U, 3)
     Z = Array{T}(undef, bm.nz, bm.batch, H); status = Matrix{Int32}(undef, bm.batch, H)
-    check(@ccall LIB.dojo_rollout(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, status::Ptr{Int32})::Cint)
+    check(@ccall $(fn(:dojo_rollout))(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, status::Ptr{Int32})::Cint)
     return Z, status
 end
 
 "which states the IFT data blocks are evaluated at: 0 = as the reference does after step! (post-update_state!), 1 = at the solved step (consistent)"
-set_gradient_mode!(bm::BatchedMechanism, mode::Integer) = check(@ccall LIB.dojo_set_gradient_mode(bm.handle::Ptr{Cvoid}, Int32(mode)::Int32)::Cint)
+set_gradient_mode!(bm::BatchedMechanism, mode::Integer) = check(@ccall $(fn(:dojo_set_gradient_mode))(bm.handle::Ptr{Cvoid}, Int32(mode)::Int32)::Cint)
 
 "external forces for every body of every environment: fext[6, Nb, B] = [state.Fext (world); state.τext (body frame)]; `nothing` removes them"
 function set_external_force!(bm::BatchedMechanism{T}, fext::Union{Nothing,Array{T,3}}) where T
-    check(@ccall LIB.dojo_set_external_force(bm.handle::Ptr{Cvoid}, (fext === nothing ? C_NULL : pointer(fext))::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_set_external_force))(bm.handle::Ptr{Cvoid}, (fext === nothing ? C_NULL : pointer(fext))::Ptr{T})::Cint)
 end
 
 "simulate!(...; record=true): as above plus the Storage rows [25, Nb, B, H] (x q v ω px pq vl ωl, storage.jl:50-67)"
@@ -140,7 +151,7 @@ function simulate_storage!(bm::BatchedMechanism{T}, z0::Matrix{T}, U::Array{T,3}
     set_options!(bm, opts)
     H = size(U, 3); Nb = length(bm.mechanism.bodies)
     Z = Array{T}(undef, bm.nz, bm.batch, H); S = Array{T}(undef, 25, Nb, bm.batch, H); status = Matrix{Int32}(undef, bm.batch, H)
-    check(@ccall LIB.dojo_simulate(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, S::Ptr{T}, status::Ptr{Int32})::Cint)
+    check(@ccall $(fn(:dojo_simulate))(bm.handle::Ptr{Cvoid}, z0::Ptr{T}, U::Ptr{T}, H::Int32, Z::Ptr{T}, S::Ptr{T}, status::Ptr{Int32})::Cint)
     return Z, S, status
 end
 
@@ -148,28 +159,28 @@ end
 function get_state(bm::BatchedMechanism{T}; contact_forces::Bool=false) where T
     n = 2 * bm.nu + (contact_forces ? length(bm.mechanism.contacts) : 0)
     obs = Matrix{T}(undef, n, bm.batch)
-    check(@ccall LIB.dojo_observe(bm.handle::Ptr{Cvoid}, obs::Ptr{T}, Int32(contact_forces)::Int32)::Cint)
+    check(@ccall $(fn(:dojo_observe))(bm.handle::Ptr{Cvoid}, obs::Ptr{T}, Int32(contact_forces)::Int32)::Cint)
     return obs
 end
 
 "get_contact_gradients(mechanism) at the solution of the last get_maximal_gradients!: jacobian_contact[12Nb, 5Nc, B]"
 function get_contact_gradients!(bm::BatchedMechanism{T}, ncontacts::Int) where T
     dc = Array{T}(undef, 5 * ncontacts, bm.nx, bm.batch)                      # ABI is row-major [B, nx, 5Nc]
-    check(@ccall LIB.dojo_contact_gradients(bm.handle::Ptr{Cvoid}, dc::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_contact_gradients))(bm.handle::Ptr{Cvoid}, dc::Ptr{T})::Cint)
     return permutedims(dc, (2, 1, 3))
 end
 
 "minimal_to_maximal(mechanism, x): batched, x is 2nu x B (per joint [Δx; Δθ; Δv; Δω]) -> z (13Nb x B)"
 function Dojo.minimal_to_maximal(bm::BatchedMechanism{T}, x::Matrix{T}) where T
     z = Matrix{T}(undef, bm.nz, bm.batch)
-    check(@ccall LIB.dojo_minimal_to_maximal(bm.handle::Ptr{Cvoid}, x::Ptr{T}, z::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_minimal_to_maximal))(bm.handle::Ptr{Cvoid}, x::Ptr{T}, z::Ptr{T})::Cint)
     return z
 end
 
 "maximal_to_minimal(mechanism, z): batched"
 function Dojo.maximal_to_minimal(bm::BatchedMechanism{T}, z::Matrix{T}) where T
     x = Matrix{T}(undef, 2 * bm.nu, bm.batch)
-    check(@ccall LIB.dojo_maximal_to_minimal(bm.handle::Ptr{Cvoid}, z::Ptr{T}, x::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_maximal_to_minimal))(bm.handle::Ptr{Cvoid}, z::Ptr{T}, x::Ptr{T})::Cint)
     return x
 end
 
@@ -177,7 +188,7 @@ end
 function Dojo.step_minimal_coordinates!(bm::BatchedMechanism{T}, x::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
     set_options!(bm, opts)
     xn = similar(x); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
-    check(@ccall LIB.dojo_step_minimal(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32})::Cint)
+    check(@ccall $(fn(:dojo_step_minimal))(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32})::Cint)
     return xn, status
 end
 
@@ -187,40 +198,79 @@ function Dojo.get_minimal_gradients!(bm::BatchedMechanism{T}, x::Matrix{T}, u::M
     nm = 2 * bm.nu
     xn = similar(x); status = Vector{Int32}(undef, bm.batch); iters = Vector{Int32}(undef, bm.batch)
     jx = Array{T}(undef, nm, nm, bm.batch); ju = Array{T}(undef, bm.nu, nm, bm.batch)         # ABI is row-major [B, 2nu, 2nu] / [B, 2nu, nu]
-    check(@ccall LIB.dojo_minimal_gradients(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, jx::Ptr{T}, ju::Ptr{T})::Cint)
+    check(@ccall $(fn(:dojo_minimal_gradients))(bm.handle::Ptr{Cvoid}, x::Ptr{T}, u::Ptr{T}, xn::Ptr{T}, status::Ptr{Int32}, iters::Ptr{Int32}, jx::Ptr{T}, ju::Ptr{T})::Cint)
     return permutedims(jx, (2, 1, 3)), permutedims(ju, (2, 1, 3)), xn, status
 end
 
 # ---- opt-in single-Mechanism drop-in ------------------------------------------------------------
-# DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) round-trip through the library (B = 1,
-# fp64) and write the solution back: body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual),
-# so step!/simulate!/get_state of DojoEnvironments keep working unchanged.
+# DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) (src/solver/mehrotra.jl:9) round-trip through the library
+# (B = 1, fp64) and write the solution back -- body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual), mechanism.μ,
+# and mechanism.system re-assembled at the solution -- so that step!, simulate!, get_maximal_gradients! and the
+# DojoEnvironments built on them (DojoEnvironments/src/environments.jl:77-84) keep working unchanged.
+# Mechanisms that were not enabled keep the reference's own mehrotra!.
 const HANDLES = IdDict{Dojo.Mechanism,BatchedMechanism{Float64}}()
-enable!(m::Dojo.Mechanism) = (HANDLES[m] = BatchedMechanism(m, 1; T=Float64); m)
+const OVERRIDE_WORLD = Ref{UInt}(0)
 
-function hip_mehrotra!(m::Dojo.Mechanism; opts=Dojo.SolverOptions{Float64}())
-    bm = HANDLES[m]
-    z = reshape(Dojo.get_maximal_state(m), :, 1)
-    u = reshape(zeros(bm.nu), :, 1)          # inputs were already applied to JF2/Jτ2 by set_input!; pass them via dojo_step's u in step! overloads
-    fext = Array{Float64,3}(undef, 6, length(m.bodies), 1)
-    for (i, b) in enumerate(m.bodies); fext[1:3, i, 1] = b.state.Fext; fext[4:6, i, 1] = b.state.τext; end
-    set_external_force!(bm, fext)
-    zn, status = Dojo.step!(bm, z, u; opts)
+"install the Dojo.mehrotra! method that dispatches enabled mechanisms to the library (done once, by the first enable!)"
+function install_override!()
+    OVERRIDE_WORLD[] != 0 && return
+    OVERRIDE_WORLD[] = Base.get_world_counter()           # the world in which Dojo's own method is still the one that runs
+    @eval function Dojo.mehrotra!(mechanism::Dojo.Mechanism{T}; opts=Dojo.SolverOptions{T}()) where T
+        bm = get(HANDLES, mechanism, nothing)
+        bm === nothing && return Base.invoke_in_world(OVERRIDE_WORLD[], Dojo.mehrotra!, mechanism; opts=opts)
+        return hip_mehrotra!(mechanism, bm; opts=opts)
+    end
+    return
+end
+
+function enable!(m::Dojo.Mechanism)
+    HANDLES[m] = BatchedMechanism(m, 1; T=Float64)
+    install_override!()
+    return m
+end
+disable!(m::Dojo.Mechanism) = (delete!(HANDLES, m); m)
+
+"""
+    hip_mehrotra!(mechanism, bm; opts)
+
+What `mehrotra!` finds when `step!` calls it (src/simulation/step.jl:11-30): `set_maximal_state!` has set x2, q2, v15, ω15 and
+`set_input!` / `input_impulse!` (src/mechanism/set.jl:40-53) have folded the controls into every body's `state.JF2`,
+`state.Jτ2` and CLEARED the joints' inputs -- so the controls cross the boundary as body impulses (`dojo_step_impulses`),
+next to `state.Fext`, `state.τext`.
+"""
+function hip_mehrotra!(m::Dojo.Mechanism, bm::BatchedMechanism{Float64}; opts=Dojo.SolverOptions{Float64}())
+    set_options!(bm, opts)
     Nb = length(m.bodies)
+    z = reshape(Dojo.get_maximal_state(m), :, 1)
+    jf = Matrix{Float64}(undef, 6Nb, 1); fext = Array{Float64,3}(undef, 6, Nb, 1)
+    for (i, b) in enumerate(m.bodies)
+        jf[6i-5:6i-3, 1] = b.state.JF2; jf[6i-2:6i, 1] = b.state.Jτ2
+        fext[1:3, i, 1] = b.state.Fext; fext[4:6, i, 1] = b.state.τext
+    end
+    set_external_force!(bm, fext)
+    zn = similar(z); status = Vector{Int32}(undef, 1); iters = Vector{Int32}(undef, 1)
+    check(@ccall $(fn(:dojo_step_impulses))(bm.handle::Ptr{Cvoid}, z::Ptr{Float64}, jf::Ptr{Float64}, zn::Ptr{Float64}, status::Ptr{Int32}, iters::Ptr{Int32})::Cint)
+    # ---- write-back (what mehrotra! mutates, SURVEY.md §8b) ----
     vel = Vector{Float64}(undef, 6Nb); ji = Vector{Float64}(undef, max(1, sum(length.(m.joints)))); cs = Vector{Float64}(undef, max(1, 8length(m.contacts)))
-    check(@ccall LIB.dojo_get_solution(bm.handle::Ptr{Cvoid}, vel::Ptr{Float64}, ji::Ptr{Float64}, cs::Ptr{Float64})::Cint)
+    check(@ccall $(fn(:dojo_get_solution))(bm.handle::Ptr{Cvoid}, vel::Ptr{Float64}, ji::Ptr{Float64}, cs::Ptr{Float64})::Cint)
     for (i, b) in enumerate(m.bodies)
         b.state.vsol[2] = SVector{3}(vel[6i-5:6i-3]); b.state.ωsol[2] = SVector{3}(vel[6i-2:6i])
-        b.state.vsol[1] = b.state.vsol[2]; b.state.ωsol[1] = b.state.ωsol[2]
+        b.state.vsol[1] = b.state.vsol[2]; b.state.ωsol[1] = b.state.ωsol[2]        # update! (src/solver/linear_system.jl:32-45)
     end
     off = 0
     for j in m.joints
         n = length(j); j.impulses[2] = SVector{n}(ji[off+1:off+n]); j.impulses[1] = j.impulses[2]; off += n
     end
     for (i, c) in enumerate(m.contacts)
-        c.impulses_dual[2] = SVector{4}(cs[8i-7:8i-4]); c.impulses[2] = SVector{4}(cs[8i-3:8i])
+        nh = length(c.impulses[2])            # N½: 4 for NonlinearContact, 1 for ImpactContact; the device exports [s(4); γ(4)] per contact either way
+        c.impulses_dual[2] = SVector{nh}(cs[8i-7:8i-8+nh]); c.impulses[2] = SVector{nh}(cs[8i-3:8i-4+nh])
         c.impulses_dual[1] = c.impulses_dual[2]; c.impulses[1] = c.impulses[2]
     end
+    mu = Vector{Float64}(undef, 1)
+    check(@ccall $(fn(:dojo_get_mu))(bm.handle::Ptr{Cvoid}, mu::Ptr{Float64})::Cint)
+    m.μ = mu[1]
+    Dojo.set_entries!(m)                      # mechanism.system: the un-factored Jacobian and residual at the solution (mehrotra.jl:69)
+    status[1] == 2 && error("Excessive angular velocity.")       # src/solver/line_search.jl:18-20
     return status[1] == 0 ? :success : :failed
 end
 

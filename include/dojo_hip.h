@@ -162,6 +162,8 @@ typedef struct DojoDims {
 
 int  dojo_device_count(void);
 const char* dojo_last_error(void);
+/* text of the last failure of a call on THIS handle ("" if none): per-handle, safe with several handles on several threads */
+const char* dojo_handle_error(DojoHandle h);
 
 int  dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t device, DojoHandle* out);
 void dojo_destroy(DojoHandle h);
@@ -184,10 +186,22 @@ int  dojo_set_refinement(DojoHandle h, double stiffness);
 int  dojo_step(DojoHandle h, const void* z, const void* u, void* z_next,
                int32_t* status, int32_t* iters, int32_t with_gradient);
 
+/* mehrotra!(mechanism; opts)  src/solver/mehrotra.jl:9 -- the seam a single-`Mechanism` drop-in overrides.
+ * When mehrotra! runs, set_input! / input_impulse! (src/mechanism/set.jl:40-53, src/joints/translational/input.jl:5-27,
+ * src/joints/rotational/input.jl:5-17) have already turned the controls into body impulses and cleared the joints' inputs:
+ * jf [B, 6Nb] = per body [state.JF2 (world frame, 3); state.Jtau2 (body frame, 3)], exactly the vector the body residual
+ * subtracts (src/integrators/constraint.jl:20-21).  Equivalent to dojo_step(z, u) for the u that produced jf; any
+ * external force set with dojo_set_external_force stays in effect.  z, z_next, status, iters as for dojo_step. */
+int  dojo_step_impulses(DojoHandle h, const void* z, const void* jf, void* z_next, int32_t* status, int32_t* iters);
+
 /* solution of the last step in get_solution order per env:
  * vel [B,6Nb] (v25,w25 per body), joint_imp [B,n_joint_impulses], contact_sg [B,8Nc] ([s;gamma] per contact).
  * Any pointer may be NULL. */
 int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_sg);
+/* mechanism.mu (the central-path parameter kappa of the docs, src/solver/mehrotra.jl:45) per environment when the solve of
+ * the last step returned, fp64 [B]: a mehrotra! drop-in writes it back and calls set_entries! so that mechanism.system
+ * holds the final un-factored Jacobian and residual like the reference leaves it (src/solver/mehrotra.jl:69). */
+int  dojo_get_mu(DojoHandle h, double* mu);
 
 /* IFT Jacobians of the last dojo_step(..., with_gradient=1):
  * dz [B,12Nb,12Nb] = jacobian_state, du [B,12Nb,nu] = jacobian_control, row-major per environment

@@ -39,6 +39,7 @@ struct IOracle {
     virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
     virtual void set_refine_steps(int n) = 0;
+    virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
 };
 
 template <class T>
@@ -52,6 +53,14 @@ struct OracleT : IOracle {
         m.opts.max_iter = o.max_iter; m.opts.max_ls = o.max_ls; m.opts.no_progress_max = o.no_progress_max;
     }
     void set_refine_steps(int n) override { m.refine_steps = n; }
+    // set_maximal_state! + set_input! (src/mechanism/set.jl:10-53): what the bodies hold when mehrotra! starts, [JF2; Jτ2] per body
+    void input_impulses(const double* z, const double* u, double* jf) override {
+        int nz = 13 * (int)m.bodies.size(), nu = m.nu();
+        std::vector<T> zz = cast(z, nz), uu = cast(u, nu);
+        m.set_maximal_state(zz.data());
+        m.set_input_all(uu.data());
+        for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { jf[6 * i + k] = (double)m.bodies[i].st.JF2[k]; jf[6 * i + 3 + k] = (double)m.bodies[i].st.Jt2[k]; }
+    }
     void dims(int* out) override {
         out[0] = m.n; out[1] = m.nu(); out[2] = m.data_dim(false); out[3] = m.data_dim(true);
         out[4] = (int)m.bodies.size(); out[5] = (int)m.joints.size(); out[6] = (int)m.contacts.size();
@@ -228,6 +237,7 @@ void orc_step_batch(void* h, int B, const double* z, const double* u, double* z_
     for (auto& x : th) x.join();
 }
 
+void orc_input_impulses(void* h, const double* z, const double* u, double* jf) { ((IOracle*)h)->input_impulses(z, u, jf); }
 // rounds of iterative refinement of every linear solve (default 2: the checker; 0: a plain LU solve like the reference's)
 void orc_set_refine_steps(void* h, int n) { ((IOracle*)h)->set_refine_steps(n); }
 

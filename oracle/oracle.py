@@ -38,6 +38,7 @@ def lib():
             getattr(_lib, name).restype = None
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_set_refine_steps.restype = None
+        _lib.orc_input_impulses.restype = None
         _lib.orc_step.restype = C.c_int
         _lib.orc_simulate_step.restype = C.c_int
         _lib.orc_simulate_step_record.restype = C.c_int
@@ -173,6 +174,13 @@ class Oracle:
             status.append(lib().orc_simulate_step_record(self.h, _p(np.ascontiguousarray(U[k], dtype=np.float64)), int(k == H - 1), _p(row := np.zeros((self.Nb, 25)))))
             rows.append(row)
         return np.stack(rows), status
+
+    def input_impulses(self, z, u):
+        """set_maximal_state! + set_input!: the body impulses [JF2 (world); Jtau2 (body)] per body that mehrotra! finds, [Nb, 6]"""
+        z = np.ascontiguousarray(z, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        jf = np.zeros(6 * self.Nb)
+        lib().orc_input_impulses(self.h, _p(z), _p(u), _p(jf))
+        return jf.reshape(self.Nb, 6)
 
     def set_refine_steps(self, n):
         """rounds of iterative refinement of every linear solve: 2 (default) = the checker, 0 = plain LU like the reference's direct solve"""

@@ -1009,3 +1009,64 @@ def test_reference_mechanisms_rollout_gpu(name, kw):
     es = np.concatenate(es)
     assert es.max() <= 1e-6, (es.max(),)
     gm.close()
+
+
+
+@pytest.mark.parametrize("cfg,batch", [(2, 16), (3, 64), (4, 32), (5, 4)])
+def test_step_impulses_is_the_mehrotra_seam(cfg, batch):
+    """dojo_step_impulses (the mehrotra!(mechanism) seam of a single-`Mechanism` drop-in, src/solver/mehrotra.jl:9): stepping
+    with the body impulses that set_input! / input_impulse! leave in state.JF2 / state.Jtau2 (here: taken from the oracle's
+    restatement of src/mechanism/set.jl:40-53) equals stepping with the controls u themselves -- and both match the oracle."""
+    spec = d.baseline_config(cfg)
+    Z, U = d.synthetic_inputs(spec, batch)
+    U = U + 0.3 * np.random.default_rng(5).standard_normal(U.shape)          # every input slot in use, the floating base too
+    o = Oracle(spec, opts=TIGHT)
+    jf = np.stack([o.input_impulses(Z[b], U[b]) for b in range(batch)])
+    assert np.abs(jf).max() > 1e-3
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=TIGHT)
+    zu, su, iu = gm.step(Z, U)
+    zj, sj, ij = gm.step_impulses(Z, jf)
+    assert np.array_equal(su, sj) and np.array_equal(iu, ij)
+    assert np.abs(zu - zj).max() < 1e-9, np.abs(zu - zj).max()                 # (u -> impulses on the device vs on the host: round-off)
+    z0, s0, _ = gm.step(Z, None)
+    assert np.abs(z0 - zj).max() > 1e-6                                       # the impulses do something
+    zo, so, io, _, _ = o.step_batch(Z, U, nthreads=8)
+    ok = (sj == 0) & (so == 0)
+    assert np.abs(zj[ok] - zo[ok]).max() < 1e-6
+    # an external force set on the handle stays in effect next to the impulses
+    F = 0.2 * np.random.default_rng(6).standard_normal((batch, spec.Nb, 6))
+    gm.set_external_force(F)
+    zf, _, _ = gm.step(Z, U); zfj, _, _ = gm.step_impulses(Z, jf)
+    assert np.abs(zf - zfj).max() < 1e-9 and np.abs(zf - zu).max() > 1e-6
+    gm.close()
+
+
+def test_errors_are_per_handle():
+    """dojo_handle_error: the text of a failure stays with the handle it happened on (thread-safe per handle)"""
+    spec = d.baseline_config(2)
+    a = api.BatchedMechanism(spec, 4, dtype="f64"); b = api.BatchedMechanism(spec, 4, dtype="f64")
+    with pytest.raises(api.DojoError):
+        a.gradients()
+    assert "with_gradient" in a.last_error() and b.last_error() == ""
+    with pytest.raises(api.DojoError):
+        b.get_solution()
+    assert "no step" in b.last_error() and "with_gradient" in a.last_error()
+    a.close(); b.close()
+
+
+def test_state_flags_after_coordinate_helpers():
+    """the coordinate helpers and the forward-only minimal step must not leave dojo_contact_gradients re-linearizing
+    at a state that does not belong to the hand-off of the last differentiable step."""
+    spec = d.baseline_config(3)
+    B = 8
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dc0 = gm.contact_gradients()
+    gm.maximal_to_minimal(zn)                      # used to overwrite the handle's copy of z
+    dc1 = gm.contact_gradients()
+    assert np.array_equal(dc0, dc1)
+    gm.step_minimal(gm.maximal_to_minimal(Z), U)   # a forward-only step: the hand-off is gone, asking again must fail loudly
+    with pytest.raises(api.DojoError):
+        gm.contact_gradients()
+    gm.close()
