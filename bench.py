@@ -86,6 +86,8 @@ def main():
         gm.set_groups(args.chunks)
     gm.set_async(True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
+    if args.backend == "nccl":
+        D.connect_handle(gm, rank, world)        # the library's own RCCL communicator (dojo_comm_init), id carried by torch.distributed
 
     def ptr(t):
         return C.c_void_p(0 if t is None else t.data_ptr())
@@ -111,7 +113,7 @@ def main():
         one_step(k)
     gm.join(torch.cuda.current_stream().cuda_stream)       # the environment groups -> torch's stream
     if args.backend == "nccl":
-        z_all = D.all_gather_states(z, world)  # all-gather of the final states over RCCL/xGMI, once per rollout chunk
+        z_all = D.all_gather_states_rccl(gm, z, world)  # dojo_allgather_dev: the final states over RCCL/xGMI, once per rollout chunk
     else:
         torch.cuda.synchronize(); z_all = D.all_gather_states(z.cpu(), world)
     barrier()

@@ -17,6 +17,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <dlfcn.h>
 
 struct DojoSim;
 namespace {
@@ -88,6 +89,7 @@ struct DojoSim {
     int *d_status = nullptr, *d_iters = nullptr;
     bool have_grad = false, have_solution = false, have_u = false;
     std::string err; std::mutex err_m;  // text of the last failure of a call on this handle (dojo_handle_error)
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator of this handle's process group (dojo_comm_init)
     hipStream_t stream = nullptr;
     // kernel timing: a ring of event triples (launch begin / between the step and the IFT kernel / end), so that
     // timed launches never make the host wait; totals are accumulated when a slot is reused or queried
@@ -296,6 +298,17 @@ __global__ void chain_out_kernel(const NodeP<double>* nodes, int Nb, int nu, int
         if (j < nm) jx[((size_t)env * nm + i) * nm + j] = (TIO)acc; else if (ju) ju[((size_t)env * nm + i) * nu + (j - nm)] = (TIO)acc;
     }
 }
+// get_next_state(mechanism) (src/mechanism/get.jl:126-134) of bodies whose stored velocities are their solution: one thread per (env, body)
+template <class TIO>
+__global__ void next_state_kernel(int Nb, double dt, int B, const TIO* z, TIO* zo) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= B * Nb) return;
+    PoseVel<double> p = load_body<double>(z + (size_t)(tid / Nb) * 13 * Nb, tid % Nb);
+    advance_body(p, dt);
+    TIO* o = zo + (size_t)tid * 13;
+    for (int i = 0; i < 3; ++i) { o[i] = (TIO)p.x[i]; o[3 + i] = (TIO)p.v[i]; o[10 + i] = (TIO)p.w[i]; }
+    for (int i = 0; i < 4; ++i) o[6 + i] = (TIO)p.q[i];
+}
 // dojo_step_impulses: external force + body impulses / dt
 template <class TIO> __global__ void fold_impulses_kernel(long long n, const TIO* fext, const TIO* jf, double inv_dt, TIO* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,6 +491,33 @@ int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, 
     return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage);
 }
 
+// RCCL, opened on first use (dojo_comm_*)
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef int (*get_unique_id_t)(UniqueId*);
+typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
+typedef int (*all_gather_t)(const void*, void*, size_t, int /*ncclDataType_t*/, void*, hipStream_t);
+typedef int (*comm_destroy_t)(void*);
+typedef const char* (*get_error_string_t)(int);
+get_unique_id_t get_unique_id = nullptr; comm_init_rank_t comm_init_rank = nullptr; all_gather_t all_gather = nullptr;
+comm_destroy_t comm_destroy = nullptr; get_error_string_t get_error_string = nullptr;
+bool load() {
+    static std::mutex m; std::lock_guard<std::mutex> g(m);
+    if (all_gather) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    get_unique_id = (get_unique_id_t)dlsym(h, "ncclGetUniqueId"); comm_init_rank = (comm_init_rank_t)dlsym(h, "ncclCommInitRank");
+    comm_destroy = (comm_destroy_t)dlsym(h, "ncclCommDestroy"); get_error_string = (get_error_string_t)dlsym(h, "ncclGetErrorString");
+    all_gather_t ag = (all_gather_t)dlsym(h, "ncclAllGather");
+    if (!get_unique_id || !comm_init_rank || !comm_destroy || !ag) { g_err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather"; return false; }
+    all_gather = ag;
+    return true;
+}
+const char* why(int rc) { return get_error_string ? get_error_string(rc) : "RCCL error"; }
+}
+
 int ensure(void** p, size_t bytes) {
     if (*p) return DOJO_OK;
     HIPCHK(hipMalloc(p, bytes ? bytes : 8));
@@ -528,6 +568,7 @@ void dojo_destroy(DojoHandle s) {
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
     if (s->fork_event) (void)hipEventDestroy(s->fork_event);
+    if (s->comm && rccl::comm_destroy) (void)rccl::comm_destroy(s->comm);
     for (auto& e : s->ring) { if (e.a) (void)hipEventDestroy(e.a); if (e.m) (void)hipEventDestroy(e.m); if (e.b) (void)hipEventDestroy(e.b); }
     delete s;
 }
@@ -576,6 +617,55 @@ int dojo_set_refinement(DojoHandle s, double stiffness) {
     Enter enter_(s);
     if (!s || stiffness != stiffness) { g_err = "dojo_set_refinement: bad argument"; return DOJO_ERR_INVALID; }   // negative: back to the tolerance-based default
     s->refine_w = stiffness; return DOJO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU: one process per GPU, the batch sharded in contiguous slices, no exchange inside the solver; the
+// one collective is an all-gather of per-rank outputs (final states of a rollout chunk, status, gradients when wanted) over
+// RCCL / xGMI.  RCCL is opened lazily (dlopen), so a single-GPU user never loads it.  The 128-byte unique id travels over
+// whatever the host already has between its processes (Julia Distributed / MPI; torch.distributed in bench.py).
+// ---------------------------------------------------------------------------------------------------------------
+// rank 0 creates the id (128 bytes) and the host hands it to every rank
+int dojo_comm_unique_id(void* id128) {
+    if (!id128) { g_err = "dojo_comm_unique_id: bad argument"; return DOJO_ERR_INVALID; }
+    if (!rccl::load()) return DOJO_ERR_DEVICE;
+    rccl::UniqueId id;
+    int rc = rccl::get_unique_id(&id);
+    if (rc != 0) { g_err = std::string("ncclGetUniqueId: ") + rccl::why(rc); return DOJO_ERR_DEVICE; }
+    std::memcpy(id128, &id, 128);
+    return DOJO_OK;
+}
+// joins the handle's device into a communicator of `world` ranks (one handle, one GPU, one process each)
+int dojo_comm_init(DojoHandle s, int32_t rank, int32_t world, const void* id128) {
+    Enter enter_(s);
+    if (!s || !id128 || world < 1 || rank < 0 || rank >= world) { g_err = "dojo_comm_init: bad argument"; return DOJO_ERR_INVALID; }
+    if (!rccl::load()) return DOJO_ERR_DEVICE;
+    HIPCHK(hipSetDevice(s->device));
+    if (s->comm) { (void)rccl::comm_destroy(s->comm); s->comm = nullptr; }
+    rccl::UniqueId id; std::memcpy(&id, id128, 128);
+    int rc = rccl::comm_init_rank(&s->comm, world, id, rank);
+    if (rc != 0) { s->comm = nullptr; g_err = std::string("ncclCommInitRank: ") + rccl::why(rc); return DOJO_ERR_DEVICE; }
+    s->comm_rank = rank; s->comm_world = world;
+    return DOJO_OK;
+}
+// recv[world][count] <- every rank's send[count] (scalars of the handle's dtype; int32 with as_int32), in rank order = the
+// order of the contiguous batch shards.  Runs on `stream` behind everything the handle has in flight.
+int dojo_allgather_dev(DojoHandle s, const void* send, void* recv, int64_t count, int32_t as_int32, void* stream) {
+    Enter enter_(s);
+    if (!s || !send || !recv || count < 0) { g_err = "dojo_allgather_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (!s->comm) { g_err = "dojo_allgather_dev: no communicator (dojo_comm_init)"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj;
+    const int dt = as_int32 ? 2 /*ncclInt32*/ : (s->dtype == DOJO_DTYPE_F32 ? 7 /*ncclFloat32*/ : 8 /*ncclFloat64*/);
+    int rc = rccl::all_gather(send, recv, (size_t)count, dt, s->comm, (hipStream_t)stream);
+    if (rc != 0) { g_err = std::string("ncclAllGather: ") + rccl::why(rc); return DOJO_ERR_DEVICE; }
+    return DOJO_OK;
+}
+int dojo_comm_info(DojoHandle s, int32_t* rank, int32_t* world) {
+    Enter enter_(s);
+    if (!s) { g_err = "dojo_comm_info: bad argument"; return DOJO_ERR_INVALID; }
+    if (rank) *rank = s->comm_rank; if (world) *world = s->comm ? s->comm_world : 1;
+    return DOJO_OK;
 }
 
 int dojo_set_gradient_mode(DojoHandle s, int32_t mode) {
@@ -1061,6 +1151,34 @@ int dojo_maximal_to_minimal(DojoHandle s, const void* z, void* x) {
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal: bad argument"; return DOJO_ERR_INVALID; }
     return coords_host(s, z, x, 13 * s->M.Nb, 2 * s->M.nu, false);
 }
+// The vector the reference's step! literally RETURNS (src/simulation/step.jl:28: get_next_state after update_state!, SURVEY.md
+// §8a Q1): the internal state z_next = (x3, v25, q3, ω25) advanced once more with its own velocities, (x3 + Δt v25, v25,
+// q3 ⊗ ξ(ω25), ω25).  dojo_step returns the internal state; a caller that wants the literal return applies this to it.
+int dojo_next_state_dev(DojoHandle s, const void* z, void* z_out, void* stream) {
+    Enter enter_(s);
+    if (!s || !z || !z_out) { g_err = "dojo_next_state_dev: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
+    if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::next_state_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, s->M.Nb, s->M.dt, s->B, (const float*)z, (float*)z_out);
+    else hipLaunchKernelGGL((ckern::next_state_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, s->M.Nb, s->M.dt, s->B, (const double*)z, (double*)z_out);
+    HIPCHK(hipGetLastError());
+    return DOJO_OK;
+}
+int dojo_next_state(DojoHandle s, const void* z, void* z_out) {
+    Enter enter_(s);
+    if (!s || !z || !z_out) { g_err = "dojo_next_state: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)s->B * 13 * s->M.Nb * s->w;
+    DevBuf a, b;
+    HIPCHK(a.alloc(bytes)); HIPCHK(b.alloc(bytes));
+    HIPCHK(hipMemcpy(a.p, z, bytes, hipMemcpyHostToDevice));
+    int rc = dojo_next_state_dev(s, a.p, b.p, nullptr);
+    if (rc != DOJO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(z_out, b.p, bytes, hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
 int dojo_step_minimal(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters) {
     Enter enter_(s);
     if (!s || !x || !x_next) { g_err = "dojo_step_minimal: bad argument"; return DOJO_ERR_INVALID; }

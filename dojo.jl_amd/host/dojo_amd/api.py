@@ -35,7 +35,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.dojo_last_error.restype = C.c_char_p
         L.dojo_handle_error.restype = C.c_char_p; L.dojo_handle_error.argtypes = [C.c_void_p]
-        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step", "dojo_step_impulses", "dojo_get_mu",
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_step_impulses", "dojo_get_mu", "dojo_next_state", "dojo_next_state_dev",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -47,8 +47,8 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
-                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
+EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_next_state", "dojo_next_state_dev", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
+                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
@@ -121,6 +121,19 @@ class BatchedMechanism:
     def join(self, stream=None):
         _chk(lib().dojo_join(self.h, C.c_void_p(stream or 0)))
 
+    # ---- multi-GPU: RCCL communicator of the handle (one process per GPU) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        _chk(lib().dojo_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        _chk(lib().dojo_comm_init(self.h, int(rank), int(world), C.c_char_p(unique_id)))
+
+    def allgather_dev(self, send_ptr, recv_ptr, count, as_int32=False, stream=None):
+        _chk(lib().dojo_allgather_dev(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_int64(int(count)), int(bool(as_int32)), C.c_void_p(stream or 0)))
+
     def set_refinement(self, stiffness):
         """Refine the linear solves of environments whose cones reach max gamma/s > stiffness (inf: never, 0: always)."""
         _chk(lib().dojo_set_refinement(self.h, C.c_double(float(stiffness))))
@@ -148,6 +161,13 @@ class BatchedMechanism:
         zn = np.empty_like(z); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
         _chk(lib().dojo_step_impulses(self.h, _p(z), _p(jf), _p(zn), _p(st), _p(it)))
         return zn, st, it
+
+    def next_state(self, z):
+        """get_next_state of a state whose velocities are its solution: maps dojo_step's return (the internal state after
+        update_state!) to the vector the reference's step! literally returns."""
+        z = self._arr(z, (self.batch, self.spec.nz)); zo = np.empty_like(z)
+        _chk(lib().dojo_next_state(self.h, _p(z), _p(zo)))
+        return zo
 
     def get_mu(self):
         mu = np.empty(self.batch, np.float64)

@@ -37,6 +37,38 @@ def all_gather_states(local, world):
     return torch.cat(out, dim=0)
 
 
+def connect_handle(gm, rank, world):
+    """Joins a BatchedMechanism's device into an RCCL communicator of the LIBRARY (dojo_comm_init): rank 0 creates the
+    128-byte id, torch.distributed (whatever backend is up) carries it to the other ranks.  The same three calls are what a
+    Julia host makes with Distributed / MPI as the carrier."""
+    if world == 1:
+        return
+    box = [gm.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    gm.comm_init(rank, world, box[0])
+
+
+def all_gather_states_rccl(gm, local, world):
+    """All-gather of equally sized per-rank device tensors through the library's own RCCL communicator (dojo_allgather_dev):
+    [B_local, ...] -> [world * B_local, ...] in rank order, on torch's current stream."""
+    if world == 1:
+        return local
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    gm.allgather_dev(local.data_ptr(), out.data_ptr(), local.numel(), as_int32=(local.dtype == torch.int32),
+                     stream=torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def sharded_step(step_fn, Z, U, rank, world):
+    """The N > 1 data path in one place: every rank steps its contiguous slice of the global batch (no exchange inside the
+    solver), the per-rank results are all-gathered in rank order.  step_fn(Z_local, U_local) -> tuple of arrays with the batch
+    as leading axis; returns the gathered tuple as torch tensors (equal on every rank).  Shards must be equally sized."""
+    lo, hi = shard_slice(len(Z), rank, world)
+    outs = step_fn(Z[lo:hi], U[lo:hi] if U is not None else None)
+    return tuple(all_gather_states(torch.as_tensor(o), world) for o in outs)
+
+
 def max_over_ranks(value, world, device="cpu"):
     if world == 1:
         return float(value)

@@ -121,6 +121,17 @@ function Dojo.step!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Do
     return zn, status
 end
 
+"""
+The vector `Dojo.step!(mechanism, z, u)` literally returns is `get_next_state` AFTER `update_state!` (src/simulation/step.jl:28),
+i.e. the mechanism's next state advanced once more; `step!(bm, ...)` above returns the mechanism's next state itself (what the
+next step and `get_state` consume).  `reference_return(bm, zn)` maps the one to the other.
+"""
+function reference_return(bm::BatchedMechanism{T}, zn::Matrix{T}) where T
+    zr = similar(zn)
+    check(@ccall $(fn(:dojo_next_state))(bm.handle::Ptr{Cvoid}, zn::Ptr{T}, zr::Ptr{T})::Cint)
+    return zr
+end
+
 "get_maximal_gradients!(mechanism, z, u; opts): batched -> (jacobian_state[12Nb,12Nb,B], jacobian_control[12Nb,nu,B])"
 function Dojo.get_maximal_gradients!(bm::BatchedMechanism{T}, z::Matrix{T}, u::Matrix{T}; opts=Dojo.SolverOptions{Float64}()) where T
     Dojo.step!(bm, z, u; opts, with_gradient=true)

@@ -194,6 +194,13 @@ int  dojo_step(DojoHandle h, const void* z, const void* u, void* z_next,
  * external force set with dojo_set_external_force stays in effect.  z, z_next, status, iters as for dojo_step. */
 int  dojo_step_impulses(DojoHandle h, const void* z, const void* jf, void* z_next, int32_t* status, int32_t* iters);
 
+/* The vector the reference's step! literally returns (src/simulation/step.jl:28: get_next_state AFTER update_state!, i.e. the
+ * internal next state advanced once more with its own velocities -- SURVEY.md section 8a Q1).  dojo_step / dojo_rollout return
+ * the internal state (x3, v25, q3, w25), which is what the next step and DojoEnvironments' get_state consume; this maps it to
+ * the literal return value: z_out = (x3 + dt v25, v25, q3 (x) xi(w25), w25) per body (src/mechanism/get.jl:126-134). */
+int  dojo_next_state(DojoHandle h, const void* z, void* z_out);
+int  dojo_next_state_dev(DojoHandle h, const void* z, void* z_out, void* stream);
+
 /* solution of the last step in get_solution order per env:
  * vel [B,6Nb] (v25,w25 per body), joint_imp [B,n_joint_impulses], contact_sg [B,8Nc] ([s;gamma] per contact).
  * Any pointer may be NULL. */
@@ -231,6 +238,23 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
 int  dojo_set_async(DojoHandle h, int32_t on);
 int  dojo_set_groups(DojoHandle h, int32_t n);
 int  dojo_join(DojoHandle h, void* stream);
+
+/* Multi-GPU (nothing to cite in the reference, which has no multi-device code).  Environments are
+ * independent: one process per GPU, each with ONE handle for its contiguous slice of the batch (rank r of W owns the r-th
+ * slice), topology and options replicated, no exchange inside the solver.  The only collective is an all-gather of per-rank
+ * outputs over RCCL / xGMI, once per rollout chunk:
+ *   dojo_comm_unique_id(id)            rank 0: 128 opaque bytes, which the host passes to the other ranks (Julia Distributed,
+ *                                      MPI, torch.distributed ...)
+ *   dojo_comm_init(h, rank, world, id) every rank: joins the handle's device into the communicator
+ *   dojo_allgather_dev(h, send, recv, count, as_int32, stream)
+ *                                      recv[world][count] <- send[count] of every rank, in rank order (= batch order);
+ *                                      elements are scalars of the handle's dtype, or int32 (status) with as_int32 != 0;
+ *                                      ordered on `stream` behind everything the handle has in flight
+ * RCCL is loaded on first use (dlopen), single-GPU callers never touch it. */
+int  dojo_comm_unique_id(void* id128);
+int  dojo_comm_init(DojoHandle h, int32_t rank, int32_t world, const void* id128);
+int  dojo_allgather_dev(DojoHandle h, const void* send, void* recv, int64_t count, int32_t as_int32, void* stream);
+int  dojo_comm_info(DojoHandle h, int32_t* rank, int32_t* world);
 int  dojo_rollout_dev(DojoHandle h, const void* z0, const void* U, int32_t H, void* Z,
                       int32_t* status, void* stream);
 

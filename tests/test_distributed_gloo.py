@@ -1,5 +1,6 @@
-"""CPU tier: the N > 1 path (batch sharding + all-gather of trajectories + max-over-ranks timing)
-with the gloo backend, world_size 2 (the production backend is RCCL)."""
+"""CPU tier: the N > 1 path (batch sharding + all-gather of trajectories + max-over-ranks timing) with the gloo backend,
+world_size 2, the shipped device program (SIMT emulator) as the per-rank step (the production backend is RCCL,
+reached through dojo_comm_init / dojo_allgather_dev: tests/test_distributed_gpu.py)."""
 import os
 import subprocess
 import sys
@@ -7,20 +8,29 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import os, sys
-sys.path.insert(0, os.path.join(%r, "dojo.jl_amd", "host"))
-import torch
+ROOT = %r
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import dojo_amd as d
 from dojo_amd import distributed as D
+from emu_wrap import emu_step
 rank, world, local = D.init_from_env(backend="gloo")
-B = 10
-lo, hi = D.shard_slice(B, rank, world)
-glob = torch.arange(B * 3, dtype=torch.float64).reshape(B, 3)
-mine = glob[lo:hi] * 2.0                      # "simulate" the shard
-out = D.all_gather_states(mine, world)
-assert torch.equal(out, glob * 2.0), (rank, out)
+# the N > 1 data path with the SHIPPED device program (SIMT emulator) as the per-rank step: BASELINE configs[3], the
+# Quadruped, sharded in contiguous slices, gathered in rank order -- equal to the unsharded batch bit for bit
+spec = d.baseline_config(4)
+B = 4
+Z, U = d.synthetic_inputs(spec, B)
+def step(z, u):
+    o = emu_step(spec, z, u, quad=True)
+    return o["z_next"], o["status"], o["iters"]
+zg, sg, ig = D.sharded_step(step, Z, U, rank, world)
 t = D.max_over_ranks(1.0 + rank, world)
 assert t == float(world)
 if rank == 0:
-    print("GLOO_OK", lo, hi)
+    zf, sf, itf = step(Z, U)
+    assert np.array_equal(zg.numpy(), zf) and np.array_equal(sg.numpy(), sf) and np.array_equal(ig.numpy(), itf), "sharded != unsharded"
+    lo, hi = D.shard_slice(B, rank, world)
+    print("GLOO_OK", lo, hi, int(ig.sum()))
 ''' % ROOT
 
 
@@ -41,5 +51,5 @@ def test_two_rank_gloo_allgather(tmp_path):
     f.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29513", str(f)], capture_output=True, text=True, timeout=300, env=env)
+                        "--master-port", "29513", str(f)], capture_output=True, text=True, timeout=900, env=env)
     assert "GLOO_OK" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,68 @@
+"""GPU tier of the multi-GPU path.  The boxes this suite runs on have ONE GPU, so:
+ * two ranks share device 0 (gloo carries the gather through the host; RCCL refuses two ranks on one device): the sharded
+   Quadruped step at the BASELINE batch, 8192 / 2 per rank, gathered == the unsharded batch, bit for bit;
+ * the library's own RCCL path (dojo_comm_unique_id / dojo_comm_init / dojo_allgather_dev) runs with world = 1."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = r"""
+import os, sys
+ROOT = %r
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host"))
+import numpy as np, torch
+import dojo_amd as d
+from dojo_amd import api, distributed as D
+rank, world, local = D.init_from_env(backend="gloo")
+spec = d.baseline_config(4)                       # Quadruped, BASELINE configs[3]: batch 8192 sharded over the ranks
+B = 8192
+Z, U = d.synthetic_inputs(spec, B)
+lo, hi = D.shard_slice(B, rank, world)
+gm = api.BatchedMechanism(spec, hi - lo, dtype="f32", device=0)
+def step(z, u):
+    zn, st, it = gm.step(z.astype(np.float32), u.astype(np.float32), with_gradient=False)
+    return zn, st, it
+zg, sg, ig = D.sharded_step(step, Z, U, rank, world)
+gm.close()
+if rank == 0:
+    full = api.BatchedMechanism(spec, B, dtype="f32", device=0)
+    zf, sf, itf = full.step(Z.astype(np.float32), U.astype(np.float32))
+    full.close()
+    assert np.array_equal(zg.numpy(), zf) and np.array_equal(sg.numpy(), sf) and np.array_equal(ig.numpy(), itf), "sharded != unsharded"
+    print("SHARD_OK", float((sf == 0).mean()))
+""" % ROOT
+
+
+def test_two_ranks_sharded_quadruped_equals_unsharded(tmp_path):
+    f = tmp_path / "worker.py"
+    f.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", str(f)], capture_output=True, text=True, timeout=900, env=env)
+    assert "SHARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_library_rccl_allgather_world_one():
+    """dojo_comm_unique_id -> dojo_comm_init -> dojo_allgather_dev through RCCL itself (a communicator of one rank)."""
+    import ctypes as C
+    import torch
+    import dojo_amd as d
+    from dojo_amd import api
+    spec = d.baseline_config(2)
+    gm = api.BatchedMechanism(spec, 64, dtype="f64")
+    uid = gm.comm_unique_id()
+    assert len(uid) == 128
+    gm.comm_init(0, 1, uid)
+    Z, U = d.synthetic_inputs(spec, 64)
+    z = torch.tensor(Z, device="cuda:0"); out = torch.empty_like(z)
+    torch.cuda.synchronize()
+    gm.allgather_dev(z.data_ptr(), out.data_ptr(), z.numel(), stream=torch.cuda.current_stream().cuda_stream)
+    st = torch.arange(64, dtype=torch.int32, device="cuda:0"); st_out = torch.empty_like(st)
+    gm.allgather_dev(st.data_ptr(), st_out.data_ptr(), st.numel(), as_int32=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, z) and torch.equal(st_out, st)
+    gm.close()

@@ -1070,3 +1070,20 @@ def test_state_flags_after_coordinate_helpers():
     with pytest.raises(api.DojoError):
         gm.contact_gradients()
     gm.close()
+
+
+def test_literal_step_return_value():
+    """dojo_next_state: the vector the reference's step! literally returns (get_next_state after update_state!)
+    from the internal state dojo_step returns -- against the oracle's z_return."""
+    spec = d.baseline_config(3)
+    B = 16
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    zn, st, it = gm.step(Z, U)
+    zr = gm.next_state(zn)
+    gm.close()
+    o = Oracle(spec, opts=TIGHT)
+    for b in range(B):
+        zs, info = o.step(Z[b], U[b])
+        if info["status"] == 0 and st[b] == 0:
+            assert np.abs(zn[b] - zs).max() < 1e-6 and np.abs(zr[b] - info["z_return"]).max() < 1e-6
