@@ -40,6 +40,8 @@ struct IOracle {
     virtual IOracle* clone() = 0;
     virtual void set_refine_steps(int n) = 0;
     virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
+    virtual void maximal_to_minimal(const double* z, double* x) = 0;
+    virtual void minimal_to_maximal(const double* x, double* z) = 0;
 };
 
 template <class T>
@@ -53,6 +55,14 @@ struct OracleT : IOracle {
         m.opts.max_iter = o.max_iter; m.opts.max_ls = o.max_ls; m.opts.no_progress_max = o.no_progress_max;
     }
     void set_refine_steps(int n) override { m.refine_steps = n; }
+    void maximal_to_minimal(const double* z, double* x) override {
+        int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
+        std::vector<T> zz = cast(z, nz), xx(nm); m.maximal_to_minimal(zz.data(), xx.data()); for (int i = 0; i < nm; ++i) x[i] = (double)xx[i];
+    }
+    void minimal_to_maximal(const double* x, double* z) override {
+        int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
+        std::vector<T> xx = cast(x, nm), zz(nz); m.minimal_to_maximal(xx.data(), zz.data()); for (int i = 0; i < nz; ++i) z[i] = (double)zz[i];
+    }
     // set_maximal_state! + set_input! (src/mechanism/set.jl:10-53): what the bodies hold when mehrotra! starts, [JF2; Jτ2] per body
     void input_impulses(const double* z, const double* u, double* jf) override {
         int nz = 13 * (int)m.bodies.size(), nu = m.nu();
@@ -237,6 +247,8 @@ void orc_step_batch(void* h, int B, const double* z, const double* u, double* z_
     for (auto& x : th) x.join();
 }
 
+void orc_maximal_to_minimal(void* h, const double* z, double* x) { ((IOracle*)h)->maximal_to_minimal(z, x); }
+void orc_minimal_to_maximal(void* h, const double* x, double* z) { ((IOracle*)h)->minimal_to_maximal(x, z); }
 void orc_input_impulses(void* h, const double* z, const double* u, double* jf) { ((IOracle*)h)->input_impulses(z, u, jf); }
 // rounds of iterative refinement of every linear solve (default 2: the checker; 0: a plain LU solve like the reference's)
 void orc_set_refine_steps(void* h, int n) { ((IOracle*)h)->set_refine_steps(n); }

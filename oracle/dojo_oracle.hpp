@@ -1110,6 +1110,69 @@ struct Mechanism {
             s.JF2 = M(3, 1); s.Jt2 = M(3, 1);
         }
     }
+    // ---------------- minimal <-> maximal coordinates ----------------
+    // maximal_to_minimal   src/mechanism/state.jl:44-66: per joint (mechanism.joints order) [c_tra; c_rot; v_tra; v_rot]
+    void maximal_to_minimal(const T* z, T* x) const {
+        int o = 0;
+        for (const Joint<T>& J : joints) {
+            M xa(3, 1), va(3, 1), wa(3, 1), xb(3, 1), vb(3, 1), wb(3, 1); Q qa, qb;
+            auto unpack = [&](int i, M& x_, M& v_, Q& q_, M& w_) {          // unpack_maximal_state  state.jl:68-76
+                const T* zi = z + 13 * i;
+                for (int k = 0; k < 3; ++k) { x_[k] = zi[k]; v_[k] = zi[3 + k]; w_[k] = zi[10 + k]; }
+                q_ = Q(zi[6], zi[7], zi[8], zi[9]);
+            };
+            unpack(J.child, xb, vb, qb, wb);
+            if (J.parent >= 0) unpack(J.parent, xa, va, qa, wa);           // (the origin: zero position / velocity, identity attitude)
+            const int nu = J.tra.nu() + J.rot.nu(); int oc = 0, ov = 0;
+            for (const Half<T>* h : {&J.tra, &J.rot}) {
+                const int n = h->nu();
+                if (n == 0) continue;
+                M c = minimal_coordinates(J, *h, xa, qa, xb, qb), v = minimal_velocities(J, *h, xa, va, qa, wa, xb, vb, qb, wb);
+                for (int k = 0; k < n; ++k) { x[o + oc + k] = c[k]; x[o + nu + ov + k] = v[k]; }
+                oc += n; ov += n;
+            }
+            o += 2 * nu;
+        }
+    }
+    // minimal_to_maximal   src/mechanism/state.jl:9-22 -> set_minimal_coordinates_velocities!  src/joints/minimal.jl:134-196,
+    // joints visited root -> leaves (the parent's maximal state first)
+    void minimal_to_maximal(const T* x, T* z) const {
+        const int Nb = (int)bodies.size();
+        std::vector<int> xoff(joints.size()); { int o = 0; for (size_t j = 0; j < joints.size(); ++j) { xoff[j] = o; o += 2 * (joints[j].tra.nu() + joints[j].rot.nu()); } }
+        std::vector<char> done(Nb, 0);
+        for (int pass = 0, left = (int)joints.size(); left > 0 && pass <= (int)joints.size(); ++pass)
+            for (size_t j = 0; j < joints.size(); ++j) {
+                const Joint<T>& J = joints[j];
+                if (done[J.child] || (J.parent >= 0 && !done[J.parent])) continue;
+                const T* xm = x + xoff[j];
+                const int nt = J.tra.nu(), nr = J.rot.nu(), nu = nt + nr;
+                M dx(nt, 1), dth(nr, 1), dv(nt, 1), dw(nr, 1);
+                for (int k = 0; k < nt; ++k) { dx[k] = xm[k]; dv[k] = xm[nu + k]; }
+                for (int k = 0; k < nr; ++k) { dth[k] = xm[nt + k]; dw[k] = xm[nu + nt + k]; }
+                M xa(3, 1), va(3, 1), wa(3, 1); Q qa;
+                if (J.parent >= 0) { const T* zp = z + 13 * J.parent; for (int k = 0; k < 3; ++k) { xa[k] = zp[k]; va[k] = zp[3 + k]; wa[k] = zp[10 + k]; } qa = Q(zp[6], zp[7], zp[8], zp[9]); }
+                M Arot = J.rot.A.t(), Atra = J.tra.A.t();                       // zerodimstaticadjoint(nullspace_mask(...))
+                M ax = nr > 0 ? Arot * dth : M(3, 1), tx = nt > 0 ? Atra * dx : M(3, 1);
+                // positions
+                Q dq = axis_angle_to_quaternion(ax);
+                Q qb = qa * J.qoff * dq;
+                M xb = xa + vector_rotate(J.vp + tx, qa) - vector_rotate(J.vc, qb);
+                // previous configuration, finite-difference configuration
+                M xa1 = next_position(xa, -va, dt); Q qa1 = next_orientation(qa, -wa, dt);
+                M tx1 = nt > 0 ? Atra * (dx - dt * dv) : M(3, 1);
+                M axw = nr > 0 ? dt * (Arot * dw) : M(3, 1);
+                Q dq1 = dq * inv(axis_angle_to_quaternion(axw));
+                Q qb1 = qa1 * J.qoff * dq1;
+                M xb1 = xa1 + vector_rotate(J.vp + tx1, qa1) - vector_rotate(J.vc, qb1);
+                // finite-difference velocity: (xb − xb1)/Δt, angular_velocity(qb1, qb, Δt) = 2/Δt V Lᵀ(qb1) qb  (integrator.jl:22-24)
+                M vb = (T(1) / dt) * (xb - xb1);
+                M wb = (T(2) / dt) * (Vmat<T>() * (LTmat(qb1) * vector(qb)));
+                T* zc = z + 13 * J.child;
+                for (int k = 0; k < 3; ++k) { zc[k] = xb[k]; zc[3 + k] = vb[k]; zc[10 + k] = wb[k]; }
+                zc[6] = qb.s; zc[7] = qb.v1; zc[8] = qb.v2; zc[9] = qb.v3;
+                done[J.child] = 1; --left;
+            }
+    }
     void get_maximal_state(T* z) const {   // mechanism/get.jl:107-117
         for (size_t i = 0; i < bodies.size(); ++i) {
             const State<T>& s = bodies[i].st; T* p = z + 13 * i;

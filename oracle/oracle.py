@@ -39,6 +39,7 @@ def lib():
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_input_impulses.restype = None
+        _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
         _lib.orc_simulate_step.restype = C.c_int
         _lib.orc_simulate_step_record.restype = C.c_int
@@ -181,6 +182,16 @@ class Oracle:
         jf = np.zeros(6 * self.Nb)
         lib().orc_input_impulses(self.h, _p(z), _p(u), _p(jf))
         return jf.reshape(self.Nb, 6)
+
+    def maximal_to_minimal(self, z):
+        """maximal_to_minimal(mechanism, z)  src/mechanism/state.jl:44-66"""
+        z = np.ascontiguousarray(z, dtype=np.float64); x = np.zeros(2 * self.nu)
+        lib().orc_maximal_to_minimal(self.h, _p(z), _p(x)); return x
+
+    def minimal_to_maximal(self, x):
+        """minimal_to_maximal(mechanism, x)  src/mechanism/state.jl:9-22"""
+        x = np.ascontiguousarray(x, dtype=np.float64); z = np.zeros(13 * self.Nb)
+        lib().orc_minimal_to_maximal(self.h, _p(x), _p(z)); return z
 
     def set_refine_steps(self, n):
         """rounds of iterative refinement of every linear solve: 2 (default) = the checker, 0 = plain LU like the reference's direct solve"""

@@ -9,6 +9,29 @@ from dojo_amd import api
 from oracle import Oracle
 
 pytestmark = pytest.mark.gpu
+
+
+class _OracleCoords:
+    """minimal <-> maximal maps of the C++ ORACLE (pinned by tests/test_oracle_minimal.py = test/minimal.jl restated): what the
+    device maps and their Jacobians are checked against"""
+    _cache = {}
+
+    @classmethod
+    def _o(cls, spec):
+        if id(spec) not in cls._cache:
+            cls._cache[id(spec)] = (spec, Oracle(spec))
+        return cls._cache[id(spec)][1]
+
+    @classmethod
+    def maximal_to_minimal(cls, spec, z):
+        return cls._o(spec).maximal_to_minimal(z)
+
+    @classmethod
+    def minimal_to_maximal(cls, spec, x):
+        return cls._o(spec).minimal_to_maximal(x)
+
+
+ocoords = _OracleCoords
 # 1e-8: tight enough for 1e-6 parity; the library refines its linear solves at such tolerances (dojo_set_refinement)
 TIGHT = d.SolverOptions(rtol=1e-8, btol=1e-8)
 
@@ -297,8 +320,8 @@ def test_gradient_is_the_derivative_of_the_gpu_step():
 
 @pytest.mark.parametrize("cfg,batch", [(1, 64), (2, 64), (3, 4096), (4, 256), (5, 64)])
 def test_minimal_maximal_maps(cfg, batch):
-    """minimal_to_maximal / maximal_to_minimal on the device (src/mechanism/state.jl:9-66) against the host restatement
-    (dojo_amd.coords, numpy) on the same inputs, plus the round trip at the full batch."""
+    """minimal_to_maximal / maximal_to_minimal on the device (src/mechanism/state.jl:9-66) against the C++ oracle's maps (pinned by
+    test/minimal.jl restated, tests/test_oracle_minimal.py) on the same inputs, plus the round trip at the full batch."""
     from dojo_amd import coords
     spec = d.baseline_config(cfg)
     Z0, U0 = d.synthetic_inputs(spec, min(batch, 64))
@@ -307,10 +330,10 @@ def test_minimal_maximal_maps(cfg, batch):
     gm = api.BatchedMechanism(spec, batch, dtype="f64")
     X = gm.maximal_to_minimal(Z)
     for b in range(0, min(batch, 64), 7):
-        assert np.abs(X[b] - coords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
+        assert np.abs(X[b] - ocoords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
     Zr = gm.minimal_to_maximal(X)
     for b in range(0, min(batch, 64), 7):
-        assert np.abs(Zr[b] - coords.minimal_to_maximal(spec, X[b])).max() < 1e-10
+        assert np.abs(Zr[b] - ocoords.minimal_to_maximal(spec, X[b])).max() < 1e-10
     # the synthetic states were built from minimal coordinates, so the round trip reproduces them (joints closed)
     assert np.abs(Zr - Z).max() < 1e-8, np.abs(Zr - Z).max()
     assert np.abs(gm.maximal_to_minimal(Zr) - X).max() < 1e-9
@@ -373,11 +396,11 @@ def _fd_coordinate_jacobians(spec, xp, zp, h=1e-6):
             out[12 * b + 6:12 * b + 9] = qmul(qconj(z0[13 * b + 6:13 * b + 10]), zd[13 * b + 6:13 * b + 10])[1:]
             out[12 * b + 9:12 * b + 12] = zd[13 * b + 10:13 * b + 13]
         return out
-    z0 = coords.minimal_to_maximal(spec, xp)
+    z0 = ocoords.minimal_to_maximal(spec, xp)
     Jm = np.zeros((12 * Nb, nm))
     for j in range(nm):
         e = np.zeros(nm); e[j] = h
-        Jm[:, j] = reduce((coords.minimal_to_maximal(spec, xp + e) - coords.minimal_to_maximal(spec, xp - e)) / (2 * h), z0)
+        Jm[:, j] = reduce((ocoords.minimal_to_maximal(spec, xp + e) - ocoords.minimal_to_maximal(spec, xp - e)) / (2 * h), z0)
     JM = np.zeros((nm, 12 * Nb))
     for b in range(Nb):
         for i in range(12):
@@ -389,7 +412,7 @@ def _fd_coordinate_jacobians(spec, xp, zp, h=1e-6):
                     ph = np.zeros(3); ph[i - 6] = sgn * h
                     z[13 * b + 6:13 * b + 10] = qmul(zp[13 * b + 6:13 * b + 10], np.concatenate([[np.sqrt(1 - h * h)], ph]))
                 else: z[13 * b + 10 + (i - 9)] += sgn * h
-                zs.append(coords.maximal_to_minimal(spec, z))
+                zs.append(ocoords.maximal_to_minimal(spec, z))
             JM[:, 12 * b + i] = (zs[0] - zs[1]) / (2 * h)
     return Jm, JM
 
@@ -415,22 +438,22 @@ def _check_minimal_gradients(spec, Z, U, mode, opts):
     B = len(Z)
     o = Oracle(spec, opts=opts)
     nchecked = 0
-    X = np.stack([coords.maximal_to_minimal(spec, Z[b]) for b in range(B)])
+    X = np.stack([ocoords.maximal_to_minimal(spec, Z[b]) for b in range(B)])
     gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
     gm.set_gradient_mode(mode)
     xn, st, it, jx, ju = gm.minimal_gradients(X, U)
     dt = spec.timestep
     for b in range(B):
-        z = coords.minimal_to_maximal(spec, X[b])
+        z = ocoords.minimal_to_maximal(spec, X[b])
         zn, info = o.step(z, U[b])
         if info["status"] != 0 or st[b] != 0:
             continue
         dz, du = o.gradients(mode)
-        assert np.abs(xn[b] - coords.maximal_to_minimal(spec, zn)).max() < 1e-6
+        assert np.abs(xn[b] - ocoords.maximal_to_minimal(spec, zn)).max() < 1e-6
         if mode == 1:
             xp, zp = X[b], zn
         else:                                   # literal: min->max at the new state, max->min at get_next_state of it
-            xp = coords.maximal_to_minimal(spec, zn); zp = zn.copy()
+            xp = ocoords.maximal_to_minimal(spec, zn); zp = zn.copy()
             for k in range(spec.Nb):
                 zp[13 * k:13 * k + 3] = zn[13 * k:13 * k + 3] + dt * zn[13 * k + 3:13 * k + 6]
                 zp[13 * k + 6:13 * k + 10] = next_orientation(zn[13 * k + 6:13 * k + 10], zn[13 * k + 10:13 * k + 13], dt)
@@ -581,7 +604,7 @@ def test_observe_ant_ars_state():
     assert np.array_equal(obs[:, 2 * spec.nu:], np.clip(gam_n, -1.0, 1.0))
     assert (gam_n > 1.0).any() or (gam_n > 1e-3).any()         # some feet are on the ground in this batch
     for b in range(0, 64, 9):
-        assert np.abs(obs[b, :2 * spec.nu] - coords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
+        assert np.abs(obs[b, :2 * spec.nu] - ocoords.maximal_to_minimal(spec, Z[b])).max() < 1e-10
     assert np.array_equal(gm.observe(), obs[:, :2 * spec.nu])
     gm.close()
 
@@ -618,11 +641,11 @@ def test_batched_environment_ant_ars_rollout():
         for k in range(H):
             state = np.concatenate([x, np.clip(gam, -1, 1)])
             action = theta[b] @ (state / np.sqrt(1e-2))          # untouched Normalizer: mean 0, var clamped to 1e-2
-            zn, info = o.step(coords.minimal_to_maximal(spec, x), np.concatenate([np.zeros(6), action]))
+            zn, info = o.step(ocoords.minimal_to_maximal(spec, x), np.concatenate([np.zeros(6), action]))
             assert info["status"] == 0
             sol = o.get_solution()
             gam = sol[spec.n_joint_impulses + 6 * spec.Nb:].reshape(Nc, 8)[:, 4]
-            xa = coords.maximal_to_minimal(spec, zn)
+            xa = ocoords.maximal_to_minimal(spec, zn)
             reward += 100.0 * (xa[0] - x[0]) / dt - 0.005 * action @ action - 0.5e-3 * (np.clip(gam, -1, 1) ** 2).sum() + 0.05
             x = xa
         assert abs(R[b] - reward) < 1e-4 * max(1.0, abs(reward)), (b, R[b], reward)
@@ -744,7 +767,7 @@ def test_random_tree_mechanisms_gpu(seed0, translational):
         # coordinate maps (spherical joints: rotation-vector coordinates) and the Storage row of the first step
         from dojo_amd import coords
         X = gm.maximal_to_minimal(Z)
-        assert np.abs(X[0] - coords.maximal_to_minimal(spec, Z[0])).max() < 1e-10
+        assert np.abs(X[0] - ocoords.maximal_to_minimal(spec, Z[0])).max() < 1e-10
         assert np.abs(gm.minimal_to_maximal(X) - Z).max() < 1e-8
         _, S, st_s = gm.simulate(Z, U[None])
         So, st_o = o.simulate_storage(Z[1], U[None, 1])
