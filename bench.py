@@ -62,12 +62,13 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     tdt = torch.float32 if args.io_dtype == "f32" else torch.float64
     w = 4 if args.io_dtype == "f32" else 8
-    # synthetic inputs: 64 seeded environments per rank tiled over the batch, distinct seeds per rank
-    Z0, U0 = d.synthetic_inputs(spec, 64, seed=20241008 + rank)
-    reps = (B + 63) // 64
-    z = torch.tensor(np.tile(Z0, (reps, 1))[:B], dtype=tdt, device=dev).contiguous()
+    # synthetic inputs: B DISTINCT seeded environments per rank (perturbed nominal states built in minimal
+    # coordinates, so the joints are closed), distinct seeds per rank; controls ~ 0.5 N(0,1) on the actuated inputs, fresh every step
+    Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008 + rank)
+    reps = 1
+    z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000 + rank]))
-    Uall = torch.tensor(0.5 * rng.standard_normal((K + W, B, spec.nu)) * (np.abs(np.tile(U0, (reps, 1))[:B]) > 0), dtype=tdt, device=dev).contiguous()
+    Uall = torch.tensor(0.5 * rng.standard_normal((K + W, B, spec.nu)) * (np.abs(U0) > 0), dtype=tdt, device=dev).contiguous()
     zn = torch.empty_like(z)
     status = torch.empty(B, dtype=torch.int32, device=dev); iters = torch.empty(B, dtype=torch.int32, device=dev)
     grad = not args.no_grad
@@ -125,7 +126,7 @@ def main():
     # of the whole batch per kernel (groups = 1), so that the hipEvent durations (on the launch stream) are those of a kernel
     # that has the GPU to itself -- the figure the rocprofv3 --kernel-trace of `bench.py --chunks 1` shows.
     gm.set_async(False); gm.set_groups(1)
-    z = torch.tensor(np.tile(Z0, (reps, 1))[:B], dtype=tdt, device=dev).contiguous()     # from the initial states again: the first steps
+    z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()                              # from the initial states again: the first steps
     torch.cuda.synchronize()                                                              # of the rollout, where (almost) nothing stalls
     one_step(0)
     torch.cuda.synchronize()

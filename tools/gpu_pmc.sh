@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --chunks 1}"   # one launch = the whole batch of 4096 environments
+ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-parity --chunks 1}"   # one launch = the whole batch of 4096 environments
 cd /tmp
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" "FETCH_SIZE" "WRITE_SIZE"; do
