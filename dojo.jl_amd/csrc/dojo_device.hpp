@@ -46,6 +46,9 @@
 #ifndef DJ_TSD
 #define DJ_TSD 0           // 1: the kernels evaluate translational springs / dampers (KernelArgs::tsd); builds of their own
 #endif
+#ifndef DJ_PIVOT_ORDER
+#define DJ_PIVOT_ORDER 1   // quad Gauss-Jordan: 1 = pivot v, λ_t, ω, λ_r; 0 = v, ω, λ_t, λ_r (see factorize_quad)
+#endif
 #ifndef DJ_SPLIT_Y
 #define DJ_SPLIT_Y 0       // IFT sweeps, fp32 ABI: 1 = park the forward-substituted right-hand sides as two floats (measured: IFT kernel +33 %, while the f32-ABI and f64-ABI gradients already agree to 2e-7 relative without it)
 #endif
@@ -1405,8 +1408,13 @@ struct LaneProgram {
             // pivot only ever receives row operations afterwards, so the factor 1/pivot commutes to the end):
             // every row then takes the same update A −= fe·prow with fe = 0 on the pivot row itself.
             TL ipown[3] = {TL(1), TL(1), TL(1)};
+            // Pivot order v, λ_t, ω, λ_r (DJ_PIVOT_ORDER = 1) instead of v, ω, λ_t, λ_r: with the translational constraint rows eliminated
+            // right after the linear velocity, the ω pivots are the inertia about the JOINT POINT (J + m r², ~1e-3) rather than about the
+            // centre of mass (~1e-5 for an Ant foot), and the elimination's growth drops by that ratio -- without pivoting, the order
+            // is all there is (numpy model of the tree elimination on the worst default-tolerance cases: 3e-5 -> 1e-8 relative).
 #pragma unroll
-            for (int p = 0; p < 12; ++p) {
+            for (int pp = 0; pp < 12; ++pp) {
+                const int p = DJ_PIVOT_ORDER ? (pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp) : pp;
                 const int o = p / 3, ro = p % 3;
                 const bool own = (q == o);
                 TL prow[12];
