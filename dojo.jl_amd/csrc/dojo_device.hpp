@@ -1015,6 +1015,12 @@ struct LaneProgram {
             v[n] = r;
         }
     }
+    // the same reduction (max) for values that differ between the four lanes of a quad: folded inside the quad first
+    template <int NV> DJ_HD void env_reduce_quad_all(T (&v)[NV]) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) { v[n] = tmax(v[n], T(wv.quad_xor(v[n], 1))); v[n] = tmax(v[n], T(wv.quad_xor(v[n], 2))); }
+        env_reduce_quad<NV>(v, [](T a_, T b_) { return a_ > b_ ? a_ : b_; });
+    }
     // the two body-row roles of every supernode post N values ...
     template <int N, class TV> DJ_HD void mail_post_roles(const TV* v) {
         wv.sync();
@@ -1100,6 +1106,7 @@ struct LaneProgram {
     T* blk = nullptr; int blk_stride = 0;
     bool refine = false;
     T wstiff = T(0);                   // max γ/s over the cones of the environment at the last evaluated iterate
+    T growth = T(0);                   // largest |multiplier| of the last factorization's Gauss-Jordan passes on this lane (no pivoting: the growth indicator)
     T dk_lim = T(0);                   // Δκ of the last solve (the multiplier slot that carries the net limit impulse)
 
     DJ_HD LaneProgram(Wave& w, const Globals<T>& g, const NodeP<T>& p, const ContactP<T>* cp, int base_, int k_, int q_, bool act, Lane<T, MAXC>& lane_, Cold<T, MAXC>& cold_)
@@ -1379,6 +1386,7 @@ struct LaneProgram {
     // shuffles and every lane updates its three rows.  No W / Z are stored: the solves use the row
     // block of S⁻¹ together with the lane's rows of U and columns of L.
     DJ_HD void factorize_quad(QuadBlocks<TL>& K) {
+        if constexpr (kTrack) growth = T(0);
         // F.Sq holds the raw rows until the lane's level is reached and the inverse rows afterwards:
         // the elimination runs in place and is a no-op (fe = 0) on lanes that are not at the level.
         TL up[3][6];
@@ -1433,6 +1441,7 @@ struct LaneProgram {
                     const TL f = A[r][p];
                     const TL g = f * ip;
                     const TL ge = at ? g : TL(0);
+                    if constexpr (kTrack) { const TL ag = ge < TL(0) ? -ge : ge; growth = (r == ro && own) ? growth : tmax(growth, T(ag)); }
                     const TL fe = (r == ro) ? (own ? TL(0) : ge) : ge;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) if (c != p) A[r][c] -= fe * prow[c];
@@ -2889,6 +2898,7 @@ struct KernelArgs {
     T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
     int* flag = nullptr;           // [B] 1: the plain step kernel deferred this environment to the refining kernels (DJ_REFINE; or null)
     T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
+    T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
@@ -3096,6 +3106,8 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #ifdef DJ_PROF
     prog.pc[7] = wv.clock() - t_all;
 #endif
+    T gr_env = T(0);
+    if constexpr (QUAD && DJ_REFINE) { if (A.diag_out) { T v1[1] = {prog.growth}; prog.template env_reduce_quad_all<1>(v1); gr_env = v1[0]; } }
     if (active && q == 0 && A.sol) {                          // hand-off to the IFT kernel, in the state precision
         T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
         for (int i = 0; i < 3; ++i) { r[i] = prog.L.v[i]; r[3 + i] = prog.L.w[i]; }
@@ -3130,6 +3142,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         TIO* o = A.z_next + (size_t)env * 13 * G.Nb + 13 * k;
         for (int i = 0; i < 13; ++i) o[i] = TIO(zn[i]);
         if (k == 0) { if (A.status) A.status[env] = status; if (A.iters) A.iters[env] = iters; if (A.mu_out) A.mu_out[env] = prog.mu; }
+        if constexpr (QUAD && DJ_REFINE) { if (k == 0 && A.diag_out) { A.diag_out[2 * env] = prog.wstiff; A.diag_out[2 * env + 1] = gr_env; } }
         if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[i]); vo[3 + i] = TIO(prog.L.w[i]); } }
         if (A.res) { TIO* ro = A.res + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 6; ++i) ro[i] = TIO(prog.rb[i]); }
 #ifdef DJ_PROF

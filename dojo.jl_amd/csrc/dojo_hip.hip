@@ -74,6 +74,7 @@ struct DojoSim {
     void *d_cz = nullptr;                   // maximal-state scratch of dojo_minimal_to_maximal / dojo_maximal_to_minimal (d_z stays the state of the last step)
     void *d_jf = nullptr;                   // dojo_step_impulses: body impulses folded into the external-force slot
     double *d_mu = nullptr;                 // [B] mechanism.μ at the end of the last step (dojo_get_mu)
+    double *d_diag = nullptr;               // [B][2] diagnostics of the last step's final linearization (dojo_get_diagnostics)
     void *d_jm = nullptr, *d_jt = nullptr, *d_jb = nullptr;   // get_minimal_gradients!: min->max Jacobian, dz * that, max->min blocks (fp64)
     // internal device buffers used by the host-pointer entry points
     const void* fext = nullptr;                     // device [B,6Nb] external forces applied by every step, or null (dojo_set_external_force)
@@ -341,12 +342,16 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
     return DOJO_OK;
 }
 
+int mapping_waves(const dj::HostModel& M);
+bool quad_mapping_of(const DojoSim* s);
 // wavefronts per workgroup of the quad mapping for this mechanism; 0 = lane mapping
 int mapping_waves(const dj::HostModel& M) {
     if (M.S <= 16) return 1;
     if (M.S <= 32 && M.maxc <= 4 && M.Nc <= 16) return 2;
     return 0;
 }
+
+bool quad_mapping_of(const DojoSim* s) { return mapping_waves(s->M) > 0; }
 
 int drain_slot(DojoSim* s, DojoSim::Ev3& e) {
     if (!e.used) return DOJO_OK;
@@ -417,6 +422,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
     A.mu_out = s->d_mu ? (T*)s->d_mu + env0 : nullptr;
+    A.diag_out = (s->d_diag && quad_mapping_of(s)) ? (T*)s->d_diag + 2 * env0 : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
     // (one Atlas per two-wavefront workgroup; contact rows pooled per contact: <= 16 contacts, <= 4 per body);
     // else one lane per supernode
@@ -563,7 +569,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
@@ -819,6 +825,23 @@ int dojo_get_mu(DojoHandle s, double* mu) {
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(mu, s->d_mu, (size_t)s->B * sizeof(double), hipMemcpyDeviceToHost));
+    return DOJO_OK;
+}
+
+// Diagnostics of the final linearization of every environment's last step (quad mappings), fp64 [B, 2]:
+// [0] max γ/s over its cones (what dojo_set_refinement's threshold is compared with), [1] the largest multiplier of the
+// un-pivoted Gauss-Jordan eliminations (growth: ~1 for a well-scaled step, >> 1e3 when a joint row repeats a stiff contact row).
+// Switched on by the first call (the following steps record them).
+int dojo_get_diagnostics(DojoHandle s, double* diag) {
+    Enter enter_(s);
+    if (!s) { g_err = "dojo_get_diagnostics: bad argument"; return DOJO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    if (!s->d_diag) {
+        HIPCHK(hipMalloc((void**)&s->d_diag, (size_t)s->B * 2 * sizeof(double)));
+        HIPCHK(hipMemset(s->d_diag, 0, (size_t)s->B * 2 * sizeof(double)));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    if (diag) HIPCHK(hipMemcpy(diag, s->d_diag, (size_t)s->B * 2 * sizeof(double), hipMemcpyDeviceToHost));
     return DOJO_OK;
 }
 

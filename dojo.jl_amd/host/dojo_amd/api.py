@@ -35,7 +35,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.dojo_last_error.restype = C.c_char_p
         L.dojo_handle_error.restype = C.c_char_p; L.dojo_handle_error.argtypes = [C.c_void_p]
-        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_step_impulses", "dojo_get_mu", "dojo_next_state", "dojo_next_state_dev",
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_step_impulses", "dojo_get_mu", "dojo_get_diagnostics", "dojo_next_state", "dojo_next_state_dev",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -47,7 +47,7 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_next_state", "dojo_next_state_dev", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
+EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_get_diagnostics", "dojo_next_state", "dojo_next_state_dev", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
                     "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -168,6 +168,13 @@ class BatchedMechanism:
         z = self._arr(z, (self.batch, self.spec.nz)); zo = np.empty_like(z)
         _chk(lib().dojo_next_state(self.h, _p(z), _p(zo)))
         return zo
+
+    def diagnostics(self, read=True):
+        """[B, 2]: max gamma/s of the cones and the largest Gauss-Jordan multiplier at the last step's final linearization
+        (the first call switches the recording on)"""
+        dg = np.zeros((self.batch, 2)) if read else None
+        _chk(lib().dojo_get_diagnostics(self.h, _p(dg)))
+        return dg
 
     def get_mu(self):
         mu = np.empty(self.batch, np.float64)

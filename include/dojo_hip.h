@@ -209,6 +209,10 @@ int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_s
  * the last step returned, fp64 [B]: a mehrotra! drop-in writes it back and calls set_entries! so that mechanism.system
  * holds the final un-factored Jacobian and residual like the reference leaves it (src/solver/mehrotra.jl:69). */
 int  dojo_get_mu(DojoHandle h, double* mu);
+/* Diagnostics of the final linearization of every environment's last step (quad mappings), fp64 [B, 2]: [0] max gamma/s over
+ * its cones (what dojo_set_refinement's threshold is compared with), [1] the largest multiplier of the device's un-pivoted
+ * Gauss-Jordan eliminations.  The first call switches the recording on (diag may be NULL), later calls read the last step. */
+int  dojo_get_diagnostics(DojoHandle h, double* diag);
 
 /* IFT Jacobians of the last dojo_step(..., with_gradient=1):
  * dz [B,12Nb,12Nb] = jacobian_state, du [B,12Nb,nu] = jacobian_control, row-major per environment

@@ -22,6 +22,9 @@ if refine is not None:
     gm.set_refinement(float(refine))
 o = Oracle(spec, opts=opts)
 bad = []
+DIAG = os.environ.get("HUNT_DIAG") == "1"
+if DIAG:
+    gm.diagnostics(read=False)
 t0 = time.time()
 for k in range(steps):
     zn, st, it = gm.step(Z, U, with_gradient=with_grad)
@@ -38,6 +41,16 @@ for k in range(steps):
     print("step %2d conv gpu %.4f orc %.4f | iters differ %4d | status differ %3d | ez q50 %.1e q99 %.1e max %.1e (>1e-6: %d) | eg q50 %.1e q99 %.1e max %.1e (>1e-6: %d) | %.0fs"
           % (k, (st == 0).mean(), (st_o == 0).mean(), int((it[ok] != it_o[ok]).sum()), int((st != st_o).sum()), q(ez, .5), q(ez, .99), q(ez, 1.0), int((ez[ok] > 1e-6).sum()),
              q(eg, .5), q(eg, .99), q(eg, 1.0), int((eg[ok] > 1e-6).sum()), time.time() - t0), flush=True)
+    if DIAG:
+        dg = gm.diagnostics()
+        w_, g_ = dg[ok, 0], dg[ok, 1]
+        hit = eg[ok] > 1e-6
+        print("   diag: growth q50 %.1e q90 %.1e q99 %.1e q99.9 %.1e | stiffness q50 %.1e q99 %.1e" % (np.quantile(g_, .5), np.quantile(g_, .9), np.quantile(g_, .99), np.quantile(g_, .999), np.quantile(w_, .5), np.quantile(w_, .99)))
+        for thr in (1e4, 1e5, 1e6, 1e7):
+            fl = g_ > thr
+            print("   growth > %.0e: flagged %.4f of the envs, catches %d of %d with eg > 1e-6; worst uncaught eg %.1e" % (thr, fl.mean(), int((fl & hit).sum()), int(hit.sum()), eg[ok][~fl].max()))
+        if hit.any():
+            print("   eg>1e-6 envs: growth", np.array2string(np.sort(g_[hit]), precision=1), "stiffness", np.array2string(np.sort(w_[hit]), precision=1))
     score = np.where(ok, np.maximum(ez, eg), 0.0) + np.where(st != st_o, 1.0, 0.0)
     for b in np.argsort(-score)[:8]:
         if score[b] > 1e-7:
