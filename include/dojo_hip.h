@@ -36,8 +36,8 @@
  * the device, which are column-major per environment (dz[B][column][row]: Julia-native, and what the kernels write coalesced).  Scalars are fp64
  * (dtype 0) or fp32 (dtype 1) as chosen at dojo_create; topology/option structs are
  * always fp64 and are cast on upload.  No exception crosses the boundary: every entry
- * point returns DOJO_OK (0) or a negative error code and dojo_last_error() gives text (one
- * process-wide string: call the library from one thread per process, as Julia does).
+ * point returns DOJO_OK (0) or a negative error code; dojo_last_error() gives the text of the last
+ * failure in the process (one mutex-guarded string) and dojo_handle_error(h) the last failure on that handle.
  *
  * Pointer arguments are *host* pointers for the plain entry points and *device*
  * pointers for the `_dev` variants (used by bench.py / torch so that inputs are
