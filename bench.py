@@ -130,12 +130,12 @@ def main():
     torch.cuda.synchronize()                                                              # of the rollout, where (almost) nothing stalls
     one_step(0)
     torch.cuda.synchronize()
-    gm.kernel_time_totals(reset=True)
-    for k in range(1, 1 + min(K, 6)):
+    per_launch = []
+    for k in range(1, 1 + min(K, 8)):
         one_step(k)
-    torch.cuda.synchronize()
-    a_ms, b_ms, n_l = gm.kernel_time_totals()
-    step_ms, ift_ms = a_ms / max(n_l, 1), b_ms / max(n_l, 1)
+        per_launch.append(gm.last_kernel_times())        # (step kernel ms, IFT kernel ms) of this launch; waits for its end event
+    step_ms = sum(a for a, _ in per_launch) / len(per_launch); ift_ms = sum(b for _, b in per_launch) / len(per_launch)
+    step_ms_best = min(a for a, _ in per_launch); ift_ms_best = min(b for _, b in per_launch)
 
     if rank == 0:
         nb, nu = spec.Nb, spec.nu
@@ -166,6 +166,12 @@ def main():
             return r
         r_step = roof("dojo_step_kernel", step_ms, bytes_fwd * B)
         r_ift = roof("dojo_grad_kernel", ift_ms, bytes_grad * B) if grad else None
+        # the same figure for the shortest of those launches: a launch whose environments all converge in ~10 iterations (a stalled
+        # environment keeps one wavefront busy for 50 iterations with exhausted line searches, 5-10x the rest of the launch)
+        for r, best in ((r_step, step_ms_best), (r_ift, ift_ms_best)):
+            if r is not None and r.get("executed_fp64_flops_per_launch") and best > 0:
+                a_ = r["executed_fp64_flops_per_launch"] / (best * 1e-3) / 1e12
+                r["best_launch"] = {"kernel_ms": best, "achieved": a_, "frac": a_ / FP64_VECTOR_PEAK_TFLOPS}
         dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
         dominant["note"] = ("fp64 vector-ALU-bound lane program; durations from hipEvents on the launch stream with the batch as ONE launch per kernel "
                             "(measured after the timed region); the HBM roofline asked for by the contract is the `hbm` member")

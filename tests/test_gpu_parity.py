@@ -1118,3 +1118,35 @@ def test_literal_step_return_value():
         zs, info = o.step(Z[b], U[b])
         if info["status"] == 0 and st[b] == 0:
             assert np.abs(zn[b] - zs).max() < 1e-6 and np.abs(zr[b] - info["z_return"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg,batch", [(2, 1000), (3, 65), (4, 33)])
+def test_ragged_batches_with_refinement(cfg, batch):
+    """Tight tolerances: the refining kernels take over some environments of a wavefront (sixteen block environments share
+    one) and leave the others to the plain kernels.  Every environment's result must not depend on the batch it ran in, and
+    must be the oracle's."""
+    spec = d.baseline_config(cfg)
+    Z0, U = d.synthetic_inputs(spec, batch)
+    o = Oracle(spec, opts=TIGHT)
+    Z = Z0.copy()
+    for _ in range(40 if cfg == 2 else 8):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=16)
+    Z[::2] = Z0[::2]                                                 # every other environment still in free flight: interleaved inside the wavefronts
+    gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=TIGHT)
+    gm.diagnostics(read=False)
+    zn, st, it = gm.step(Z, U, with_gradient=True)
+    dz, du = gm.gradients()
+    dg = gm.diagnostics()
+    gm.close()
+    assert (dg[:, 0] > 1e4).any() and (dg[:, 0] < 1e4).any()          # both kinds of environment are present
+    g1 = api.BatchedMechanism(spec, 1, dtype="f64", opts=TIGHT)
+    picks = sorted({0, batch // 2, batch - 1, int(np.argmax(dg[:, 0])), int(np.argmin(dg[:, 0]))})
+    for b in picks:
+        z1, s1, i1 = g1.step(Z[b:b + 1], U[b:b + 1], with_gradient=True)
+        dz1, du1 = g1.gradients()
+        assert np.array_equal(z1[0], zn[b]) and s1[0] == st[b] and i1[0] == it[b]
+        assert np.array_equal(dz1[0], dz[b]) and np.array_equal(du1[0], du[b])
+        zo, info = o.step(Z[b], U[b])
+        if info["status"] == 0 and st[b] == 0 and it[b] <= REGULAR_ITERS:
+            assert info["iters"] == it[b] and np.abs(zn[b] - zo).max() < 1e-6
+    g1.close()
