@@ -270,9 +270,12 @@ def measured_valu_utilization():
 def cpu_baseline(spec, grad):
     """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on all host cores: one
     persistent thread per core, every thread owns a copy of the mechanism and walks 64 environments of the same synthetic
-    batch (dense KKT, partial-pivot LU WITHOUT the checker's refinement rounds: one factorization and two solves per
-    Newton iteration like src/solver/mehrotra.jl:36-49, one dense solve for the IFT like src/gradients/state.jl:99);
-    rounds are added until >= 10 s of CPU work have been timed.  The clock starts once all threads are running."""
+    batch, once per solver variant; the clock starts when all threads are running.  Linear solves without the checker's
+    refinement rounds: one factorization and two solves per Newton iteration like src/solver/mehrotra.jl:36-49, one
+    factorization + 170 right-hand sides for the IFT (src/gradients/state.jl:99).
+      value  = the BLOCK-SPARSE variant SURVEY.md §8d asks for: sparse LU without pivoting in the elimination order of the
+               mechanism graph (contacts and limits first, then the tree leaves -> root), the structure of the reference's LDU;
+      dense  = the dense 206 x 206 partial-pivot LU (what the checker itself uses, without its refinement)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dojo_amd as d
     from oracle import Oracle
@@ -281,15 +284,15 @@ def cpu_baseline(spec, grad):
     o.set_refine_steps(0)
     nsample = 64 * cores
     Z, U = d.synthetic_inputs(spec, nsample)
-    el = o.time_batch(Z, U, with_grad=grad, nthreads=cores, rounds=1)
-    rounds = 1
-    if el * cores < 10.0:
-        extra = int(min(64, max(1, (10.0 / max(el * cores, 1e-3)))))
-        el += o.time_batch(Z, U, with_grad=grad, nthreads=cores, rounds=extra)
-        rounds += extra
-    return {"value": nsample * rounds / el, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_seconds": el * cores,
-            "sample": "%d Ant env-steps (fwd%s): %d rounds over 64 synthetic environments per thread on %d persistent threads; C++ oracle, dense 206x206 KKT, "
-                      "plain partial-pivot LU (block-sparse variant not built)" % (nsample * rounds, "+grad" if grad else "", rounds, cores)}
+    out = {}
+    for name, sparse in (("sparse", True), ("dense", False)):
+        o.set_sparse_solver(sparse)
+        el = o.time_batch(Z, U, with_grad=grad, nthreads=cores, rounds=1)
+        out[name] = {"value": nsample / el, "cpu_seconds": el * cores}
+    return {"value": out["sparse"]["value"], "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],
+            "dense": out["dense"]["value"],
+            "sample": "%d Ant env-steps (fwd%s) per variant: 64 synthetic environments per thread on %d persistent threads; C++ oracle, fp64; value = block-sparse "
+                      "no-pivot LU in the mechanism graph's elimination order, dense = 206x206 partial-pivot LU" % (nsample, "+grad" if grad else "", cores)}
 
 
 if __name__ == "__main__":

@@ -39,6 +39,8 @@ struct IOracle {
     virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
     virtual void set_refine_steps(int n) = 0;
+    virtual void set_sparse_solver(int on) = 0;
+    virtual long long sparse_flops() = 0;
     virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
     virtual void maximal_to_minimal(const double* z, double* x) = 0;
     virtual void minimal_to_maximal(const double* x, double* z) = 0;
@@ -55,6 +57,8 @@ struct OracleT : IOracle {
         m.opts.max_iter = o.max_iter; m.opts.max_ls = o.max_ls; m.opts.no_progress_max = o.no_progress_max;
     }
     void set_refine_steps(int n) override { m.refine_steps = n; }
+    void set_sparse_solver(int on) override { m.sparse_solver = on != 0; }
+    long long sparse_flops() override { return m.splu.flops_factor; }
     void maximal_to_minimal(const double* z, double* x) override {
         int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
         std::vector<T> zz = cast(z, nz), xx(nm); m.maximal_to_minimal(zz.data(), xx.data()); for (int i = 0; i < nm; ++i) x[i] = (double)xx[i];
@@ -250,6 +254,9 @@ void orc_step_batch(void* h, int B, const double* z, const double* u, double* z_
 void orc_maximal_to_minimal(void* h, const double* z, double* x) { ((IOracle*)h)->maximal_to_minimal(z, x); }
 void orc_minimal_to_maximal(void* h, const double* x, double* z) { ((IOracle*)h)->minimal_to_maximal(x, z); }
 void orc_input_impulses(void* h, const double* z, const double* u, double* jf) { ((IOracle*)h)->input_impulses(z, u, jf); }
+// timing variant of the linear solves: 1 = sparse no-pivot LU in the elimination order of the mechanism graph (SparseLU)
+void orc_set_sparse_solver(void* h, int on) { ((IOracle*)h)->set_sparse_solver(on); }
+long long orc_sparse_flops(void* h) { return ((IOracle*)h)->sparse_flops(); }
 // rounds of iterative refinement of every linear solve (default 2: the checker; 0: a plain LU solve like the reference's)
 void orc_set_refine_steps(void* h, int n) { ((IOracle*)h)->set_refine_steps(n); }
 

@@ -22,6 +22,7 @@
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
 #pragma once
+#include <functional>
 #include "oracle_math.hpp"
 #include "../include/dojo_hip.h"
 #include <limits>
@@ -136,6 +137,8 @@ struct Mechanism {
     int last_iters = 0;
     bool verbose = false; T last_alpha = 1;
     int refine_steps = 2;         // rounds of iterative refinement of every linear solve (DenseLU::solve_refined); 0 = plain LU, as timed by bench.py's cpu_baseline
+    bool sparse_solver = false;   // timing variant: SparseLU (no pivoting, elimination order of the mechanism graph) instead of DenseLU
+    mutable SparseLU<T> splu;
     bool excessive_w = false;
 
     // ---------------- construction from the C-POD topology ----------------
@@ -1035,6 +1038,31 @@ struct Mechanism {
         }
     }
 
+    // Elimination order of the block-sparse timing variant: the cone pairs of every contact and joint limit first (each
+    // complementarity row paired with its γ column, each slack / constraint row with its s column, so that no pivot is a
+    // structural zero), then the kinematic tree leaves -> root with every joint's equality rows right after its child body --
+    // the order GraphBasedSystems' DFS gives the reference (contacts are leaves of the graph).
+    void build_sparse_order() const {
+        std::vector<int> pr, pc;
+        for (size_t j = 0; j < joints.size(); ++j) { int o = joff[j];
+            for (const Half<T>* h : {&joints[j].tra, &joints[j].rot}) { const int Nb = h->Nb();
+                for (int i = 0; i < Nb; ++i) { pr.push_back(o + Nb + i); pc.push_back(o + i); }          // slack row  <-> s
+                for (int i = 0; i < Nb; ++i) { pr.push_back(o + i); pc.push_back(o + Nb + i); }          // comp row   <-> γ
+                o += h->N(); } }
+        for (size_t k = 0; k < contacts.size(); ++k) { const int o = coff[k], nh = contacts[k].nh();
+            if (nh == 1) { pr.push_back(o + 1); pc.push_back(o); pr.push_back(o); pc.push_back(o + 1); continue; }
+            const int rws[8] = {4, 6, 7, 5, 0, 2, 3, 1}, cls[8] = {0, 2, 3, 5, 4, 6, 7, 1};              // (k1,s1) (k3,s3) (k4,s4) (k2,γ2) (c1,γ1) (c3,γ3) (c4,γ4) (c2,s2)
+            for (int i = 0; i < 8; ++i) { pr.push_back(o + rws[i]); pc.push_back(o + cls[i]); } }
+        std::vector<std::vector<int>> ch(bodies.size() + 1); std::vector<int> jof(bodies.size(), -1);
+        for (size_t j = 0; j < joints.size(); ++j) { ch[joints[j].parent + 1].push_back(joints[j].child); jof[joints[j].child] = (int)j; }
+        std::vector<int> stack, post; std::vector<char> seen(bodies.size() + 1, 0);
+        std::function<void(int)> dfs = [&](int b) { for (int c : ch[b + 1]) dfs(c); if (b >= 0) post.push_back(b); };
+        dfs(-1);
+        for (int b : post) { for (int i = 0; i < 6; ++i) { pr.push_back(boff[b] + i); pc.push_back(boff[b] + i); }
+            const int j = jof[b]; if (j < 0) continue; int o = joff[j];
+            for (const Half<T>* h : {&joints[j].tra, &joints[j].rot}) { const int Nb = h->Nb(); for (int i = 0; i < h->nl; ++i) { pr.push_back(o + 2 * Nb + i); pc.push_back(o + 2 * Nb + i); } o += h->N(); } }
+        splu.set_permutation(pr, pc);
+    }
     // =====================================================================
     // mehrotra!   src/solver/mehrotra.jl:9-73
     // =====================================================================
@@ -1051,8 +1079,11 @@ struct Mechanism {
             if (verbose) std::printf("%3d  bvio %.3e  rvio %.3e  alpha %.3e  mu %.3e\n", it, (double)bvio, (double)rvio, (double)last_alpha, (double)mutarget);
             if (rvio < T(opts.rtol) && bvio < T(opts.btol)) { status = DOJO_STATUS_SUCCESS; break; }
             rcache = b;                                   // pull_residual!
+            if (sparse_solver) { if (splu.n != n) build_sparse_order(); splu.factor(A); splu.solve(b.data(), 1); }
+            else {
             lu.factor(A, n);                              // ldu_factorization!
             lu.solve_refined(b.data(), 1, refine_steps);  // ldu_backsubstitution!  -> Δaff in b
+            }
             T aaff = cone_line_search(T(0.95), T(0.95));
             T nu_, nuaff; centering(aaff, nu_, nuaff);
             T ratio = nuaff / (nu_ + T(1e-20));
@@ -1063,7 +1094,7 @@ struct Mechanism {
             mu = mutarget;
             correction();
             b = rcache;                                   // push_residual!
-            lu.solve_refined(b.data(), 1, refine_steps);
+            if (sparse_solver) splu.solve(b.data(), 1); else lu.solve_refined(b.data(), 1, refine_steps);
             T tau = std::fmax(T(0.95), T(1) - std::fmax(rvio, bvio) * std::fmax(rvio, bvio));
             T alpha = cone_line_search(tau, std::fmin(tau, T(0.95)));
             last_alpha = alpha;
@@ -1486,7 +1517,8 @@ struct Mechanism {
         int nc = (int)cols.size();
         std::vector<T> R((size_t)n * nc);
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + cols[c]];
-        DenseLU<T> lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps);   // data_jacobian = solmat \ datamat
+        if (sparse_solver) { if (splu.n != n) build_sparse_order(); splu.factor(solmat); splu.solve(R.data(), nc); }
+        else { DenseLU<T> lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps); }   // data_jacobian = solmat \ datamat
         std::fill(jac_state, jac_state + (size_t)nx * nx, T(0));
         std::fill(jac_control, jac_control + (size_t)nx * nu_, T(0));
         auto out = [&](int row, int c) -> T& { return c < nx ? jac_state[(size_t)row * nx + c] : jac_control[(size_t)row * nu_ + (c - nx)]; };

@@ -38,6 +38,7 @@ def lib():
             getattr(_lib, name).restype = None
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_set_refine_steps.restype = None
+        _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
@@ -196,6 +197,13 @@ class Oracle:
     def set_refine_steps(self, n):
         """rounds of iterative refinement of every linear solve: 2 (default) = the checker, 0 = plain LU like the reference's direct solve"""
         lib().orc_set_refine_steps(self.h, int(n))
+
+    def set_sparse_solver(self, on=True):
+        """timing variant (bench.py cpu_baseline): sparse LU without pivoting in the elimination order of the mechanism graph"""
+        lib().orc_set_sparse_solver(self.h, int(bool(on)))
+
+    def sparse_flops(self):
+        return int(lib().orc_sparse_flops(self.h))
 
     def time_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1, rounds=1):
         """wall-clock seconds for `rounds` passes over the batch on `nthreads` persistent threads (results discarded)"""

@@ -293,4 +293,64 @@ struct DenseLU {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Sparse LU WITHOUT pivoting on a row- and column-permuted matrix with a static fill pattern: what a block-sparse CPU
+// implementation of the reference's solve costs (GraphBasedSystems' LDU eliminates the graph leaves -> root without
+// pivoting; SURVEY.md §8d asks for this variant next to the dense one in bench.py's cpu_baseline).  Timing
+// infrastructure: the checker itself stays on DenseLU::solve_refined.
+//   A' = A[prow][:, pcol];  pattern = entries of A' that were ever non-zero, closed under elimination (symbolic phase,
+//   redone when a later matrix has an entry outside it); numeric phase and solves visit pattern entries only.
+// ---------------------------------------------------------------------------
+template <class T>
+struct SparseLU {
+    int n = 0; std::vector<int> prow, pcol;           // A'(i, j) = A(prow[i], pcol[j])
+    std::vector<char> pat;                            // n x n, closed under elimination
+    std::vector<std::vector<int>> lrows, ucols;       // per pivot k: rows i > k with (i,k) in the pattern, columns j > k with (k,j)
+    std::vector<T> w;                                 // n x n working copy: L (unit, multipliers) and U in place
+    bool analyzed = false; long long flops_factor = 0;
+    void set_permutation(const std::vector<int>& pr, const std::vector<int>& pc) { prow = pr; pcol = pc; n = (int)pr.size(); analyzed = false; }
+    void analyze(const std::vector<T>& A) {
+        pat.assign((size_t)n * n, 0);
+        for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) if (A[(size_t)prow[i] * n + pcol[j]] != T(0)) pat[(size_t)i * n + j] = 1; pat[(size_t)i * n + i] = 1; }
+        lrows.assign(n, {}); ucols.assign(n, {}); flops_factor = 0;
+        for (int k = 0; k < n; ++k) {
+            for (int i = k + 1; i < n; ++i) if (pat[(size_t)i * n + k]) lrows[k].push_back(i);
+            for (int j = k + 1; j < n; ++j) if (pat[(size_t)k * n + j]) ucols[k].push_back(j);
+            for (int i : lrows[k]) for (int j : ucols[k]) pat[(size_t)i * n + j] = 1;              // fill
+            flops_factor += 2LL * (long long)lrows[k].size() * (long long)ucols[k].size();
+        }
+        w.assign((size_t)n * n, T(0)); analyzed = true;
+    }
+    bool factor(const std::vector<T>& A) {
+        if (!analyzed) analyze(A);
+        for (int i = 0; i < n; ++i) { const T* ai = &A[(size_t)prow[i] * n]; T* wi = &w[(size_t)i * n]; const char* pi = &pat[(size_t)i * n];
+            for (int j = 0; j < n; ++j) { const T v = ai[pcol[j]]; if (v != T(0) && !pi[j]) { analyze_union(A); return factor(A); } wi[j] = pi[j] ? v : T(0); } }
+        for (int k = 0; k < n; ++k) {
+            const T piv = w[(size_t)k * n + k]; if (piv == T(0)) return false;
+            const T ip = T(1) / piv; const T* wk = &w[(size_t)k * n];
+            for (int i : lrows[k]) { T* wi = &w[(size_t)i * n]; const T f = wi[k] * ip; wi[k] = f; if (f != T(0)) for (int j : ucols[k]) wi[j] -= f * wk[j]; }
+        }
+        return true;
+    }
+    void analyze_union(const std::vector<T>& A) {        // a matrix with entries outside the pattern: widen it
+        std::vector<char> old = pat; const bool had = analyzed;
+        analyze(A);
+        if (had) { for (size_t i = 0; i < old.size(); ++i) if (old[i]) pat[i] = 1;               // keep the old entries, close again
+            std::vector<T> ones((size_t)n * n, T(0)); for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (pat[(size_t)i * n + j]) ones[(size_t)prow[i] * n + pcol[j]] = T(1);
+            analyze(ones); }
+    }
+    // B[n][nrhs] row-major, rows in the ORIGINAL row order; the solution comes back in the original column (unknown) order
+    void solve(T* B, int nrhs) const {
+        std::vector<T> y((size_t)n * nrhs);
+        for (int i = 0; i < n; ++i) std::memcpy(&y[(size_t)i * nrhs], &B[(size_t)prow[i] * nrhs], sizeof(T) * nrhs);
+        for (int k = 0; k < n; ++k) { const T* yk = &y[(size_t)k * nrhs]; for (int i : lrows[k]) { const T f = w[(size_t)i * n + k]; if (f != T(0)) { T* yi = &y[(size_t)i * nrhs]; for (int j = 0; j < nrhs; ++j) yi[j] -= f * yk[j]; } } }
+        for (int k = n - 1; k >= 0; --k) {
+            T* yk = &y[(size_t)k * nrhs];
+            for (int c : ucols[k]) { const T f = w[(size_t)k * n + c]; if (f != T(0)) { const T* yc = &y[(size_t)c * nrhs]; for (int j = 0; j < nrhs; ++j) yk[j] -= f * yc[j]; } }
+            const T ip = T(1) / w[(size_t)k * n + k]; for (int j = 0; j < nrhs; ++j) yk[j] *= ip;
+        }
+        for (int i = 0; i < n; ++i) std::memcpy(&B[(size_t)pcol[i] * nrhs], &y[(size_t)i * nrhs], sizeof(T) * nrhs);
+    }
+};
+
 } // namespace orc

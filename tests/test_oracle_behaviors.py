@@ -184,3 +184,24 @@ def test_impact_contact_is_frictionless():
     assert abs(z[3] - 1.0) < 1e-9 and abs(z[4] - 0.5) < 1e-9 and abs(z[12] - 0.3) < 1e-9
     gam = o.get_solution()[6:].reshape(4, 2)[:, 1]
     assert abs(gam.sum() - 9.81 * spec.timestep) < 1e-6          # Σγ = m g Δt
+
+
+def test_block_sparse_timing_variant_matches_the_dense_solver():
+    """bench.py's cpu_baseline times a block-sparse variant of the oracle (SparseLU: no pivoting, elimination order of the
+    mechanism graph).  Same Newton iterate paths and, to round-off, the same states and Jacobians as the dense pivoted solver."""
+    import dojo_amd as d
+    from oracle import Oracle
+    for cfg in (2, 3, 4):
+        spec = d.baseline_config(cfg)
+        Z, U = d.synthetic_inputs(spec, 8)
+        o = Oracle(spec)
+        for _ in range(6):
+            Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+        Zd, sd, itd, dzd, dud = o.step_batch(Z, U, with_grad=True, nthreads=4)
+        o.set_sparse_solver(True); o.set_refine_steps(0)
+        Zs, ss, its, dzs, dus = o.step_batch(Z, U, with_grad=True, nthreads=4)
+        ok = (sd == 0) & (ss == 0)
+        assert np.array_equal(sd, ss) and np.array_equal(itd[ok], its[ok])
+        assert np.abs(Zd[ok] - Zs[ok]).max() < 1e-9
+        for b in np.nonzero(ok)[0]:
+            assert np.abs(dzd[b] - dzs[b]).max() <= 1e-6 * max(1.0, np.abs(dzd[b]).max())
