@@ -222,7 +222,7 @@ def parity_vs_cpu(spec, B, device):
         gm = g64 if name == "f64" else api.BatchedMechanism(spec, B, dtype="f32", device=device)
         zn, st, it = gm.step(Zi, Ui, with_gradient=True)
         dz, du = gm.gradients()
-        Zo, st_o, it_o, dz_o, du_o = o.step_batch(Zi.astype(np.float64), Ui.astype(np.float64), with_grad=True, nthreads=cores)
+        Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Zi) if name == "f32" else Zi, Ui.astype(np.float64), with_grad=True, nthreads=cores)   # fp32: the state the buffer stands for
         ok = (st == 0) & (st_o == 0)
         ez = np.abs(zn.astype(np.float64) - Zo).max(axis=1)[ok]
         eg = np.array([max(np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()), np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max())) for b in np.nonzero(ok)[0]])

@@ -3007,6 +3007,10 @@ constexpr int FAC_PER_LANE = 72;
     DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
     for (int i = 0; i < 13; ++i) zb[i] = active ? T(A.z[(size_t)env * 13 * G.Nb + 13 * k + i]) : T(0);                   \
+    if (sizeof(TIO) < sizeof(T) && active) {   /* a narrower ABI type cannot hold a unit quaternion: the state it stands for is (x, v, q/|q|, ω) */ \
+        const T iq_ = trcp(tsqrt(zb[6] * zb[6] + zb[7] * zb[7] + zb[8] * zb[8] + zb[9] * zb[9]));                         \
+        for (int i = 6; i < 10; ++i) zb[i] *= iq_;                                                                        \
+    }                                                                                                                     \
     const bool has_u = A.u != nullptr;                                                                                    \
     if (active && has_u) for (int i = 0; i < 6; ++i) if (i < P.nu_t + P.nu_r) ue[i] = T(A.u[(size_t)env * G.nu + P.u_off + i]); \
     T fe[6] = {0, 0, 0, 0, 0, 0};                                                                                         \

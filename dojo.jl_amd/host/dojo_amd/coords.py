@@ -225,3 +225,13 @@ def synthetic_inputs(spec, batch, seed=20241008, height=0.3, rot_sigma=0.1, vel_
             o += 2 * n; iu += n
         Z[b] = minimal_to_maximal(spec, x)
     return Z, U
+
+
+def fp32_abi_state(Z):
+    """The fp64 state an fp32-ABI buffer stands for (include/dojo_hip.h): values rounded to fp32, every quaternion
+    renormalized -- what the CPU oracle is given when it is compared with an fp32-ABI handle."""
+    Zr = np.asarray(Z, dtype=np.float32).astype(np.float64)
+    shp = Zr.shape
+    Zb = Zr.reshape(-1, 13)
+    Zb[:, 6:10] /= np.linalg.norm(Zb[:, 6:10], axis=1, keepdims=True)
+    return Zb.reshape(shp)

@@ -35,7 +35,10 @@
  * z[B][13*Nb], u[B][nu], dz[B][12*Nb][12*Nb], du[B][12*Nb][nu] -- except the Jacobians the `_dev` variants leave on
  * the device, which are column-major per environment (dz[B][column][row]: Julia-native, and what the kernels write coalesced).  Scalars are fp64
  * (dtype 0) or fp32 (dtype 1) as chosen at dojo_create; topology/option structs are
- * always fp64 and are cast on upload.  No exception crosses the boundary: every entry
+ * always fp64 and are cast on upload.  All arithmetic is fp64 in both modes.  An fp32 buffer cannot hold a unit
+ * quaternion: with dtype 1 the state a z stands for is (x, v, q/|q|, omega), the kernels normalize q on load (the
+ * reference never renormalizes; its formulas mix rotation_matrix, which scales with |q|^2, and vector_rotate, which
+ * does not, so a 1e-7 norm error would otherwise be amplified by stiff contacts).  No exception crosses the boundary: every entry
  * point returns DOJO_OK (0) or a negative error code; dojo_last_error() gives the text of the last
  * failure in the process (one mutex-guarded string) and dojo_handle_error(h) the last failure on that handle.
  *

@@ -13,7 +13,7 @@ g64 = api.BatchedMechanism(spec, B, dtype="f64"); g32 = api.BatchedMechanism(spe
 for _ in range(8):
     Z, st, it = g64.step(Z, U)
 Z32 = Z.astype(np.float32); U32 = U.astype(np.float32)
-Zr = Z32.astype(np.float64); Ur = U32.astype(np.float64)
+Zr = d.fp32_abi_state(Z32); Ur = U32.astype(np.float64)
 za, sa, ia = g64.step(Zr, Ur, with_gradient=True); dza, dua = g64.gradients()
 zb, sb, ib = g32.step(Z32, U32, with_gradient=True); dzb, dub = g32.gradients()
 o = Oracle(spec)
