@@ -87,8 +87,16 @@ def main():
         gm.set_groups(args.chunks)
     gm.set_async(True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
-    if args.backend == "nccl":
-        D.connect_handle(gm, rank, world)        # the library's own RCCL communicator (dojo_comm_init), id carried by torch.distributed
+    lib_gather = False
+    if args.backend == "nccl" and world > 1 and os.environ.get("DOJO_BENCH_GATHER", "library") == "library":
+        try:
+            D.connect_handle(gm, rank, world)    # the library's own RCCL communicator (dojo_comm_init), id carried by torch.distributed
+            lib_gather = True
+        except Exception as e:                   # (never seen; the torch collective below is the same RCCL all-gather)
+            print("dojo_comm_init failed on rank %d (%s): gathering with torch.distributed" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([1 if lib_gather else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks or none
+        lib_gather = bool(flag.item())
 
     def ptr(t):
         return C.c_void_p(0 if t is None else t.data_ptr())
@@ -114,7 +122,8 @@ def main():
         one_step(k)
     gm.join(torch.cuda.current_stream().cuda_stream)       # the environment groups -> torch's stream
     if args.backend == "nccl":
-        z_all = D.all_gather_states_rccl(gm, z, world)  # dojo_allgather_dev: the final states over RCCL/xGMI, once per rollout chunk
+        # the final states over RCCL/xGMI, once per rollout chunk: dojo_allgather_dev (the library's communicator), else torch's
+        z_all = D.all_gather_states_rccl(gm, z, world) if lib_gather else D.all_gather_states(z, world)
     else:
         torch.cuda.synchronize(); z_all = D.all_gather_states(z.cpu(), world)
     barrier()

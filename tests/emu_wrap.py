@@ -30,7 +30,12 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False, quad=False, fext=None):
+def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, envs_per_wave=1, debug=False, quad=False, fext=None, refine=None):
+    """refine: stiffness threshold of the refining kernels (dojo_set_refinement); None = the library's policy (1e4 when the
+    tolerances are tighter than the reference's defaults, never otherwise).  Handed to the emulator in EMU_REFINE_W."""
+    o_ = opts or SolverOptions()
+    thr = refine if refine is not None else (1e4 if (o_.rtol <= 1e-7 or o_.btol <= 1e-6) else float("inf"))
+    os.environ["EMU_REFINE_W"] = "inf" if thr == float("inf") else repr(float(thr))
     Z = np.ascontiguousarray(np.atleast_2d(Z), dtype=np.float64); B = Z.shape[0]
     U = None if U is None else np.ascontiguousarray(np.atleast_2d(U), dtype=np.float64)
     topo, keep = spec.to_ctypes()

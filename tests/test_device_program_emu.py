@@ -319,3 +319,26 @@ def test_more_reference_mechanisms(name, kw, pre):
     dz, du = o.gradients(mode=1)
     assert np.abs(r["dz"][0] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
     assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
+
+
+@pytest.mark.parametrize("cfg,pre", [(3, 6), (1, 2)])
+def test_refining_kernels_match_oracle(cfg, pre):
+    """The refining twins of the two kernels (dojo_stepp_kernel / dojo_gradp_kernel: iterative refinement of every Newton
+    solve and of every IFT column against the uncondensed blocks) with every environment sent there (threshold 0, as
+    dojo_set_refinement(h, 0) does), next to the plain kernels: the same iteration count as the oracle, and a refined
+    gradient closer to the oracle's than 1e-7."""
+    spec = d.baseline_config(cfg)
+    o = Oracle(spec, opts=TIGHT)
+    Z, U = d.synthetic_inputs(spec, 1)
+    z, u = Z[0], U[0]
+    for _ in range(pre):
+        z, _ = o.step(z, u)
+    zo, info = o.step(z, u)
+    dz, du = o.gradients(0)
+    r = emu_step(spec, z, u, opts=TIGHT, grad=True, quad=True, refine=0.0)
+    p = emu_step(spec, z, u, opts=TIGHT, grad=True, quad=True, refine=float("inf"))
+    assert r["status"][0] == info["status"] == 0 and r["iters"][0] == info["iters"]
+    assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+    scale = max(1.0, np.abs(dz).max())
+    assert np.abs(r["dz"][0] - dz).max() < 1e-7 * scale and np.abs(r["du"][0] - du).max() < 1e-7 * scale
+    assert np.abs(p["dz"][0] - dz).max() < 1e-5 * scale        # the plain kernels: usable, not refined
