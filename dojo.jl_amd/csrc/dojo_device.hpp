@@ -75,6 +75,9 @@ constexpr double REG = 1e-10;     // src/Dojo.jl:4
 #define DJ_STATUS_SUCCESS 0
 #define DJ_STATUS_FAILED 1
 #define DJ_STATUS_EXCESSIVE_W 2
+#ifndef DJ_TRACK_GROWTH
+#define DJ_TRACK_GROWTH 0          // 1: the Gauss-Jordan passes record their largest |multiplier| (dojo_get_diagnostics, tools/hunt_parity.py); ~2 % of the step kernel
+#endif
 #define DJ_STATUS_DEFERRED 3      // internal: the environment's cones became stiff; the refining kernels re-solve it (never reaches the caller)
 
 template <class T>
@@ -1218,6 +1221,7 @@ struct LaneProgram {
     // Also reduces the stiffness of the evaluated iterate, wstiff = max γ/s over the cones of the environment (DJ_REFINE).
     DJ_HD void violations(T& rvio, T& bvio) {
         T r = T(0), b = T(0), wq = T(0);
+        const bool track_stiffness = G.refine_w < T(1e300);      // wave-uniform: no threshold (reference-default options), no stiffness arithmetic
         if (active) {
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rb[i]));
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rj[i]));          // only the Nλ equality rows (padded slots are 0)
@@ -1231,14 +1235,14 @@ struct LaneProgram {
                     b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
                     b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
                 }
-                if constexpr (kTrack) {
+                if (kTrack && track_stiffness) {
                     wq = tmax(wq, (g[0] + T(REG)) * trcp(s[0] + T(REG)));
                     if (G.contact_model == 0) wq = tmax(wq, (g[1] + T(REG)) * trcp(s[1] + T(REG)));
                 }
             }
             if (lim_on()) {
                 b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1]));
-                if constexpr (kTrack) { wq = tmax(wq, (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG))); wq = tmax(wq, (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG))); }
+                if (kTrack && track_stiffness) { wq = tmax(wq, (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG))); wq = tmax(wq, (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG))); }
             }
         }
         if constexpr (QUAD && DJ_LDS_REDUCE) {
@@ -1386,7 +1390,7 @@ struct LaneProgram {
     // shuffles and every lane updates its three rows.  No W / Z are stored: the solves use the row
     // block of S⁻¹ together with the lane's rows of U and columns of L.
     DJ_HD void factorize_quad(QuadBlocks<TL>& K) {
-        if constexpr (kTrack) growth = T(0);
+        if constexpr (kTrack && DJ_TRACK_GROWTH) growth = T(0);
         // F.Sq holds the raw rows until the lane's level is reached and the inverse rows afterwards:
         // the elimination runs in place and is a no-op (fe = 0) on lanes that are not at the level.
         TL up[3][6];
@@ -1441,7 +1445,7 @@ struct LaneProgram {
                     const TL f = A[r][p];
                     const TL g = f * ip;
                     const TL ge = at ? g : TL(0);
-                    if constexpr (kTrack) { const TL ag = ge < TL(0) ? -ge : ge; growth = (r == ro && own) ? growth : tmax(growth, T(ag)); }
+                    if constexpr (kTrack && DJ_TRACK_GROWTH) { const TL ag = ge < TL(0) ? -ge : ge; growth = (r == ro && own) ? growth : tmax(growth, T(ag)); }
                     const TL fe = (r == ro) ? (own ? TL(0) : ge) : ge;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) if (c != p) A[r][c] -= fe * prow[c];

@@ -377,13 +377,23 @@ int acquire_slot(DojoSim* s, int* idx) {
 // environment running into max_iter (one wavefront, ~5x the mean step time) delays only itself while the other groups'
 // launches keep the GPU busy.  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 // streams that share a queue serialize, so the count stays below that.
+// Refinement threshold: explicit (dojo_set_refinement) or tied to the requested tolerances -- the reference's defaults
+// (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
+double refine_threshold(const DojoSim* s) {
+    return s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol <= 1e-7 || s->opts.btol <= 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
+}
 size_t group_count(const DojoSim* s, bool want) {
     const size_t B = (size_t)s->B;
     size_t NG = (want && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
     if (s->groups > 0) NG = std::min<size_t>((size_t)s->groups, std::max<size_t>(1, B / 64));
     const char* hq = getenv("GPU_MAX_HW_QUEUES");
     const int nq = hq ? atoi(hq) : 4;
-    return std::min<size_t>(NG, (size_t)std::max(1, nq - 1));
+    NG = std::min<size_t>(NG, (size_t)std::max(1, nq - 1));
+    // The refining kernels keep 2-6 KB of scratch per lane, and ROCr sizes a hardware queue's scratch for a full GPU of such
+    // wavefronts (~3 GB): sixteen queues asking for it at once end in HSA_STATUS_ERROR_OUT_OF_RESOURCES (the queue aborts the
+    // process).  With refinement in force the batch is stepped as at most three groups (seen green; the default queue count).
+    if (std::isfinite(refine_threshold(s))) NG = std::min<size_t>(NG, 3);
+    return NG;
 }
 int ensure_groups(DojoSim* s, size_t NG) {
     while (s->gstreams.size() < NG) {
@@ -410,9 +420,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
     auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
     dj::KernelArgs<TIO, T> A;
-    // Refinement threshold: explicit (dojo_set_refinement) or tied to the requested tolerances -- the reference's defaults
-    // (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
-    const double rw_ = s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol <= 1e-7 || s->opts.btol <= 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
+    const double rw_ = refine_threshold(s);
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode, rw_);
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);

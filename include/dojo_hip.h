@@ -214,7 +214,9 @@ int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_s
 int  dojo_get_mu(DojoHandle h, double* mu);
 /* Diagnostics of the final linearization of every environment's last step (quad mappings), fp64 [B, 2]: [0] max gamma/s over
  * its cones (what dojo_set_refinement's threshold is compared with), [1] the largest multiplier of the device's un-pivoted
- * Gauss-Jordan eliminations.  The first call switches the recording on (diag may be NULL), later calls read the last step. */
+ * Gauss-Jordan eliminations.  The first call switches the recording on (diag may be NULL), later calls read the last step.
+ * [0] is 0 while no refinement threshold is in force (reference-default options and no dojo_set_refinement: the kernels then
+ * skip the stiffness arithmetic); [1] is 0 unless the library was built with -DDJ_TRACK_GROWTH=1 (a diagnostics build). */
 int  dojo_get_diagnostics(DojoHandle h, double* diag);
 
 /* IFT Jacobians of the last dojo_step(..., with_gradient=1):
