@@ -59,6 +59,8 @@ def main():
     dev = torch.device("cuda", local)
 
     spec = d.baseline_config(args.config)
+    if os.environ.get("DOJO_BENCH_ONE_CONTACT_PER_BODY") == "1":     # kernel experiments only (tools/gpu_r2_i.sh): a different mechanism, never a reported configuration
+        seen = set(); spec.contacts = [c for c in spec.contacts if not (c.body in seen or seen.add(c.body))]
     B, K, W = args.batch, args.steps, args.warmup
     tdt = torch.float32 if args.io_dtype == "f32" else torch.float64
     w = 4 if args.io_dtype == "f32" else 8

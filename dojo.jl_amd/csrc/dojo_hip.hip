@@ -41,13 +41,13 @@ extern "C" {
 DJ_DECL(dojo_launch_float_1_1) DJ_DECL(dojo_launch_float_4_1) DJ_DECL(dojo_launch_float_8_1)
 DJ_DECL(dojo_launch_double_1_1) DJ_DECL(dojo_launch_double_4_1) DJ_DECL(dojo_launch_double_8_1)
 DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launch_double_4_0) DJ_DECL(dojo_launch_double_8_0)
-DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2)
+DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_launch_float_1_2) DJ_DECL(dojo_launch_double_1_2)
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
 #define DJ_CDECL(n) int n(const void*, int, void*);
 DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
 DJ_CDECL(dojo_launch_cgrad_double_1_1) DJ_CDECL(dojo_launch_cgrad_double_4_1) DJ_CDECL(dojo_launch_cgrad_double_8_1)
-DJ_CDECL(dojo_launch_cgrad_float_4_2) DJ_CDECL(dojo_launch_cgrad_double_4_2)
+DJ_CDECL(dojo_launch_cgrad_float_4_2) DJ_CDECL(dojo_launch_cgrad_double_4_2) DJ_CDECL(dojo_launch_cgrad_float_1_2) DJ_CDECL(dojo_launch_cgrad_double_1_2)
 DJ_CDECL(dojo_launch_cgrad_tsd_float_1_1) DJ_CDECL(dojo_launch_cgrad_tsd_float_4_1) DJ_CDECL(dojo_launch_cgrad_tsd_double_1_1) DJ_CDECL(dojo_launch_cgrad_tsd_double_4_1)
 #undef DJ_DECL
 }
@@ -466,7 +466,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         typedef int (*claunch_t)(const void*, int, void*);
         claunch_t cf = s->M.has_tsd ? (s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_tsd_float_1_1 : dojo_launch_cgrad_tsd_double_1_1)
                                                       : (f32 ? dojo_launch_cgrad_tsd_float_4_1 : dojo_launch_cgrad_tsd_double_4_1))
-                     : NW == 2 ? (f32 ? dojo_launch_cgrad_float_4_2 : dojo_launch_cgrad_double_4_2)
+                     : NW == 2 ? (s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_float_1_2 : dojo_launch_cgrad_double_1_2) : (f32 ? dojo_launch_cgrad_float_4_2 : dojo_launch_cgrad_double_4_2))
                      : s->M.maxc <= 1 ? (f32 ? dojo_launch_cgrad_float_1_1 : dojo_launch_cgrad_double_1_1)
                      : s->M.maxc <= 4 ? (f32 ? dojo_launch_cgrad_float_4_1 : dojo_launch_cgrad_double_4_1)
                                       : (f32 ? dojo_launch_cgrad_float_8_1 : dojo_launch_cgrad_double_8_1);
@@ -479,7 +479,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     launcher_t fn;
     if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
                                           : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
-    else if (NW == 2) fn = f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2;
+    else if (NW == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_2 : dojo_launch_double_1_2) : (f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2);
     else if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
                  : s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_1 : dojo_launch_double_4_1)
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
