@@ -228,19 +228,24 @@ def parity_vs_cpu(spec, B, device):
     g64 = api.BatchedMechanism(spec, B, dtype="f64", device=device)
     for _ in range(8):
         Z, st, it = g64.step(Z, U)
-    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+    # f64_refined: the same step with every linear solve of every environment refined against the uncondensed blocks
+    # (dojo_set_refinement(h, 0): what a caller who needs the 1e-6 bound on EVERY environment switches on; slower, not the timed path)
+    for name, dt in (("f64", np.float64), ("f64_refined", np.float64), ("f32", np.float32)):
         Zi, Ui = Z.astype(dt), U.astype(dt)
-        gm = g64 if name == "f64" else api.BatchedMechanism(spec, B, dtype="f32", device=device)
+        gm = g64 if dt == np.float64 else api.BatchedMechanism(spec, B, dtype="f32", device=device)
+        if name == "f64_refined":
+            gm.set_refinement(0.0)
         zn, st, it = gm.step(Zi, Ui, with_gradient=True)
         dz, du = gm.gradients()
-        Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Zi) if name == "f32" else Zi, Ui.astype(np.float64), with_grad=True, nthreads=cores)   # fp32: the state the buffer stands for
+        if name != "f64_refined":                # (the refined leg is checked against the fp64 leg's oracle run: same inputs)
+            Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Zi) if name == "f32" else Zi, Ui.astype(np.float64), with_grad=True, nthreads=cores)   # fp32: the state the buffer stands for
         ok = (st == 0) & (st_o == 0)
         ez = np.abs(zn.astype(np.float64) - Zo).max(axis=1)[ok]
         eg = np.array([max(np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()), np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max())) for b in np.nonzero(ok)[0]])
         out[name] = {"converged_both": int(ok.sum()), "status_mismatch": int((st != st_o).sum()), "iters_mismatch": int((it[ok] != it_o[ok]).sum()),
                      "state_inf_err_max": float(ez.max()), "grad_inf_err_max": float(eg.max()), "grad_inf_err_q99": float(np.quantile(eg, 0.99)),
                      "grad_inf_err_q50": float(np.quantile(eg, 0.5)), "n_grad_err_above_1e-6": int((eg > 1e-6).sum())}
-        del dz, du, dz_o, du_o
+        del dz, du
         if gm is not g64:
             gm.close()
     g64.close()
