@@ -89,14 +89,32 @@ def main():
         gm.set_groups(args.chunks)
     gm.set_async(True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
-    lib_gather = False
-    if args.backend == "nccl" and world > 1 and os.environ.get("DOJO_BENCH_GATHER", "library") == "library":
-        try:
-            D.connect_handle(gm, rank, world)    # the library's own RCCL communicator (dojo_comm_init), id carried by torch.distributed
-            lib_gather = True
-        except Exception as e:                   # (never seen; the torch collective below is the same RCCL all-gather)
-            print("dojo_comm_init failed on rank %d (%s): gathering with torch.distributed" % (rank, e), file=sys.stderr)
-        flag = torch.tensor([1 if lib_gather else 0], device=dev)
+    lib_gather, lib_stuck = False, False
+    gather_pref = os.environ.get("DOJO_BENCH_GATHER", "library")       # "torch": never try the library's communicator; "library-force": try it under gloo too (plumbing check of the fall-back)
+    if world > 1 and ((args.backend == "nccl" and gather_pref == "library") or gather_pref == "library-force"):
+        # The library's own RCCL communicator (dojo_comm_init; the id travels over torch.distributed) and one probe gather,
+        # before the timed region and under a watchdog: this path has only ever run with one rank (the boxes of this pool have
+        # one GPU), so a failure or a hang must cost nothing but the fall-back to torch's all-gather (the same RCCL call).
+        import threading
+        res = {}
+
+        def _connect():
+            try:
+                torch.cuda.set_device(dev)
+                D.connect_handle(gm, rank, world)
+                probe = torch.full((8,), float(rank), device=dev, dtype=tdt)
+                got = D.all_gather_states_rccl(gm, probe, world)
+                torch.cuda.synchronize()
+                res["ok"] = bool((got.view(world, 8)[:, 0].cpu() == torch.arange(world, dtype=tdt)).all())
+            except Exception as e:
+                res["err"] = e
+        th = threading.Thread(target=_connect, daemon=True)
+        th.start(); th.join(float(os.environ.get("DOJO_BENCH_COMM_TIMEOUT", "120")))
+        lib_stuck = th.is_alive()
+        lib_gather = bool(res.get("ok", False)) and not lib_stuck
+        if not lib_gather:
+            print("rank %d: library RCCL communicator not usable (%s): gathering with torch.distributed" % (rank, "timeout" if lib_stuck else res.get("err", "probe mismatch")), file=sys.stderr)
+        flag = torch.tensor([1 if lib_gather else 0], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks or none
         lib_gather = bool(flag.item())
 
@@ -123,7 +141,7 @@ def main():
     for k in range(W, W + K):
         one_step(k)
     gm.join(torch.cuda.current_stream().cuda_stream)       # the environment groups -> torch's stream
-    if args.backend == "nccl":
+    if args.backend == "nccl" or lib_gather:
         # the final states over RCCL/xGMI, once per rollout chunk: dojo_allgather_dev (the library's communicator), else torch's
         z_all = D.all_gather_states_rccl(gm, z, world) if lib_gather else D.all_gather_states(z, world)
     else:
@@ -206,8 +224,12 @@ def main():
             res["grad_inf_err_vs_cpu"] = parity_vs_cpu(spec, B, local)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(spec, grad)
-        print(json.dumps(res))
+        if world > 1:
+            res["config"]["final_gather"] = "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"
+        print(json.dumps(res), flush=True)
     if world > 1:
+        if lib_stuck:                            # a thread is still inside the library's communicator set-up: leave without the teardown that would wait for it
+            sys.stdout.flush(); sys.stderr.flush(); os._exit(0)
         dist.destroy_process_group()
 
 
