@@ -213,6 +213,62 @@ function Dojo.get_minimal_gradients!(bm::BatchedMechanism{T}, x::Matrix{T}, u::M
     return permutedims(jx, (2, 1, 3)), permutedims(ju, (2, 1, 3)), xn, status
 end
 
+# ---- device-resident batches, scheduling, multi-GPU ------------------------------------------------
+# Everything below takes raw device pointers (Ptr{Cvoid}: `pointer(::ROCArray)` of AMDGPU.jl, or whatever allocator owns
+# the handle's GPU) and a hipStream_t as Ptr{Cvoid} (C_NULL = the null stream); nothing is synchronized (dojo_hip.h,
+# "device-pointer variants").  A training loop keeps z, u, dz, du on the device and calls step_dev! per step.
+const DevPtr = Ptr{Cvoid}
+
+"number of GPUs the library sees"
+device_count() = Int(@ccall $(fn(:dojo_device_count))()::Cint)
+
+"one differentiable step on device buffers: z [nz, B], u [nu, B] -> z_next, status [B], iters [B], dz [nx, nx, B], du [nx, nu, B] (dz = du = C_NULL: forward only)"
+function step_dev!(bm::BatchedMechanism, z::DevPtr, u::DevPtr, z_next::DevPtr, status::DevPtr, iters::DevPtr,
+                   dz::DevPtr=C_NULL, du::DevPtr=C_NULL; stream::DevPtr=C_NULL)
+    check(@ccall $(fn(:dojo_step_dev))(bm.handle::Ptr{Cvoid}, z::Ptr{Cvoid}, u::Ptr{Cvoid}, z_next::Ptr{Cvoid}, status::Ptr{Cvoid}, iters::Ptr{Cvoid},
+                                       dz::Ptr{Cvoid}, du::Ptr{Cvoid}, stream::Ptr{Cvoid})::Cint)
+end
+
+"environment groups of step_dev! (0: the library's choice, 1: one launch on the caller's stream); needs GPU_MAX_HW_QUEUES >= groups + 1"
+set_groups!(bm::BatchedMechanism, n::Integer) = check(@ccall $(fn(:dojo_set_groups))(bm.handle::Ptr{Cvoid}, n::Int32)::Cint)
+"asynchronous environment groups: consecutive step_dev! calls chain per group; join!(bm; stream) orders `stream` behind everything in flight"
+set_async!(bm::BatchedMechanism, on::Bool) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, on::Int32)::Cint)
+join!(bm::BatchedMechanism; stream::DevPtr=C_NULL) = check(@ccall $(fn(:dojo_join))(bm.handle::Ptr{Cvoid}, stream::Ptr{Cvoid})::Cint)
+
+"""
+    set_refinement!(bm, stiffness)
+
+Iterative refinement of the linear solves (Newton directions and IFT columns) of every environment whose cones reach
+max γ/s > `stiffness` (Inf: never, 0: always).  Default: 1e4 when `opts.rtol <= 1e-7` or `opts.btol <= 1e-6`, never at the
+reference's default tolerances (DESIGN.md §4.5).
+"""
+set_refinement!(bm::BatchedMechanism, stiffness::Real) = check(@ccall $(fn(:dojo_set_refinement))(bm.handle::Ptr{Cvoid}, Float64(stiffness)::Cdouble)::Cint)
+
+# Multi-GPU: one Julia process per GPU (Distributed / MPI.jl), each with ONE BatchedMechanism for its contiguous slice of
+# the batch.  Rank 0 creates the 128-byte id, the host carries it to the other ranks, every rank joins; allgather! then
+# moves per-rank device buffers over RCCL / xGMI in rank (= batch) order -- once per rollout chunk, not per step.
+#   id = myrank == 0 ? DojoHIP.comm_unique_id() : nothing
+#   id = MPI.bcast(id, 0, comm)                        # or Distributed.remotecall_fetch
+#   DojoHIP.comm_init!(bm, myrank, nranks, id)
+#   DojoHIP.allgather!(bm, pointer(z_local), pointer(z_all), length(z_local))
+"128 opaque bytes identifying a new RCCL communicator (call on rank 0 only)"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(@ccall $(fn(:dojo_comm_unique_id))(id::Ptr{UInt8})::Cint)
+    return id
+end
+comm_init!(bm::BatchedMechanism, rank::Integer, world::Integer, id::Vector{UInt8}) =
+    check(@ccall $(fn(:dojo_comm_init))(bm.handle::Ptr{Cvoid}, rank::Int32, world::Int32, id::Ptr{UInt8})::Cint)
+"recv[count, world] <- send[count] of every rank; elements of the handle's dtype, or Int32 with `as_int32` (status / iteration buffers)"
+allgather!(bm::BatchedMechanism, send::DevPtr, recv::DevPtr, count::Integer; as_int32::Bool=false, stream::DevPtr=C_NULL) =
+    check(@ccall $(fn(:dojo_allgather_dev))(bm.handle::Ptr{Cvoid}, send::Ptr{Cvoid}, recv::Ptr{Cvoid}, count::Int64, as_int32::Int32, stream::Ptr{Cvoid})::Cint)
+"(rank, world) of the handle's communicator, (0, 1) before comm_init!"
+function comm_info(bm::BatchedMechanism)
+    r = Ref{Int32}(0); w = Ref{Int32}(1)
+    check(@ccall $(fn(:dojo_comm_info))(bm.handle::Ptr{Cvoid}, r::Ref{Int32}, w::Ref{Int32})::Cint)
+    return Int(r[]), Int(w[])
+end
+
 # ---- opt-in single-Mechanism drop-in ------------------------------------------------------------
 # DojoHIP.enable!(mechanism) makes Dojo.mehrotra!(mechanism) (src/solver/mehrotra.jl:9) round-trip through the library
 # (B = 1, fp64) and write the solution back -- body.state.vsol/ωsol, joint.impulses, contact.impulses(_dual), mechanism.μ,
