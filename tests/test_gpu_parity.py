@@ -114,7 +114,7 @@ def _grad_errors(spec, Z, U, opts, mode=0, dtype="f64", refine=None):
     dz, du = gm.gradients()
     gm.close()
     o = Oracle(spec, opts=opts)
-    Zo, st_o, it_o, dz_o, du_o = o.step_batch(Z, U, with_grad=True, grad_mode=mode, nthreads=os.cpu_count() or 8)
+    Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Z) if dtype == "f32" else Z, U, with_grad=True, grad_mode=mode, nthreads=os.cpu_count() or 8)
     ok = np.nonzero((st == 0) & (st_o == 0))[0]
     ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
     eu = np.array([np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok]) if spec.nu else np.zeros(len(ok))
@@ -122,25 +122,34 @@ def _grad_errors(spec, Z, U, opts, mode=0, dtype="f64", refine=None):
     return ok, ez, eu, es, it[ok], it_o[ok], int((st != st_o).sum())
 
 
-@pytest.mark.parametrize("cfg,B,pre", [(2, 1024, 30), (4, 8192, 8), (5, 2048, 6)])
-def test_parity_at_the_other_baseline_batches(cfg, B, pre):
+@pytest.mark.parametrize("cfg,B,pre,dtype", [(2, 1024, 30, "f64"), (4, 8192, 8, "f64"), (5, 2048, 6, "f64"), (4, 8192, 8, "f32"), (5, 2048, 6, "f32")])
+def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
     """BASELINE configs[1], [3], [4] at their full batches with DISTINCT seeded environments (Block-on-plane 1024, Quadruped
     8192 -- the batch its line shards over 8 GPUs -- and Atlas 2048), reference-default options, after `pre` closed-loop
     steps: one differentiable step against the oracle on all host cores.  Regular solves (<= REGULAR_ITERS iterations on both
     sides; Atlas' four coplanar foot contacts stall 3-4 % of the solves at max_iter in the oracle as well): equal iteration
-    counts, state max <= 1e-6, gradient q99 <= 1e-6 and max <= 1e-4 (plain kernels, as timed)."""
+    counts, state max <= 1e-6, gradient q99 <= 1e-6 and max <= 1e-4 (plain kernels, as timed).  fp32 ABI (what BASELINE
+    quotes configs 3-5 in; the oracle steps the state the fp32 buffer stands for): state <= 1e-5 (output rounding of
+    |z| <= ~1e2), gradient max <= 1e-3 (the north-star bound for fp32)."""
     spec = d.baseline_config(cfg)
     Z, U = d.synthetic_inputs(spec, B)
     gm = api.BatchedMechanism(spec, B, dtype="f64")
     for _ in range(pre):
         Z, st, it = gm.step(Z, U)
     gm.close()
-    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions())
+    f32 = dtype == "f32"
+    if f32:
+        Z = Z.astype(np.float32).astype(np.float64); U = U.astype(np.float32).astype(np.float64)   # what the fp32 buffers hold
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions(), dtype=dtype)
     reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
     assert reg.sum() > 0.9 * B and nstat <= 0.01 * B, (reg.sum(), nstat)
     assert np.array_equal(itg[reg], ito[reg])
-    assert es[reg].max() <= 1e-6, es[reg].max()
+    assert es[reg].max() <= (1e-5 if f32 else 1e-6), es[reg].max()
     eg = np.maximum(ez, eu)[reg]
+    if f32:
+        print("\nBASELINE cfg %d B %d fp32 ABI: regular %d, state max %.2e, gradient q50 %.2e q99 %.2e max %.2e" % (cfg, B, int(reg.sum()), es[reg].max(), np.quantile(eg, 0.5), np.quantile(eg, 0.99), eg.max()))
+        assert eg.max() <= 1e-3, eg.max()
+        return
     print("\nBASELINE cfg %d B %d: converged on both sides %d, regular %d, status mismatches %d, state max %.2e, gradient q50 %.2e q99 %.2e max %.2e, above 1e-6: %d"
           % (cfg, B, len(ok), int(reg.sum()), nstat, es[reg].max(), np.quantile(eg, 0.5), np.quantile(eg, 0.99), eg.max(), int((eg > 1e-6).sum())))
     assert np.quantile(eg, 0.99) <= 1e-6 and eg.max() <= 1e-4, (np.quantile(eg, 0.99), eg.max())
