@@ -1029,9 +1029,12 @@ struct Mechanism {
         }
     }
     // line_search!  line_search.jl:1-34
+    long stat_ls_calls = 0, stat_ls_trials = 0;        // statistics for tools/ (how many residual evaluations a line search takes)
     void line_search(T alpha, T rvio, T bvio, T& rc, T& bc) {
         int scale = 0; rc = std::numeric_limits<T>::infinity(); bc = rc;
+        ++stat_ls_calls;
         for (int it = 0; it < opts.max_ls; ++it) {
+            ++stat_ls_trials;
             candidate_step(alpha, scale);
             rc = residual_violation(); bc = bilinear_violation();
             if (rc > rvio && bc > bvio) scale += 1; else return;

@@ -39,6 +39,7 @@ def lib():
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong
+        _lib.orc_ls_stats.restype = None
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
@@ -201,6 +202,12 @@ class Oracle:
     def set_sparse_solver(self, on=True):
         """timing variant (bench.py cpu_baseline): sparse LU without pivoting in the elimination order of the mechanism graph"""
         lib().orc_set_sparse_solver(self.h, int(bool(on)))
+
+    def ls_stats(self):
+        """(line searches, residual evaluations) of this instance since creation (single-environment calls only)"""
+        out = (C.c_longlong * 2)()
+        lib().orc_ls_stats(self.h, out)
+        return int(out[0]), int(out[1])
 
     def sparse_flops(self):
         return int(lib().orc_sparse_flops(self.h))
