@@ -63,6 +63,9 @@
 #ifndef DJ_REFINE_STEPS
 #define DJ_REFINE_STEPS 2  // rounds per solve (the contraction per round is ~ε·γ/s·cond of the un-stiff part; nearly redundant joint / contact rows need two)
 #endif
+#ifndef DJ_CONDENSE_OWN_ROWS
+#define DJ_CONDENSE_OWN_ROWS 1   // quad mapping: the contact condensation computes only the lane's own three body rows (108 instead of 648 multiply-adds per contact)
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -1160,15 +1163,29 @@ struct LaneProgram {
         T d[6];
         for (int i = 0; i < 3; ++i) { d[i] = P.m * L.v[i] + L.dconst[i]; d[3 + i] = T(0.5) * dt * (kb.c * Jw[i] + wxJw[i]) + L.dconst[3 + i]; }
         for (int i = 0; i < 6; ++i) d[i] -= E.imp_b[i];
-        // contacts
-        ContactEval<T> CE[MAXC];
+        // contacts.  With several contacts per body (MAXC > 1) everything one contact contributes (impulse on the body, its
+        // cone-row residuals, its curvature term of the ω block and the rows the condensation reads from LDS) is consumed
+        // inside its own iteration, so that one ContactEval is live at a time (Atlas step kernel: 714 -> 202 spilled VGPRs,
+        // +9 % env-steps/s; Block +12 %); with one contact the blocks are added after the body terms (the MAXC = 1 register
+        // allocation is 1 % faster that way, same session).  joint_eval has zeroed / filled K by now.
+        constexpr bool kEarly = MAXC > 1;
+        ContactEval<T> CE[kEarly ? 1 : MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
-                contact_eval<JAC>(CE[c], CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
-                for (int i = 0; i < 6; ++i) d[i] -= CE[c].imp[i];
-                for (int i = 0; i < 4; ++i) cres[c][i] = CE[c].c[i];
+                ContactEval<T>& CEc = CE[kEarly ? 0 : c];
+                contact_eval<JAC>(CEc, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
+                for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i];
+                for (int i = 0; i < 4; ++i) cres[c][i] = CEc.c[i];
                 if (G.contact_model == 1) cres[c][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
+                if (JAC && kEarly) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CEc.Dww[3 * i + j]);
+                    ContactCold<T>& cc_ = ccold(c);
+                    for (int i = 0; i < 18; ++i) { cc_.C134[i] = CEc.C134[i]; cc_.G134[i] = CEc.G134[i]; }
+                }
             } else { for (int i = 0; i < 4; ++i) cres[c][i] = T(0); }
         }
         // what this lane's joint applies to the parent body travels up the tree
@@ -1199,14 +1216,16 @@ struct LaneProgram {
                 K.addS(6 + i, 6 + i, (i < P.nl_t) ? T(REG) : T(1));
                 K.addS(9 + i, 9 + i, (i < P.nl_r) ? T(REG) : T(1));
             }
+            if constexpr (!kEarly) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                if (c < P.ncontact) {
+                for (int c = 0; c < MAXC; ++c) {
+                    if (c < P.ncontact) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CE[c].Dww[3 * i + j]);
-                    { ContactCold<T>& cc_ = ccold(c); for (int i = 0; i < 18; ++i) { cc_.C134[i] = CE[c].C134[i]; cc_.G134[i] = CE[c].G134[i]; } }
+                            for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CE[c].Dww[3 * i + j]);
+                        { ContactCold<T>& cc_ = ccold(c); for (int i = 0; i < 18; ++i) { cc_.C134[i] = CE[c].C134[i]; cc_.G134[i] = CE[c].G134[i]; } }
+                    }
                 }
             }
             for (int j = 0; j < 3; ++j) { F.th_a[j] = E.th_a[j]; F.th_b[j] = E.th_b[j]; }
@@ -1313,6 +1332,27 @@ struct LaneProgram {
                 contact_coef(Q, c, rc, r58);
                 const ContactCold<T>& cc_ = ccold(c);
                 // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
+#if DJ_CONDENSE_OWN_ROWS
+                if constexpr (QUAD) {
+                    // quad mapping: only the two body-row roles hold such rows, three each -- M = coef C134 once (3 x 6), then
+                    // the lane's rows G134[:, 3q + i]ᵀ M (the rows are picked by address in LDS, not by selects over six)
+                    if (q < 2) {
+                        T Mc[3][6];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) Mc[a][j] = Q.coef[3 * a] * cc_.C134[j] + Q.coef[3 * a + 1] * cc_.C134[6 + j] + Q.coef[3 * a + 2] * cc_.C134[12 + j];
+                        const T* gq = cc_.G134 + 3 * q;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const T g0 = gq[i], g1 = gq[6 + i], g2 = gq[12 + i];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) K.S[i][j] -= TL(g0 * Mc[0][j] + g1 * Mc[1][j] + g2 * Mc[2][j]);
+                        }
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
