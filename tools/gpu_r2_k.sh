@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B inside one session: one ContactEval live at a time in evaluate() (new) against the previous build (old).
+# A/B inside one session: current build (lib) against the previous one (lib_old).
 cd $GRAFT_REPO_ROOT
 echo "=== Ant"; bash tools/gpu_ab.sh old
-echo "=== Atlas B=2048"; bash tools/gpu_ab.sh old --config 5 --batch 2048 --steps 10 --warmup 2
-echo "=== Block B=1024 fwd+grad"; bash tools/gpu_ab.sh old --config 2 --batch 1024 --steps 20 --warmup 3
+echo "=== Ant, one launch per kernel"; bash tools/gpu_ab.sh old --chunks 1
+echo "=== Quadruped B=8192"; bash tools/gpu_ab.sh old --config 4 --batch 8192 --steps 10 --warmup 2
+echo "=== parity"; timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "baseline_batch or forward_parity or gradient_parity" 2>&1 | tail -3
