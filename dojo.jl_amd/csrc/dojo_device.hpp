@@ -71,6 +71,9 @@
                            // third less code, parity-green on the emulator and the GPU -- and 11 % SLOWER on the GPU (Ant step kernel 4.86-4.92 against 4.37 ms
                            // in one session, three variants of the control flow: scratch 416 instead of 256 B/lane inside the hot loop) -> off
 #endif
+#ifndef DJ_SCHUR_LEAN
+#define DJ_SCHUR_LEAN 1      // quad factorization: Schur complement with 18 (not 54) gathered U entries and 18 (not 36) partial sums in flight: 49 -> 39 spilled VGPRs, +1.4 % (same session)
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -1509,6 +1512,48 @@ struct LaneProgram {
             if (lev > 0) {   // level 0 = the roots of the trees: nothing to pass up (wave-uniform skip)
             // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero -- except with a
             // translational damper, whose force on the child body depends on the parent's velocity: DJ_TSD builds)
+#if DJ_SCHUR_LEAN
+            // Tq = S⁻¹(own rows) U gathered one source role at a time (18 values in flight instead of 54), then the 6x6 product
+            // L Tq in two row halves (rows 0:3 end on role 0, rows 3:6 on role 1): 18 partial sums in flight instead of 36
+            constexpr int U0 = DJ_TSD ? 0 : 1;
+            TL Tq[3][6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Tq[i][j] = TL(0);
+#pragma unroll
+            for (int o = U0; o < 4; ++o) {
+#pragma unroll
+                for (int m_ = 0; m_ < 3; ++m_)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const TL u_ = wv.quad_bcast(F.Uq[m_][j], o);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) Tq[i][j] += A[i][3 * o + m_] * u_;
+                    }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                TL part[18];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) part[6 * i + j] = F.Lq[3 * h + i][0] * Tq[0][j] + F.Lq[3 * h + i][1] * Tq[1][j] + F.Lq[3 * h + i][2] * Tq[2][j];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) { part[i] += wv.quad_xor(part[i], 1); }
+#pragma unroll
+                for (int i = 0; i < 18; ++i) { part[i] += wv.quad_xor(part[i], 2); }
+                if (at && has_parent) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            if (h == 0) up[i][j] = (q == 0) ? TL(K.D[i][j]) - part[6 * i + j] : TL(0);
+                            else up[i][j] = (q == 1) ? TL(K.D[i][j]) - part[6 * i + j] : up[i][j];
+                        }
+                }
+            }
+#else
             TL Uf[12][6];
             constexpr int U0 = DJ_TSD ? 0 : 1;
 #pragma unroll
@@ -1547,6 +1592,7 @@ struct LaneProgram {
                         up[i][j] = (q < 2) ? TL(K.D[i][j]) - rowv : TL(0);
                     }
             }
+#endif
             }
         }
     }
