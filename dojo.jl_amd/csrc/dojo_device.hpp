@@ -74,6 +74,9 @@
 #ifndef DJ_SCHUR_LEAN
 #define DJ_SCHUR_LEAN 1      // quad factorization: Schur complement with 18 (not 54) gathered U entries and 18 (not 36) partial sums in flight: 49 -> 39 spilled VGPRs, +1.4 % (same session)
 #endif
+#ifndef DJ_YPARK
+#define DJ_YPARK 1          // fp32 ABI: the IFT parks y in an fp64 buffer of its own (KernelArgs::ypark) instead of the fp32 output slots
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -1120,6 +1123,7 @@ struct LaneProgram {
     static constexpr bool kRefine = kTrack && Wave::kRefine;
     enum { BLK_PER_LANE = 90 };        // S rows 3x12, U rows 3x6, L columns 6x3, Dup rows 3x6
     T* blk = nullptr; int blk_stride = 0;
+    T* ypark = nullptr;                // this lane's first slot of the workgroup's y park (KernelArgs::ypark; body-row roles only)
     bool refine = false;
     T wstiff = T(0);                   // max γ/s over the cones of the environment at the last evaluated iterate
     T growth = T(0);                   // largest |multiplier| of the last factorization's Gauss-Jordan passes on this lane (no pivoting: the growth indicator)
@@ -1612,6 +1616,12 @@ struct LaneProgram {
         typedef typename KA::io_type TIO;
         typedef TL TG;
         constexpr bool kSplitY = DJ_SPLIT_Y && sizeof(TIO) < sizeof(TG);      // park y as (high, low) halves when the ABI type is narrower
+        // fp32 ABI: y − S⁻¹(U Δ_parent) cancels in the down-sweep, and a y rounded to fp32 costs stiff environments their gradient
+        // (Ant, 4096 environments: max 1.2e-3 relative against 1.4e-5 with an exact y) -- the parked y goes to a buffer of its own in
+        // the arithmetic type, [batch][column][row][role lane]: one 256-byte run per store / load of a wavefront
+        constexpr bool ypk = DJ_YPARK && MODE == 0 && !kSplitY && sizeof(TIO) < sizeof(TG);   // (the host allocates KernelArgs::ypark whenever this holds)
+        const int yW = wv.width() >> 1;                       // role lanes (two body-row roles per supernode) of the workgroup
+        T* const yp0 = ypark;                                 // this lane's slot of batch 0, column 0, row 0
         constexpr int NC = 6;
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
@@ -1768,7 +1778,9 @@ struct LaneProgram {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? p0_ : p1_) : TG(0); }
                     if (q < 2 && col_ok(b, cI)) {
-                        TIO* o = cb + (size_t)cx * nx; o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]);
+                        if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
+                        TIO* o = cb + (size_t)cx * nx;
+                        if constexpr (!ypk) { o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
                         // fp32 ABI: the parked y keeps its low half in the x3 / φ3 slots of the same column (free until the down-sweep writes
                         // them): y − S⁻¹(U Δ_parent) cancels, and an fp32 y costs stiff environments their gradient (measured: 0.1 relative)
                         if constexpr (kSplitY) { o[0] = TIO(yy[0] - TG(TIO(yy[0]))); o[1] = TIO(yy[1] - TG(TIO(yy[1]))); o[2] = TIO(yy[2] - TG(TIO(yy[2]))); }
@@ -1788,7 +1800,7 @@ struct LaneProgram {
         T Mq[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Mq[i] = q == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
-        typedef typename std::conditional<kSplitY, TG, TIO>::type TY;
+        typedef typename std::conditional<kSplitY || ypk, TG, TIO>::type TY;
         TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
             const bool v_ = active && q < 2 && b_ >= 0 && b_ < NB;
@@ -1798,6 +1810,12 @@ struct LaneProgram {
             for (int n = 0; n < NC; ++n) {
                 const bool ok_ = v_ && col_ok(b_, n);
                 const TIO* o_ = cbn + (size_t)((isS_ && n >= 3) ? n + 3 : n) * nx;
+                if constexpr (ypk) {
+                    const T* yi = yp0 + (size_t)(((v_ ? b_ : 0) * NC + n) * 3) * yW;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? TG(yi[i * yW]) : TG(0);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { if constexpr (kSplitY) ynext[n][i] = ok_ ? TG(o_[3 + i]) + TG(o_[i]) : TG(0); else ynext[n][i] = ok_ ? o_[3 + i] : TIO(0); }
             }
@@ -3099,6 +3117,9 @@ struct KernelArgs {
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
     T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
+    long long ypark_stride = 0;    // elements per workgroup of ypark
+    T* ypark = nullptr;            // [workgroups][batches][6][3][lanes / 2] quad mapping, ABI type narrower than the arithmetic: the IFT's forward-substituted
+                                   // right-hand sides in full precision between the two sweeps (or null: they wait in the output buffer, in the ABI type)
     int* flag = nullptr;           // [B] 1: the plain step kernel deferred this environment to the refining kernels (DJ_REFINE; or null)
     T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
     T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
@@ -3206,6 +3227,7 @@ constexpr int FAC_PER_LANE = 72;
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \
+        if (A.ypark) prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + ((lane >> 2) * 2 + (q & 1));  \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \

@@ -85,6 +85,7 @@ struct DojoSim {
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
     void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
+    void* d_ypark = nullptr;            // fp32 ABI, quad mapping: the IFT's forward-substituted right-hand sides between its two sweeps, in fp64
     int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
     double refine_w = -1.0;             // refine once max γ/s of an environment exceeds this (dojo_set_refinement); < 0: chosen from the tolerances
     int *d_status = nullptr, *d_iters = nullptr;
@@ -452,6 +453,13 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
     }
     A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
+    A.ypark = nullptr; A.ypark_stride = 0;
+    if (g && quad && sizeof(TIO) < sizeof(T) && dc == nullptr) {          // (DJ_YPARK: dojo_device.hpp, gradient_columns_quad)
+        const size_t batches = 2 * Nb + (nu + 5) / 6;
+        A.ypark_stride = (long long)(batches * 18 * (64 * NW / 2));
+        if (!s->d_ypark) HIPCHK(hipMalloc(&s->d_ypark, waves_total * (size_t)A.ypark_stride * sizeof(T)));
+        A.ypark = (T*)s->d_ypark + wave0 * (size_t)A.ypark_stride;
+    }
     A.blk = nullptr; A.flag = nullptr;
     if (quad && A.G.refine_w < INFINITY) {                  // the refining kernels follow the plain ones (dojo_kernels.hip)
         if (!s->d_blk) HIPCHK(hipMalloc(&s->d_blk, waves_total * 90 * 64 * NW * sizeof(T)));
@@ -577,7 +585,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, s->d_ypark, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);

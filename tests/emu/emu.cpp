@@ -117,6 +117,8 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
     std::vector<T> facbuf((dz && QUAD) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
+    std::vector<T> yparkbuf; A.ypark = nullptr;
+    if (dz && QUAD && sizeof(TIO) < sizeof(T)) { A.ypark_stride = (long long)((2 * M.Nb + (M.nu + 5) / 6) * 18 * (W / 2)); yparkbuf.resize((size_t)nwaves * A.ypark_stride); A.ypark = yparkbuf.data(); }
     // the same two launches as the product: step kernel, then (when gradients are wanted) the IFT kernel
     // the product's launches: step kernel, refining step kernel (quad mapping; re-solves what the first deferred), IFT kernel,
     // refining IFT kernel

@@ -148,7 +148,7 @@ def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
     eg = np.maximum(ez, eu)[reg]
     if f32:
         print("\nBASELINE cfg %d B %d fp32 ABI: regular %d, state max %.2e, gradient q50 %.2e q99 %.2e max %.2e" % (cfg, B, int(reg.sum()), es[reg].max(), np.quantile(eg, 0.5), np.quantile(eg, 0.99), eg.max()))
-        assert eg.max() <= 1e-3, eg.max()
+        assert eg.max() <= 1e-4, eg.max()                 # (bound: 1e-3; measured 1e-7 Quadruped, 7e-7 Atlas)
         return
     print("\nBASELINE cfg %d B %d: converged on both sides %d, regular %d, status mismatches %d, state max %.2e, gradient q50 %.2e q99 %.2e max %.2e, above 1e-6: %d"
           % (cfg, B, len(ok), int(reg.sum()), nstat, es[reg].max(), np.quantile(eg, 0.5), np.quantile(eg, 0.99), eg.max(), int((eg > 1e-6).sum())))
@@ -218,6 +218,12 @@ def test_parity_at_the_baseline_batch_distinct_seeds():
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions(), refine=1e4)
     assert len(ok) > 0.99 * B and nstat == 0 and np.array_equal(itg, ito)
     assert es.max() <= 1e-6 and max(ez.max(), eu.max()) <= 1e-6, (es.max(), ez.max(), eu.max())
+    # the fp32 ABI, what bench.py times (BASELINE quotes this configuration in fp32; bound 1e-3): the oracle steps the state the
+    # fp32 buffer stands for
+    Zf = Z.astype(np.float32).astype(np.float64); Uf = U.astype(np.float32).astype(np.float64)
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Zf, Uf, d.SolverOptions(), dtype="f32")
+    assert len(ok) > 0.99 * B and nstat == 0 and np.array_equal(itg, ito)
+    assert es.max() <= 1e-5 and max(ez.max(), eu.max()) <= 1e-4, (es.max(), ez.max(), eu.max())
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, TIGHT)
     reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
     assert len(ok) > 0.99 * B and nstat == 0 and np.array_equal(itg[reg], ito[reg])
@@ -244,7 +250,7 @@ def test_gradient_parity_f32_io():
     assert len(ok) > 25 and np.array_equal(it[ok], it_o[ok])
     assert np.abs(zn[ok] - Zo[ok]).max() < 1e-5
     ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
-    assert ez.max() < 1e-3, ez.max()                   # north-star bound for fp32, as a maximum
+    assert ez.max() < 1e-4, ez.max()                   # north-star bound for fp32: 1e-3; the IFT parks its intermediate y in fp64 (DJ_YPARK), measured ~1e-7
     gm.close()
 
 
