@@ -38,7 +38,9 @@
  * always fp64 and are cast on upload.  All arithmetic is fp64 in both modes.  An fp32 buffer cannot hold a unit
  * quaternion: with dtype 1 the state a z stands for is (x, v, q/|q|, omega), the kernels normalize q on load (the
  * reference never renormalizes; its formulas mix rotation_matrix, which scales with |q|^2, and vector_rotate, which
- * does not, so a 1e-7 norm error would otherwise be amplified by stiff contacts).  No exception crosses the boundary: every entry
+ * does not, so a 1e-7 norm error would otherwise be amplified by stiff contacts).  Differentiable steps of a dtype-1 handle keep an
+ * internal fp64 work buffer of 8 * 18 * lanes/2 bytes per environment group and gradient column batch (Ant: 129 KB per
+ * environment) so that fp32 outputs carry fp32 rounding only.  No exception crosses the boundary: every entry
  * point returns DOJO_OK (0) or a negative error code; dojo_last_error() gives the text of the last
  * failure in the process (one mutex-guarded string) and dojo_handle_error(h) the last failure on that handle.
  *
