@@ -243,7 +243,7 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
  * launch on `stream`.  dojo_set_async(h, 1) drops the join: consecutive dojo_step_dev calls then chain per group (group g
  * of call k+1 runs behind group g of call k and behind what `stream` held at call time), and dojo_join(h, stream)
  * -- or any host-pointer entry point -- orders `stream` behind everything in flight.  The caller must not touch the
- * outputs, nor overwrite the inputs, of un-joined calls.  dojo_set_groups(h, n): n groups (n <= 0: automatic; 1: a
+ * outputs, nor overwrite the inputs, of un-joined calls.  dojo_set_groups(h, n): n groups, at most 16 (n <= 0: automatic; 1: a
  * single launch on the caller's stream).  ROCm runs at most GPU_MAX_HW_QUEUES (default 4) streams concurrently: set it
  * to >= groups + 1 before the HIP runtime starts.  (No counterpart in the reference, which is single-threaded.) */
 int  dojo_set_async(DojoHandle h, int32_t on);
