@@ -66,3 +66,20 @@ def test_library_rccl_allgather_world_one():
     torch.cuda.synchronize()
     assert torch.equal(out, z) and torch.equal(st_out, st)
     gm.close()
+
+
+def test_bench_two_ranks_plumbing():
+    """bench.py's N > 1 path (torchrun, barrier + max-over-ranks timing, final all-gather, one JSON line from rank 0) on a
+    one-GPU box: two ranks share device 0 and gloo carries the collectives (--backend gloo); with DOJO_BENCH_GATHER=library-force
+    the library's RCCL communicator is tried first and must fall back cleanly (RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DOJO_BENCH_GATHER="library-force", DOJO_BENCH_COMM_TIMEOUT="60")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 512 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]       # whole-job aggregate over both ranks
+    assert "torch.distributed" in res["config"]["final_gather"]
