@@ -342,3 +342,25 @@ def test_refining_kernels_match_oracle(cfg, pre):
     scale = max(1.0, np.abs(dz).max())
     assert np.abs(r["dz"][0] - dz).max() < 1e-7 * scale and np.abs(r["du"][0] - du).max() < 1e-7 * scale
     assert np.abs(p["dz"][0] - dz).max() < 1e-5 * scale        # the plain kernels: usable, not refined
+
+
+@pytest.mark.parametrize("cfg,pre", [(3, 5), (2, 6)])
+def test_fp32_abi_gradients_match_oracle(cfg, pre):
+    """fp32 buffers at the ABI (the mode bench.py times): the state an fp32 buffer stands for has unit quaternions (normalized
+    on load), the IFT parks its forward-substituted right-hand sides in an fp64 buffer of its own (KernelArgs::ypark) -- what
+    is left against the oracle on that state is the rounding of the fp32 outputs."""
+    spec = d.baseline_config(cfg)
+    o = Oracle(spec)
+    Z, U = d.synthetic_inputs(spec, 2)
+    for _ in range(pre):
+        Z = np.stack([o.step(Z[b], U[b])[0] for b in range(2)])
+    Z32 = Z.astype(np.float32).astype(np.float64); U32 = U.astype(np.float32).astype(np.float64)
+    r = emu_step(spec, Z32, U32, dtype="f32", grad=True, quad=True)
+    for b in range(2):
+        zo, info = o.step(d.fp32_abi_state(Z32[b]), U32[b])
+        dz, du = o.gradients(0)
+        assert r["status"][b] == info["status"] == 0 and r["iters"][b] == info["iters"]
+        assert np.abs(r["z_next"][b] - zo).max() < 1e-5
+        assert np.abs(r["dz"][b] - dz).max() < 1e-5 * max(1.0, np.abs(dz).max())
+        if spec.nu:
+            assert np.abs(r["du"][b] - du).max() < 1e-5 * max(1.0, np.abs(du).max())
