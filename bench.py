@@ -223,7 +223,8 @@ def main():
         if grad and not args.no_parity and world == 1:
             res["grad_inf_err_vs_cpu"] = parity_vs_cpu(spec, B, local)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(spec, grad)
+            ex = [r_.get("executed_fp64_flops_per_launch") for r_ in (dominant, other) if r_ is not None]
+            res["cpu_baseline"] = cpu_baseline(spec, grad, mean_iters, (sum(ex) / B) if (ex and all(ex)) else None)
         if world > 1:
             res["config"]["final_gather"] = "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"
         print(json.dumps(res), flush=True)
@@ -305,7 +306,7 @@ def measured_valu_utilization():
     return out
 
 
-def cpu_baseline(spec, grad):
+def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
     """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on all host cores: one
     persistent thread per core, every thread owns a copy of the mechanism and walks 64 environments of the same synthetic
     batch, once per solver variant; the clock starts when all threads are running.  Linear solves without the checker's
@@ -327,8 +328,19 @@ def cpu_baseline(spec, grad):
         o.set_sparse_solver(sparse)
         el = o.time_batch(Z, U, with_grad=grad, nthreads=cores, rounds=1)
         out[name] = {"value": nsample / el, "cpu_seconds": el * cores}
+    # what a block-sparse direct method needs per env-step (flops of the sparse LU above, multiply-add = 2): one factorization
+    # + two solves per Newton iteration, one factorization + one solve per Jacobian column -- the "useful" share of what the
+    # kernels execute (roofline.executed_fp64_flops_per_launch also counts assembly, line searches, replicated and masked lanes)
+    o.set_sparse_solver(True); o.step(Z[0], U[0])
+    fF, fS = o.sparse_flops(), o.sparse_solve_flops()
+    ncol = 12 * spec.Nb + spec.nu
+    la = {"factor": fF, "solve_per_rhs": fS, "per_newton_iteration": fF + 2 * fS, "ift": (fF + ncol * fS) if grad else 0}
+    if mean_iters:
+        la["per_env_step"] = mean_iters * la["per_newton_iteration"] + la["ift"]
+        if executed_flops_per_env:
+            la["frac_of_executed_fp64"] = la["per_env_step"] / executed_flops_per_env
     return {"value": out["sparse"]["value"], "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],
-            "dense": out["dense"]["value"],
+            "dense": out["dense"]["value"], "sparse_lu_flops": la,
             "sample": "%d Ant env-steps (fwd%s) per variant: 64 synthetic environments per thread on %d persistent threads; C++ oracle, fp64; value = block-sparse "
                       "no-pivot LU in the mechanism graph's elimination order, dense = 206x206 partial-pivot LU" % (nsample, "+grad" if grad else "", cores)}
 

@@ -41,6 +41,7 @@ struct IOracle {
     virtual void set_refine_steps(int n) = 0;
     virtual void set_sparse_solver(int on) = 0;
     virtual long long sparse_flops() = 0;
+    virtual long long sparse_solve_flops() = 0;
     virtual void ls_stats(long long* out) = 0;
     virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
     virtual void maximal_to_minimal(const double* z, double* x) = 0;
@@ -60,6 +61,7 @@ struct OracleT : IOracle {
     void set_refine_steps(int n) override { m.refine_steps = n; }
     void set_sparse_solver(int on) override { m.sparse_solver = on != 0; }
     long long sparse_flops() override { return m.splu.flops_factor; }
+    long long sparse_solve_flops() override { return m.splu.flops_solve; }
     void ls_stats(long long* out) override { out[0] = m.stat_ls_calls; out[1] = m.stat_ls_trials; }
     void maximal_to_minimal(const double* z, double* x) override {
         int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
@@ -259,6 +261,7 @@ void orc_input_impulses(void* h, const double* z, const double* u, double* jf) {
 // timing variant of the linear solves: 1 = sparse no-pivot LU in the elimination order of the mechanism graph (SparseLU)
 void orc_set_sparse_solver(void* h, int on) { ((IOracle*)h)->set_sparse_solver(on); }
 long long orc_sparse_flops(void* h) { return ((IOracle*)h)->sparse_flops(); }
+long long orc_sparse_solve_flops(void* h) { return ((IOracle*)h)->sparse_solve_flops(); }   // per right-hand side
 // line-search statistics of this instance since creation: out[0] = line searches, out[1] = residual evaluations (trials)
 void orc_ls_stats(void* h, long long* out) { ((IOracle*)h)->ls_stats(out); }
 // rounds of iterative refinement of every linear solve (default 2: the checker; 0: a plain LU solve like the reference's)

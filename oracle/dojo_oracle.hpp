@@ -1435,7 +1435,7 @@ struct Mechanism {
     // body_constraint_jacobian_contact_data  data.jl:152-171: 6 x 5
     M body_constraint_jacobian_contact_data(const Contact<T>& c) const {
         const State<T>& s = bodies[c.body].st;
-        M xp3 = x3(s); Q qp3 = q3(s); const M& g = c.gam[1];
+        Q qp3 = q3(s); const M& g = c.gam[1];
         M X = hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());
         M dp = -dskew_dp(VRmat(qp3) * LTVTmat(qp3) * X * g);
         M drad = (-dskew_dp(VRmat(qp3) * LTVTmat(qp3) * X * g)) * ((-rotation_matrix(inv(qp3))) * c.normal.t());

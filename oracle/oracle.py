@@ -38,7 +38,7 @@ def lib():
             getattr(_lib, name).restype = None
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_set_refine_steps.restype = None
-        _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong
+        _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
         _lib.orc_ls_stats.restype = None
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
@@ -211,6 +211,10 @@ class Oracle:
 
     def sparse_flops(self):
         return int(lib().orc_sparse_flops(self.h))
+
+    def sparse_solve_flops(self):
+        """flops of one forward + backward substitution with the block-sparse factors (per right-hand side)"""
+        return int(lib().orc_sparse_solve_flops(self.h))
 
     def time_batch(self, Z, U=None, with_grad=False, grad_mode=0, nthreads=1, rounds=1):
         """wall-clock seconds for `rounds` passes over the batch on `nthreads` persistent threads (results discarded)"""

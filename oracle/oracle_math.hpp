@@ -307,7 +307,7 @@ struct SparseLU {
     std::vector<char> pat;                            // n x n, closed under elimination
     std::vector<std::vector<int>> lrows, ucols;       // per pivot k: rows i > k with (i,k) in the pattern, columns j > k with (k,j)
     std::vector<T> w;                                 // n x n working copy: L (unit, multipliers) and U in place
-    bool analyzed = false; long long flops_factor = 0;
+    bool analyzed = false; long long flops_factor = 0, flops_solve = 0;     // per factorization / per right-hand side (multiply-adds counted as 2)
     void set_permutation(const std::vector<int>& pr, const std::vector<int>& pc) { prow = pr; pcol = pc; n = (int)pr.size(); analyzed = false; }
     void analyze(const std::vector<T>& A) {
         pat.assign((size_t)n * n, 0);
@@ -319,6 +319,7 @@ struct SparseLU {
             for (int i : lrows[k]) for (int j : ucols[k]) pat[(size_t)i * n + j] = 1;              // fill
             flops_factor += 2LL * (long long)lrows[k].size() * (long long)ucols[k].size();
         }
+        flops_solve = n; for (int k = 0; k < n; ++k) flops_solve += 2LL * (long long)(lrows[k].size() + ucols[k].size());
         w.assign((size_t)n * n, T(0)); analyzed = true;
     }
     bool factor(const std::vector<T>& A) {
