@@ -92,7 +92,6 @@ struct DojoSim {
     bool have_grad = false, have_solution = false, have_u = false;
     std::string err; std::mutex err_m;  // text of the last failure of a call on this handle (dojo_handle_error)
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator of this handle's process group (dojo_comm_init)
-    hipStream_t stream = nullptr;
     // kernel timing: a ring of event triples (launch begin / between the step and the IFT kernel / end), so that
     // timed launches never make the host wait; totals are accumulated when a slot is reused or queried
     struct Ev3 { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool has_mid = false, used = false; int n = 1; };
@@ -729,7 +728,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
         s->pending = true;
         if (!s->async && (rc = join_groups(s, st))) return rc;
     }
-    if (rc == DOJO_OK) { s->stream = st; s->have_solution = true; }
+    if (rc == DOJO_OK) s->have_solution = true;
     return rc;
 }
 
@@ -932,7 +931,7 @@ static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, 
     cur = last;
     { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = false; e.n = H; e.used = true; s->last_slot = slot; }
     if (!Z && cur != (const char*)s->d_zn) HIPCHK(hipMemcpyAsync(s->d_zn, cur, B * nz * w, hipMemcpyDeviceToDevice, st));
-    s->stream = st; s->have_solution = true; s->have_grad = false;
+    s->have_solution = true; s->have_grad = false;
     return DOJO_OK;
 }
 
