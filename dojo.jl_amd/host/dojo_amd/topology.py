@@ -179,7 +179,7 @@ class MechanismSpec:
     @property
     def n_joint_impulses(self): return sum(j.N for j in self.joints)
     @property
-    def n_solution(self): return self.n_joint_impulses + 6 * self.Nb + sum(2 if c.model == 1 else 8 for c in self.contacts)
+    def n_solution(self): return self.n_joint_impulses + 6 * self.Nb + sum({1: 2, 2: 12}.get(c.model, 8) for c in self.contacts)      # [s; γ] per contact: N = 8 (NonlinearContact), 2 (ImpactContact), 12 (LinearContact)
 
     def body_index(self, name): return [b.name for b in self.bodies].index(name)
     def joint_index(self, name): return [j.name for j in self.joints].index(name)

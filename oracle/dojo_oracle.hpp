@@ -78,8 +78,8 @@ template <class T>
 struct Contact {
     using M = SM<T>;
     int body = 0;
-    int model = 0;                 // 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl)
-    int nh() const { return model == 1 ? 1 : 4; }     // N½: γ and s each
+    int model = 0;                 // 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl), 2: LinearContact (src/contacts/linear.jl)
+    int nh() const { return model == 1 ? 1 : model == 2 ? 6 : 4; }     // N½: γ and s each (LinearContact: [γ ψ β1..β4])
     T mu = 0;                      // friction_coefficient
     M normal, tangent, origin, offset; T radius = 0;   // 1x3, 2x3, 3, 3
     M gam[2] = {M(4, 1), M(4, 1)}; // impulses       (γ)
@@ -634,6 +634,14 @@ struct Mechanism {
     // =====================================================================
     // CONTACT (NonlinearContact + SphereHalfSpaceCollision, child = origin)
     // =====================================================================
+    // friction_parameterization of LinearContact  linear.jl:33-38
+    static M friction_parameterization() { return M(4, 2, {0, 1,  0, -1,  1, 0,  -1, 0}); }
+    // force_mapping(:parent, model, ...): [n' 0 T'P'] (contact.jl:141-154; P = I for NonlinearContact), n' for ImpactContact (impact.jl:106-118)
+    M force_mapping(const Contact<T>& c) const {
+        if (c.model == 1) return c.normal.t();
+        if (c.model == 2) return hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t() * friction_parameterization().t());
+        return hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());
+    }
     // contact_point(:parent, ...)  sphere_halfspace.jl:55-62
     M contact_point_parent(const Contact<T>& c, const M& xp, const Q& qp) const {
         return xp + vector_rotate(c.origin, qp) - c.offset - c.radius * c.normal.t();
@@ -656,6 +664,11 @@ struct Mechanism {
         M vt = relative_tangential_velocity(c, xp, qp, st.vsol[1], st.wsol[1]);
         const M& g = c.gam[1]; const M& s = c.s[1];
         if (c.model == 1) return M::vec({d - s[0]});                      // impact.jl:41-54
+        if (c.model == 2) {                                               // linear.jl:71-102: [d − sγ; μγ − Σβ − sψ; P vt + ψ 1 − sβ]
+            M pv = friction_parameterization() * vt;
+            return M::vec({d - s[0], c.mu * g[0] - (g[2] + g[3] + g[4] + g[5]) - s[1],
+                           pv[0] + g[1] - s[2], pv[1] + g[1] - s[3], pv[2] + g[1] - s[4], pv[3] + g[1] - s[5]});
+        }
         return M::vec({d - s[0], c.mu * g[0] - g[1], vt[0] - s[2], vt[1] - s[3]});
     }
     static M cone_product(const M& u, const M& v) {   // cone.jl:6-8 (3-vectors)
@@ -668,6 +681,7 @@ struct Mechanism {
     M contact_complementarity(const Contact<T>& c) const {
         const M& g = c.gam[1]; const M& s = c.s[1];
         if (c.model == 1) return M::vec({g[0] * s[0]});                    // complementarity.jl:16 (γ .* s)
+        if (c.model == 2) { M r(6, 1); for (int i = 0; i < 6; ++i) r[i] = g[i] * s[i]; return r; }   // complementarity.jl:16
         M cp = cone_product(sub(g, 1, 3), sub(s, 1, 3));
         return M::vec({g[0] * s[0], cp[0], cp[1], cp[2]});
     }
@@ -677,6 +691,12 @@ struct Mechanism {
         if (c.model == 1) {   // impact.jl:56-62: [γ s; −1 0] (columns s, γ) with γ, s + REG·neutral_vector
             M D2(2, 2); D2(0, 0) = g[0] + T(REG); D2(0, 1) = s[0] + T(REG); D2(1, 0) = T(-1); D2(1, 1) = T(0);
             return D2;
+        }
+        if (c.model == 2) {   // linear.jl:49-69: [∇s ∇γ], ∇s = [Diag(γ); −I], ∇γ = [Diag(s); M(μ)], with γ, s + REG·ones(6)
+            M D12(12, 12);
+            for (int i = 0; i < 6; ++i) { D12(i, i) = g[i] + T(REG); D12(6 + i, i) = T(-1); D12(i, 6 + i) = s[i] + T(REG); }
+            D12(7, 6) = c.mu; for (int i = 2; i < 6; ++i) { D12(7, 6 + i) = T(-1); D12(6 + i, 7) = T(1); }
+            return D12;
         }
         g[0] += T(REG); g[1] += T(REG); s[0] += T(REG); s[1] += T(REG);   // + REG * neutral_vector = [1,1,0,0]
         M D(8, 8);
@@ -694,8 +714,7 @@ struct Mechanism {
     M contact_impulse_map(const Contact<T>& c) const {
         const State<T>& st = bodies[c.body].st;
         M xp = x3(st); Q qp = q3(st);
-        M X = c.model == 1 ? c.normal.t()                          // force_mapping(ImpactContact)  impact.jl:106-118
-                           : hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());   // [n' 0 T'] (friction_parameterization = I)
+        M X = force_mapping(c);
         M cp = contact_point_parent(c, xp, qp);
         M Qm = rotation_matrix(inv(qp)) * skew(cp - xp) * X;
         return vcat(X, Qm);
@@ -715,6 +734,10 @@ struct Mechanism {
         Q q = next_orientation(qp, -wp, dt);
         M dq_dw = rotational_integrator_jacobian_velocity(q, wp, dt);
         if (c.model == 1) return hcat(dt * dd_dx, dd_dq * dq_dw);   // impact.jl:76-104
+        if (c.model == 2) {                                          // contact.jl:37-77 with the 4x2 friction_parameterization
+            M P = friction_parameterization();
+            return hcat(vcat(vcat(dt * dd_dx, M(1, 3)), P * dvt_dv), vcat(vcat(dd_dq * dq_dw, M(1, 3)), P * (dvt_dw + dvt_dq * dq_dw)));
+        }
         M V = vcat(vcat(dt * dd_dx, M(1, 3)), dvt_dv);
         M Om = vcat(vcat(dd_dq * dq_dw, M(1, 3)), dvt_dw + dvt_dq * dq_dw);
         return hcat(V, Om);
@@ -738,15 +761,16 @@ struct Mechanism {
     M contact_constraint_jacobian_configuration(const Contact<T>& c) const {
         const State<T>& st = bodies[c.body].st;
         M xp = x3(st); Q qp = q3(st); const M& vp = st.vsol[1]; const M& wp = st.wsol[1];
-        M X = vcat(vcat(c.normal, M(1, 3)), dvt_dx_parent(c, xp, qp, vp, wp));
-        M Qm = vcat(vcat(c.normal * dvector_rotate_dq(c.origin, qp), M(1, 4)), dvt_dq_parent(c, xp, qp, vp, wp));
+        M Pm = c.model == 2 ? friction_parameterization() : M::eye(2);      // contact.jl:9-35
+        M X = vcat(vcat(c.normal, M(1, 3)), Pm * dvt_dx_parent(c, xp, qp, vp, wp));
+        M Qm = vcat(vcat(c.normal * dvector_rotate_dq(c.origin, qp), M(1, 4)), Pm * dvt_dq_parent(c, xp, qp, vp, wp));
         return hcat(X, Qm);
     }
     // impulse_map_jacobian(:parent,:parent, model, pbody, cbody, λ, timestep): 6x7  contact.jl:102-138
     M contact_impulse_map_jacobian(const Contact<T>& c) const {
         const State<T>& st = bodies[c.body].st;
         M xp = x3(st); Q qp = q3(st); const M& lam = c.gam[1];
-        M X = c.model == 1 ? c.normal.t() : hcat(hcat(c.normal.t(), M(3, 1)), c.tangent.t());
+        M X = force_mapping(c);
         M Xx(3, 3), Xq(3, 4);     // ∂force_mapping_jvp∂x / ∂q vanish for a half-space
         M cp = contact_point_parent(c, xp, qp);
         M r = cp - xp; Q qi = inv(qp);
@@ -758,7 +782,7 @@ struct Mechanism {
         return vcat(hcat(Xx, Xq), hcat(Qx, Qq));
     }
     void reset_contact(Contact<T>& c) {   // contacts/constraints.jl:79-86, neutral_vector nonlinear.jl:99
-        M nv = c.model == 1 ? M::vec({1}) : M::vec({1, 1, 0, 0});       // neutral_vector: contact.jl:202 / nonlinear.jl:99
+        M nv = c.model == 1 ? M::vec({1}) : c.model == 2 ? M::vec({1, 1, 1, 1, 1, 1}) : M::vec({1, 1, 0, 0});       // neutral_vector: contact.jl:202 (ones(N½)) / nonlinear.jl:99
         c.gam[0] = nv; c.gam[1] = nv; c.s[0] = nv; c.s[1] = nv;
     }
     // initialize!(contact)   solver/initialization.jl:7-49
@@ -781,7 +805,7 @@ struct Mechanism {
     void initialize_contact(Contact<T>& c) {
         // the generic initialize! (initialization.jl:1-5) discards what initialize_positive_orthant! returns: for an
         // ImpactContact the variables stay at the neutral vector of reset!
-        if (c.model == 1) return;
+        if (c.model != 0) return;         // (ImpactContact and LinearContact take the generic method)
         for (int k = 0; k < 2; ++k) {
             T g0 = c.gam[k][0], s0 = c.s[k][0]; initialize_positive_orthant(g0, s0);
             M gs = sub(c.gam[k], 1, 3), ss = sub(c.s[k], 1, 3); initialize_second_order_cone(gs, ss);
@@ -883,6 +907,7 @@ struct Mechanism {
             Contact<T>& c = contacts[k];
             put(coff[k], coff[k], contact_constraint_jacobian(c));
             M comp = contact_complementarity(c); comp[0] -= mu; if (c.model == 0) comp[1] -= mu;   // complementarityμ: − μ·neutral_vector
+            if (c.model == 2) for (int i = 1; i < 6; ++i) comp[i] -= mu;
             putv(coff[k], vcat(-comp, -contact_constraint(c)));
             put(boff[c.body], coff[k], hcat(M(6, c.nh()), -contact_impulse_map(c)));
             put(coff[k], boff[c.body], vcat(M(c.nh(), 6), contact_constraint_jacobian_velocity(c)));
@@ -947,8 +972,9 @@ struct Mechanism {
         for (size_t k = 0; k < contacts.size(); ++k) {
             Contact<T>& c = contacts[k]; const T* D = &b[coff[k]];
             const M& s = c.s[1]; const M& g = c.gam[1];
-            if (c.model == 1) {   // line_search.jl:68-83
-                a = std::fmin(std::fmin(a, positive_orthant_step_length(s[0], D[0], tort)), positive_orthant_step_length(g[0], D[1], tort));
+            if (c.model != 0) {   // line_search.jl:68-83: ImpactContact and LinearContact, all N½ pairs on the positive orthant
+                const int nh = c.nh();
+                for (int i = 0; i < nh; ++i) a = std::fmin(std::fmin(a, positive_orthant_step_length(s[i], D[i], tort)), positive_orthant_step_length(g[i], D[nh + i], tort));
                 continue;
             }
             T as_ort = positive_orthant_step_length(s[0], D[0], tort);
@@ -977,7 +1003,7 @@ struct Mechanism {
             Contact<T>& c = contacts[k]; const T* D = &b[coff[k]];
             const int nh = c.nh();
             for (int i = 0; i < nh; ++i) { p0 += c.s[1][i] * c.gam[1][i]; p1 += (c.s[1][i] + aaff * D[i]) * (c.gam[1][i] + aaff * D[nh + i]); }
-            p2 += c.model == 1 ? T(1) : T(2);   // cone_degree: N½ (contact.jl:203) / 2 for NonlinearContact (nonlinear.jl:101)
+            p2 += c.model == 0 ? T(2) : T(nh);  // cone_degree: N½ (contact.jl:203) / 2 for NonlinearContact (nonlinear.jl:101)
         }
         for (size_t j = 0; j < joints.size(); ++j) {
             Joint<T>& J = joints[j]; int o = 0;
@@ -997,7 +1023,7 @@ struct Mechanism {
     void correction() {
         for (size_t k = 0; k < contacts.size(); ++k) {
             const T* D = &b[coff[k]]; T* r = &rcache[coff[k]];
-            if (contacts[k].model == 1) { r[0] += -D[0] * D[1] + mu; continue; }   // correction.jl:13-19
+            if (contacts[k].model != 0) { const int nh = contacts[k].nh(); for (int i = 0; i < nh; ++i) r[i] += -D[i] * D[nh + i] + mu; continue; }   // correction.jl:13-19
             M cp = cone_product(M::vec({D[1], D[2], D[3]}), M::vec({D[5], D[6], D[7]}));
             r[0] += -D[0] * D[4] + mu; r[1] += -cp[0] + mu; r[2] += -cp[1]; r[3] += -cp[2];
         }

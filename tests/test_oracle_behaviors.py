@@ -186,6 +186,34 @@ def test_impact_contact_is_frictionless():
     assert abs(gam.sum() - 9.81 * spec.timestep) < 1e-6          # Σγ = m g Δt
 
 
+def test_linear_contact_friction_pyramid():
+    """LinearContact (src/contacts/linear.jl): impact + friction with the linearized cone |b_x| + |b_y| <= mu gamma (four
+    directions: friction_parameterization, linear.jl:33-38).  A block sliding along a parameterization axis decelerates at mu g
+    like the NonlinearContact block; sliding along the diagonal of the pyramid it gets mu g / sqrt(2); at rest the normal
+    impulses carry its weight and all twelve cone variables of every contact satisfy their complementarity."""
+    mu, g, T = 0.2, 9.81, 20
+    def slide(contact_type, v0):
+        spec = d.get_block(contact_type=contact_type, contact_corners=4, friction_coefficient=mu)
+        o = Oracle(spec, opts=d.SolverOptions(rtol=1e-10, btol=1e-10))
+        z = d.initialize(spec, position=[0, 0, 0.0], velocity=[v0[0], v0[1], 0.0], angular_velocity=[0.0, 0.0, 0.0])   # (position of the bottom face: initialize_block!)
+        for _ in range(5):                       # settle on the floor
+            z, info = o.step(z, np.zeros(6)); assert info["status"] == 0
+        v_a = z[3:5].copy()
+        for _ in range(T):
+            z, info = o.step(z, np.zeros(6)); assert info["status"] == 0
+        return spec, o, np.linalg.norm(v_a - z[3:5]) / (T * spec.timestep), z
+    _, _, a_non_x, _ = slide("nonlinear", [1.5, 0.0])
+    spec, o, a_lin_x, z = slide("linear", [1.5, 0.0])
+    assert abs(a_non_x - mu * g) < 2e-3 * mu * g and abs(a_lin_x - mu * g) < 2e-3 * mu * g
+    _, _, a_non_d, _ = slide("nonlinear", [1.5 / np.sqrt(2), 1.5 / np.sqrt(2)])
+    _, _, a_lin_d, _ = slide("linear", [1.5 / np.sqrt(2), 1.5 / np.sqrt(2)])
+    assert abs(a_non_d - mu * g) < 2e-3 * mu * g
+    assert abs(a_lin_d - mu * g / np.sqrt(2)) < 5e-3 * mu * g
+    sg = o.get_solution()[6:].reshape(4, 12)                       # [s(6); gamma(6)] per contact
+    assert np.abs(sg[:, :6] * sg[:, 6:]).max() < 1e-9 and sg.min() > -1e-12
+    assert abs(sg[:, 6].sum() - g * spec.timestep) < 1e-6          # sum of the normal impulses = m g dt
+
+
 def test_block_sparse_timing_variant_matches_the_dense_solver():
     """bench.py's cpu_baseline times a block-sparse variant of the oracle (SparseLU: no pivoting, elimination order of the
     mechanism graph).  Same Newton iterate paths and, to round-off, the same states and Jacobians as the dense pivoted solver."""

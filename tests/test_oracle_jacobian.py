@@ -57,6 +57,9 @@ CASES = [
     ("npendulum", dict(springs=1.0, dampers=0.2)),
     ("twister", dict(springs=1.0, dampers=0.2)),
     ("sphere", dict()),
+    ("sphere", dict(contact_type="linear")),     # test/jacobian.jl:92,113: contact_type=:linear (LinearContact, src/contacts/linear.jl)
+    ("sphere", dict(contact_type="impact")),     # test/jacobian.jl:93,114
+    ("block", dict(contact_type="linear")),
     ("cartpole", dict(dampers=0.1)),
     ("block2d", dict()),
     ("dzhanibekov", dict()),
