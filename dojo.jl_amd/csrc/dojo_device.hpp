@@ -77,6 +77,14 @@
 #ifndef DJ_YPARK
 #define DJ_YPARK 1          // fp32 ABI: the IFT parks y in an fp64 buffer of its own (KernelArgs::ypark) instead of the fp32 output slots
 #endif
+#ifndef DJ_LINEAR
+#define DJ_LINEAR 0         // 1: builds for LinearContact mechanisms (src/contacts/linear.jl: six cone pairs [γ ψ β1..β4] per contact, all on the positive
+                            // orthant; forward only, like the reference) -- the step kernel alone, no refinement, no IFT
+#endif
+#if DJ_LINEAR
+#undef DJ_REFINE
+#define DJ_REFINE 0
+#endif
 #ifndef DJ_LS_IN_LDS
 #define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
@@ -84,6 +92,8 @@
 namespace dj {
 
 constexpr int MAXCH = 4;          // children per body supported by the lane program
+constexpr bool kLinear = DJ_LINEAR != 0;
+constexpr int NCV = kLinear ? 6 : 4;      // cone variable pairs (s, γ) per contact: NonlinearContact 4 (ImpactContact uses the first), LinearContact 6
 constexpr double REG = 1e-10;     // src/Dojo.jl:4
 
 #define DJ_STATUS_SUCCESS 0
@@ -134,7 +144,7 @@ struct Lane {
     T v[3], w[3];
     T lam[6];                    // equality multipliers: 3 translational slots, 3 rotational slots
     T ls[2], lg[2];              // rotational joint limit: s = (s_up, s_lo), γ = (γ_up, γ_lo)
-    T cs[MAXC][4], cg[MAXC][4];
+    T cs[MAXC][NCV], cg[MAXC][NCV];
 };
 
 // factor data of one supernode, kept between the two solves of a Mehrotra iteration and
@@ -156,11 +166,11 @@ struct Factors {
 };
 
 template <class T, int MAXC>
-struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][4], cg[MAXC][4]; };   // solution variables at the start of a line search
+struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][NCV], cg[MAXC][NCV]; };   // solution variables at the start of a line search
 
 template <class T, int MAXC>
 struct Step {                    // Newton step of this lane's unknowns
-    T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][4], dcg[MAXC][4];
+    T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][NCV], dcg[MAXC][NCV];
 };
 
 
@@ -874,7 +884,7 @@ DJ_HD void tra_limit_eval(JointEval<T>& E, const NodeP<T>& P, const JointCfg<T>&
 // contact evaluation at (x3, q3) of the body: residual rows, impulse, and (JAC) C/G blocks
 // ------------------------------------------------------------------------------------------------
 template <class T>
-struct ContactEval { T c[4]; T imp[6]; T C134[18]; T G134[18]; T Dww[9]; T c1p[3], c34p[6], Qraw[9]; };   // raw = before Φ
+struct ContactEval { T c[NCV]; T imp[6]; T C134[18]; T G134[18]; T Dww[9]; T c1p[3], c34p[6], Qraw[9]; };   // raw = before Φ
 
 template <bool JAC, class T>
 DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& kb, const T* v, const T* w, const T* s, const T* gam, T dt) {
@@ -888,11 +898,20 @@ DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& k
     v3cross(t, Rw, l);
     for (int i = 0; i < 3; ++i) vp[i] = v[i] + t[i];                              // contact_point_velocity (velocity.jl:2-4)
     E.c[0] = dist - s[0];
-    E.c[1] = K.mu * gam[0] - gam[1];
-    E.c[2] = v3dot(&K.t[0], vp) - s[2];
-    E.c[3] = v3dot(&K.t[3], vp) - s[3];
     T F[3], tau[3], lxF[3];
-    for (int i = 0; i < 3; ++i) F[i] = K.n[i] * gam[0] + K.t[i] * gam[2] + K.t[3 + i] * gam[3];
+    if constexpr (kLinear) {
+        // LinearContact (linear.jl:71-102), variables [γ ψ β1..β4]: μγ − Σβ − sψ;  P vt + ψ 1 − sβ with the friction_parameterization
+        // P = [0 1; 0 −1; 1 0; −1 0] (linear.jl:33-38);  force = n γ + Tᵀ Pᵀ β = n γ + t1 (β3 − β4) + t2 (β1 − β2)  (contact.jl:141-154)
+        const T vt1 = v3dot(&K.t[0], vp), vt2 = v3dot(&K.t[3], vp), psi = gam[1];
+        E.c[1] = K.mu * gam[0] - (gam[2] + gam[3] + gam[4] + gam[5]) - s[1];
+        E.c[2] = vt2 + psi - s[2]; E.c[3] = -vt2 + psi - s[3]; E.c[4] = vt1 + psi - s[4]; E.c[5] = -vt1 + psi - s[5];
+        for (int i = 0; i < 3; ++i) F[i] = K.n[i] * gam[0] + K.t[i] * (gam[4] - gam[5]) + K.t[3 + i] * (gam[2] - gam[3]);
+    } else {
+        E.c[1] = K.mu * gam[0] - gam[1];
+        E.c[2] = v3dot(&K.t[0], vp) - s[2];
+        E.c[3] = v3dot(&K.t[3], vp) - s[3];
+        for (int i = 0; i < 3; ++i) F[i] = K.n[i] * gam[0] + K.t[i] * gam[2] + K.t[3 + i] * gam[3];
+    }
     v3cross(lxF, l, F);
     m3tvec(tau, kb.R3, lxF);
     for (int i = 0; i < 3; ++i) { E.imp[i] = F[i]; E.imp[3 + i] = tau[i]; }
@@ -1111,7 +1130,7 @@ struct LaneProgram {
 #define DJ_PE(i) ((void)0)
 #endif
     // residual pieces of the last evaluation
-    T rb[6], rj[6], theta, cres[MAXC][4];
+    T rb[6], rj[6], theta, cres[MAXC][NCV];
     // Iterative refinement of the linear solves (DJ_REFINE, quad mapping).  `refine` is a per-environment flag (sticky once the
     // cones are stiff); the un-factored, contact-UNcondensed supernode rows of the last linearization live in global memory
     // (KernelArgs::blk, [workgroup][BLK_PER_LANE][lanes]: lane index fastest), written only while some environment of the
@@ -1190,8 +1209,8 @@ struct LaneProgram {
                 ContactEval<T>& CEc = CE[kEarly ? 0 : c];
                 contact_eval<JAC>(CEc, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
                 for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i];
-                for (int i = 0; i < 4; ++i) cres[c][i] = CEc.c[i];
-                if (G.contact_model == 1) cres[c][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
+                for (int i = 0; i < NCV; ++i) cres[c][i] = CEc.c[i];
+                if (!kLinear && G.contact_model == 1) cres[c][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
                 if (JAC && kEarly) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
@@ -1200,7 +1219,7 @@ struct LaneProgram {
                     ContactCold<T>& cc_ = ccold(c);
                     for (int i = 0; i < 18; ++i) { cc_.C134[i] = CEc.C134[i]; cc_.G134[i] = CEc.G134[i]; }
                 }
-            } else { for (int i = 0; i < 4; ++i) cres[c][i] = T(0); }
+            } else { for (int i = 0; i < NCV; ++i) cres[c][i] = T(0); }
         }
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
@@ -1260,10 +1279,11 @@ struct LaneProgram {
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rj[i]));          // only the Nλ equality rows (padded slots are 0)
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                for (int i = 0; i < 4; ++i) r = tmax(r, tabs(cres[c][i]));
+                for (int i = 0; i < NCV; ++i) r = tmax(r, tabs(cres[c][i]));
                 const T* g = L.cg[c]; const T* s = L.cs[c];
                 b = tmax(b, tabs(g[0] * s[0]));
-                if (G.contact_model == 0) {
+                if constexpr (kLinear) { for (int i = 1; i < NCV; ++i) b = tmax(b, tabs(g[i] * s[i])); }      // complementarity.jl:16 (γ .* s)
+                else if (G.contact_model == 0) {
                     b = tmax(b, tabs(g[1] * s[1] + g[2] * s[2] + g[3] * s[3]));
                     b = tmax(b, tabs(g[1] * s[2] + s[1] * g[2]));
                     b = tmax(b, tabs(g[1] * s[3] + s[1] * g[3]));
@@ -1288,12 +1308,13 @@ struct LaneProgram {
     // ---------------------------------------------------------------- condensation of cone rows
     // comp-row right-hand sides (r1..r4 per contact, r_cu, r_cl for the limit) -> condensed rhs
     // additions for the parent (ra) and own (rbody) body rows; coefficients for the recovery.
-    struct ConeRhs { T cc[MAXC][4]; T lim[2]; };
+    struct ConeRhs { T cc[MAXC][NCV]; T lim[2]; };
 
     DJ_HD void cone_rhs_from_state(ConeRhs& R, T mu_asm) const {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const T* g = L.cg[c]; const T* s = L.cs[c];
+            if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) R.cc[c][i] = -(g[i] * s[i] - mu_asm); continue; }   // complementarityμ: − μ·ones(6)
             R.cc[c][0] = -(g[0] * s[0] - mu_asm);
             R.cc[c][1] = -(g[1] * s[1] + g[2] * s[2] + g[3] * s[3] - mu_asm);
             R.cc[c][2] = -(g[1] * s[2] + s[1] * g[2]);
@@ -1304,10 +1325,36 @@ struct LaneProgram {
     }
 
     // contact condensation coefficients: Δγ_{1,3,4} = k0 + coef·(C134 Δw);  also Δs2 etc. for recovery
-    struct CCoef { T k0[3], coef[9]; T a1, b1, den, al2, al3, al4, g0, g1, g2, h0, h1, h2; };
+    struct CCoef { T k0[3], coef[9]; T a1, b1, den, al2, al3, al4, g0, g1, g2, h0, h1, h2;
+                   T le[kLinear ? 4 : 1], lw[kLinear ? 4 : 1], kpsi, pn, p1, p2; };     // (LinearContact: Δβ_i = le_i − lw_i (±t + Δψ), Δψ = kpsi + pn n + p1 t1 + p2 t2)
     DJ_HD void contact_coef(CCoef& Q, int c, const T* rc /*r1..r4*/, const T* r58 /*−constraint rows*/) const {
         const ContactP<T>& K = CP[P.contact[c]];
         const T* gam = L.cg[c]; const T* s = L.cs[c];
+        if constexpr (kLinear) {
+            // LinearContact: six orthant pairs, γ̃ = γ + REG, s̃ = s + REG on all of them (linear.jl:49-69).  With n = C1Δw, t1 = C3Δw,
+            // t2 = C4Δw (rows of C134):   Δsγ = n − r5;   Δsψ = μΔγ − ΣΔβ − r6;   Δsβ = (t2, −t2, t1, −t1) + Δψ − r7..10;
+            //   γ̃_i Δs_i + s̃_i Δγ_i = rc_i  =>  Δγ = a1 + b1 n;  Δβ_i = e_i − w_i(±t + Δψ), w_i = β̃_i/s̃β_i, e_i = (rc_i + β̃_i r_i)/s̃β_i;
+            //   Δψ (s̃ψ + ψ̃ Σw) = rc_ψ + ψ̃(r6 + Σe) − ψ̃ μ Δγ − ψ̃[(w3 − w4) t1 + (w1 − w2) t2].
+            // The body rows see γ and the tangential impulse b = Pᵀβ = (β3 − β4, β1 − β2) through G134, as for the nonlinear cone.
+            const T g0t = gam[0] + T(REG), s0t = s[0] + T(REG), is0 = trcp(s0t);
+            Q.a1 = (rc[0] + g0t * r58[0]) * is0; Q.b1 = -g0t * is0;
+            T E_ = T(0), W_ = T(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T bt = gam[2 + i] + T(REG), isb = trcp(s[2 + i] + T(REG));
+                Q.lw[i] = bt * isb; Q.le[i] = (rc[2 + i] + bt * r58[2 + i]) * isb;
+                E_ += Q.le[i]; W_ += Q.lw[i];
+            }
+            const T pt = gam[1] + T(REG), spt = s[1] + T(REG), iden = trcp(spt + pt * W_);
+            Q.kpsi = (rc[1] + pt * (r58[1] + E_) - pt * K.mu * Q.a1) * iden;
+            Q.pn = -pt * K.mu * Q.b1 * iden; Q.p1 = -pt * (Q.lw[2] - Q.lw[3]) * iden; Q.p2 = -pt * (Q.lw[0] - Q.lw[1]) * iden;
+            const T d1 = Q.lw[2] - Q.lw[3], d2 = Q.lw[0] - Q.lw[1];
+            Q.k0[0] = Q.a1; Q.k0[1] = (Q.le[2] - Q.le[3]) - d1 * Q.kpsi; Q.k0[2] = (Q.le[0] - Q.le[1]) - d2 * Q.kpsi;
+            Q.coef[0] = Q.b1; Q.coef[1] = T(0); Q.coef[2] = T(0);
+            Q.coef[3] = -d1 * Q.pn; Q.coef[4] = -(Q.lw[2] + Q.lw[3]) - d1 * Q.p1; Q.coef[5] = -d1 * Q.p2;
+            Q.coef[6] = -d2 * Q.pn; Q.coef[7] = -d2 * Q.p1; Q.coef[8] = -(Q.lw[0] + Q.lw[1]) - d2 * Q.p2;
+            return;
+        }
         T g1t = gam[0] + T(REG), s1t = s[0] + T(REG);
         Q.g0 = gam[1] + T(REG); Q.g1 = gam[2]; Q.g2 = gam[3];
         Q.h0 = s[1] + T(REG); Q.h1 = s[2]; Q.h2 = s[3];
@@ -1342,7 +1389,7 @@ struct LaneProgram {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < P.ncontact) {
-                CCoef Q; T rc[4] = {0, 0, 0, 0}, r58[4] = {0, 0, 0, 0};
+                CCoef Q; T rc[NCV] = {}, r58[NCV] = {};
                 contact_coef(Q, c, rc, r58);
                 const ContactCold<T>& cc_ = ccold(c);
                 // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
@@ -1975,7 +2022,7 @@ struct LaneProgram {
     // Generic right-hand side: rk0 = rhs of the body (6) and joint-equality (6) rows, R = rhs of the
     // cone (complementarity) rows, rs = rhs of the two limit slack rows, r58 = rhs of the contact
     // constraint rows, upx = direct rhs contribution to the parent's body rows.
-    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D, T* dva_out = nullptr) {
+    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, Step<T, MAXC>& D, T* dva_out = nullptr) {
         T rk[12], up[6];
         for (int i = 0; i < 12; ++i) rk[i] = rk0[i];
         for (int i = 0; i < 6; ++i) up[i] = upx[i];
@@ -2018,6 +2065,20 @@ struct LaneProgram {
                 T cw[3];
                 for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += ccold(c).C134[6 * a + j] * D.dv[j] + ccold(c).C134[6 * a + 3 + j] * D.dw[j]; }
                 const CCoef& q = Q[c];
+                if constexpr (kLinear) {                               // recovery of the twelve LinearContact variables (see contact_coef)
+                    const T n_ = cw[0], t1_ = cw[1], t2_ = cw[2];
+                    const T dgam = q.a1 + q.b1 * n_, dpsi = q.kpsi + q.pn * n_ + q.p1 * t1_ + q.p2 * t2_;
+                    const T ct[4] = {t2_, -t2_, t1_, -t1_};
+                    T sb = T(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const T db = q.le[i] - q.lw[i] * (ct[i] + dpsi);
+                        D.dcg[c][2 + i] = db; D.dcs[c][2 + i] = ct[i] + dpsi - r58[c][2 + i]; sb += db;
+                    }
+                    D.dcg[c][0] = dgam; D.dcs[c][0] = n_ - r58[c][0];
+                    D.dcg[c][1] = dpsi; D.dcs[c][1] = K.mu * dgam - sb - r58[c][1];
+                    continue;
+                }
                 T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
                 T dg1 = q.a1 + q.b1 * cw[0];
                 T dg2 = K.mu * dg1 - r58[c][1];
@@ -2029,7 +2090,7 @@ struct LaneProgram {
                 const T fz = G.contact_model == 1 ? T(0) : T(1);      // ImpactContact: the friction block stays at the neutral vector
                 D.dcs[c][0] = ds1; D.dcs[c][1] = fz * ds2; D.dcs[c][2] = fz * ds3; D.dcs[c][3] = fz * ds4;
                 D.dcg[c][0] = dg1; D.dcg[c][1] = fz * dg2; D.dcg[c][2] = fz * dg3; D.dcg[c][3] = fz * dg4;
-            } else { for (int i = 0; i < 4; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
+            } else { for (int i = 0; i < NCV; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
         }
     }
 
@@ -2070,10 +2131,10 @@ struct LaneProgram {
 
     // Newton right-hand side: −residual with the given cone-row right-hand sides
     DJ_HD void solve(const ConeRhs& R, Step<T, MAXC>& D) {
-        T rk[12], rs[2] = {0, 0}, r58[MAXC][4], upx[6] = {0, 0, 0, 0, 0, 0};
+        T rk[12], rs[2] = {0, 0}, r58[MAXC][NCV], upx[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) { rk[i] = -rb[i]; rk[6 + i] = -rj[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r58[c][i] = -cres[c][i];
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) r58[c][i] = -cres[c][i];
         if (lim_on()) {
             rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
             rs[1] = -(L.ls[1] - (theta - lim_lo()));
@@ -2110,7 +2171,7 @@ struct LaneProgram {
             for (int j = 0; j < 6; ++j) { o[(size_t)(36 + 6 * i + j) * W] = T(K.U[i][j]); o[(size_t)(54 + 6 * i + j) * W] = T(K.L[j][i]); o[(size_t)(72 + 6 * i + j) * W] = T(K.D[i][j]); }
         }
     }
-    DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[4], const T* upx, Step<T, MAXC>& D, T* dva) {
+    DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, Step<T, MAXC>& D, T* dva) {
         const T* bl = blk;
         const size_t W = (size_t)blk_stride;
         T xk[12];
@@ -2214,6 +2275,10 @@ struct LaneProgram {
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
                 a = tmin(a, ort_step(L.cs[c][0], D.dcs[c][0], tort));
                 a = tmin(a, ort_step(L.cg[c][0], D.dcg[c][0], tort));
+                if constexpr (kLinear) {                                   // line_search.jl:68-83: every pair on the positive orthant
+                    for (int i = 1; i < NCV; ++i) { a = tmin(a, ort_step(L.cs[c][i], D.dcs[c][i], tort)); a = tmin(a, ort_step(L.cg[c][i], D.dcg[c][i], tort)); }
+                    continue;
+                }
                 a = tmin(a, soc_step(&L.cs[c][1], &D.dcs[c][1], tsoc));
                 a = tmin(a, soc_step(&L.cg[c][1], &D.dcg[c][1], tsoc));
             }
@@ -2233,7 +2298,7 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[i];
         for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[i]; B.lg[i] = L.lg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { B.cs[c][i] = L.cs[c][i]; B.cg[c][i] = L.cg[c][i]; }
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) { B.cs[c][i] = L.cs[c][i]; B.cg[c][i] = L.cg[c][i]; }
     }
     DJ_HD int candidate_step(const SolSnap<T, MAXC>& B, const Step<T, MAXC>& D, T f) {
         int bad = 0;
@@ -2245,7 +2310,7 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) L.lam[i] = B.lam[i] + f * D.dlam[i];
         for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { L.cs[c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
+        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) { L.cs[c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
         return bad;
     }
 
@@ -2279,6 +2344,7 @@ struct LaneProgram {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {                                                  // reset! to [1,1,0,0] then initialize! -> 1.5·[1,1,0,0]
                 // (the generic initialize! of an ImpactContact discards its result, initialization.jl:1-5: it starts from reset!'s 1)
+                if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) L.cs[c][i] = L.cg[c][i] = T(1); continue; }   // LinearContact: reset!'s ones(6), generic initialize! (no effect)
                 const T c0_ = G.contact_model == 1 ? T(1) : T(1.5);
                 L.cs[c][0] = L.cs[c][1] = c0_; L.cs[c][2] = L.cs[c][3] = T(0);
                 L.cg[c][0] = L.cg[c][1] = c0_; L.cg[c][2] = L.cg[c][3] = T(0);
@@ -2388,9 +2454,9 @@ struct LaneProgram {
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
                 // cone_degree: 2 for NonlinearContact (nonlinear.jl:101), N½ = 1 for ImpactContact (contact.jl:203), whose
                 // pinned friction variables do not take part
-                const int nv_ = G.contact_model == 1 ? 1 : 4;
-                for (int i = 0; i < 4; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
-                p2 += G.contact_model == 1 ? T(1) : T(2);
+                const int nv_ = kLinear ? NCV : (G.contact_model == 1 ? 1 : 4);
+                for (int i = 0; i < NCV; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
+                p2 += kLinear ? T(NCV) : (G.contact_model == 1 ? T(1) : T(2));      // (LinearContact: cone_degree = N½ = 6, contact.jl:203)
             }
             if (lim_on()) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
         }
@@ -2407,6 +2473,7 @@ struct LaneProgram {
         // correction!: cached residual += [−Δs∘Δγ + μ]   src/solver/correction.jl
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
+            if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) R.cc[c][i] += -D.dcs[c][i] * D.dcg[c][i] + mutarget; continue; }   // correction.jl:13-19
             R.cc[c][0] += -D.dcs[c][0] * D.dcg[c][0] + mutarget;
             R.cc[c][1] += -(D.dcs[c][1] * D.dcg[c][1] + D.dcs[c][2] * D.dcg[c][2] + D.dcs[c][3] * D.dcg[c][3]) + mutarget;
             R.cc[c][2] += -(D.dcs[c][1] * D.dcg[c][2] + D.dcg[c][1] * D.dcs[c][2]);
@@ -3390,8 +3457,8 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         if (A.contact_sg) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                TIO* co = A.contact_sg + (size_t)env * 8 * G.Nc + 8 * P.contact[c];
-                for (int i = 0; i < 4; ++i) { co[i] = TIO(prog.L.cs[c][i]); co[4 + i] = TIO(prog.L.cg[c][i]); }
+                TIO* co = A.contact_sg + (size_t)env * (2 * NCV) * G.Nc + (2 * NCV) * P.contact[c];       // [s; γ] per contact (8; LinearContact builds: 12)
+                for (int i = 0; i < NCV; ++i) { co[i] = TIO(prog.L.cs[c][i]); co[NCV + i] = TIO(prog.L.cg[c][i]); }
             }
         }
     }

@@ -44,6 +44,7 @@ DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launc
 DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_launch_float_1_2) DJ_DECL(dojo_launch_double_1_2)
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
+DJ_DECL(dojo_launch_lin_float_1_1) DJ_DECL(dojo_launch_lin_float_4_1) DJ_DECL(dojo_launch_lin_double_1_1) DJ_DECL(dojo_launch_lin_double_4_1)     // LinearContact builds
 #define DJ_CDECL(n) int n(const void*, int, void*);
 DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
 DJ_CDECL(dojo_launch_cgrad_double_1_1) DJ_CDECL(dojo_launch_cgrad_double_4_1) DJ_CDECL(dojo_launch_cgrad_double_8_1)
@@ -380,8 +381,11 @@ int acquire_slot(DojoSim* s, int* idx) {
 // Refinement threshold: explicit (dojo_set_refinement) or tied to the requested tolerances -- the reference's defaults
 // (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
 double refine_threshold(const DojoSim* s) {
+    if (s->M.contact_model == 2) return (double)INFINITY;       // LinearContact builds carry no refining kernels
     return s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol <= 1e-7 || s->opts.btol <= 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
 }
+// scalars per contact in the exported [s; gamma] block: 8 (NonlinearContact; ImpactContact uses the first of each four), 12 (LinearContact)
+size_t csg_per(const DojoSim* s) { return s->M.contact_model == 2 ? 12 : 8; }
 size_t group_count(const DojoSim* s, bool want) {
     const size_t B = (size_t)s->B;
     size_t NG = (want && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
@@ -425,7 +429,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
-    A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, 8 * s->M.Nc);
+    A.vel = off(vel, 6 * Nb); A.joint_imp = off(jimp, s->M.n_joint_imp); A.contact_sg = off(csg, csg_per(s) * s->M.Nc);
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
@@ -442,8 +446,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = (dz != nullptr) || (dc != nullptr);
-    if (g && s->M.contact_model == 1) {   // the reference has no data Jacobians for ImpactContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
-        g_err = "gradients are not available for ImpactContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
+    if (g && s->M.contact_model != 0) {   // the reference has no data Jacobians for ImpactContact / LinearContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
+        g_err = "gradients are not available for ImpactContact / LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
     }
     A.sol = nullptr;
     if (g) {
@@ -484,7 +488,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         return DOJO_OK;
     }
     launcher_t fn;
-    if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
+    if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
+    else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
                                           : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
     else if (NW == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_2 : dojo_launch_double_1_2) : (f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2);
     else if (quad) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_1 : dojo_launch_double_1_1)
@@ -572,6 +577,9 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (s->M.has_tsd && (mapping_waves(s->M) != 1 || s->M.maxc > 4)) {
         g_err = "translational springs/dampers need the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
+    if (s->M.contact_model == 2 && (mapping_waves(s->M) != 1 || s->M.maxc > 4 || s->M.has_tsd)) {
+        g_err = "LinearContact needs the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body, no translational springs / dampers / limits)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    }
     s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
     s->opts = dj::default_options();
     if (hipSetDevice(device) != hipSuccess) { g_err = "dojo_create: hipSetDevice failed"; delete s; return DOJO_ERR_DEVICE; }
@@ -599,7 +607,7 @@ int dojo_get_dims(DojoHandle s, DojoDims* d) {
     if (!s || !d) { g_err = "dojo_get_dims: bad argument"; return DOJO_ERR_INVALID; }
     d->n_bodies = s->M.Nb; d->n_joints = (int)s->M.nodes.size(); d->n_contacts = s->M.Nc;
     d->nz = 13 * s->M.Nb; d->nx = 12 * s->M.Nb; d->nu = s->M.nu; d->n_joint_impulses = s->M.n_joint_imp;
-    d->n_solution = s->M.n_joint_imp + 6 * s->M.Nb + 8 * s->M.Nc; d->lanes_per_env = s->M.S;
+    d->n_solution = s->M.n_joint_imp + 6 * s->M.Nb + csg_per(s) * s->M.Nc; d->lanes_per_env = s->M.S;
     return DOJO_OK;
 }
 
@@ -704,7 +712,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     int rc;
     if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
-    if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_csg, B * (csg_per(s) * s->M.Nc + 1) * w))) return rc;
     if ((rc = ensure((void**)&s->d_mu, B * sizeof(double)))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t NG = group_count(s, true);
@@ -828,7 +836,7 @@ int dojo_get_solution(DojoHandle s, void* vel, void* joint_imp, void* contact_sg
     size_t B = s->B, w = s->w;
     if (vel) HIPCHK(hipMemcpy(vel, s->d_vel, B * 6 * s->M.Nb * w, hipMemcpyDeviceToHost));
     if (joint_imp && s->M.n_joint_imp) HIPCHK(hipMemcpy(joint_imp, s->d_jimp, B * s->M.n_joint_imp * w, hipMemcpyDeviceToHost));
-    if (contact_sg && s->M.Nc) HIPCHK(hipMemcpy(contact_sg, s->d_csg, B * 8 * s->M.Nc * w, hipMemcpyDeviceToHost));
+    if (contact_sg && s->M.Nc) HIPCHK(hipMemcpy(contact_sg, s->d_csg, B * csg_per(s) * s->M.Nc * w, hipMemcpyDeviceToHost));
     return DOJO_OK;
 }
 
@@ -885,6 +893,7 @@ int dojo_gradients(DojoHandle s, void* dz, void* du) {
 // internal next state; storage != null records save_to_storage! rows [H][B][Nb][25] of every solved step
 static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* storage, void* stream) {
     if (!s || !z0 || H < 1) { g_err = "dojo_rollout_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (storage && s->M.contact_model == 2) { g_err = "dojo_simulate: Storage rows are not available for LinearContact mechanisms (use dojo_rollout)"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
     int rc;
@@ -892,7 +901,7 @@ static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, 
     if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
     if ((rc = ensure(&s->d_vel, B * 6 * s->M.Nb * w))) return rc;
     if ((rc = ensure(&s->d_jimp, B * (s->M.n_joint_imp + 1) * w))) return rc;
-    if ((rc = ensure(&s->d_csg, B * (8 * s->M.Nc + 1) * w))) return rc;
+    if ((rc = ensure(&s->d_csg, B * (csg_per(s) * s->M.Nc + 1) * w))) return rc;
     if (storage && (rc = ensure(&s->d_res, B * 6 * s->M.Nb * w))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const char* cur = (const char*)z0;
@@ -1050,6 +1059,7 @@ int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_for
     if (!z) z = s->d_zn;                   // the state the last host-buffer / minimal-coordinate step left on the handle
     if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
     if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
+    if (contact_forces && s->M.contact_model == 2) { g_err = "dojo_observe: contact forces are not available for LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }
     const int Nc = contact_forces ? s->M.Nc : 0, ld = 2 * s->M.nu + Nc;

@@ -13,7 +13,7 @@ namespace dj {
 
 struct HostModel {
     int Nb = 0, Nc = 0, S = 1, nu = 0, n_joint_imp = 0, maxch = 0, maxlevel = 0, maxc = 0;
-    int contact_model = 0;       // 0: NonlinearContact, 1: ImpactContact (one model per mechanism)
+    int contact_model = 0;       // 0: NonlinearContact, 1: ImpactContact, 2: LinearContact (one model per mechanism)
     std::vector<NodeP<double>> nodes;
     std::vector<ContactP<double>> contacts;
     std::vector<TraSD<double>> tsd;   // [Nb + 1] translational springs / dampers per supernode (+ the idle slot's zero entry)
@@ -111,7 +111,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         if (P.ncontact > M.maxc) M.maxc = P.ncontact;
         ContactP<double>& Q = M.contacts[c];
         for (int i = 0; i < 3; ++i) { Q.n[i] = K.normal[i]; Q.o[i] = K.origin[i]; Q.off[i] = K.offset[i]; }
-        if (K.model != 0 && K.model != 1) { M.error = "unknown contact model (0 = NonlinearContact, 1 = ImpactContact)"; return DOJO_ERR_UNSUPPORTED; }
+        if (K.model != 0 && K.model != 1 && K.model != 2) { M.error = "unknown contact model (0 = NonlinearContact, 1 = ImpactContact, 2 = LinearContact)"; return DOJO_ERR_UNSUPPORTED; }
         if (c > 0 && K.model != M.contact_model) { M.error = "mixing contact models in one mechanism is not supported"; return DOJO_ERR_UNSUPPORTED; }
         M.contact_model = K.model;
         // ImpactContact (src/contacts/impact.jl) runs as the nonlinear model without its friction block: no tangents,

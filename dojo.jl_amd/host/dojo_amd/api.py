@@ -83,13 +83,14 @@ class BatchedMechanism:
         self.np_dtype = np.float32 if dtype in ("f32", np.float32) else np.float64
         self.dtype_code = 1 if self.np_dtype == np.float32 else 0
         self._topo, self._keep = spec.to_ctypes()
+        self.csg_per = 12 if any(c.model == 2 for c in spec.contacts) else 8     # exported [s; γ] scalars per contact (LinearContact: 6 + 6)
         self.h = C.c_void_p()
         _chk(lib().dojo_create(C.byref(self._topo), self.batch, self.dtype_code, int(device), C.byref(self.h)))
         d = CDims()
         _chk(lib().dojo_get_dims(self.h, C.byref(d)))
         self.dims = d
         # (the device exports [s(4); γ(4)] per contact for every contact model: an ImpactContact's entries are [s, 1, 0, 0, γ, 1, 0, 0])
-        assert d.nu == spec.nu and d.n_joint_impulses == spec.n_joint_impulses and d.n_solution == spec.n_joint_impulses + 6 * spec.Nb + 8 * len(spec.contacts)
+        assert d.nu == spec.nu and d.n_joint_impulses == spec.n_joint_impulses and d.n_solution == spec.n_joint_impulses + 6 * spec.Nb + self.csg_per * len(spec.contacts)
         self.set_options(opts or SolverOptions())
 
     def close(self):
@@ -188,9 +189,9 @@ class BatchedMechanism:
         B, s = self.batch, self.spec
         vel = np.empty((B, 6 * s.Nb), self.np_dtype)
         ji = np.empty((B, max(s.n_joint_impulses, 1)), self.np_dtype)
-        cs = np.empty((B, max(8 * len(s.contacts), 1)), self.np_dtype)
+        cs = np.empty((B, max(self.csg_per * len(s.contacts), 1)), self.np_dtype)
         _chk(lib().dojo_get_solution(self.h, _p(vel), _p(ji), _p(cs)))
-        return vel, ji[:, :s.n_joint_impulses], cs[:, :8 * len(s.contacts)]
+        return vel, ji[:, :s.n_joint_impulses], cs[:, :self.csg_per * len(s.contacts)]
 
     def gradients(self):
         B, s = self.batch, self.spec

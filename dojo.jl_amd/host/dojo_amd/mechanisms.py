@@ -80,7 +80,7 @@ def box_inertia(x, y, z, m):                                          # src/bodi
     return m / 12.0 * np.diag([y * y + z * z, x * x + z * z, x * x + y * y])
 
 
-CONTACT_MODELS = {"nonlinear": 0, "impact": 1, "linear": 2}     # "linear": LinearContact, src/contacts/linear.jl (CPU oracle only so far: dojo_create rejects it)
+CONTACT_MODELS = {"nonlinear": 0, "impact": 1, "linear": 2}     # "linear": LinearContact, src/contacts/linear.jl (forward only, like the reference)
 
 
 def contact_constraint(name, body, normal, friction_coefficient=1.0, contact_origin=np.zeros(3), contact_radius=0.0,

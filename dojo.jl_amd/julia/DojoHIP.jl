@@ -72,11 +72,12 @@ function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
                      pad(Dojo.vector(j.rotational.orientation_offset), 4), half(j.translational), half(j.rotational)) for j in m.joints]
     contacts = CContact[]
     for c in m.contacts
-        (c.model isa Dojo.NonlinearContact || c.model isa Dojo.ImpactContact) || error("DojoHIP: only NonlinearContact and ImpactContact are supported")
+        (c.model isa Dojo.NonlinearContact || c.model isa Dojo.ImpactContact || c.model isa Dojo.LinearContact) || error("DojoHIP: unknown contact model")
         impact = c.model isa Dojo.ImpactContact
         col = c.model.collision
         col isa Dojo.SphereHalfSpaceCollision || error("DojoHIP: only SphereHalfSpaceCollision is supported")
-        push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : 0, impact ? 0.0 : c.model.friction_coefficient, pad(col.contact_normal', 3),
+        # (LinearContact: the library has the reference's friction_parameterization [0 1; 0 -1; 1 0; -1 0] built in, src/contacts/linear.jl:33-38)
+        push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : (c.model isa Dojo.LinearContact ? 2 : 0), impact ? 0.0 : c.model.friction_coefficient, pad(col.contact_normal', 3),
                                  impact ? ntuple(_ -> 0.0, 6) : pad(vec(permutedims(Matrix(col.contact_tangent))), 6), pad(col.contact_origin, 3),
                                  col.contact_radius, pad(col.contact_offset, 3)))
     end
@@ -318,7 +319,8 @@ function hip_mehrotra!(m::Dojo.Mechanism, bm::BatchedMechanism{Float64}; opts=Do
     zn = similar(z); status = Vector{Int32}(undef, 1); iters = Vector{Int32}(undef, 1)
     check(@ccall $(fn(:dojo_step_impulses))(bm.handle::Ptr{Cvoid}, z::Ptr{Float64}, jf::Ptr{Float64}, zn::Ptr{Float64}, status::Ptr{Int32}, iters::Ptr{Int32})::Cint)
     # ---- write-back (what mehrotra! mutates, SURVEY.md §8b) ----
-    vel = Vector{Float64}(undef, 6Nb); ji = Vector{Float64}(undef, max(1, sum(length.(m.joints)))); cs = Vector{Float64}(undef, max(1, 8length(m.contacts)))
+    per = any(c -> c.model isa Dojo.LinearContact, m.contacts) ? 12 : 8      # exported [s; γ] scalars per contact (dojo_hip.h, dojo_get_solution)
+    vel = Vector{Float64}(undef, 6Nb); ji = Vector{Float64}(undef, max(1, sum(length.(m.joints)))); cs = Vector{Float64}(undef, max(1, per * length(m.contacts)))
     check(@ccall $(fn(:dojo_get_solution))(bm.handle::Ptr{Cvoid}, vel::Ptr{Float64}, ji::Ptr{Float64}, cs::Ptr{Float64})::Cint)
     for (i, b) in enumerate(m.bodies)
         b.state.vsol[2] = SVector{3}(vel[6i-5:6i-3]); b.state.ωsol[2] = SVector{3}(vel[6i-2:6i])
@@ -329,8 +331,9 @@ function hip_mehrotra!(m::Dojo.Mechanism, bm::BatchedMechanism{Float64}; opts=Do
         n = length(j); j.impulses[2] = SVector{n}(ji[off+1:off+n]); j.impulses[1] = j.impulses[2]; off += n
     end
     for (i, c) in enumerate(m.contacts)
-        nh = length(c.impulses[2])            # N½: 4 for NonlinearContact, 1 for ImpactContact; the device exports [s(4); γ(4)] per contact either way
-        c.impulses_dual[2] = SVector{nh}(cs[8i-7:8i-8+nh]); c.impulses[2] = SVector{nh}(cs[8i-3:8i-4+nh])
+        nh = length(c.impulses[2])            # N½: 4 for NonlinearContact, 1 for ImpactContact (the device exports [s(4); γ(4)] for both), 6 for LinearContact ([s(6); γ(6)])
+        o = per * (i - 1); h = per ÷ 2
+        c.impulses_dual[2] = SVector{nh}(cs[o+1:o+nh]); c.impulses[2] = SVector{nh}(cs[o+h+1:o+h+nh])
         c.impulses_dual[1] = c.impulses_dual[2]; c.impulses[1] = c.impulses[2]
     end
     mu = Vector{Float64}(undef, 1)

@@ -115,8 +115,10 @@ typedef struct DojoJoint {
  * (src/contacts/nonlinear.jl:12-48, src/contacts/collisions/sphere_halfspace.jl:11-22) */
 typedef struct DojoContact {
     int32_t body;                 /* parent_id as index into bodies[]                      */
-    int32_t model;                /* 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl;
-                                     forward only: the reference has no data Jacobians for it, src/gradients/data.jl:152-192) */
+    int32_t model;                /* 0: NonlinearContact (src/contacts/nonlinear.jl), 1: ImpactContact (src/contacts/impact.jl),
+                                     2: LinearContact (src/contacts/linear.jl: friction pyramid, cone variables [gamma psi beta1..4]);
+                                     1 and 2 forward only: the reference has no data Jacobians for them (src/gradients/data.jl:152-192);
+                                     one model per mechanism; 2: <= 16 bodies, <= 4 contacts per body                        */
     double  friction_coefficient;
     double  normal[3];            /* collision.contact_normal (1x3)                        */
     double  tangent[6];           /* collision.contact_tangent (2x3, row-major)            */
@@ -207,7 +209,8 @@ int  dojo_next_state(DojoHandle h, const void* z, void* z_out);
 int  dojo_next_state_dev(DojoHandle h, const void* z, void* z_out, void* stream);
 
 /* solution of the last step in get_solution order per env:
- * vel [B,6Nb] (v25,w25 per body), joint_imp [B,n_joint_impulses], contact_sg [B,8Nc] ([s;gamma] per contact).
+ * vel [B,6Nb] (v25,w25 per body), joint_imp [B,n_joint_impulses], contact_sg [B,8Nc] ([s(4);gamma(4)] per contact; an
+ * ImpactContact uses the first of each four; LinearContact mechanisms: [B,12Nc], [s(6);gamma(6)]).
  * Any pointer may be NULL. */
 int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_sg);
 /* mechanism.mu (the central-path parameter kappa of the docs, src/solver/mehrotra.jl:45) per environment when the solve of

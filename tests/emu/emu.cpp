@@ -99,7 +99,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     auto castv = [](const double* p, size_t n) { std::vector<TIO> v(p ? n : 0); for (size_t i = 0; i < v.size(); ++i) v[i] = TIO(p[i]); return v; };
     std::vector<TIO> zt = castv(z, (size_t)B * nz), ut = castv(u, (size_t)B * M.nu);
     std::vector<TIO> zn((size_t)B * nz), velt(vel ? (size_t)B * 6 * M.Nb : 0), jt(jimp ? (size_t)B * std::max(M.n_joint_imp, 1) : 0),
-        ct(csg ? (size_t)B * 8 * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
+        ct(csg ? (size_t)B * (2 * dj::NCV) * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
     dj::KernelArgs<TIO, T> A;
     { const char* rw = std::getenv("EMU_REFINE_W"); A.G = dj::make_globals<T>(M, opts, grad_mode, rw ? std::atof(rw) : INFINITY); }
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
@@ -158,12 +158,12 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
             for (int i = 0; i < 13; ++i) zb[i] = T(zt[(size_t)e * nz + 13 * k + i]);
             for (int i = 0; i < 3; ++i) { v[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + i]); w[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + 3 + i]); }
             for (int i = 0; i < 6; ++i) rb[i] = T(rest[(size_t)e * 6 * M.Nb + 6 * k + i]);
-            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * 8 * M.Nc, rb, fext ? fe : (const T*)nullptr);
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr);
             for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
         }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
     for (size_t i = 0; i < (jimp ? (size_t)B * M.n_joint_imp : 0); ++i) jimp[i] = jt[i];
-    for (size_t i = 0; i < (csg ? (size_t)B * 8 * M.Nc : 0); ++i) csg[i] = ct[i];
+    for (size_t i = 0; i < (csg ? (size_t)B * (2 * dj::NCV) * M.Nc : 0); ++i) csg[i] = ct[i];
     for (size_t i = 0; i < dzt.size(); ++i) dz[i] = dzt[i];
     for (size_t i = 0; i < dbgt.size(); ++i) dbg[i] = dbgt[i];
     for (size_t i = 0; i < (du ? (size_t)B * nx * M.nu : 0); ++i) du[i] = dut[i];

@@ -8,6 +8,21 @@ from dojo_amd.topology import CTopology, CSolverOptions, SolverOptions
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
+_lib_lin = None
+
+
+def lib_linear():
+    """the emulator compiled with -DDJ_LINEAR=1 (LinearContact builds of the device source: six cone pairs per contact)"""
+    global _lib_lin
+    if _lib_lin is None:
+        so = os.path.join(_HERE, "emu", "libemu_lin.so")
+        src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
+                                                         for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DDJ_LINEAR=1", "-o", so, src[0]])
+        _lib_lin = C.CDLL(so)
+        _lib_lin.emu_step.restype = C.c_int
+    return _lib_lin
 
 
 def lib():
@@ -42,7 +57,8 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     o = (opts or SolverOptions()).to_c()
     nx, nu = 12 * spec.Nb, spec.nu
     Zn = np.zeros_like(Z); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
-    vel = np.zeros((B, 6 * spec.Nb)); jimp = np.zeros((B, max(spec.n_joint_impulses, 1))); csg = np.zeros((B, max(8 * len(spec.contacts), 1)))
+    vel = np.zeros((B, 6 * spec.Nb)); jimp = np.zeros((B, max(spec.n_joint_impulses, 1))); linear = any(c.model == 2 for c in spec.contacts); cper = 12 if linear else 8
+    csg = np.zeros((B, max(cper * len(spec.contacts), 1)))
     dz = np.zeros((B, nx, nx)) if grad else None
     du = np.zeros((B, max(nu, 1), nx)) if grad else None
     dbg = np.zeros((B, spec.Nb, 512)) if debug else None
@@ -51,11 +67,11 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     stor = np.zeros((B, spec.Nb, 25))
     fext = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(B, 6 * spec.Nb))
     err = C.create_string_buffer(256)
-    rc = lib().emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
+    rc = (lib_linear() if linear else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
-    out = dict(z_next=Zn, status=st, iters=it, vel=vel, storage=stor, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :8 * len(spec.contacts)])
+    out = dict(z_next=Zn, status=st, iters=it, vel=vel, storage=stor, joint_imp=jimp[:, :spec.n_joint_impulses], contact_sg=csg[:, :cper * len(spec.contacts)])
     if debug:
         out["dbg"] = dbg
     if grad:

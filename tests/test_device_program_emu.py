@@ -364,3 +364,28 @@ def test_fp32_abi_gradients_match_oracle(cfg, pre):
         assert np.abs(r["dz"][b] - dz).max() < 1e-5 * max(1.0, np.abs(dz).max())
         if spec.nu:
             assert np.abs(r["du"][b] - du).max() < 1e-5 * max(1.0, np.abs(du).max())
+
+
+@pytest.mark.parametrize("name,kw,v0", [("sphere", dict(), [1.0, 0.4, 0.0]), ("block", dict(contact_corners=4, friction_coefficient=0.3), [1.2, 0.9, 0.0]),
+                                        ("block", dict(contact_corners=4, friction_coefficient=0.3), [0.0, 0.0, 0.0])])
+def test_linear_contact_matches_oracle(name, kw, v0):
+    """LinearContact (src/contacts/linear.jl; -DDJ_LINEAR builds of the device source: six orthant pairs [γ ψ β1..β4] per contact,
+    condensed onto the body block through the same three directions as the nonlinear cone): free flight, impact, sliding along
+    and across the pyramid's axes and rest, against the oracle -- equal Newton iteration counts, states, and all twelve
+    exported cone variables of every contact."""
+    spec = d.get_mechanism(name, contact_type="linear", **kw)
+    o = Oracle(spec, opts=TIGHT)
+    z = d.initialize(spec, position=[0, 0, 0.05], velocity=v0, angular_velocity=[0.3, -0.2, 0.5]) if name == "block" else d.initialize(spec)
+    if name == "sphere":
+        z = z.copy(); z[2] = 0.52; z[3:6] = v0; z[10:13] = [0.5, -1.0, 0.2]
+    u = np.zeros(spec.nu)
+    for k in range(14):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z, u, opts=TIGHT, quad=True)
+        # (the impact step of the sphere runs into max_iter in the oracle as well: the iterate paths still agree to round-off)
+        assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"], (k, r["status"][0], info["status"], r["iters"][0], info["iters"])
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-8, (k, np.abs(r["z_next"][0] - zo).max())
+        sg = o.get_solution()[6 * spec.Nb + spec.n_joint_impulses:]
+        assert np.abs(r["contact_sg"][0] - sg).max() < 1e-7 * max(1.0, np.abs(sg).max()), k
+        z = zo
+    assert (sg.reshape(-1, 12)[:, 6] > 1e-4).any()                  # in contact by the end

@@ -764,6 +764,56 @@ def test_external_force_behaviour_and_parity():
     gm.close()
 
 
+@pytest.mark.parametrize("name,kw,dtype", [("block", dict(contact_corners=4, friction_coefficient=0.3), "f64"), ("sphere", dict(), "f64"),
+                                           ("block", dict(contact_corners=4, friction_coefficient=0.3), "f32")])
+def test_linear_contact_parity_and_properties(name, kw, dtype):
+    """LinearContact (src/contacts/linear.jl; forward only, as in the reference): batches of blocks / spheres
+    thrown onto the floor against the oracle -- the same Newton iterate paths (status and iteration counts, stalled impact steps
+    included), states and all twelve cone variables per contact; then the friction pyramid at batch 1024: a block sliding along
+    a parameterization axis decelerates at mu g, along the diagonal at mu g / sqrt(2); gradients are refused loudly."""
+    spec = d.get_mechanism(name, contact_type="linear", **kw)
+    B = 128
+    rng = np.random.default_rng(5)
+    if name == "block":
+        Z = np.stack([d.initialize(spec, position=[0, 0, rng.uniform(0.0, 0.2)], velocity=rng.normal(size=3), angular_velocity=rng.normal(size=3) * 0.5) for _ in range(B)])
+    else:
+        Z = np.tile(d.initialize(spec), (B, 1)); Z[:, 2] = 0.5 + rng.uniform(0.0, 0.2, B); Z[:, 3:6] = rng.normal(size=(B, 3)); Z[:, 10:13] = rng.normal(size=(B, 3))
+    U = np.zeros((B, spec.nu))
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8) if dtype == "f64" else d.SolverOptions()
+    gm = api.BatchedMechanism(spec, B, dtype=dtype, opts=opts)
+    o = Oracle(spec, opts=opts)
+    z = Z.astype(gm.np_dtype).astype(np.float64) if dtype == "f32" else Z.copy()
+    nconv = 0
+    for k in range(20):
+        zg, st, it = gm.step(z.astype(gm.np_dtype), U.astype(gm.np_dtype))
+        zo, st_o, it_o, _, _ = o.step_batch(d.fp32_abi_state(z) if dtype == "f32" else z, U, nthreads=16)
+        reg = (it <= REGULAR_ITERS) & (it_o <= REGULAR_ITERS)
+        assert np.array_equal(st[reg], st_o[reg]) and np.array_equal(it[reg], it_o[reg]) and reg.mean() > 0.8
+        assert np.abs(zg[reg].astype(np.float64) - zo[reg]).max() < (1e-8 if dtype == "f64" else 1e-5)
+        nconv += int(((st == 0) & reg).sum())
+        z = zo.astype(np.float32).astype(np.float64) if dtype == "f32" else zo
+    assert nconv > 0.8 * 20 * B
+    _, _, sg = gm.get_solution()
+    assert sg.shape == (B, 12 * len(spec.contacts))
+    if dtype == "f64":
+        with pytest.raises(api.DojoError):
+            gm.step(z, U, with_gradient=True)
+    gm.close()
+    if name != "block" or dtype != "f64":
+        return
+    mu, g, T, Bb = 0.3, 9.81, 20, 1024
+    zb = np.tile(d.initialize(spec, position=[0, 0, 0.0], velocity=[2.0, 0.0, 0.0], angular_velocity=[0, 0, 0]), (Bb, 1))
+    zb[Bb // 2:, 3] = zb[Bb // 2:, 4] = 2.0 / np.sqrt(2)              # second half: along the diagonal of the pyramid
+    gm = api.BatchedMechanism(spec, Bb, dtype="f64", opts=d.SolverOptions(rtol=1e-10, btol=1e-10))
+    Zt, st = gm.rollout(zb, None, steps=5 + T)
+    gm.close()
+    assert (st == 0).all()
+    v = Zt.reshape(5 + T, Bb, 13)[:, :, 3:5]
+    dec = np.linalg.norm(v[4] - v[-1], axis=1) / (T * spec.timestep)
+    assert np.abs(dec[:Bb // 2] - mu * g).max() < 2e-3 * mu * g
+    assert np.abs(dec[Bb // 2:] - mu * g / np.sqrt(2)).max() < 5e-3 * mu * g
+
+
 def test_impact_contact_parity_and_properties():
     """ImpactContact blocks (src/contacts/impact.jl) against the oracle at batch 128, the size-independent
     frictionless properties at batch 1024, and the loud refusal of gradients (the reference has no data Jacobians either)."""
