@@ -66,11 +66,6 @@
 #ifndef DJ_CONDENSE_OWN_ROWS
 #define DJ_CONDENSE_OWN_ROWS 1   // quad mapping: the contact condensation computes only the lane's own three body rows (108 instead of 648 multiply-adds per contact)
 #endif
-#ifndef DJ_FUSED_LOOP
-#define DJ_FUSED_LOOP 0    // 1: rotated Newton loop with ONE set_entries! site (LaneProgram::mehrotra_fused): one residual evaluation less per iteration and a
-                           // third less code, parity-green on the emulator and the GPU -- and 11 % SLOWER on the GPU (Ant step kernel 4.86-4.92 against 4.37 ms
-                           // in one session, three variants of the control flow: scratch 416 instead of 256 B/lane inside the hot loop) -> off
-#endif
 #ifndef DJ_SCHUR_LEAN
 #define DJ_SCHUR_LEAN 1      // quad factorization: Schur complement with 18 (not 54) gathered U entries and 18 (not 36) partial sums in flight: 49 -> 39 spilled VGPRs, +1.4 % (same session)
 #endif
@@ -1098,8 +1093,6 @@ struct LaneProgram {
     bool pool_by_id = false; int pool_base = 0;
     // Newton step + line-search base iterate once per supernode in LDS (single-wave quad mapping with one contact per body: there is room)
     static constexpr bool kLsInLds = DJ_LS_IN_LDS && QUAD && Wave::kLockstep && Wave::kWaves == 1 && MAXC == 1;
-    // (the CPU emulator's free-running lanes keep the step in lane-local storage; it runs the same rotated loop so that the CPU tier covers it)
-    static constexpr bool kFusedLoop = DJ_FUSED_LOOP && QUAD && MAXC == 1 && Wave::kWaves == 1 && (kLsInLds || !Wave::kLockstep);
     char* ls_lds = nullptr;
     char* lane_slots = nullptr; int lane_slot_stride = 0;   // lock-step quad mapping: the Lane blocks of all supernodes of the workgroup (parents are read in place)
     DJ_HD const Lane<T, MAXC>& parent_state() const { return *(const Lane<T, MAXC>*)(lane_slots + (size_t)((has_parent ? base + stride * P.parent : qb) >> 2) * lane_slot_stride); }
@@ -2489,105 +2482,6 @@ struct LaneProgram {
         return cone_line_search(D, tau, tmin(tau, T(0.95)));
     }
 
-    // The same iteration with ONE set_entries! site (DJ_FUSED_LOOP; mappings that keep the Newton step and the line-search base
-    // iterate in LDS).  Trial 0 of the line search of iteration n-1 and the set_entries! evaluation that follows an accepted trial
-    // are the same point, and almost every line search accepts trial 0 (Ant: 1.01 residual evaluations per search), so the loop
-    // is rotated: every pass starts by evaluating the residual WITH its Jacobian blocks at the trial iterate; if that trial
-    // is accepted (or it is the initial iterate) condensation and factorization follow directly, otherwise the remaining trials
-    // evaluate the residual only and the blocks are evaluated once more at the accepted iterate.  Same operations on the same
-    // values in the same order as the loop below -- minus one residual evaluation per iteration, and with one inlined copy
-    // of the assembly + factorization instead of two (the step kernel's code shrinks by a third).
-    DJ_HD int mehrotra_fused(int& iters_out, bool need_factors, int status, int excessive, T mutarget, T undercut, int no_progress) {
-        Step<T, MAXC> D_local; SolSnap<T, MAXC> base_local;
-        Step<T, MAXC>& D = kLsInLds ? *(Step<T, MAXC>*)ls_lds : D_local;
-        SolSnap<T, MAXC>& base_sol = kLsInLds ? *(SolSnap<T, MAXC>*)(ls_lds + sizeof(Step<T, MAXC>)) : base_local;
-        T rvio = T(0), bvio = T(0), rc = T(0), bc = T(0), f = T(0);
-        bool done = false, searching = false;
-        int iters = 0;
-        for (int n = 1; ; ++n) {
-            QuadBlocks<TL> Kq(F.Sq, F.Uq, F.Lq, q);                     // the lane's rows, assembled in place in the factor storage
-            // ---- residual + Jacobian blocks at the trial iterate (n = 1: the initial iterate, no step to take)
-            DJ_PB();
-            for (int pass = 0; pass < 2; ++pass) {
-                int bad = 0;
-                if (n > 1) bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
-                evaluate<true>(Kq);
-                T r2, b2;
-                violations(r2, b2);
-                if (n == 1) { rvio = r2; bvio = b2; break; }
-                if (pass == 1) break;                                   // the blocks at the accepted iterates; rc, bc are those of the accepted trials
-                // line_search!  src/solver/line_search.jl:1-34 (halving; the last trial is taken if all are rejected): trial 0
-                {
-                    T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)};
-                    if constexpr (DJ_LDS_REDUCE) env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; });
-                    else vb[0] = T(env_or(wv, (active && searching) ? bad : 0, envl));
-                    if (searching) {
-                        excessive |= vb[0] > T(0.5) ? 1 : 0;
-                        rc = r2; bc = b2;
-                        if (r2 > rvio && b2 > bvio) { if (1 < G.max_ls) f *= T(0.5); } else searching = false;
-                    }
-                }
-                if (G.max_ls <= 1 || !wv.any(active && searching)) break;
-                // the remaining trials: residual only
-                for (int ls = 1; ls < G.max_ls; ++ls) {
-                    if (!wv.any(active && searching)) break;
-                    bad = candidate_step(base_sol, D, f);
-                    { NullBlocks nk; evaluate<false>(nk); }
-                    violations(r2, b2);
-                    T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)};
-                    if constexpr (DJ_LDS_REDUCE) env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; });
-                    else vb[0] = T(env_or(wv, (active && searching) ? bad : 0, envl));
-                    if (searching) {
-                        excessive |= vb[0] > T(0.5) ? 1 : 0;
-                        rc = r2; bc = b2;
-                        if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
-                    }
-                }
-            }
-            DJ_PE(3);
-            if (n > 1 && !done) {                                       // the bookkeeping that closes iteration n - 1
-                bool made = (!(rc < G.rtol) && rc < T(0.8) * rvio) || (!(bc < G.btol) && bc < T(0.8) * bvio);
-                if (made) no_progress = no_progress > 0 ? no_progress - 1 : 0; else no_progress += 1;
-                rvio = rc; bvio = bc;
-                if (no_progress >= G.no_progress_max) undercut *= G.no_progress_undercut;
-                mu = mutarget;
-                if constexpr (kTrack) refine = refine || (wstiff > G.refine_w);    // (wstiff: from the accepted trial's violations)
-            }
-            // Forward-only launch, every environment of the workgroup converged: the next iteration would only flag success
-            // (mehrotra.jl:23-27) -- do that here and skip the condensation + factorization nobody will use.
-            if (!need_factors && n <= G.max_iter) {
-                const bool conv = done || (rvio < G.rtol && bvio < G.btol);
-                if (!wv.any(active && !conv)) { if (!done) { status = DJ_STATUS_SUCCESS; done = true; } break; }
-            }
-            // ---- the rest of set_entries!: condensation of the cone rows, factorization (cone rows carry the new μ from here on)
-            DJ_PB();
-            condense_limits(Kq);
-            if constexpr (kRefine) { if (blk != nullptr && wv.any(refine)) store_blocks(Kq); }
-            condense_contacts(Kq);
-            DJ_PE(0); DJ_PB();
-            factorize_quad(Kq);
-            DJ_PE(1);
-#ifdef DJ_DEBUG
-            if (n == 1 && dbg_on) { iters_out = 0; return 0; }   // wave-uniform early exit of the test hook
-#endif
-            if (n > G.max_iter) break;
-            // ---- iteration n (src/solver/mehrotra.jl:23-49)
-            if (!done && rvio < G.rtol && bvio < G.btol) { status = DJ_STATUS_SUCCESS; done = true; }
-            if constexpr (kTrack && !kRefine) { if (!done && refine) { status = DJ_STATUS_DEFERRED; done = true; } }   // left to the refining kernel
-            if (!wv.any(active && !done)) break;
-            if (!done) iters = n;
-            const T alpha = newton_direction(D, rvio, bvio, undercut, mutarget);
-            // the line search of this iteration starts with the next pass' evaluation
-            searching = !done && G.max_ls > 0;
-            f = searching ? alpha : T(0);                               // finished environments (and max_ls = 0) keep their iterate
-            rc = rvio; bc = bvio;
-            snapshot(base_sol);
-        }
-        if (excessive && status != DJ_STATUS_DEFERRED) status = DJ_STATUS_EXCESSIVE_W;
-        iters_out = iters;
-        return status;
-    }
-
     // need_factors: the caller goes on to the IFT (which re-uses the final factors); a forward-only step may skip the
     // set_entries! + factorization after the iteration that converged.
     DJ_HD int mehrotra(int& iters_out, bool need_factors = true) {
@@ -2596,7 +2490,6 @@ struct LaneProgram {
         int no_progress = 0;
         mu = T(0);
         if constexpr (kTrack) refine = T(1) > G.refine_w;        // reset! / initialize! leave every cone at γ/s = 1
-        if constexpr (kFusedLoop) return mehrotra_fused(iters_out, need_factors, status, excessive, mutarget, undercut, no_progress);
         linearize();
         typename QuadKType<TL, QUAD>::type Kq(F.Sq, F.Uq, F.Lq, q);   // quad mapping: the lane's rows, assembled in place in the factor storage
 #ifdef DJ_DEBUG
