@@ -46,7 +46,10 @@
  *
  * Pointer arguments are *host* pointers for the plain entry points and *device*
  * pointers for the `_dev` variants (used by bench.py / torch so that inputs are
- * resident in HBM when the timed region starts).
+ * resident in HBM when the timed region starts).  The host-pointer entry points synchronize the DEVICE
+ * (hipDeviceSynchronize), not a stream: they may follow `_dev` calls that ran on caller streams the handle does not
+ * keep (a non-blocking caller stream is not ordered with the null stream), and they move their data over PCIe anyway;
+ * latency-sensitive callers stay on the `_dev` variants, which never synchronize.
  */
 #ifndef DOJO_HIP_H
 #define DOJO_HIP_H
