@@ -389,3 +389,25 @@ def test_linear_contact_matches_oracle(name, kw, v0):
         assert np.abs(r["contact_sg"][0] - sg).max() < 1e-7 * max(1.0, np.abs(sg).max()), k
         z = zo
     assert (sg.reshape(-1, 12)[:, 6] > 1e-4).any()                  # in contact by the end
+
+
+@pytest.mark.parametrize("name,kw", [("snake", dict(num_bodies=3)), ("twister", dict(num_bodies=3))])
+def test_linear_contact_on_articulated_mechanisms(name, kw):
+    """LinearContact on several bodies of a tree (two contacts per snake link: the MAXC = 4 LinearContact build; joints and
+    contacts in one supernode): actuated free fall and landing against the oracle, equal iterate paths and states."""
+    spec = d.get_mechanism(name, contact_type="linear", **kw)
+    o = Oracle(spec, opts=TIGHT)
+    z = d.initialize(spec); u = 0.2 * np.ones(spec.nu)
+    touched = False
+    for k in range(60):
+        zo, info = o.step(z, u)
+        if k % 3 == 0 or touched:
+            r = emu_step(spec, z, u, opts=TIGHT, quad=True)
+            assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"], (k, r["iters"][0], info["iters"])
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-8, (k, np.abs(r["z_next"][0] - zo).max())
+        sg = o.get_solution()[6 * spec.Nb + spec.n_joint_impulses:].reshape(-1, 12)
+        touched = touched or bool((sg[:, 6] > 1e-4).any())
+        z = zo
+        if touched and k > 45:
+            break
+    assert touched
