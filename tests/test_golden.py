@@ -80,3 +80,42 @@ def test_gpu_matches_golden_mechanisms(key):
         assert np.abs(dz[0] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
         if spec.nu:
             assert np.abs(du[0] - GM[key + "_du0"]).max() <= 1e-6 * max(1.0, np.abs(GM[key + "_du0"]).max())
+
+
+# ---- contact models that are forward only in the reference (LinearContact, ImpactContact) ----
+GC = np.load(os.path.join(ROOT, "tests", "golden", "oracle_steps_contacts.npz"))
+CONTACTS = {"block_linear": ("block", dict(contact_type="linear", contact_corners=4, friction_coefficient=0.3)),
+            "sphere_linear": ("sphere", dict(contact_type="linear")),
+            "block_impact": ("block", dict(contact_type="impact", contact_corners=4))}
+
+
+@pytest.mark.parametrize("key", sorted(CONTACTS))
+def test_oracle_reproduces_golden_contacts(key):
+    name, kw = CONTACTS[key]
+    spec = d.get_mechanism(name, **kw)
+    o = Oracle(spec, opts=OPTS)
+    Z = GC[key + "_z"]; U = np.zeros((len(Z), spec.nu))
+    Zn, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    assert np.array_equal(st, GC[key + "_status"]) and np.array_equal(it, GC[key + "_iters"])
+    assert np.abs(Zn - GC[key + "_zn"]).max() < 1e-12
+    o.step(Z[0], U[0])
+    assert np.abs(o.get_solution()[6 * spec.Nb + spec.n_joint_impulses:] - GC[key + "_sg"][0]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", sorted(CONTACTS))
+def test_gpu_matches_golden_contacts(key):
+    from dojo_amd import api
+    name, kw = CONTACTS[key]
+    spec = d.get_mechanism(name, **kw)
+    Z = GC[key + "_z"]; U = np.zeros((len(Z), spec.nu))
+    gm = api.BatchedMechanism(spec, len(Z), dtype="f64", opts=OPTS)
+    zn, st, it = gm.step(Z, U)
+    _, _, sg = gm.get_solution()
+    gm.close()
+    assert np.array_equal(st, GC[key + "_status"]) and np.array_equal(it, GC[key + "_iters"])
+    assert np.abs(zn - GC[key + "_zn"]).max() < 1e-8
+    ref = GC[key + "_sg"]
+    if key == "block_impact":                                   # the device exports [s(4); γ(4)] per contact for an ImpactContact: entries 0 and 4
+        sg = sg.reshape(len(Z), -1, 8)[:, :, [0, 4]].reshape(len(Z), -1)
+    assert np.abs(sg - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())

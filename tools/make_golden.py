@@ -49,3 +49,30 @@ for key, (kw, B, pre) in MECHS.items():
     out[key + "_dz0"] = dz[0]; out[key + "_du0"] = du[0]
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps_mechanisms.npz"), **out)
 print("wrote tests/golden/oracle_steps_mechanisms.npz", {k: v.shape for k, v in out.items() if k.endswith("_z")}, {k: v for k, v in out.items() if k.endswith("_status")})
+
+
+# Contact models that are forward only in the reference (no data Jacobians): LinearContact, ImpactContact.
+# tests/golden/oracle_steps_contacts.npz: thrown blocks / spheres a few steps after touching the floor.
+CONTACTS = {"block_linear": ("block", dict(contact_type="linear", contact_corners=4, friction_coefficient=0.3)),
+            "sphere_linear": ("sphere", dict(contact_type="linear")),
+            "block_impact": ("block", dict(contact_type="impact", contact_corners=4))}
+out = {}
+rng = np.random.default_rng(11)
+for key, (name, kw) in CONTACTS.items():
+    spec = d.get_mechanism(name, **kw)
+    o = Oracle(spec, opts=d.SolverOptions(rtol=1e-8, btol=1e-8))
+    B = 4
+    if name == "block":
+        Z = np.stack([d.initialize(spec, position=[0, 0, rng.uniform(0.0, 0.05)], velocity=rng.normal(size=3), angular_velocity=rng.normal(size=3) * 0.5) for _ in range(B)])
+    else:
+        Z = np.tile(d.initialize(spec), (B, 1)); Z[:, 2] = 0.5 + rng.uniform(0.0, 0.05, B); Z[:, 3:6] = rng.normal(size=(B, 3)); Z[:, 10:13] = rng.normal(size=(B, 3))
+    U = np.zeros((B, spec.nu))
+    for _ in range(14):
+        Z, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    Zn, st, it, _, _ = o.step_batch(Z, U, nthreads=4)
+    sg = []
+    for b in range(B):
+        o.step(Z[b], U[b]); sg.append(o.get_solution()[6 * spec.Nb + spec.n_joint_impulses:])
+    out[key + "_z"] = Z; out[key + "_zn"] = Zn; out[key + "_status"] = st; out[key + "_iters"] = it; out[key + "_sg"] = np.stack(sg)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_steps_contacts.npz"), **out)
+print("wrote tests/golden/oracle_steps_contacts.npz", {k: v.shape for k, v in out.items() if k.endswith("_sg")}, {k: v for k, v in out.items() if k.endswith("_status") or k.endswith("_iters")})
