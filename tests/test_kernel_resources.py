@@ -1,0 +1,29 @@
+"""Guard on the register footprint of the headline kernels (Ant / Quadruped: fp32 ABI, MAXC = 1, quad mapping).  With all 512
+registers of a SIMD in use the step kernel's speed follows its spills (256 -> 416 B/lane of scratch cost
+11 %), and small edits anywhere in the lane program move the allocator -- this test makes such a change visible on the CPU tier.
+Reads the object __graft_entry__.build() leaves in dojo.jl_amd/csrc/build (skipped when it is not there)."""
+import os
+import re
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, "dojo.jl_amd", "csrc", "build", "k_float_1_1.o")
+TOOL = os.path.join(ROOT, "tools", "kernel_resources.sh")
+
+
+@pytest.mark.skipif(not (os.path.exists(OBJ) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")), reason="no built object / no llvm tools")
+def test_headline_kernels_keep_their_register_footprint():
+    out = subprocess.run(["bash", TOOL, OBJ], capture_output=True, text=True, timeout=300).stdout
+    res = {}
+    for ln in out.splitlines():
+        m = re.search(r"\.name:\s+(dojo_\w+?_kernel)I.*?\.private_segment_fixed_size:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", ln)
+        lds = re.search(r"\.group_segment_fixed_size:\s+(\d+)", ln)
+        if m:
+            res[m.group(1)] = (int(m.group(2)), int(m.group(3)), int(lds.group(1)) if lds else None)
+    assert "dojo_step_kernel" in res and "dojo_grad_kernel" in res, out
+    scratch, spills, lds = res["dojo_step_kernel"]
+    assert scratch <= 256 and spills <= 45, ("step kernel: scratch %d B/lane, %d spilled VGPRs (was 256 / 39)" % (scratch, spills))
+    assert lds <= 40960, lds                                  # four workgroups (one wave per SIMD) per CU
+    scratch, spills, lds = res["dojo_grad_kernel"]
+    assert scratch <= 1200 and lds <= 40960, (scratch, lds)   # (its spills sit in the once-per-step prologue, not in the sweeps)
