@@ -296,4 +296,33 @@ double orc_time_batch(void* h, int B, const double* z, const double* u, int with
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// Unit functions of the restatement, for the reference's own unit tests restated in tests/test_oracle_units.py
+// (test/integrator.jl, test/mrp.jl): `what` selects the function, `in` / `out` are flat fp64 arrays (matrices row-major).
+//   0 next_orientation(q[4], w[3], dt) -> q'[4]                       src/integrators/integrator.jl:22-28
+//   1 rotational_integrator_jacobian_velocity(q, w, dt) -> 4x3        integrator.jl:50-52
+//   2 rotational_integrator_jacobian_orientation(q, w, dt; attjac=false) -> 4x4   integrator.jl:54-62
+//   3 rotational_integrator_jacobian_orientation(...; attjac=true) -> 4x3
+//   4 mrp(q[4]) -> 3     5 dmrpdq(q) -> 3x4     6 axis(q) -> 3     7 daxisdq(q) -> 3x4      src/orientation/mrp.jl
+//   8 rotation_vector(q) -> 3     9 drotation_vectordq(q) -> 3x4                              mrp.jl:61-78
+int orc_unit(int what, const double* in, double* out) {
+    using M = orc::SM<double>; using Q = orc::Quat<double>;
+    auto put = [&](const M& m) { for (int i = 0; i < m.r * m.c; ++i) out[i] = m.a[i]; };
+    const Q q(in[0], in[1], in[2], in[3]);
+    const M qv = M::vec({in[0], in[1], in[2], in[3]});
+    const M w = M::vec({in[4], in[5], in[6]}); const double dt = in[7];
+    switch (what) {
+        case 0: put(orc::vector(orc::next_orientation(q, w, dt))); return 4;
+        case 1: put(orc::rotational_integrator_jacobian_velocity(q, w, dt)); return 12;
+        case 2: put(orc::rotational_integrator_jacobian_orientation(q, w, dt, false)); return 16;
+        case 3: put(orc::rotational_integrator_jacobian_orientation(q, w, dt, true)); return 12;
+        case 4: put(orc::mrp(qv)); return 3;
+        case 5: put(orc::dmrpdq(qv)); return 12;
+        case 6: put(orc::axis_of(qv)); return 3;
+        case 7: put(orc::daxisdq(qv)); return 12;
+        case 8: put(orc::rotation_vector(q)); return 3;
+        case 9: put(orc::drotation_vectordq(q)); return 12;
+    }
+    return -1;
+}
+
 } // extern "C"

@@ -40,6 +40,7 @@ def lib():
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
         _lib.orc_ls_stats.restype = None
+        _lib.orc_unit.restype = C.c_int
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
@@ -230,3 +231,12 @@ class Oracle:
         du = np.zeros((B, nx, self.nu)) if with_grad else None
         lib().orc_step_batch(self.h, B, _p(Z), _p(U), _p(Zn), _p(st), _p(it), int(with_grad), grad_mode, _p(dz), _p(du), nthreads)
         return Zn, st, it, dz, du
+
+
+def unit(what, q, w=(0.0, 0.0, 0.0), dt=0.01):
+    """unit functions of the restatement (oracle/capi.cpp: orc_unit): flat fp64 result"""
+    inp = np.array(list(q) + list(w) + [dt], dtype=np.float64)
+    out = np.zeros(16)
+    n = lib().orc_unit(int(what), _p(inp), _p(out))
+    assert n > 0
+    return out[:n].copy()

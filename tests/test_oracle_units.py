@@ -1,0 +1,45 @@
+"""The reference's unit tests of the integrator and rotation-vector Jacobians, restated on the oracle's functions
+(test/integrator.jl:1-41, test/mrp.jl:1-19): analytic Jacobians against central finite differences (the reference uses
+ForwardDiff; tolerance 1e-8 there, 1e-7 here for the O(h^2) differences)."""
+import numpy as np
+import pytest
+import oracle
+
+H = 1e-6
+
+
+def _fd(f, x):
+    x = np.asarray(x, float); cols = []
+    for i in range(len(x)):
+        e = np.zeros_like(x); e[i] = H
+        cols.append((f(x + e) - f(x - e)) / (2 * H))
+    return np.stack(cols, axis=1)
+
+
+def _rand_quat(rng):
+    q = rng.normal(size=4); return q / np.linalg.norm(q)
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102])
+def test_integrator_jacobians(seed):
+    # test/integrator.jl:1-41
+    rng = np.random.default_rng(seed)
+    q0, w0, dt = _rand_quat(rng), rng.normal(size=3), 0.01
+    Jw = oracle.unit(1, q0, w0, dt).reshape(4, 3)
+    assert np.abs(_fd(lambda w: oracle.unit(0, q0, w, dt), w0) - Jw).max() < 1e-7                    # ∇ω next_orientation
+    Jq = oracle.unit(2, q0, w0, dt).reshape(4, 4)
+    assert np.abs(_fd(lambda q: oracle.unit(0, q, w0, dt), q0) - Jq).max() < 1e-7                    # ∇q (attjac = false)
+    s, v = q0[0], q0[1:]
+    LVT = np.vstack([-v, s * np.eye(3) + np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])])       # LVᵀmat(q)
+    assert np.abs(Jq @ LVT - oracle.unit(3, q0, w0, dt).reshape(4, 3)).max() < 1e-12                 # attjac = true
+
+
+def test_mrp_and_rotation_vector_jacobians():
+    # test/mrp.jl:1-19
+    q = np.array([1, 2, 3, 4.0]); q /= np.linalg.norm(q)
+    assert np.abs(oracle.unit(5, q).reshape(3, 4) - _fd(lambda x: oracle.unit(4, x), q)).max() < 1e-7
+    assert np.abs(oracle.unit(7, q).reshape(3, 4) - _fd(lambda x: oracle.unit(6, x), q)).max() < 1e-7
+    assert np.abs(oracle.unit(9, q).reshape(3, 4) - _fd(lambda x: oracle.unit(8, x), q)).max() < 1e-7
+    one = np.array([1.0, 0, 0, 0])
+    assert np.abs(oracle.unit(5, one).reshape(3, 4) - _fd(lambda x: oracle.unit(4, x), one)).max() < 1e-7
+    assert np.abs(oracle.unit(9, one).reshape(3, 4) - _fd(lambda x: oracle.unit(8, x), one)).max() < 1e-5        # (zero rotation: 1e-5 in the reference too)
