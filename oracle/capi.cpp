@@ -43,6 +43,7 @@ struct IOracle {
     virtual long long sparse_flops() = 0;
     virtual long long sparse_solve_flops() = 0;
     virtual void ls_stats(long long* out) = 0;
+    virtual int joint_unit(int joint, int half, int what, const double* in, double* out) = 0;
     virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
     virtual void maximal_to_minimal(const double* z, double* x) = 0;
     virtual void minimal_to_maximal(const double* x, double* z) = 0;
@@ -63,6 +64,24 @@ struct OracleT : IOracle {
     long long sparse_flops() override { return m.splu.flops_factor; }
     long long sparse_solve_flops() override { return m.splu.flops_solve; }
     void ls_stats(long long* out) override { out[0] = m.stat_ls_calls; out[1] = m.stat_ls_trials; }
+    // unit functions of one joint half at given configurations in = [xa(3) qa(4) xb(3) qb(4)]:
+    //   what 0: displacement (translational/minimal.jl:4-12; rotational/minimal.jl:4-11, vmat = true) -> 3
+    //   what 1 / 2: displacement_jacobian_configuration(:parent / :child, ...; attjac = true) -> [X Q] 3x6   (joints/joint.jl:141-153)
+    int joint_unit(int joint, int half, int what, const double* in, double* out) override {
+        using M = orc::SM<T>; using Q = orc::Quat<T>;
+        const orc::Joint<T>& J = m.joints[joint]; const orc::Half<T>& h = half ? J.rot : J.tra;
+        const M xa = M::vec({(T)in[0], (T)in[1], (T)in[2]}), xb = M::vec({(T)in[7], (T)in[8], (T)in[9]});
+        const Q qa = Q((T)in[3], (T)in[4], (T)in[5], (T)in[6]), qb = Q((T)in[10], (T)in[11], (T)in[12], (T)in[13]);
+        if (what == 0) {
+            M d = half ? orc::Vmat(m.rot_displacement_q(J, qa, qb)) : m.tra_displacement(J, xa, qa, xb, qb);
+            for (int i = 0; i < 3; ++i) out[i] = (double)d[i];
+            return 3;
+        }
+        M X, Qm; m.disp_jac(what == 1, J, h, xa, qa, xb, qb, true, X, Qm);
+        M XQ = orc::hcat(X, Qm);
+        for (int i = 0; i < 18; ++i) out[i] = (double)XQ.a[i];
+        return 18;
+    }
     void maximal_to_minimal(const double* z, double* x) override {
         int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
         std::vector<T> zz = cast(z, nz), xx(nm); m.maximal_to_minimal(zz.data(), xx.data()); for (int i = 0; i < nm; ++i) x[i] = (double)xx[i];
@@ -304,6 +323,7 @@ double orc_time_batch(void* h, int B, const double* z, const double* u, int with
 //   3 rotational_integrator_jacobian_orientation(...; attjac=true) -> 4x3
 //   4 mrp(q[4]) -> 3     5 dmrpdq(q) -> 3x4     6 axis(q) -> 3     7 daxisdq(q) -> 3x4      src/orientation/mrp.jl
 //   8 rotation_vector(q) -> 3     9 drotation_vectordq(q) -> 3x4                              mrp.jl:61-78
+int orc_joint_unit(void* h, int joint, int half, int what, const double* in, double* out) { return ((IOracle*)h)->joint_unit(joint, half, what, in, out); }
 int orc_unit(int what, const double* in, double* out) {
     using M = orc::SM<double>; using Q = orc::Quat<double>;
     auto put = [&](const M& m) { for (int i = 0; i < m.r * m.c; ++i) out[i] = m.a[i]; };

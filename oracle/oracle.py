@@ -40,7 +40,7 @@ def lib():
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
         _lib.orc_ls_stats.restype = None
-        _lib.orc_unit.restype = C.c_int
+        _lib.orc_unit.restype = C.c_int; _lib.orc_joint_unit.restype = C.c_int
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
@@ -209,6 +209,12 @@ class Oracle:
         out = (C.c_longlong * 2)()
         lib().orc_ls_stats(self.h, out)
         return int(out[0]), int(out[1])
+
+    def joint_unit(self, joint, half, what, xa, qa, xb, qb):
+        """displacement (what 0) / displacement_jacobian_configuration(:parent 1 | :child 2; attjac) of one joint half (0 translational, 1 rotational)"""
+        inp = np.concatenate([xa, qa, xb, qb]).astype(np.float64); out = np.zeros(18)
+        n = lib().orc_joint_unit(self.h, int(joint), int(half), int(what), _p(inp), _p(out))
+        return out[:n].copy()
 
     def sparse_flops(self):
         return int(lib().orc_sparse_flops(self.h))

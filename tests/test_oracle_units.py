@@ -43,3 +43,31 @@ def test_mrp_and_rotation_vector_jacobians():
     one = np.array([1.0, 0, 0, 0])
     assert np.abs(oracle.unit(5, one).reshape(3, 4) - _fd(lambda x: oracle.unit(4, x), one)).max() < 1e-7
     assert np.abs(oracle.unit(9, one).reshape(3, 4) - _fd(lambda x: oracle.unit(8, x), one)).max() < 1e-5        # (zero rotation: 1e-5 in the reference too)
+
+
+def _lvt(q):
+    s, v = q[0], q[1:]
+    return np.vstack([-v, s * np.eye(3) + np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])])
+
+
+@pytest.mark.parametrize("name,kw,joint,half", [("pendulum", dict(), 0, 1), ("slider", dict(), 0, 0), ("twister", dict(num_bodies=3), 1, 0),
+                                                ("twister", dict(num_bodies=3), 2, 1), ("snake", dict(num_bodies=3), 1, 0)])
+def test_displacement_jacobians(name, kw, joint, half):
+    """test/impulse_map.jl:4-95 ("Displacement Jacobian"): displacement_jacobian_configuration(:parent | :child, joint half, xa, qa,
+    xb, qb; attjac = true) against the derivative of displacement(...) w.r.t. (x, q) times the attitude Jacobian, at random
+    configurations, for rotational and translational halves (joints with non-trivial vertices / axes included)."""
+    import dojo_amd as d
+    spec = d.get_mechanism(name, **kw)
+    o = oracle.Oracle(spec)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        xa, xb, qa, qb = rng.normal(size=3), rng.normal(size=3), _rand_quat(rng), _rand_quat(rng)
+        for what, (x, q) in ((1, (xa, qa)), (2, (xb, qb))):
+            J0 = o.joint_unit(joint, half, what, xa, qa, xb, qb).reshape(3, 6)
+            def disp(z):
+                if what == 1:
+                    return o.joint_unit(joint, half, 0, z[:3], z[3:], xb, qb)
+                return o.joint_unit(joint, half, 0, xa, qa, z[:3], z[3:])
+            J1 = _fd(disp, np.concatenate([x, q]))
+            att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
+            assert np.abs(J0 - J1 @ att).max() < 1e-7
