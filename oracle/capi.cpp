@@ -77,6 +77,17 @@ struct OracleT : IOracle {
             for (int i = 0; i < 3; ++i) out[i] = (double)d[i];
             return 3;
         }
+        if (what >= 3) {
+            // what 3 / 4: impulse_transform(:parent / :child, ...) * p -> 6 (joints/impulses.jl:4-8), p = in[14:17]
+            // what 5..8: impulse_transform_jacobian(relative, jacobian, ..., p) -> 6x6, (relative, jacobian) = (parent,parent), (parent,child),
+            //            (child,parent), (child,child)   (translational/impulses.jl:9-46, rotational/impulses.jl:9-39)
+            const M p = M::vec({(T)in[14], (T)in[15], (T)in[16]});
+            if (what <= 4) { M r = m.impulse_transform(what == 3, J, h, xa, qa, xb, qb) * p; for (int i = 0; i < 6; ++i) out[i] = (double)r[i]; return 6; }
+            const int k = what - 5;
+            M Jm = m.impulse_transform_jacobian(k < 2, (k % 2) == 0, J, h, xa, qa, xb, qb, p);
+            for (int i = 0; i < 36; ++i) out[i] = (double)Jm.a[i];
+            return 36;
+        }
         M X, Qm; m.disp_jac(what == 1, J, h, xa, qa, xb, qb, true, X, Qm);
         M XQ = orc::hcat(X, Qm);
         for (int i = 0; i < 18; ++i) out[i] = (double)XQ.a[i];

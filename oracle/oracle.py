@@ -210,9 +210,10 @@ class Oracle:
         lib().orc_ls_stats(self.h, out)
         return int(out[0]), int(out[1])
 
-    def joint_unit(self, joint, half, what, xa, qa, xb, qb):
-        """displacement (what 0) / displacement_jacobian_configuration(:parent 1 | :child 2; attjac) of one joint half (0 translational, 1 rotational)"""
-        inp = np.concatenate([xa, qa, xb, qb]).astype(np.float64); out = np.zeros(18)
+    def joint_unit(self, joint, half, what, xa, qa, xb, qb, p=None):
+        """displacement (what 0) / displacement_jacobian_configuration(:parent 1 | :child 2; attjac) / impulse_transform * p (3 | 4) /
+        impulse_transform_jacobian (5..8: pp, pc, cp, cc) of one joint half (0 translational, 1 rotational); see oracle/capi.cpp"""
+        inp = np.concatenate([xa, qa, xb, qb, np.zeros(3) if p is None else p]).astype(np.float64); out = np.zeros(36)
         n = lib().orc_joint_unit(self.h, int(joint), int(half), int(what), _p(inp), _p(out))
         return out[:n].copy()
 

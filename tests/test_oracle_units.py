@@ -71,3 +71,24 @@ def test_displacement_jacobians(name, kw, joint, half):
             J1 = _fd(disp, np.concatenate([x, q]))
             att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
             assert np.abs(J0 - J1 @ att).max() < 1e-7
+
+
+@pytest.mark.parametrize("name,kw,joint,half", [("pendulum", dict(), 0, 1), ("slider", dict(), 0, 0), ("twister", dict(num_bodies=3), 1, 0),
+                                                ("twister", dict(num_bodies=3), 2, 1)])
+def test_impulse_transform_jacobians(name, kw, joint, half):
+    """test/impulse_map.jl:77-160: impulse_transform_jacobian(relative, jacobian, joint half, xa, qa, xb, qb, p) against the derivative
+    of impulse_transform(relative, ...) * p w.r.t. the configuration of the `jacobian` body, times the attitude Jacobian."""
+    import dojo_amd as d
+    spec = d.get_mechanism(name, **kw)
+    o = oracle.Oracle(spec)
+    rng = np.random.default_rng(4)
+    xa, xb, qa, qb, p0 = rng.normal(size=3), rng.normal(size=3), _rand_quat(rng), _rand_quat(rng), rng.normal(size=3)
+    for k, (rel_parent, jac_parent) in enumerate(((True, True), (True, False), (False, True), (False, False))):
+        J0 = o.joint_unit(joint, half, 5 + k, xa, qa, xb, qb, p0).reshape(6, 6)
+        x, q = (xa, qa) if jac_parent else (xb, qb)
+        def f(z):
+            if jac_parent:
+                return o.joint_unit(joint, half, 3 if rel_parent else 4, z[:3], z[3:], xb, qb, p0)
+            return o.joint_unit(joint, half, 3 if rel_parent else 4, xa, qa, z[:3], z[3:], p0)
+        att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
+        assert np.abs(J0 - _fd(f, np.concatenate([x, q])) @ att).max() < 1e-6
