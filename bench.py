@@ -42,6 +42,14 @@ def main():
                     "(plumbing check of the N > 1 path on a box with fewer GPUs than ranks: ranks share devices, the gather goes through the host)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: spawn the N ranks here (one process per GPU; the same command line under
+    # torch.distributed.run on 127.0.0.1), fail loudly if the node has fewer than N devices.  Under a launcher (WORLD_SIZE set)
+    # --gpus must agree with it.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, args.backend))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+
     # one hardware queue per environment group: ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware
     # queues, and streams that share a queue serialize (measured: 4 groups on the default 4 queues run at 0.6x, not 1.1x)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(24, args.chunks + 8)))
@@ -55,6 +63,8 @@ def main():
     rank, world, local = D.init_from_env(backend=args.backend)    # "nccl" IS RCCL on ROCm
     if args.backend != "nccl":
         local = local % torch.cuda.device_count()                 # plumbing check only: ranks may share a device
+    elif local >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d (local rank %d) has no GPU of its own: %d device(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -148,6 +158,11 @@ def main():
         torch.cuda.synchronize(); z_all = D.all_gather_states(z.cpu(), world)
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
+    rank_devices = None
+    if world > 1:                                 # which device every rank ran on (rank 0 prints it)
+        box = [None] * world
+        dist.all_gather_object(box, "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(local)))
+        rank_devices = box
     ok_frac = float((status == 0).float().mean().item())
     mean_iters = float(iters.float().mean().item())
 
@@ -227,11 +242,31 @@ def main():
             res["cpu_baseline"] = cpu_baseline(spec, grad, mean_iters, (sum(ex) / B) if (ex and all(ex)) else None)
         if world > 1:
             res["config"]["final_gather"] = "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"
+            res["config"]["rank_devices"] = rank_devices
         print(json.dumps(res), flush=True)
     if world > 1:
         if lib_stuck:                            # a thread is still inside the library's communicator set-up: leave without the teardown that would wait for it
             sys.stdout.flush(); sys.stderr.flush(); os._exit(0)
         dist.destroy_process_group()
+
+
+def spawn_ranks(n, backend):
+    """Re-executes this command line as n ranks on this node (torch.distributed.run, rendezvous on 127.0.0.1, a free port).
+    The device count is checked first -- through the library, not torch, so that the parent never creates a GPU context."""
+    import socket
+    import subprocess
+    if backend == "nccl":                         # (--backend gloo: ranks may share devices, plumbing check)
+        from dojo_amd import api
+        have = api.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but this node has %d GPU(s)\n" % (n, have))
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def parity_vs_cpu(spec, B, device):
@@ -263,11 +298,22 @@ def parity_vs_cpu(spec, B, device):
         if name != "f64_refined":                # (the refined leg is checked against the fp64 leg's oracle run: same inputs)
             Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Zi) if name == "f32" else Zi, Ui.astype(np.float64), with_grad=True, nthreads=cores)   # fp32: the state the buffer stands for
         ok = (st == 0) & (st_o == 0)
+        idx = np.nonzero(ok)[0]
         ez = np.abs(zn.astype(np.float64) - Zo).max(axis=1)[ok]
-        eg = np.array([max(np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()), np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max())) for b in np.nonzero(ok)[0]])
+        ea = np.array([max(np.abs(dz[b] - dz_o[b]).max(), np.abs(du[b] - du_o[b]).max()) for b in idx])                  # absolute inf-norm
+        eg = np.array([max(np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()), np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max())) for b in idx])
+        # environments whose two solves ended at different points (both within the solver's tolerances, states more than the 1e-6
+        # bound apart -- long solves that wander at mu ~ 1e-12): their Jacobians are Jacobians of different points; listed, not hidden
+        tol_s = 1e-6 if dt == np.float64 else 1e-5
+        apart = ez > tol_s
+        same = ~apart
         out[name] = {"converged_both": int(ok.sum()), "status_mismatch": int((st != st_o).sum()), "iters_mismatch": int((it[ok] != it_o[ok]).sum()),
-                     "state_inf_err_max": float(ez.max()), "grad_inf_err_max": float(eg.max()), "grad_inf_err_q99": float(np.quantile(eg, 0.99)),
-                     "grad_inf_err_q50": float(np.quantile(eg, 0.5)), "n_grad_err_above_1e-6": int((eg > 1e-6).sum())}
+                     "state_inf_err_max": float(ez.max()), "n_state_err_above_bound": int(apart.sum()), "state_bound": tol_s,
+                     "grad_inf_err_max": float(eg[same].max()), "grad_abs_inf_err_max": float(ea[same].max()), "grad_inf_err_q99": float(np.quantile(eg, 0.99)),
+                     "grad_inf_err_q50": float(np.quantile(eg, 0.5)), "n_grad_err_above_1e-6": int((eg[same] > 1e-6).sum()),
+                     "jacobian_inf_norm_max": float(max(np.abs(dz_o[b]).max() for b in idx)),
+                     "solves_that_ended_apart": [{"env": int(idx[i]), "iters": int(it[idx[i]]), "iters_cpu": int(it_o[idx[i]]), "state_err": float(ez[i]), "grad_err": float(eg[i])} for i in np.nonzero(apart)[0][:16]],
+                     "note": "grad errors are per-environment inf-norms, relative = / max(1, |J_cpu|_inf), absolute next to it; maxima over every environment that converged on both sides and whose states agree within state_bound (the others are listed)"}
         del dz, du
         if gm is not g64:
             gm.close()
@@ -307,27 +353,32 @@ def measured_valu_utilization():
 
 
 def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
-    """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on all host cores: one
-    persistent thread per core, every thread owns a copy of the mechanism and walks 64 environments of the same synthetic
-    batch, once per solver variant; the clock starts when all threads are running.  Linear solves without the checker's
-    refinement rounds: one factorization and two solves per Newton iteration like src/solver/mehrotra.jl:36-49, one
-    factorization + 170 right-hand sides for the IFT (src/gradients/state.jl:99).
+    """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on the host's PHYSICAL cores: one
+    persistent thread pinned to each core, every thread owns a copy of the mechanism (its workspaces and symbolic factorization
+    are set up by one untimed step) and walks 128 environments of the same synthetic batch, once per solver variant; the clock
+    starts when all threads are ready.  The same loop on ONE thread gives `single_thread` and the parallel efficiency.
+    Linear solves without the checker's refinement rounds: one factorization and two solves per Newton iteration like
+    src/solver/mehrotra.jl:36-49, one factorization + 170 right-hand sides for the IFT (src/gradients/state.jl:99).
       value  = the BLOCK-SPARSE variant SURVEY.md §8d asks for: sparse LU without pivoting in the elimination order of the
                mechanism graph (contacts and limits first, then the tree leaves -> root), the structure of the reference's LDU;
       dense  = the dense 206 x 206 partial-pivot LU (what the checker itself uses, without its refinement)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dojo_amd as d
+    import oracle as orc
     from oracle import Oracle
-    cores = os.cpu_count() or 1
+    cores = orc.physical_cores() or (os.cpu_count() or 1)
     o = Oracle(spec)
     o.set_refine_steps(0)
-    nsample = 64 * cores
+    per_thread = 128
+    nsample = per_thread * cores
     Z, U = d.synthetic_inputs(spec, nsample)
     out = {}
     for name, sparse in (("sparse", True), ("dense", False)):
         o.set_sparse_solver(sparse)
+        el1 = o.time_batch(Z[:per_thread // 2], U[:per_thread // 2], with_grad=grad, nthreads=1, rounds=1)
         el = o.time_batch(Z, U, with_grad=grad, nthreads=cores, rounds=1)
-        out[name] = {"value": nsample / el, "cpu_seconds": el * cores}
+        single = (per_thread // 2) / el1
+        out[name] = {"value": nsample / el, "cpu_seconds": el * cores + el1, "single_thread": single, "parallel_efficiency": (nsample / el) / (cores * single)}
     # what a block-sparse direct method needs per env-step (flops of the sparse LU above, multiply-add = 2): one factorization
     # + two solves per Newton iteration, one factorization + one solve per Jacobian column -- the "useful" share of what the
     # kernels execute (roofline.executed_fp64_flops_per_launch also counts assembly, line searches, replicated and masked lanes)
@@ -339,10 +390,14 @@ def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
         la["per_env_step"] = mean_iters * la["per_newton_iteration"] + la["ift"]
         if executed_flops_per_env:
             la["frac_of_executed_fp64"] = la["per_env_step"] / executed_flops_per_env
-    return {"value": out["sparse"]["value"], "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],
-            "dense": out["dense"]["value"], "sparse_lu_flops": la,
-            "sample": "%d Ant env-steps (fwd%s) per variant: 64 synthetic environments per thread on %d persistent threads; C++ oracle, fp64; value = block-sparse "
-                      "no-pivot LU in the mechanism graph's elimination order, dense = 206x206 partial-pivot LU" % (nsample, "+grad" if grad else "", cores)}
+    return {"value": out["sparse"]["value"], "unit": "env-steps/s", "cores": cores, "threads": cores, "kind": "port",
+            "single_thread": out["sparse"]["single_thread"], "parallel_efficiency": out["sparse"]["parallel_efficiency"],
+            "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],
+            "dense": out["dense"]["value"], "dense_single_thread": out["dense"]["single_thread"], "dense_parallel_efficiency": out["dense"]["parallel_efficiency"],
+            "logical_cpus": os.cpu_count(), "sparse_lu_flops": la,
+            "sample": "%d Ant env-steps (fwd%s) per variant: %d synthetic environments per thread, one pinned thread on each of the %d physical cores (after one untimed "
+                      "step per thread); C++ oracle, fp64; value = block-sparse no-pivot LU in the mechanism graph's elimination order, dense = 206x206 partial-pivot LU"
+                      % (nsample, "+grad" if grad else "", per_thread, cores)}
 
 
 if __name__ == "__main__":

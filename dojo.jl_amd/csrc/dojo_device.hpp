@@ -104,6 +104,8 @@ struct Globals {
     T dt, idt2 /* 1/dt² */, input_scaling, g[3];
     T rtol, btol, undercut, no_progress_undercut;
     T refine_w;                  // refine the linear solves of an environment once max γ/s over its cones exceeds this (inf: never, 0: always)
+    T ift_lu_w;                  // IFT (quad mapping): a workgroup whose explicit supernode inverses have an entry beyond this runs its column sweeps through
+                                 // LU-form solves of a factorization of its own (0: always, inf: never; DESIGN.md §5 "LU-form sweeps")
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
@@ -1136,6 +1138,7 @@ struct LaneProgram {
     enum { BLK_PER_LANE = 90 };        // S rows 3x12, U rows 3x6, L columns 6x3, Dup rows 3x6
     T* blk = nullptr; int blk_stride = 0;
     T* ypark = nullptr;                // this lane's first slot of the workgroup's y park (KernelArgs::ypark; body-row roles only)
+    T* ypark_lane = nullptr;           // the same with one slot per lane (LU-form sweeps: all four roles park)
     bool refine = false;
     T wstiff = T(0);                   // max γ/s over the cones of the environment at the last evaluated iterate
     T growth = T(0);                   // largest |multiplier| of the last factorization's Gauss-Jordan passes on this lane (no pivoting: the growth indicator)
@@ -1641,6 +1644,205 @@ struct LaneProgram {
         }
     }
 
+
+    // ---------------------------------------------------------------- quad mapping: LU form of the tree elimination (IFT)
+    // The Newton loop inverts every 12x12 supernode matrix explicitly (factorize_quad) and its solves are products with those
+    // inverses:  y = S⁻¹ r  on the way up,  x = y − S⁻¹(U x_parent)  on the way down.  Where a joint row repeats a stiff contact
+    // row (a foot in sticking contact behind a Fixed joint: entries ~γ/s ~ 1e6 .. 1e8 next to inertias of 1e-5) the blocks of
+    // S⁻¹ are differences of terms many orders larger than themselves, and y and S⁻¹(U x_parent) are both large against their
+    // difference -- harmless for the Newton iteration (it self-corrects), but the IFT columns lose five digits on about one Ant
+    // environment in a thousand (gradient errors up to 2e-5 relative; tools/model/dev_rhs_model.py reproduces it block by block).
+    // The IFT therefore factors the same final linearization once more, as the plain LU of the whole tree system in the
+    // elimination order (supernodes leaves -> root, inside a supernode v, λt, ω, λr), which is backward stable with the growth
+    // this order has (~30): every pivot of a supernode also eliminates the six body rows of its PARENT, so that
+    //   Lm / Um   the lane's rows of L11 − I and of D⁻¹U11 − I (S = L11 U11), zero-filled: select-free substitutions (staged, see below)
+    //   F.Uq      becomes T = L11⁻¹ U            (rows of this supernode x parent's velocity)
+    //   F.Lq      becomes m = L U11⁻¹            (the parent's body rows' multipliers, columns of this supernode)
+    //   K.D       becomes Dup − m T              (Schur complement onto the parent's diagonal block)
+    // and a solve is  ỹ = L11⁻¹ r;  r_parent −= m ỹ  on the way up,  x = U11⁻¹(ỹ − T x_parent)  on the way down: per column 33 + 18
+    // multiply-adds and 11 DPP broadcasts each way (the products with the explicit inverse: 36 + 18 and 12).  What waits between
+    // the sweeps is ỹ, all twelve rows of it.
+    struct QuadLU { TL Lm[3][12], Um[3][12], di[3]; };
+    static constexpr DJ_HD int lu_piv(int pp) { return DJ_PIVOT_ORDER ? (pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp) : pp; }   // pp-th pivot (an involution: also the position of column c)
+    static constexpr DJ_HD int lu_rolepos(int o) { return DJ_PIVOT_ORDER ? (o == 1 ? 2 : o == 2 ? 1 : o) : o; }                         // position of role o's rows in the pivot order
+
+    // forward substitution with the unit lower factor for NCOLS right-hand sides at once (r[n] = the lane's three rows of column n):
+    // the columns are independent chains, which is what hides the DPP and FMA latencies
+    template <int NCOLS> DJ_HD void lu_forward_quad(const TL (&Lm)[3][12], TL (&r)[NCOLS][3]) {
+#pragma unroll
+        for (int pp = 0; pp < 11; ++pp) {                      // (nothing comes after the last pivot)
+            const int p = lu_piv(pp), o = p / 3, ro = p % 3;
+            TL yp[NCOLS];
+#pragma unroll
+            for (int n = 0; n < NCOLS; ++n) yp[n] = wv.quad_bcast(r[n][ro], o);
+#pragma unroll
+            for (int n = 0; n < NCOLS; ++n)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r[n][i] -= Lm[i][p] * yp[n];
+        }
+    }
+    // x = U11⁻¹ r: scaling by the reciprocal pivots, then backward substitution with the unit upper factor
+    template <int NCOLS> DJ_HD void lu_backward_quad(const TL (&Um)[3][12], const TL (&di)[3], TL (&r)[NCOLS][3]) {
+#pragma unroll
+        for (int n = 0; n < NCOLS; ++n)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) r[n][i] *= di[i];
+#pragma unroll
+        for (int pp = 11; pp > 0; --pp) {                      // (nothing comes before the first pivot)
+            const int p = lu_piv(pp), o = p / 3, ro = p % 3;
+            TL xp[NCOLS];
+#pragma unroll
+            for (int n = 0; n < NCOLS; ++n) xp[n] = wv.quad_bcast(r[n][ro], o);
+#pragma unroll
+            for (int n = 0; n < NCOLS; ++n)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r[n][i] -= Um[i][p] * xp[n];
+        }
+    }
+
+    // The factors wait in global memory (KernelArgs::lu, [workgroup][LU_PER_LANE][lanes]: lane index fastest) while the data blocks
+    // are assembled, and each sweep loads only its half: L11, m for the up-sweep, U11, T, D⁻¹ for the down-sweep -- 54 / 57 values
+    // per lane in registers instead of 111 (all of them resident cost the sweeps ~30 scratch accesses per pipeline step, which one
+    // wave per SIMD cannot hide: the sweeps ran at half speed).
+    enum { LU_LM = 0, LU_M = 36, LU_UM = 54, LU_T = 90, LU_DI = 108, LU_PER_LANE = 112 };
+    T* lu = nullptr; int lu_stride = 0;
+    DJ_HD void store_lu(const QuadLU& W) {
+        T* o = lu; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { o[(size_t)(LU_LM + 12 * i + j) * S_] = T(W.Lm[i][j]); o[(size_t)(LU_UM + 12 * i + j) * S_] = T(W.Um[i][j]); }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { o[(size_t)(LU_M + 3 * j + i) * S_] = T(F.Lq[j][i]); o[(size_t)(LU_T + 6 * i + j) * S_] = has_parent ? T(F.Uq[i][j]) : T(0); }
+            o[(size_t)(LU_DI + i) * S_] = T(W.di[i]);
+        }
+    }
+    DJ_HD void load_lu_up(TL (&Lm)[3][12], TL (&m)[6][3]) const {
+        const T* o = lu; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) Lm[i][j] = TL(o[(size_t)(LU_LM + 12 * i + j) * S_]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[j][i] = TL(o[(size_t)(LU_M + 3 * j + i) * S_]);
+        }
+    }
+    DJ_HD void load_lu_down(TL (&Um)[3][12], TL (&Tq)[3][6], TL (&di)[3]) const {
+        const T* o = lu; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) Um[i][j] = TL(o[(size_t)(LU_UM + 12 * i + j) * S_]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Tq[i][j] = TL(o[(size_t)(LU_T + 6 * i + j) * S_]);
+            di[i] = TL(o[(size_t)(LU_DI + i) * S_]);
+        }
+    }
+
+    // Rows stay distributed as in factorize_quad: role q owns rows 3q .. 3q+2 of S and U, columns 3q .. 3q+2 of L, roles 0 / 1
+    // rows 0:3 / 3:6 of Dup.  On lanes that are not at the current level every update has a zero multiplier.
+    DJ_HD void factorize_quad_lu(QuadBlocks<TL>& K, QuadLU& W) {
+        TL up[3][6];
+        TL (&A)[3][12] = F.Sq;
+        const int rq = lu_rolepos(q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            W.di[i] = TL(1);                                       // (idle supernode slots: an identity system; their lanes run the sweeps too)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { W.Lm[i][j] = TL(0); W.Um[i][j] = TL(0); }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) up[i][j] = TL(0);
+        }
+        for (int lev = G.maxlevel; lev >= 0; --lev) {
+            const bool at = active && P.level == lev;
+            TL acc[18], upf[18];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
+            mail_post_roles<18>(upf);
+            mail_add_children<18>(acc, at, G.maxch_lev[lev]);
+            if (at && q < 2) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) A[i][j] += acc[6 * i + j];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 12; ++pp) {
+                const int p = lu_piv(pp), o = p / 3, ro = p % 3, opos = lu_rolepos(o);
+                // the pivot row over the columns still to come: [S (later columns) | U]
+                TL prow[12], pU[6];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) prow[c] = (lu_piv(c) >= pp) ? wv.quad_bcast(A[ro][c], o) : TL(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) pU[j] = wv.quad_bcast(F.Uq[ro][j], o);
+                const TL ip = Wave::rcp(at ? prow[p] : TL(1));
+                // rows of this supernode that come later in the order
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool later = at && (rq > opos || (rq == opos && r > ro));
+                    const TL f = A[r][p] * ip;
+                    const TL fe = later ? f : TL(0);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) if (lu_piv(c) > pp) A[r][c] -= fe * prow[c];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) F.Uq[r][j] -= fe * pU[j];
+                    A[r][p] = later ? f : A[r][p];
+                }
+                // the six body rows of the parent: multipliers m_i = (parent row i, column p) / pivot, from the lane that owns column p
+                if (lev > 0) {                                   // (uniform; the roots have no parent rows)
+                    TL m[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { const TL t_ = F.Lq[i][ro] * ip; m[i] = wv.quad_bcast(t_, o); }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const bool laterc = at && (rq > opos || (rq == opos && cc > ro));
+                        const TL c0_ = prow[cc], c1_ = prow[3 + cc], c2_ = prow[6 + cc], c3_ = prow[9 + cc];
+                        const TL pm = q == 0 ? c0_ : q == 1 ? c1_ : q == 2 ? c2_ : c3_;   // the pivot row's entry in this lane's column cc
+                        const TL pme = laterc ? pm : TL(0);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) F.Lq[i][cc] -= m[i] * pme;
+                    }
+                    const bool own = at && q == o;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) F.Lq[i][ro] = own ? m[i] : F.Lq[i][ro];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const TL m0_ = m[i], m1_ = m[3 + i];
+                        const TL mm = (at && q < 2) ? (q == 0 ? m0_ : m1_) : TL(0);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) K.D[i][j] -= mm * pU[j];
+                    }
+                }
+            }
+            if (at) {
+                // this supernode is done: split its in-place factors into the zero-filled triangles the substitutions read
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int pos = 3 * rq + r;                  // this row's place in the pivot order
+                    TL dg = TL(1);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) { const TL a_ = A[r][c]; dg = (lu_piv(c) == pos) ? a_ : dg; }
+                    const TL di_ = Wave::rcp(dg);
+                    W.di[r] = di_;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) {
+                        const TL a_ = A[r][c];
+                        W.Lm[r][c] = (lu_piv(c) < pos) ? a_ : TL(0);
+                        W.Um[r][c] = (lu_piv(c) > pos) ? a_ * di_ : TL(0);
+                    }
+                }
+            }
+            if (lev > 0 && at && has_parent) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) up[i][j] = q < 2 ? TL(K.D[i][j]) : TL(0);
+            }
+        }
+    }
+
     // quad mapping: IFT column solves  X = solmat⁻¹ · datamat  (DESIGN.md §5).
     // Columns travel through the tree six at a time ("batches") and the two sweeps are software-
     // pipelined over the batches: in step t of the up-sweep a supernode at level l works on batch
@@ -1651,7 +1853,8 @@ struct LaneProgram {
     // the column, which the down-sweep then overwrites with the final values).
     // MODE 0: state + control columns (get_maximal_gradients);  MODE 1: contact-data columns (get_contact_gradients):
     // one batch per contact of the environment, five columns (friction, radius, origin), owner = the contact's body.
-    template <int MODE = 0, class KA, class RH, class KN>
+    // LUF: the sweeps are the forward / backward substitutions of the tree's LU form (factorize_quad_lu) instead of products with the explicit inverses F.Sq.
+    template <int MODE = 0, bool LUF = false, class KA, class RH, class KN>
     DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0, const SweepP& sp) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
@@ -1660,13 +1863,21 @@ struct LaneProgram {
         // (Ant, 4096 environments: max 1.2e-3 relative against 1.4e-5 with an exact y) -- the parked y goes to a buffer of its own in
         // the arithmetic type, [batch][column][row][role lane]: one 256-byte run per store / load of a wavefront
         constexpr bool ypk = DJ_YPARK && MODE == 0 && !kSplitY && sizeof(TIO) < sizeof(TG);   // (the host allocates KernelArgs::ypark whenever this holds)
-        const int yW = wv.width() >> 1;                       // role lanes (two body-row roles per supernode) of the workgroup
-        T* const yp0 = ypark;                                 // this lane's slot of batch 0, column 0, row 0
+        // explicit-inverse sweeps: the two body-row roles park y;  LU-form sweeps: all four roles park ỹ (the joint rows too)
+        const int yW = LUF ? wv.width() : wv.width() >> 1;
+        T* const yp0 = LUF ? ypark_lane : ypark;              // this lane's slot of batch 0, column 0, row 0
+        // LU form, ABI type = arithmetic type: ỹ waits in the output column itself, in the twelve rows of the lane's body: role 0 -> the
+        // v rows, role 1 -> the ω rows (the slots the explicit sweeps use), roles 2 / 3 -> the x3 / φ3 rows, which nobody writes before
+        // the down-sweep has fetched them (the fetch of a batch is issued one step before its output stores, by the same wavefront)
+        const int prk_off = (q == 0 ? 3 : q == 1 ? 9 : q == 2 ? 0 : 6) - 6 * q;     // relative to row0 = 12 k + 6 q
         constexpr int NC = 6;
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
         const int ro = q == 1 ? 3 : 0;                         // first body row owned by roles 0 / 1
-        const TG (&Sg)[3][12] = F.Sq; const TG (&Ug)[3][6] = F.Uq; const TG (&Lg)[6][3] = F.Lq;
+        const TG (&Sg)[3][12] = F.Sq;
+        TG LmU[LUF ? 3 : 1][12], mU[6][LUF ? 3 : 1];             // LU form: L11 − I and the parent rows' multipliers m, for the up-sweep
+        if constexpr (LUF) load_lu_up(LmU, mU);
+        const auto& Lg = [&]() -> const TG (&)[6][3] { if constexpr (LUF) return mU; else return F.Lq; }();
         const int nbs = MODE == 0 ? 2 * G.Nb : 0;              // state batches: (body kk, configuration | velocity columns)
         const int nbu = MODE == 0 ? ((A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0) : G.Nc;   // control batches: six input columns each | contact batches
         const int NB = nbs + nbu;
@@ -1745,6 +1956,53 @@ struct LaneProgram {
                 r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18; u_off_ = 0;
             }
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            if constexpr (LUF) {
+                // the six columns of the batch together: right-hand sides, one LU-form solve of all six, then the messages
+                TG r3a[NC][3], ua[NC][3];
+#pragma unroll
+                for (int cI = 0; cI < NC; ++cI) {
+                    TG r_[3], u_[3];
+                    if constexpr (MODE == 0) {
+                        const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
+                        const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
+                        const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
+                            r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
+                            u_[i] = um * TG(R.a[iu + i * 6]);
+                        }
+                        r_[2] += wkm * TG(R.a[sl_off + cI]);
+                    } else {
+                        const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { r_[i] = rm * TG(R.a[r_off + i * 6 + cI]); u_[i] = TG(0); }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0); ua[cI][i] = u_[i]; }
+                }
+                lu_forward_quad<NC>(LmU, r3a);                     // ỹ = L11⁻¹ r
+#pragma unroll
+                for (int cI = 0; cI < NC; ++cI) {
+                    const int cx = (isS && cI >= 3) ? cI + 3 : cI;
+                    const TG (&yy)[3] = r3a[cI];
+                    TG part[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) part[i] = Lg[i][0] * yy[0] + Lg[i][1] * yy[1] + Lg[i][2] * yy[2];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
+                    if (valid) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? ua[cI][i] - (q == 0 ? p0_ : p1_) : TG(0); }
+                        if (col_ok(b, cI)) {
+                            if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
+                            else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
+                        }
+                    }
+                }
+            } else {
 #if DJ_RHS_PREFETCH
             double pre_d[3] = {0, 0, 0}; typename std::remove_cv<typename std::remove_reference<decltype(R.a[0])>::type>::type pre_r[3] = {}, pre_u[3] = {}, pre_s = 0;
 #endif
@@ -1827,11 +2085,15 @@ struct LaneProgram {
                     }
                 }
             }
+            }
         }
 #ifdef DJ_PROF
         unsigned long long td0 = wv.clock();
 #endif
         // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
+        TG UmD[LUF ? 3 : 1][12], TD[LUF ? 3 : 1][6], diD[3];       // LU form: D⁻¹U11 − I, T = L11⁻¹U and the reciprocal pivots, for the down-sweep
+        if constexpr (LUF) load_lu_down(UmD, TD, diD);
+        const auto& Ug = [&]() -> const TG (&)[3][6] { if constexpr (LUF) return TD; else return F.Uq; }();
         TG d3[NC][3];
 #pragma unroll
         for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
@@ -1843,8 +2105,8 @@ struct LaneProgram {
         typedef typename std::conditional<kSplitY || ypk, TG, TIO>::type TY;
         TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
-            const bool v_ = active && q < 2 && b_ >= 0 && b_ < NB;
-            TIO* const cbn = colbase(v_ ? b_ : 0);
+            const bool v_ = active && (LUF || q < 2) && b_ >= 0 && b_ < NB;
+            TIO* const cbn = colbase(v_ ? b_ : 0) + (LUF ? prk_off - 3 : 0);
             const bool isS_ = b_ < nbs;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
@@ -1883,9 +2145,30 @@ struct LaneProgram {
 #pragma unroll
                 for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { pall[n][i] = TG(p0[3 * n + i]); pall[n][3 + i] = TG(p1[3 * n + i]); }
             }
+            TG t3a[NC][3];
+            if constexpr (LUF) {                                    // x = U11⁻¹ (ỹ − T x_parent) of the six columns
+#pragma unroll
+                for (int n = 0; n < NC; ++n) {
+                    const bool ok_ = valid && col_ok(b, n);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { TG a_ = ok_ ? TG(ycur[n][i]) : TG(0);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) a_ -= Ug[i][j] * pall[n][j];
+                        t3a[n][i] = a_; }
+                }
+                lu_backward_quad<NC>(UmD, diD, t3a);
+            }
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
                 const TG (&pa_)[6] = pall[n];
+                const bool o_ok = valid && q < 2 && col_ok(b, n);
+                TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
+                if constexpr (LUF) {
+                    if (valid) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) d3[n][i] = t3a[n][i];
+                    }
+                } else {
                 TG t3[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
@@ -1897,8 +2180,6 @@ struct LaneProgram {
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
-                const bool o_ok = valid && q < 2 && col_ok(b, n);
-                TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -1908,6 +2189,7 @@ struct LaneProgram {
                         TG y = o_ok ? TG(ycur[n][i]) : TG(0);
                         d3[n][i] = has_parent ? y - a_ : y;
                     }
+                }
                 }
                 if (o_ok) {
                     // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows)
@@ -2589,6 +2871,33 @@ struct LaneProgram {
         return status;
     }
 
+    // the final linearization once more at the restored solution, factored in LU form and staged (quad mapping, IFT kernels)
+    DJ_HD void lu_prepare() {
+        if constexpr (QUAD) {
+        QuadBlocks<TL> K(F.Sq, F.Uq, F.Lq, q);
+        evaluate<true>(K);
+        condense_limits(K);
+        condense_contacts(K);
+        DJ_PE(0); DJ_PB();
+#ifdef DJ_DEBUG
+        if (std::getenv("DJ_DUMP_BLOCKS") && active && base == 0) {   // model input (tools/model): the condensed supernode rows of this lane
+            static char buf_[64][4096]; char* b_ = buf_[wv.lane() & 63]; int n_ = std::snprintf(b_, 4096, "BLK %d %d %d", k, q, P.parent);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 12; ++j) n_ += std::snprintf(b_ + n_, 4096 - n_, " %.17g", (double)K.S[i][j]);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) n_ += std::snprintf(b_ + n_, 4096 - n_, " %.17g", (double)K.U[i][j]);
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) n_ += std::snprintf(b_ + n_, 4096 - n_, " %.17g", (double)K.L[i][j]);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) n_ += std::snprintf(b_ + n_, 4096 - n_, " %.17g", (double)K.D[i][j]);
+            std::snprintf(b_ + n_, 4096 - n_, "\n"); std::fputs(b_, stderr);
+        }
+#endif
+        // (a root's joint hangs on the origin, whose "velocity" is no unknown: its U block was assembled like any other, but the
+        //  down-sweep must not apply it -- store_lu writes T = 0 for the roots)
+        QuadLU W;
+        factorize_quad_lu(K, W);
+        store_lu(W);
+        DJ_PE(1); DJ_PB();
+        }
+    }
+
     // ---------------------------------------------------------------- IFT gradients
     // get_maximal_gradients (src/gradients/state.jl:78-126): data_jacobian = solmat \ datamat for the
     // state columns [x2 v15 φ2 ω15] of every body and the control columns of every joint, then the
@@ -2606,6 +2915,28 @@ struct LaneProgram {
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
         DJ_PB();
+        // ---- quad mapping: LU-form factors of this workgroup's own, where the explicit inverses are ill-conditioned ----
+        // The indicator is the largest entry of the supernode inverses the Newton loop left behind: a multiplier block that
+        // repeats a stiff contact row shows up there as ~γ/s (factorize_quad_lu's comment).  The workgroup then linearizes once
+        // more at the restored solution -- the same final linearization -- and factors it as L U.
+        bool lu_wave = false;
+        if constexpr (QUAD && !PRECISE) {
+            if (G.ift_lu_w < T(1e300) && lu != nullptr) {          // (uniform)
+                T big = T(0);
+                if (G.ift_lu_w > T(0)) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) big = tmax(big, tabs(T(F.Sq[i][j])));
+                }
+                lu_wave = G.ift_lu_w <= T(0) || wv.any(active && !(big <= G.ift_lu_w));
+#ifdef DJ_DEBUG
+                if (std::getenv("DJ_DUMP_IND")) { T v1[1] = {big}; env_reduce_quad_all<1>(v1); if (active && k == 0 && q == 0) std::fprintf(stderr, "IND %d %.4e\n", env, (double)v1[0]); }
+#endif
+                if (lu_wave) lu_prepare();
+
+            }
+        }
         // ---- kinematics of the solution (chain) ----
         T own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6], va[3], wa[3];
         if (lane_slots) {
@@ -2780,6 +3111,9 @@ struct LaneProgram {
 #pragma unroll
                             for (int cn = 0; cn < MAXC; ++cn) if (cn < ncon) for (int j = 0; j < 4; ++j) v += GK[cn][row][j] * Cc[cn][j][cI];
                             R.own_cfg[o_ + cI] = (double)v;
+#ifdef DJ_DEBUG
+                            if (std::getenv("DJ_DUMP_BLOCKS") && env == 0 && active && ncon > 0) { T fold = v - OwnB[row][cc]; std::fprintf(stderr, "RHS k %d row %d col %d own %.6e folded %.6e total %.17g\n", k, row, cI, (double)OwnB[row][cc], (double)fold, (double)v); }
+#endif
                             R.a[QuadRhs<TB>::ROWNV + o_ + cI] = TB(OwnB[row][cc + 3]);
                             R.a[QuadRhs<TB>::UOWN + o_ + cI] = TB(UpOwn[row][cI]);
                             R.a[QuadRhs<TB>::UPAR + o_ + cI] = TB(UpPar[row][cI]);
@@ -2794,8 +3128,18 @@ struct LaneProgram {
                 }
             }
             wv.sync();
+#ifdef DJ_DEBUG
+            if (std::getenv("DJ_DUMP_BLOCKS") && env == 0 && active && q == 0) {
+                static char buf2_[64][16384]; char* b_ = buf2_[wv.lane() & 63]; int n_ = std::snprintf(b_, 16384, "QRHS %d %.17g", k, (double)wk);
+                for (int i = 0; i < QuadRhs<TB>::SIZE; ++i) n_ += std::snprintf(b_ + n_, 16384 - n_, " %.17g", (double)R.a[i]);
+                for (int i = 0; i < 36; ++i) n_ += std::snprintf(b_ + n_, 16384 - n_, " %.17g", (double)R.own_cfg[i]);
+                std::snprintf(b_ + n_, 16384 - n_, "\n"); std::fputs(b_, stderr);
+            }
+            wv.sync();
+#endif
             DJ_PE(5); DJ_PB();
-            gradient_columns_quad(A, env, R, wk, kb0, sp);
+            if (lu_wave) gradient_columns_quad<0, true>(A, env, R, wk, kb0, sp);
+            else gradient_columns_quad(A, env, R, wk, kb0, sp);
             DJ_PE(6);
             return;
         }
@@ -2908,6 +3252,10 @@ struct LaneProgram {
     DJ_HD void gradients_contact(const KA& A, int env) {
         static_assert(QUAD, "contact-data gradients are implemented for the quad mapping");
         const T dt = G.dt;
+        // LU-form sweeps (when they are in force for every workgroup): this kernel factors the linearization itself -- the state-column
+        // kernel's factors may belong to another launch, or its workgroup may have left the environment to the refining kernel
+        const bool lu_form = G.ift_lu_w <= T(0) && lu != nullptr;
+        if (lu_form) lu_prepare();
         Kin<T> kb0;
         kin_of(kb0, L.x2, L.q2, L.v, L.w, dt);
         T x2e[3], q2e[4];
@@ -2988,7 +3336,8 @@ struct LaneProgram {
                     for (int j = 0; j < 6; ++j) R.a[c * 36 + (i / 3) * 18 + (i % 3) * 6 + j] = (double)rhs[c][i][j];
         }
         wv.sync();
-        gradient_columns_quad<1>(A, env, R, T(0), kb0, sp);
+        if (lu_form) gradient_columns_quad<1, true>(A, env, R, T(0), kb0, sp);
+        else gradient_columns_quad<1>(A, env, R, T(0), kb0, sp);
     }
 
     // update_state!  src/bodies/set.jl:22-36: -> (x3, v25, q3, ω25) = the next maximal state of this body
@@ -3075,7 +3424,8 @@ struct KernelArgs {
     TIO* dc;                       // [B][5Nc cols][12Nb rows] contact-data Jacobian (get_contact_gradients), or null
     TIO* res;                      // [B,6Nb] or null          body residual rows at the solution (for the Storage kernel)
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
-    T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (or null)
+    T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (explicit inverses; or null: nobody reads them)
+    T* lu = nullptr;               // [workgroups][LU_PER_LANE = 112][lanes] quad mapping: the IFT kernel's own LU-form factors between its phases (or null)
     T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
     long long ypark_stride = 0;    // elements per workgroup of ypark
     T* ypark = nullptr;            // [workgroups][batches][6][3][lanes / 2] quad mapping, ABI type narrower than the arithmetic: the IFT's forward-substituted
@@ -3133,7 +3483,9 @@ struct StepLds {
     static constexpr int rhs_off = 0;
     // (contact-data kernel: the mailbox keeps its own room behind the phase-A data; packed right behind the ConRhs blocks
     //  the last supernode's block read back zeros on the GPU -- not understood, the kernel is not LDS-critical)
-    static constexpr int mail_off = (QUAD && GRAD == 2) ? a_end : (QUAD && GRAD) ? rhs_off + rhs_bytes : a_end;
+    // (IFT kernel: behind both the phase-A data and the right-hand sides -- a workgroup that factors its own LU form
+    //  (gradients) evaluates the linearization, which uses the mailbox while NodeP / Lane / Cold / the contact rows are alive)
+    static constexpr int mail_off = (QUAD && GRAD == 2) ? a_end : (QUAD && GRAD) ? lds_imax(a_end, rhs_off + rhs_bytes) : a_end;
     static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
     static constexpr int qred_off = red_off + 64;                    // per-supernode values of the environment reductions (3 at a time)
     static constexpr int bytes = qred_off + (QUAD ? 3 * NSN * 8 : 0);
@@ -3186,8 +3538,10 @@ constexpr int FAC_PER_LANE = 72;
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
+        if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * 112 * wv.width() + lane; prog.lu_stride = wv.width(); }                \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \
-        if (A.ypark) prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + ((lane >> 2) * 2 + (q & 1));  \
+        if (A.ypark) { prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + ((lane >> 2) * 2 + (q & 1));  \
+                       prog.ypark_lane = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + lane; }                 \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \
@@ -3242,7 +3596,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #ifdef DJ_PROF
     unsigned long long t_all = wv.clock();
 #endif
-    if constexpr (QUAD) {                                     // the final factors of the Newton loop, as the step kernel left them
+    if constexpr (QUAD) { if (A.fac != nullptr) {              // the final factors of the Newton loop, as the step kernel left them (uniform)
         const T* f = A.fac + (size_t)wave_index * FAC_PER_LANE * wv.width() + lane;
         const int W = wv.width();
 #pragma unroll
@@ -3252,7 +3606,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) { prog.F.Uq[i][j] = TL(f[(size_t)(36 + 6 * i + j) * W]); prog.F.Lq[j][i] = TL(f[(size_t)(54 + 6 * i + j) * W]); }
         }
-    } else {
+    } } else {
         prog.linearize();                                     // lane mapping: rebuild the final linearization instead
     }
     if constexpr (MODE == 0) prog.gradients(A, env);

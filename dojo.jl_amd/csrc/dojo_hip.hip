@@ -83,8 +83,11 @@ struct DojoSim {
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // environment groups (rollouts, dojo_step_dev)
     int groups = -1;                    // environment groups of dojo_step_dev: -1 = chosen from the batch size, 1 = one launch on the caller's stream
     bool async = false, pending = false;   // dojo_set_async: dojo_step_dev returns without joining the groups into the caller's stream
+    size_t last_NG = 0, last_per = 0;      // environment-group partition of the last grouped dojo_step_dev (per-group chaining assumes it repeats)
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
-    void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping)
+    void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping; explicit-inverse consumers only)
+    void* d_lu = nullptr;               // the IFT kernel's LU-form factors between its phases (quad mapping)
+    double ift_lu_w = 0.0;              // threshold of the LU-form IFT sweeps (Globals::ift_lu_w): 0 = every workgroup (default), INFINITY = none
     void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
     void* d_ypark = nullptr;            // fp32 ABI, quad mapping: the IFT's forward-substituted right-hand sides between its two sweeps, in fp64
     int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
@@ -115,7 +118,13 @@ using namespace dj::coords;
 template <class S, class TIO> __device__ __forceinline__ PoseVel<S> load_body(const TIO* z, int b) {
     PoseVel<S> p;
     for (int i = 0; i < 3; ++i) { p.x[i] = S((double)z[13 * b + i]); p.v[i] = S((double)z[13 * b + 3 + i]); p.w[i] = S((double)z[13 * b + 10 + i]); }
-    for (int i = 0; i < 4; ++i) p.q[i] = S((double)z[13 * b + 6 + i]);
+    double q_[4];
+    for (int i = 0; i < 4; ++i) q_[i] = (double)z[13 * b + 6 + i];
+    if (sizeof(TIO) < sizeof(double)) {    // a narrower ABI type cannot hold a unit quaternion: the state it stands for is (x, v, q/|q|, ω), as in the step / IFT kernels (DJ_LANE_SETUP)
+        const double iq_ = 1.0 / sqrt(q_[0] * q_[0] + q_[1] * q_[1] + q_[2] * q_[2] + q_[3] * q_[3]);
+        for (int i = 0; i < 4; ++i) q_[i] *= iq_;
+    }
+    for (int i = 0; i < 4; ++i) p.q[i] = S(q_[i]);
     return p;
 }
 template <class S> __device__ __forceinline__ PoseVel<S> origin_body() {
@@ -426,6 +435,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     dj::KernelArgs<TIO, T> A;
     const double rw_ = refine_threshold(s);
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode, rw_);
+    A.G.ift_lu_w = T(s->ift_lu_w);
+    { static const char* lw_ = std::getenv("DOJO_IFT_LU_W"); if (lw_) A.G.ift_lu_w = T(std::atof(lw_)); }   // experiments: threshold of the LU-form IFT sweeps
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
@@ -454,12 +465,16 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
         A.sol = (T*)s->d_sol + env0 * s->M.S * dj::sol_record<8>();          // any record size <= sol_record<8> fits this spacing
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
+        if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * 112 * 64 * NW * sizeof(T)));
     }
-    A.fac = (g && quad) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
+    // the explicit inverses travel only when somebody reads them: the refining IFT kernel, or explicit-inverse sweeps (ift_lu_w > 0)
+    const bool want_fac = A.G.refine_w < INFINITY || A.G.ift_lu_w > T(0);
+    A.fac = (g && quad && want_fac) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
+    A.lu = (g && quad) ? (T*)s->d_lu + wave0 * 112 * 64 * NW : nullptr;
     A.ypark = nullptr; A.ypark_stride = 0;
     if (g && quad && sizeof(TIO) < sizeof(T) && dc == nullptr) {          // (DJ_YPARK: dojo_device.hpp, gradient_columns_quad)
         const size_t batches = 2 * Nb + (nu + 5) / 6;
-        A.ypark_stride = (long long)(batches * 18 * (64 * NW / 2));
+        A.ypark_stride = (long long)(batches * 18 * (64 * NW));      // all four roles park (LU-form sweeps)
         if (!s->d_ypark) HIPCHK(hipMalloc(&s->d_ypark, waves_total * (size_t)A.ypark_stride * sizeof(T)));
         A.ypark = (T*)s->d_ypark + wave0 * (size_t)A.ypark_stride;
     }
@@ -592,7 +607,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_blk, s->d_ypark, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
@@ -724,8 +739,12 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
         // the previous call on the same internal stream.  join: the caller's stream waits for all groups -- unless the handle
         // is asynchronous (dojo_set_async), where consecutive calls chain per group and dojo_join() does it once.
         if ((rc = ensure_groups(s, NG))) return rc;
-        HIPCHK(hipEventRecord(s->fork_event, st));
         const size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;       // multiple of 64: whole wavefronts for every mapping
+        // per-group chaining needs the same partition as the call still in flight: group g must cover the environments group g
+        // covered.  Options, refinement or the group count may have changed it -- then everything in flight is joined first.
+        if (s->pending && (s->last_NG != NG || s->last_per != per) && (rc = join_groups(s, st))) return rc;
+        s->last_NG = NG; s->last_per = per;
+        HIPCHK(hipEventRecord(s->fork_event, st));
         for (size_t gi = 0; gi < NG; ++gi) {
             const size_t env0 = gi * per;
             if (env0 >= B) break;
@@ -1034,6 +1053,7 @@ int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stre
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
+    { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const int B = s->B, T_ = 64;
     if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::min2max_kernel<float>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const float*)x, (float*)z);
     else hipLaunchKernelGGL((ckern::min2max_kernel<double>), dim3((B + T_ - 1) / T_), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->d_order, s->M.Nb, s->M.nu, s->M.dt, B, (const double*)x, (double*)z);
@@ -1044,6 +1064,7 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
+    { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
     if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::max2min_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const float*)z, (float*)x, 2 * s->M.nu);
     else hipLaunchKernelGGL((ckern::max2min_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, (const dj::NodeP<double>*)s->d_nodes, s->M.Nb, s->M.nu, s->M.dt, s->B, (const double*)z, (double*)x, 2 * s->M.nu);
@@ -1097,8 +1118,12 @@ int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_ne
     int rc;
     if ((rc = ensure(&s->d_z, B * nz * w))) return rc;
     if ((rc = ensure(&s->d_zn, B * nz * w))) return rc;
+    // (asynchronous handle: environment groups of the previous call may still read d_z / write d_zn, and the kernels that follow
+    //  the step on `stream` read what its groups write -- both sides of the step are joined into the caller's stream here)
+    if ((rc = join_groups(s, (hipStream_t)stream))) return rc;
     if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
     if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, nullptr, nullptr, stream))) return rc;
+    if ((rc = join_groups(s, (hipStream_t)stream))) return rc;
     s->have_grad = false;
     return dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream);
 }
@@ -1123,8 +1148,10 @@ int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void*
     if ((rc = ensure(&s->d_jm, B * nx * (nm + 1) * sizeof(double)))) return rc;
     if ((rc = ensure(&s->d_jt, B * nx * (nm + 1) * sizeof(double)))) return rc;
     if ((rc = ensure(&s->d_jb, B * Nb * 12 * 24 * sizeof(double)))) return rc;
+    if ((rc = join_groups(s, st))) return rc;              // (asynchronous handle: see dojo_step_minimal_dev)
     if ((rc = dojo_minimal_to_maximal_dev(s, x, s->d_z, stream))) return rc;
     if ((rc = dojo_step_dev(s, s->d_z, u, s->d_zn, status, iters, s->d_dz, s->d_du, stream))) return rc;
+    if ((rc = join_groups(s, st))) return rc;
     s->have_grad = false;          // the hand-off belongs to (d_z, the CALLER's u): the host variant below re-arms the flag with its own copy of u
     if ((rc = dojo_maximal_to_minimal_dev(s, s->d_zn, x_next, stream))) return rc;
     const bool literal = s->grad_mode == DOJO_GRAD_REFERENCE;
@@ -1206,6 +1233,7 @@ int dojo_next_state_dev(DojoHandle s, const void* z, void* z_out, void* stream) 
     Enter enter_(s);
     if (!s || !z || !z_out) { g_err = "dojo_next_state_dev: bad argument"; return DOJO_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
+    { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
     if (s->dtype == DOJO_DTYPE_F32) hipLaunchKernelGGL((ckern::next_state_kernel<float>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, s->M.Nb, s->M.dt, s->B, (const float*)z, (float*)z_out);
     else hipLaunchKernelGGL((ckern::next_state_kernel<double>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, (hipStream_t)stream, s->M.Nb, s->M.dt, s->B, (const double*)z, (double*)z_out);

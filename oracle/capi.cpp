@@ -8,6 +8,10 @@
 #include <chrono>
 #include <memory>
 #include <algorithm>
+#include <cstdio>
+#include <sched.h>
+#include <pthread.h>
+#include <malloc.h>
 
 using namespace orc;
 
@@ -299,7 +303,28 @@ void orc_set_refine_steps(void* h, int n) { ((IOracle*)h)->set_refine_steps(n); 
 
 // bench.py's cpu_baseline leg: every thread owns a clone of the mechanism and walks its share of the B environments `rounds`
 // times (results discarded); the clock starts once all threads stand at the barrier.  Returns the wall-clock seconds.
+// physical cores this process may run on (one hardware thread per core): what a CPU baseline should be timed on
+static std::vector<int> physical_cpus() {
+    cpu_set_t set; CPU_ZERO(&set);
+    std::vector<int> cpus;
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return cpus;
+    std::vector<int> seen_core;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &set)) continue;
+        char path[128]; std::snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        int first = c;
+        if (FILE* f = std::fopen(path, "r")) { if (std::fscanf(f, "%d", &first) != 1) first = c; std::fclose(f); }
+        if (first == c || !CPU_ISSET(first, &set)) cpus.push_back(c);      // the first sibling of every core (or a core whose first sibling is not ours)
+    }
+    return cpus;
+}
+int orc_physical_cores(void) { return (int)physical_cpus().size(); }
+
+// Large blocks stay in the per-thread malloc arenas (no mmap / munmap per call: those serialize a multi-threaded batch in the kernel)
+namespace { struct MallocTuning { MallocTuning() { mallopt(M_MMAP_THRESHOLD, 512 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); } } malloc_tuning_; }
+
 double orc_time_batch(void* h, int B, const double* z, const double* u, int with_grad, int grad_mode, int nthreads, int rounds) {
+    const std::vector<int> cpus = physical_cpus();
     IOracle* base = (IOracle*)h; int d[7]; base->dims(d);
     const int nz = 13 * d[4], nu = d[1], nx = 12 * d[4];
     nthreads = std::max(1, std::min(nthreads, B));
@@ -307,7 +332,11 @@ double orc_time_batch(void* h, int B, const double* z, const double* u, int with
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) {
         th.emplace_back([&, t]() {
+            if (!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[t % cpus.size()], &one); pthread_setaffinity_np(pthread_self(), sizeof(one), &one); }   // one thread per physical core
             std::unique_ptr<IOracle> o(base->clone());
+            { int it0 = 0; std::vector<double> z0(nz);           // untimed first step: the clone's workspaces and symbolic factorization
+              o->step(z + (size_t)t * nz, u ? u + (size_t)t * nu : nullptr, z0.data(), nullptr, &it0);
+              if (with_grad) { std::vector<double> g0((size_t)nx * nx), g1((size_t)nx * std::max(nu, 1)); o->gradients(grad_mode, g0.data(), g1.data()); } }
             std::vector<double> zs(nz), dz(with_grad ? (size_t)nx * nx : 0), du(with_grad ? (size_t)nx * std::max(nu, 1) : 0);
             ready.fetch_add(1);
             while (!go.load()) std::this_thread::yield();

@@ -139,6 +139,7 @@ struct Mechanism {
     int refine_steps = 2;         // rounds of iterative refinement of every linear solve (DenseLU::solve_refined); 0 = plain LU, as timed by bench.py's cpu_baseline
     bool sparse_solver = false;   // timing variant: SparseLU (no pivoting, elimination order of the mechanism graph) instead of DenseLU
     mutable SparseLU<T> splu;
+    mutable std::vector<T> w_Dm, w_R; mutable DenseLU<T> w_lu;      // get_maximal_gradients' workspaces
     bool excessive_w = false;
 
     // ---------------- construction from the C-POD topology ----------------
@@ -1535,7 +1536,7 @@ struct Mechanism {
     // =====================================================================
     void get_maximal_gradients(const std::vector<T>& solmat, T* jac_state, T* jac_control) const {
         int Nb = (int)bodies.size(), nx = 12 * Nb, nu_ = nu(), nd;
-        std::vector<T> Dm; jacobian_data(Dm, nd);
+        std::vector<T>& Dm = w_Dm; jacobian_data(Dm, nd);      // (workspaces kept between calls: oracle_math.hpp, DenseLU::solve_refined)
         // columns: state [x2(14:16) v15(8:10) φ2(17:19) ω15(11:13)] per body, control 1:nu_j per joint
         std::vector<int> cols;
         int o = 0; std::vector<int> jc, bc;
@@ -1544,10 +1545,10 @@ struct Mechanism {
         for (int i = 0; i < Nb; ++i) { for (int k : {13, 14, 15, 7, 8, 9, 16, 17, 18, 10, 11, 12}) cols.push_back(bc[i] + k); }
         for (size_t j = 0; j < joints.size(); ++j) for (int k = 0; k < joints[j].nu(); ++k) cols.push_back(jc[j] + k);
         int nc = (int)cols.size();
-        std::vector<T> R((size_t)n * nc);
+        std::vector<T>& R = w_R; R.resize((size_t)n * nc);
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + cols[c]];
         if (sparse_solver) { if (splu.n != n) build_sparse_order(); splu.factor(solmat); splu.solve(R.data(), nc); }
-        else { DenseLU<T> lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps); }   // data_jacobian = solmat \ datamat
+        else { DenseLU<T>& lu = w_lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps); }   // data_jacobian = solmat \ datamat
         std::fill(jac_state, jac_state + (size_t)nx * nx, T(0));
         std::fill(jac_control, jac_control + (size_t)nx * nu_, T(0));
         auto out = [&](int row, int c) -> T& { return c < nx ? jac_state[(size_t)row * nx + c] : jac_control[(size_t)row * nu_ + (c - nx)]; };

@@ -37,6 +37,7 @@ def lib():
                      "orc_body_velocity_solution", "orc_save_to_storage", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
             getattr(_lib, name).restype = None
         _lib.orc_time_batch.restype = C.c_double
+        _lib.orc_physical_cores.restype = C.c_int
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
         _lib.orc_ls_stats.restype = None
@@ -238,6 +239,11 @@ class Oracle:
         du = np.zeros((B, nx, self.nu)) if with_grad else None
         lib().orc_step_batch(self.h, B, _p(Z), _p(U), _p(Zn), _p(st), _p(it), int(with_grad), grad_mode, _p(dz), _p(du), nthreads)
         return Zn, st, it, dz, du
+
+
+def physical_cores():
+    """physical cores this process may run on (one hardware thread per core; orc_time_batch pins one thread to each)"""
+    return int(lib().orc_physical_cores())
 
 
 def unit(what, q, w=(0.0, 0.0, 0.0), dt=0.01):

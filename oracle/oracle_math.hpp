@@ -247,6 +247,7 @@ template <class T>
 struct DenseLU {
     int n = 0; std::vector<T> lu; std::vector<int> piv;
     std::vector<T> a0;            // the matrix itself, kept for solve_refined
+    mutable std::vector<T> w_rhs, w_r; mutable std::vector<long double> w_acc;     // solve_refined's workspaces
     bool factor(const std::vector<T>& A, int n_) {
         n = n_; lu = A; a0 = A; piv.resize(n);
         for (int k = 0; k < n; ++k) {
@@ -277,9 +278,11 @@ struct DenseLU {
     // cond(A) reaches 1e10 -- the iterate path of a 20..40-iteration solve amplifies it to the parity bound.)
     void solve_refined(T* B, int nrhs, int steps) const {
         if (steps <= 0) { solve(B, nrhs); return; }
-        std::vector<T> rhs(B, B + (size_t)n * nrhs), r((size_t)n * nrhs);
+        // (workspaces live with the factorization: a 200 x 170 block is past malloc's mmap threshold, and an mmap / page-fault /
+        //  munmap round per solve serializes the threads of a multi-threaded batch in the kernel)
+        std::vector<T>& rhs = w_rhs; std::vector<T>& r = w_r; std::vector<long double>& acc = w_acc;
+        rhs.assign(B, B + (size_t)n * nrhs); r.resize((size_t)n * nrhs); acc.resize(nrhs);
         solve(B, nrhs);
-        std::vector<long double> acc(nrhs);
         for (int s = 0; s < steps; ++s) {
             for (int i = 0; i < n; ++i) {
                 for (int j = 0; j < nrhs; ++j) acc[j] = (long double)rhs[(size_t)i * nrhs + j];
@@ -341,8 +344,9 @@ struct SparseLU {
             analyze(ones); }
     }
     // B[n][nrhs] row-major, rows in the ORIGINAL row order; the solution comes back in the original column (unknown) order
+    mutable std::vector<T> w_y;                           // solve's workspace (kept: see DenseLU::solve_refined)
     void solve(T* B, int nrhs) const {
-        std::vector<T> y((size_t)n * nrhs);
+        std::vector<T>& y = w_y; y.resize((size_t)n * nrhs);
         for (int i = 0; i < n; ++i) std::memcpy(&y[(size_t)i * nrhs], &B[(size_t)prow[i] * nrhs], sizeof(T) * nrhs);
         for (int k = 0; k < n; ++k) { const T* yk = &y[(size_t)k * nrhs]; for (int i : lrows[k]) { const T f = w[(size_t)i * n + k]; if (f != T(0)) { T* yi = &y[(size_t)i * nrhs]; for (int j = 0; j < nrhs; ++j) yi[j] -= f * yk[j]; } } }
         for (int k = n - 1; k >= 0; --k) {

@@ -83,3 +83,69 @@ def test_bench_two_ranks_plumbing():
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
     assert abs(res["value"] - 2 * 512 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]       # whole-job aggregate over both ranks
     assert "torch.distributed" in res["config"]["final_gather"]
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py re-executes itself as two ranks (torch.distributed.run on 127.0.0.1)
+    and rank 0 prints the one JSON line with n_gpus = 2 and the device of every rank (gloo: the two ranks share the one GPU)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and len(res["config"]["rank_devices"]) == 2
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "GPU(s)" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+RCCL_WORKER = r"""
+import os, sys
+ROOT = %r
+sys.path.insert(0, os.path.join(ROOT, "dojo.jl_amd", "host"))
+import numpy as np, torch
+import dojo_amd as d
+from dojo_amd import api, distributed as D
+rank, world, local = D.init_from_env(backend="nccl")
+torch.cuda.set_device(local)
+spec = d.baseline_config(4)
+B = 1024
+Z, U = d.synthetic_inputs(spec, B)
+lo, hi = D.shard_slice(B, rank, world)
+gm = api.BatchedMechanism(spec, hi - lo, dtype="f32", device=local)
+D.connect_handle(gm, rank, world)                      # dojo_comm_unique_id on rank 0 -> dojo_comm_init on every rank
+z = torch.tensor(Z[lo:hi], dtype=torch.float32, device="cuda:%%d" %% local); u = torch.tensor(U[lo:hi], dtype=torch.float32, device=z.device)
+zn = torch.empty_like(z); st = torch.empty(hi - lo, dtype=torch.int32, device=z.device); it = torch.empty_like(st)
+import ctypes as C
+api._chk(api.lib().dojo_step_dev(gm.h, C.c_void_p(z.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(zn.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(it.data_ptr()), None, None,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+zg = D.all_gather_states_rccl(gm, zn, world); sg = D.all_gather_states_rccl(gm, st, world)     # dojo_allgather_dev over RCCL / xGMI
+torch.cuda.synchronize()
+gm.close()
+if rank == 0:
+    full = api.BatchedMechanism(spec, B, dtype="f32", device=0)
+    zf, sf, itf = full.step(Z.astype(np.float32), U.astype(np.float32)); full.close()
+    assert np.array_equal(zg.cpu().numpy(), zf) and np.array_equal(sg.cpu().numpy(), sf), "gathered != unsharded"
+    print("RCCL_OK", world)
+""" % ROOT
+
+
+def test_library_rccl_allgather_two_ranks(tmp_path):
+    """dojo_allgather_dev with TWO ranks on two GPUs: the sharded Quadruped step, gathered through the library's RCCL communicator,
+    equals the unsharded batch bit for bit.  Needs a node with >= 2 GPUs (the boxes of the development pool have one: skipped there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    f = tmp_path / "rccl_worker.py"
+    f.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(f)], capture_output=True, text=True, timeout=900, env=env)
+    assert "RCCL_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
