@@ -39,6 +39,7 @@ struct IOracle {
     virtual int simulate_step_record(const double* u, int last, double* row) = 0;
     virtual void body_velocity_solution(double* v) = 0;
     virtual void save_to_storage(double* out) = 0;
+    virtual void energy_of_storage_row(const double* row, double* ke_pe) = 0;
     virtual void debug_assemble(const double* z, const double* u, double* A, double* b) = 0;
     virtual void check_solution(const double* z, const double* u, const double* sol, double* viol) = 0;
     virtual IOracle* clone() = 0;
@@ -206,6 +207,10 @@ struct OracleT : IOracle {
         std::vector<T> o(25 * m.bodies.size()); m.save_to_storage(o.data());
         for (size_t i = 0; i < o.size(); ++i) out[i] = (double)o[i];
     }
+    void energy_of_storage_row(const double* row, double* ke_pe) override {
+        std::vector<T> r(25 * m.bodies.size()); for (size_t i = 0; i < r.size(); ++i) r[i] = T(row[i]);
+        T ke, pe; m.energy_of_storage_row(r.data(), ke, pe); ke_pe[0] = (double)ke; ke_pe[1] = (double)pe;
+    }
     void debug_assemble(const double* z, const double* u, double* A, double* b) override {
         // state of mehrotra! right after its first set_entries! (mehrotra.jl:10-21)
         int nz = 13 * (int)m.bodies.size(), nu = m.nu();
@@ -260,6 +265,8 @@ int  orc_simulate_step(void* h, const double* u, int last) { return ((IOracle*)h
 int  orc_simulate_step_record(void* h, const double* u, int last, double* row) { return ((IOracle*)h)->simulate_step_record(u, last, row); }
 void orc_body_velocity_solution(void* h, double* v) { ((IOracle*)h)->body_velocity_solution(v); }
 void orc_save_to_storage(void* h, double* out) { ((IOracle*)h)->save_to_storage(out); }
+// kinetic_energy / potential_energy (src/mechanics/energy.jl) of one Storage row [Nb][25] -> out = {ke, pe}
+void orc_energy_of_storage_row(void* h, const double* row, double* out) { ((IOracle*)h)->energy_of_storage_row(row, out); }
 
 void orc_debug_assemble(void* h, const double* z, const double* u, double* A, double* b) { ((IOracle*)h)->debug_assemble(z, u, A, b); }
 

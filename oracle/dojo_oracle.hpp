@@ -1306,6 +1306,33 @@ struct Mechanism {
             p[3] = s.q2.s; p[4] = s.q2.v1; p[5] = s.q2.v2; p[6] = s.q2.v3;
         }
     }
+    // kinetic_energy / potential_energy of one Storage row (src/mechanics/energy.jl:24-92): row = save_to_storage's [Nb][25].
+    //   ke = Σ ½ m vl·vl + ½ ωlᵀ J ωl                               (:33-41, the momentum-derived velocities vl, ωl of the row)
+    //   pe = −Σ m g·x  +  Σ_{joints with springs, halves with spring > 0} ½ |spring_force(:parent, ...)|² / spring     (:61-90)
+    void energy_of_storage_row(const T* row, T& ke, T& pe) const {
+        ke = T(0); pe = T(0);
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            const Body<T>& B = bodies[i]; const T* p = row + 25 * i;
+            M vl = M::vec({p[19], p[20], p[21]}), wl = M::vec({p[22], p[23], p[24]}), x = M::vec({p[0], p[1], p[2]});
+            ke += T(0.5) * B.mass * dot(vl, vl) + T(0.5) * dot(wl, B.inertia * wl);
+            pe -= B.mass * dot(gravity, x);
+        }
+        auto cfg = [&](int b, M& x, Q& q) {
+            if (b < 0) { x = origin.x2; q = origin.q2; return; }       // current_configuration(mechanism.origin.state)
+            const T* p = row + 25 * b; x = M::vec({p[0], p[1], p[2]}); q = Q(p[3], p[4], p[5], p[6]);
+        };
+        for (auto& J : joints) {
+            if (!J.spring) continue;
+            M xa, xb; Q qa, qb; cfg(J.parent, xa, qa); cfg(J.child, xb, qb);
+            for (const Half<T>* h : {&J.tra, &J.rot}) {
+                if (!(h->spring > T(0))) continue;
+                M force;
+                if (!h->is_rot) { M distance = h->spring_offset - minimal_coordinates(J, *h, xa, qa, xb, qb); force = h->spring * (h->A.t() * distance); }   // translational/springs.jl:5-15
+                else force = rot_spring_force(true, J, *h, xa, qa, xb, qb, true, false);                                                                          // rotational/springs.jl:5-24
+                pe += T(0.5) * dot(force, force) / h->spring;
+            }
+        }
+    }
     void initialize_simulation() {   // simulate.jl:53-58
         for (auto& B : bodies) { set_previous_configuration(B.st); B.st.JF2 = M(3, 1); B.st.Jt2 = M(3, 1); }
         for (auto& B : bodies) { B.st.vsol[0] = B.st.v15; B.st.vsol[1] = B.st.v15; B.st.wsol[0] = B.st.w15; B.st.wsol[1] = B.st.w15; }

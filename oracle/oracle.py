@@ -34,7 +34,7 @@ def lib():
         for name in ("orc_destroy", "orc_set_options", "orc_dims", "orc_get_solution", "orc_set_solution", "orc_gradients",
                      "orc_get_data", "orc_set_data", "orc_evaluate_residual", "orc_full_matrix", "orc_data_matrix",
                      "orc_data_attjac", "orc_set_state", "orc_get_state", "orc_set_external_force",
-                     "orc_body_velocity_solution", "orc_save_to_storage", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
+                     "orc_body_velocity_solution", "orc_save_to_storage", "orc_energy_of_storage_row", "orc_step_batch", "orc_debug_assemble", "orc_check_solution"):
             getattr(_lib, name).restype = None
         _lib.orc_time_batch.restype = C.c_double
         _lib.orc_physical_cores.restype = C.c_int
@@ -158,6 +158,15 @@ class Oracle:
         """save_to_storage!(mechanism, storage, k) (storage.jl:50-67) for the body states as they are now:
         [Nb, 25] = x2(3) q2(4) v15(3) w15(3) px(3) pq(3) vl(3) wl(3)."""
         out = np.zeros((self.Nb, 25)); lib().orc_save_to_storage(self.h, _p(out)); return out
+
+    def energy(self, rows):
+        """kinetic_energy, potential_energy (src/mechanics/energy.jl:24-92) of Storage rows [H, Nb, 25] (or one row [Nb, 25]) -> (ke [H], pe [H])"""
+        rows = np.ascontiguousarray(rows, dtype=np.float64); one = rows.ndim == 2
+        R = rows[None] if one else rows
+        out = np.zeros((len(R), 2))
+        for k in range(len(R)):
+            lib().orc_energy_of_storage_row(self.h, _p(np.ascontiguousarray(R[k])), _p(out[k]))
+        return (out[0, 0], out[0, 1]) if one else (out[:, 0], out[:, 1])
 
     def simulate(self, z0, steps, control=None):
         """simulate!(mechanism, steps, storage, control!)  -> list of maximal states after each step.
