@@ -30,9 +30,6 @@
 #include <cstdlib>
 #endif
 
-#ifndef DJ_RHS_PREFETCH
-#define DJ_RHS_PREFETCH 1      // IFT up-sweep: fetch the next column's right-hand-side values from LDS before the current column's products (one wave per SIMD has nothing else to hide the LDS latency with)
-#endif
 #ifndef DJ_FUSE_LS
 #define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
                            // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
@@ -48,9 +45,6 @@
 #endif
 #ifndef DJ_PIVOT_ORDER
 #define DJ_PIVOT_ORDER 1   // quad Gauss-Jordan: 1 = pivot v, λ_t, ω, λ_r; 0 = v, ω, λ_t, λ_r (see factorize_quad)
-#endif
-#ifndef DJ_SPLIT_Y
-#define DJ_SPLIT_Y 0       // IFT sweeps, fp32 ABI: 1 = park the forward-substituted right-hand sides as two floats (measured: IFT kernel +33 %, while the f32-ABI and f64-ABI gradients already agree to 2e-7 relative without it)
 #endif
 #ifndef DJ_RHS_T
 #define DJ_RHS_T TIO       // quad mapping: type of the IFT right-hand-side blocks in LDS (the ABI type; double was measured: +25 % IFT kernel time, same error)
@@ -68,9 +62,6 @@
 #endif
 #ifndef DJ_SCHUR_LEAN
 #define DJ_SCHUR_LEAN 1      // quad factorization: Schur complement with 18 (not 54) gathered U entries and 18 (not 36) partial sums in flight: 49 -> 39 spilled VGPRs, +1.4 % (same session)
-#endif
-#ifndef DJ_YPARK
-#define DJ_YPARK 1          // fp32 ABI: the IFT parks y in an fp64 buffer of its own (KernelArgs::ypark) instead of the fp32 output slots
 #endif
 #ifndef DJ_LINEAR
 #define DJ_LINEAR 0         // 1: builds for LinearContact mechanisms (src/contacts/linear.jl: six cone pairs [γ ψ β1..β4] per contact, all on the positive
@@ -104,8 +95,6 @@ struct Globals {
     T dt, idt2 /* 1/dt² */, input_scaling, g[3];
     T rtol, btol, undercut, no_progress_undercut;
     T refine_w;                  // refine the linear solves of an environment once max γ/s over its cones exceeds this (inf: never, 0: always)
-    T ift_lu_w;                  // IFT (quad mapping): a workgroup whose explicit supernode inverses have an entry beyond this runs its column sweeps through
-                                 // LU-form solves of a factorization of its own (0: always, inf: never; DESIGN.md §5 "LU-form sweeps")
     int max_iter, max_ls, no_progress_max;
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
@@ -301,24 +290,31 @@ struct GradBlocks {
 };
 // Quad mapping: the IFT right-hand sides of one supernode, laid out per role (lane q owns rows
 // 3q..3q+2) with the cone condensation already folded in, so that the column sweeps load their
-// rows with one address computation and no divergence.  Flat array, offsets below; odd word count.
+// rows with one address computation and no divergence.  Three flat arrays:
+//   a       the body-row blocks, in the ABI type (an fp32 rounding of these moves the gradient by < 1e-7 relative)
+//   jd      the joint rows and the joint-limit slack rows, in double: they are constraint rows -- their right-hand sides reach
+//           the velocities amplified by 1/Δt and more, and rounded to fp32 they cost up to 1.4e-5 of the gradient (measured on
+//           the fp32-ABI Ant batch, tools/hunt_f32.py; the body-row blocks: no effect)
+//   own_cfg the owner's body rows of the configuration columns with the cone condensation folded in, in double (the folded
+//           terms ~γ/s cancel against the stiff rows of the factors)
 template <class TB>
 struct alignas(8) QuadRhs {
     enum { ROWNV = 0,     // [2 roles][3 rows][6]  owner body rows, velocity columns (v15 ω15)
-           ROWNJ = 36,    // [2][3][6]  owner joint rows (roles 2, 3), configuration columns (x2 φ2)
-           RPAR = 72,     // [4][3][6]  rows of this supernode for the PARENT's configuration columns
-           UOWN = 144,    // [2][3][6]  what the owner's configuration columns put on the parent's body rows
-           UPAR = 180,    // [2][3][6]  the same for the parent's own configuration columns
-           UB = 216,      // [2][3][6]  control columns: child body rows
-           UA = 252,      // [2][3][6]  control columns: parent body rows
-           SLO = 288,     // [6]  joint-limit slack rows, owner's configuration columns  (applied as t·wκ·sl in the sweep:
-           SLP = 294,     // [6]  ... parent's configuration columns                       rounding must stay along t)
-           SIZE = 300 };
+           RPARB = 36,    // [2][3][6]  body rows of this supernode for the PARENT's configuration columns
+           UOWN = 72,     // [2][3][6]  what the owner's configuration columns put on the parent's body rows
+           UPAR = 108,    // [2][3][6]  the same for the parent's own configuration columns
+           UB = 144,      // [2][3][6]  control columns: child body rows
+           UA = 180,      // [2][3][6]  control columns: parent body rows
+           SIZE = 216 };
+    enum { ROWNJ = 0,     // [2 roles][3][6]  owner joint rows (roles 2, 3), configuration columns (x2 φ2)
+           RPARJ = 36,    // [2][3][6]  joint rows of this supernode for the PARENT's configuration columns
+           SLO = 72,      // [6]  joint-limit slack rows, owner's configuration columns   (enter the Δκ row as σ·slack in the sweep)
+           SLP = 78,      // [6]  ... parent's configuration columns
+           JSIZE = 84 };
     TB a[SIZE];
-    // owner body rows of the configuration columns, cone condensation folded in: kept in double even with
-    // fp32 ABI buffers (the folded terms ~γ/s cancel against the stiff rows of S⁻¹)      [2 roles][3][6]
-    double own_cfg[36];
-    double pad_[(SIZE * sizeof(TB) / 8 + 36) % 2 == 0 ? 1 : 2];     // odd stride in 8-byte words
+    double jd[JSIZE];
+    double own_cfg[36];                                            // [2 roles][3][6]
+    double pad_[(SIZE * sizeof(TB) / 8 + JSIZE + 36) % 2 == 0 ? 1 : 2];     // odd stride in 8-byte words
 };
 // Quad mapping: the right-hand sides of the contact-data columns (get_contact_gradients, src/gradients/contact.jl):
 // per contact of the supernode, per body-row role, 3 rows x 6 columns (5 used: friction, radius, origin(3)); cone
@@ -1137,8 +1133,7 @@ struct LaneProgram {
     static constexpr bool kRefine = kTrack && Wave::kRefine;
     enum { BLK_PER_LANE = 90 };        // S rows 3x12, U rows 3x6, L columns 6x3, Dup rows 3x6
     T* blk = nullptr; int blk_stride = 0;
-    T* ypark = nullptr;                // this lane's first slot of the workgroup's y park (KernelArgs::ypark; body-row roles only)
-    T* ypark_lane = nullptr;           // the same with one slot per lane (LU-form sweeps: all four roles park)
+    T* ypark = nullptr;                // this lane's first slot of the workgroup's ỹ park (KernelArgs::ypark: one slot per lane, all four roles park)
     bool refine = false;
     T wstiff = T(0);                   // max γ/s over the cones of the environment at the last evaluated iterate
     T growth = T(0);                   // largest |multiplier| of the last factorization's Gauss-Jordan passes on this lane (no pivoting: the growth indicator)
@@ -1847,37 +1842,30 @@ struct LaneProgram {
     // Columns travel through the tree six at a time ("batches") and the two sweeps are software-
     // pipelined over the batches: in step t of the up-sweep a supernode at level l works on batch
     // t − (maxlevel − l), in step t of the down-sweep on batch t − l.  Every lane therefore does one
-    // useful block product per step instead of idling at the other levels' turns, and the whole
-    // IFT costs (batches + depth) steps per sweep instead of batches × depth.  The forward-substituted
-    // right-hand sides y wait between the two sweeps in the output buffer itself (the v / ω slots of
-    // the column, which the down-sweep then overwrites with the final values).
+    // useful block substitution per step instead of idling at the other levels' turns, and the whole
+    // IFT costs (batches + depth) steps per sweep instead of batches × depth.
+    // The sweeps are the forward / backward substitutions of the tree's LU form (factorize_quad_lu):
+    //   up    ỹ = L11⁻¹ (r + Σ_children messages);  message to the parent's body rows: u − m ỹ
+    //   down  x = U11⁻¹ (ỹ − T x_parent)
+    // Between the sweeps ỹ -- all twelve rows of every supernode -- waits in the output column itself (ABI type = arithmetic
+    // type: role 0 -> the v rows of the lane's body, role 1 -> the ω rows, roles 2 / 3 -> the x3 / φ3 rows; nobody writes those
+    // before the down-sweep has fetched them: the fetch of a batch is issued one step before its output stores, by the same
+    // wavefront) or, with a narrower ABI type, in a buffer of its own in the arithmetic type (KernelArgs::ypark,
+    // [batch][column][row][lane]: every store / load of a wavefront is one 512-byte run): a rounded ỹ costs stiff
+    // environments their gradient.
     // MODE 0: state + control columns (get_maximal_gradients);  MODE 1: contact-data columns (get_contact_gradients):
     // one batch per contact of the environment, five columns (friction, radius, origin), owner = the contact's body.
-    // LUF: the sweeps are the forward / backward substitutions of the tree's LU form (factorize_quad_lu) instead of products with the explicit inverses F.Sq.
-    template <int MODE = 0, bool LUF = false, class KA, class RH, class KN>
+    template <int MODE = 0, class KA, class RH, class KN>
     DJ_HD void gradient_columns_quad(const KA& A, int env, const RH& R, T wk, const KN& kb0, const SweepP& sp) {
         typedef typename KA::io_type TIO;
         typedef TL TG;
-        constexpr bool kSplitY = DJ_SPLIT_Y && sizeof(TIO) < sizeof(TG);      // park y as (high, low) halves when the ABI type is narrower
-        // fp32 ABI: y − S⁻¹(U Δ_parent) cancels in the down-sweep, and a y rounded to fp32 costs stiff environments their gradient
-        // (Ant, 4096 environments: max 1.2e-3 relative against 1.4e-5 with an exact y) -- the parked y goes to a buffer of its own in
-        // the arithmetic type, [batch][column][row][role lane]: one 256-byte run per store / load of a wavefront
-        constexpr bool ypk = DJ_YPARK && MODE == 0 && !kSplitY && sizeof(TIO) < sizeof(TG);   // (the host allocates KernelArgs::ypark whenever this holds)
-        // explicit-inverse sweeps: the two body-row roles park y;  LU-form sweeps: all four roles park ỹ (the joint rows too)
-        const int yW = LUF ? wv.width() : wv.width() >> 1;
-        T* const yp0 = LUF ? ypark_lane : ypark;              // this lane's slot of batch 0, column 0, row 0
-        // LU form, ABI type = arithmetic type: ỹ waits in the output column itself, in the twelve rows of the lane's body: role 0 -> the
-        // v rows, role 1 -> the ω rows (the slots the explicit sweeps use), roles 2 / 3 -> the x3 / φ3 rows, which nobody writes before
-        // the down-sweep has fetched them (the fetch of a batch is issued one step before its output stores, by the same wavefront)
-        const int prk_off = (q == 0 ? 3 : q == 1 ? 9 : q == 2 ? 0 : 6) - 6 * q;     // relative to row0 = 12 k + 6 q
+        constexpr bool ypk = sizeof(TIO) < sizeof(TG);          // (the host allocates KernelArgs::ypark whenever this holds)
+        const int yW = wv.width();
+        T* const yp0 = ypark;                                  // this lane's slot of batch 0, column 0, row 0
+        const int prk_off = (q == 0 ? 3 : q == 1 ? 9 : q == 2 ? 0 : 6) - 6 * q;     // ỹ's rows in the output column, relative to row0 = 12 k + 6 q
         constexpr int NC = 6;
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
-        const int ro = q == 1 ? 3 : 0;                         // first body row owned by roles 0 / 1
-        const TG (&Sg)[3][12] = F.Sq;
-        TG LmU[LUF ? 3 : 1][12], mU[6][LUF ? 3 : 1];             // LU form: L11 − I and the parent rows' multipliers m, for the up-sweep
-        if constexpr (LUF) load_lu_up(LmU, mU);
-        const auto& Lg = [&]() -> const TG (&)[6][3] { if constexpr (LUF) return mU; else return F.Lq; }();
         const int nbs = MODE == 0 ? 2 * G.Nb : 0;              // state batches: (body kk, configuration | velocity columns)
         const int nbu = MODE == 0 ? ((A.du != nullptr && G.nu > 0) ? (G.nu + NC - 1) / NC : 0) : G.Nc;   // control batches: six input columns each | contact batches
         const int NB = nbs + nbu;
@@ -1900,6 +1888,9 @@ struct LaneProgram {
         // does column cI of batch b exist?  (padding columns of the last control batch / the sixth column of a contact batch)
         auto col_ok = [=](int b, int cI) -> bool { return b < nbs || (MODE == 0 ? NC * (b - nbs) + cI < ncol_u : cI < 5); };
         // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
+        {
+        TG Lm[3][12], mq[6][3];                                // L11 − I and the parent rows' multipliers m (load_lu_up)
+        load_lu_up(Lm, mq);
         TG send3[NC][3];
 #pragma unroll
         for (int n = 0; n < NC; ++n) send3[n][0] = send3[n][1] = send3[n][2] = TG(0);
@@ -1907,9 +1898,9 @@ struct LaneProgram {
             const int b = t - (G.maxlevel - lvl);
             const bool valid = active && b >= 0 && b < NB;
             // the children finished this batch in the previous step
-            TG acc[3 * NC], snd[3 * NC];
+            TG acc[3 * NC];
 #pragma unroll
-            for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { acc[3 * n + i] = TG(0); snd[3 * n + i] = send3[n][i]; }
+            for (int i = 0; i < 3 * NC; ++i) acc[i] = TG(0);
 #ifdef DJ_PROF
             unsigned long long tg0 = wv.clock();
 #endif
@@ -1917,7 +1908,7 @@ struct LaneProgram {
                 wv.sync();
                 if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
-                    for (int i = 0; i < 3 * NC; ++i) ms_[i] = (double)snd[i]; }
+                    for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)send3[n][i]; }
                 wv.sync();
 #pragma unroll
                 for (int ci = 0; ci < MAXCH; ++ci) {
@@ -1935,191 +1926,108 @@ struct LaneProgram {
             const int kk = b >> 1, typ = b & 1;
             const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (sp.parent == kk);
             // where this lane's rows of the batch's right-hand sides live in the supernode's QuadRhs (all blocks are [.][3][6]):
-            //   own batch: body roles: own_cfg (configuration columns, double) | ROWNV (velocity columns); joint roles: ROWNJ | 0
-            //   parent's configuration batch: RPAR[q] ;  control batch: UB on the owner (child body of the joint)
-            //   parent-row parts (roles 0, 1): UOWN / UPAR / UA
+            //   body roles (ABI-type block a):   own batch: own_cfg (configuration columns, double) | ROWNV (velocity columns);
+            //                                    parent's configuration batch: RPARB;  control batch: UB on the owner (child body of the joint)
+            //   joint roles (double block jd):   own configuration batch: ROWNJ;  parent's configuration batch: RPARJ
+            //   parent-row parts (roles 0, 1):   UOWN / UPAR / UA
             const int cu0 = NC * (b - nbs) - sp.u_off;            // control batch: local input index of column 0
-            int r_off, u_off_;
-            bool od = false; TG rm_s = TG(0), um_s = TG(0), wkm = TG(0); int sl_off = 0, cl = -1;
+            int r_off = 0, j_off = 0, u_off_ = 0, sl_off = 0, cl = -1;
+            bool od = false; TG rm_s = TG(0), um_s = TG(0), wkm = TG(0);
             if constexpr (MODE == 0) {
-                r_off = isS ? (mine ? (q < 2 ? RH::ROWNV : RH::ROWNJ) + qh * 18 : RH::RPAR + q * 18) : RH::UB + qh * 18 + cu0;
+                r_off = isS ? (mine ? RH::ROWNV : RH::RPARB) + qh * 18 : RH::UB + qh * 18 + cu0;
+                j_off = (mine ? RH::ROWNJ : RH::RPARJ) + qh * 18;
                 u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
                 od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
                 rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0); um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
-                // joint-limit condensation: slack rows (rs, −rs) -> body rows += t_b wκ rs, parent body rows += t_a wκ rs
-                wkm = (sp.nlim_r > 0 && q == ((DJ_TSD && sp.nlim_r == 2) ? 2 : 3) && (mine || par) && typ == 0) ? TG(wk) : TG(0);       // σ on the Δκ row = row 2 of role 3
+                // joint-limit condensation: the slack rows (rs, −rs) enter the Δκ row (row 2 of role 3; role 2 for a translational limit) as σ rs
+                wkm = (sp.nlim_r > 0 && q == ((DJ_TSD && sp.nlim_r == 2) ? 2 : 3) && (mine || par) && typ == 0) ? TG(wk) : TG(0);
                 sl_off = mine ? RH::SLO : RH::SLP;
             } else {
                 // contact batch b - nbs = contact index of the environment; cl = its slot on this supernode (or -1)
 #pragma unroll
                 for (int c_ = 0; c_ < MAXC; ++c_) if (c_ < sp.ncontact && sp.contact[c_] == b - nbs) cl = c_;
-                r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18; u_off_ = 0;
+                r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18;
             }
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
-            if constexpr (LUF) {
-                // the six columns of the batch together: right-hand sides, one LU-form solve of all six, then the messages
-                TG r3a[NC][3], ua[NC][3];
-#pragma unroll
-                for (int cI = 0; cI < NC; ++cI) {
-                    TG r_[3], u_[3];
-                    if constexpr (MODE == 0) {
-                        const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
-                        const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
-                        const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
-                            r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
-                            u_[i] = um * TG(R.a[iu + i * 6]);
-                        }
-                        r_[2] += wkm * TG(R.a[sl_off + cI]);
-                    } else {
-                        const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { r_[i] = rm * TG(R.a[r_off + i * 6 + cI]); u_[i] = TG(0); }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0); ua[cI][i] = u_[i]; }
-                }
-                lu_forward_quad<NC>(LmU, r3a);                     // ỹ = L11⁻¹ r
-#pragma unroll
-                for (int cI = 0; cI < NC; ++cI) {
-                    const int cx = (isS && cI >= 3) ? cI + 3 : cI;
-                    const TG (&yy)[3] = r3a[cI];
-                    TG part[6];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) part[i] = Lg[i][0] * yy[0] + Lg[i][1] * yy[1] + Lg[i][2] * yy[2];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
-                    if (valid) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? ua[cI][i] - (q == 0 ? p0_ : p1_) : TG(0); }
-                        if (col_ok(b, cI)) {
-                            if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
-                            else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
-                        }
-                    }
-                }
-            } else {
-#if DJ_RHS_PREFETCH
-            double pre_d[3] = {0, 0, 0}; typename std::remove_cv<typename std::remove_reference<decltype(R.a[0])>::type>::type pre_r[3] = {}, pre_u[3] = {}, pre_s = 0;
-#endif
+            // the six columns of the batch together: right-hand sides, one forward substitution of all six, then the messages
+            TG r3a[NC][3], ua[NC][3];
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
-                const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
                 TG r_[3], u_[3];
                 if constexpr (MODE == 0) {
                     const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
                     const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
-                    const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0;
-#if DJ_RHS_PREFETCH
-                    // raw right-hand-side values of the NEXT column are fetched from LDS before this column's products
-                    if (cI == 0) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { pre_d[i] = R.own_cfg[qh * 18 + i * 6]; pre_r[i] = R.a[ir + i * 6]; pre_u[i] = R.a[iu + i * 6]; }
-                        pre_s = R.a[sl_off];
-                    }
-                    double cur_d[3]; decltype(pre_r[0] + pre_r[0]) cur_r[3], cur_u[3], cur_s = pre_s;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { cur_d[i] = pre_d[i]; cur_r[i] = pre_r[i]; cur_u[i] = pre_u[i]; }
-                    if (cI + 1 < NC) {
-                        const bool uok1 = !isS && valid && q < 2 && (cu0 + cI + 1) >= 0 && (cu0 + cI + 1) < myu;
-                        const int ir1 = (isS || uok1) ? r_off + cI + 1 : 0, iu1 = (isS || uok1) ? u_off_ + cI + 1 : 0;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { pre_d[i] = R.own_cfg[qh * 18 + i * 6 + cI + 1]; pre_r[i] = R.a[ir1 + i * 6]; pre_u[i] = R.a[iu1 + i * 6]; }
-                        pre_s = R.a[sl_off + cI + 1];
-                    }
+                    const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0, ij = isS ? j_off + cI : 0;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        r_[i] = od ? TG(cur_d[i]) : rm * TG(cur_r[i]);
-                        u_[i] = um * TG(cur_u[i]);
-                    }
-                    r_[2] += wkm * TG(cur_s);
-#else
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]);
-                        r_[i] = od ? dv_ : rm * TG(R.a[ir + i * 6]);
+                        const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]), av_ = TG(R.a[ir + i * 6]), jv_ = TG(R.jd[ij + i * 6]);
+                        r_[i] = od ? dv_ : rm * (q < 2 ? av_ : jv_);
                         u_[i] = um * TG(R.a[iu + i * 6]);
                     }
-                    r_[2] += wkm * TG(R.a[sl_off + cI]);
-#endif
+                    r_[2] += wkm * TG(R.jd[sl_off + cI]);
                 } else {
                     const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { r_[i] = rm * TG(R.a[r_off + i * 6 + cI]); u_[i] = TG(0); }
                 }
-                TG r3[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) r3[i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0);
-                TG rf[12];
+                for (int i = 0; i < 3; ++i) { r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0); ua[cI][i] = u_[i]; }
+            }
+            lu_forward_quad<NC>(Lm, r3a);                         // ỹ = L11⁻¹ r
 #pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) rf[3 * o + i] = wv.quad_bcast(r3[i], o);
-                TG yy[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
-#pragma unroll
-                    for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * rf[m_];
-                    yy[i] = a_; }
+            for (int cI = 0; cI < NC; ++cI) {
+                const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
+                const TG (&yy)[3] = r3a[cI];
                 TG part[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) part[i] = Lg[i][0] * yy[0] + Lg[i][1] * yy[1] + Lg[i][2] * yy[2];
+                for (int i = 0; i < 6; ++i) part[i] = mq[i][0] * yy[0] + mq[i][1] * yy[1] + mq[i][2] * yy[2];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
                 if (valid) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? TG(u_[i]) - (q == 0 ? p0_ : p1_) : TG(0); }
-                    if (q < 2 && col_ok(b, cI)) {
+                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? ua[cI][i] - (q == 0 ? p0_ : p1_) : TG(0); }
+                    if (col_ok(b, cI)) {
                         if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
-                        TIO* o = cb + (size_t)cx * nx;
-                        if constexpr (!ypk) { o[3] = TIO(yy[0]); o[4] = TIO(yy[1]); o[5] = TIO(yy[2]); }
-                        // fp32 ABI: the parked y keeps its low half in the x3 / φ3 slots of the same column (free until the down-sweep writes
-                        // them): y − S⁻¹(U Δ_parent) cancels, and an fp32 y costs stiff environments their gradient (measured: 0.1 relative)
-                        if constexpr (kSplitY) { o[0] = TIO(yy[0] - TG(TIO(yy[0]))); o[1] = TIO(yy[1] - TG(TIO(yy[1]))); o[2] = TIO(yy[2] - TG(TIO(yy[2]))); }
+                        else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
                     }
                 }
             }
-            }
+        }
         }
 #ifdef DJ_PROF
         unsigned long long td0 = wv.clock();
 #endif
         // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
-        TG UmD[LUF ? 3 : 1][12], TD[LUF ? 3 : 1][6], diD[3];       // LU form: D⁻¹U11 − I, T = L11⁻¹U and the reciprocal pivots, for the down-sweep
-        if constexpr (LUF) load_lu_down(UmD, TD, diD);
-        const auto& Ug = [&]() -> const TG (&)[3][6] { if constexpr (LUF) return TD; else return F.Uq; }();
+        TG Um[3][12], Tq[3][6], di[3];                          // D⁻¹U11 − I, T = L11⁻¹U and the reciprocal pivots (load_lu_down)
+        load_lu_down(Um, Tq, di);
         TG d3[NC][3];
 #pragma unroll
         for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
-        // the parked y of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
+        // the parked ỹ of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
         // away and nothing else hides it with one wave per SIMD)
         T Mq[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Mq[i] = q == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
-        typedef typename std::conditional<kSplitY || ypk, TG, TIO>::type TY;
+        typedef typename std::conditional<ypk, TG, TIO>::type TY;
         TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
-            const bool v_ = active && (LUF || q < 2) && b_ >= 0 && b_ < NB;
-            TIO* const cbn = colbase(v_ ? b_ : 0) + (LUF ? prk_off - 3 : 0);
+            const bool v_ = active && b_ >= 0 && b_ < NB;
+            TIO* const cbn = colbase(v_ ? b_ : 0) + prk_off;
             const bool isS_ = b_ < nbs;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
                 const bool ok_ = v_ && col_ok(b_, n);
-                const TIO* o_ = cbn + (size_t)((isS_ && n >= 3) ? n + 3 : n) * nx;
                 if constexpr (ypk) {
                     const T* yi = yp0 + (size_t)(((v_ ? b_ : 0) * NC + n) * 3) * yW;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? TG(yi[i * yW]) : TG(0);
-                    continue;
-                }
+                } else {
+                    const TIO* o_ = cbn + (size_t)((isS_ && n >= 3) ? n + 3 : n) * nx;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { if constexpr (kSplitY) ynext[n][i] = ok_ ? TG(o_[3 + i]) + TG(o_[i]) : TG(0); else ynext[n][i] = ok_ ? o_[3 + i] : TIO(0); }
+                    for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? o_[i] : TIO(0);
+                }
             }
         };
         fetch_y(0 - lvl);
@@ -2145,54 +2053,27 @@ struct LaneProgram {
 #pragma unroll
                 for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { pall[n][i] = TG(p0[3 * n + i]); pall[n][3 + i] = TG(p1[3 * n + i]); }
             }
-            TG t3a[NC][3];
-            if constexpr (LUF) {                                    // x = U11⁻¹ (ỹ − T x_parent) of the six columns
-#pragma unroll
-                for (int n = 0; n < NC; ++n) {
-                    const bool ok_ = valid && col_ok(b, n);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { TG a_ = ok_ ? TG(ycur[n][i]) : TG(0);
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) a_ -= Ug[i][j] * pall[n][j];
-                        t3a[n][i] = a_; }
-                }
-                lu_backward_quad<NC>(UmD, diD, t3a);
-            }
+            // x = U11⁻¹ (ỹ − T x_parent) of the six columns (T = 0 on the roots: store_lu)
+            TG x3[NC][3];
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
-                const TG (&pa_)[6] = pall[n];
-                const bool o_ok = valid && q < 2 && col_ok(b, n);
-                TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
-                if constexpr (LUF) {
-                    if (valid) {
+                const bool ok_ = valid && col_ok(b, n);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) d3[n][i] = t3a[n][i];
-                    }
-                } else {
-                TG t3[3];
+                for (int i = 0; i < 3; ++i) { TG a_ = ok_ ? TG(ycur[n][i]) : TG(0);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
+                    for (int j = 0; j < 6; ++j) a_ -= Tq[i][j] * pall[n][j];
+                    x3[n][i] = a_; }
+            }
+            lu_backward_quad<NC>(Um, di, x3);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) a_ += Ug[i][j] * pa_[j];
-                    t3[i] = a_; }
-                TG tf[12];
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) tf[3 * o + i] = wv.quad_bcast(t3[i], o);
+            for (int n = 0; n < NC; ++n) {
                 if (valid) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        TG a_ = TG(0);
-#pragma unroll
-                        for (int m_ = 0; m_ < 12; ++m_) a_ += Sg[i][m_] * tf[m_];
-                        TG y = o_ok ? TG(ycur[n][i]) : TG(0);
-                        d3[n][i] = has_parent ? y - a_ : y;
-                    }
+                    for (int i = 0; i < 3; ++i) d3[n][i] = x3[n][i];
                 }
-                }
-                if (o_ok) {
+                if (valid && q < 2 && col_ok(b, n)) {
                     // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows)
+                    TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
                     T d_[3] = {T(d3[n][0]), T(d3[n][1]), T(d3[n][2])};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -2915,28 +2796,8 @@ struct LaneProgram {
         const T dt = G.dt;
         const int nx = 12 * G.Nb;
         DJ_PB();
-        // ---- quad mapping: LU-form factors of this workgroup's own, where the explicit inverses are ill-conditioned ----
-        // The indicator is the largest entry of the supernode inverses the Newton loop left behind: a multiplier block that
-        // repeats a stiff contact row shows up there as ~γ/s (factorize_quad_lu's comment).  The workgroup then linearizes once
-        // more at the restored solution -- the same final linearization -- and factors it as L U.
-        bool lu_wave = false;
-        if constexpr (QUAD && !PRECISE) {
-            if (G.ift_lu_w < T(1e300) && lu != nullptr) {          // (uniform)
-                T big = T(0);
-                if (G.ift_lu_w > T(0)) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 12; ++j) big = tmax(big, tabs(T(F.Sq[i][j])));
-                }
-                lu_wave = G.ift_lu_w <= T(0) || wv.any(active && !(big <= G.ift_lu_w));
-#ifdef DJ_DEBUG
-                if (std::getenv("DJ_DUMP_IND")) { T v1[1] = {big}; env_reduce_quad_all<1>(v1); if (active && k == 0 && q == 0) std::fprintf(stderr, "IND %d %.4e\n", env, (double)v1[0]); }
-#endif
-                if (lu_wave) lu_prepare();
-
-            }
-        }
+        // ---- quad mapping: the final linearization once more at the restored solution, factored in LU form (factorize_quad_lu) ----
+        if constexpr (QUAD && !PRECISE) lu_prepare();
         // ---- kinematics of the solution (chain) ----
         T own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6], va[3], wa[3];
         if (lane_slots) {
@@ -3099,7 +2960,7 @@ struct LaneProgram {
             QuadRhs<TB>& R = *(QuadRhs<TB>*)gb_lds;
             if (q == 0) {
 #pragma unroll
-                for (int cI = 0; cI < 6; ++cI) { R.a[QuadRhs<TB>::SLO + cI] = TB(lim ? sl_own[cI] : T(0)); R.a[QuadRhs<TB>::SLP + cI] = TB(lim ? sl_par[cI] : T(0)); }
+                for (int cI = 0; cI < 6; ++cI) { R.jd[QuadRhs<TB>::SLO + cI] = (double)(lim ? sl_own[cI] : T(0)); R.jd[QuadRhs<TB>::SLP + cI] = (double)(lim ? sl_par[cI] : T(0)); }
 #pragma unroll
                 for (int row = 0; row < 12; ++row) {
                     const int qh_ = (row / 3) & 1, i = row % 3, o_ = qh_ * 18 + i * 6;
@@ -3111,35 +2972,22 @@ struct LaneProgram {
 #pragma unroll
                             for (int cn = 0; cn < MAXC; ++cn) if (cn < ncon) for (int j = 0; j < 4; ++j) v += GK[cn][row][j] * Cc[cn][j][cI];
                             R.own_cfg[o_ + cI] = (double)v;
-#ifdef DJ_DEBUG
-                            if (std::getenv("DJ_DUMP_BLOCKS") && env == 0 && active && ncon > 0) { T fold = v - OwnB[row][cc]; std::fprintf(stderr, "RHS k %d row %d col %d own %.6e folded %.6e total %.17g\n", k, row, cI, (double)OwnB[row][cc], (double)fold, (double)v); }
-#endif
                             R.a[QuadRhs<TB>::ROWNV + o_ + cI] = TB(OwnB[row][cc + 3]);
                             R.a[QuadRhs<TB>::UOWN + o_ + cI] = TB(UpOwn[row][cI]);
                             R.a[QuadRhs<TB>::UPAR + o_ + cI] = TB(UpPar[row][cI]);
                             R.a[QuadRhs<TB>::UB + o_ + cI] = TB(UB[row][cI]);
                             R.a[QuadRhs<TB>::UA + o_ + cI] = TB(UA[row][cI]);
-                            R.a[QuadRhs<TB>::RPAR + (row / 3) * 18 + i * 6 + cI] = TB(ParB[row][cI]);
+                            R.a[QuadRhs<TB>::RPARB + o_ + cI] = TB(ParB[row][cI]);
                         } else {
-                            R.a[QuadRhs<TB>::ROWNJ + o_ + cI] = TB(OwnJ[row - 6][cI]);
-                            R.a[QuadRhs<TB>::RPAR + (row / 3) * 18 + i * 6 + cI] = TB(ParJ[row - 6][cI]);
+                            R.jd[QuadRhs<TB>::ROWNJ + o_ + cI] = (double)OwnJ[row - 6][cI];
+                            R.jd[QuadRhs<TB>::RPARJ + o_ + cI] = (double)ParJ[row - 6][cI];
                         }
                     }
                 }
             }
             wv.sync();
-#ifdef DJ_DEBUG
-            if (std::getenv("DJ_DUMP_BLOCKS") && env == 0 && active && q == 0) {
-                static char buf2_[64][16384]; char* b_ = buf2_[wv.lane() & 63]; int n_ = std::snprintf(b_, 16384, "QRHS %d %.17g", k, (double)wk);
-                for (int i = 0; i < QuadRhs<TB>::SIZE; ++i) n_ += std::snprintf(b_ + n_, 16384 - n_, " %.17g", (double)R.a[i]);
-                for (int i = 0; i < 36; ++i) n_ += std::snprintf(b_ + n_, 16384 - n_, " %.17g", (double)R.own_cfg[i]);
-                std::snprintf(b_ + n_, 16384 - n_, "\n"); std::fputs(b_, stderr);
-            }
-            wv.sync();
-#endif
             DJ_PE(5); DJ_PB();
-            if (lu_wave) gradient_columns_quad<0, true>(A, env, R, wk, kb0, sp);
-            else gradient_columns_quad(A, env, R, wk, kb0, sp);
+            gradient_columns_quad(A, env, R, wk, kb0, sp);
             DJ_PE(6);
             return;
         }
@@ -3252,10 +3100,9 @@ struct LaneProgram {
     DJ_HD void gradients_contact(const KA& A, int env) {
         static_assert(QUAD, "contact-data gradients are implemented for the quad mapping");
         const T dt = G.dt;
-        // LU-form sweeps (when they are in force for every workgroup): this kernel factors the linearization itself -- the state-column
-        // kernel's factors may belong to another launch, or its workgroup may have left the environment to the refining kernel
-        const bool lu_form = G.ift_lu_w <= T(0) && lu != nullptr;
-        if (lu_form) lu_prepare();
+        // this kernel factors the final linearization itself: the state-column kernel's staged factors may belong to another launch,
+        // or its workgroup may have left the environment to the refining kernel
+        lu_prepare();
         Kin<T> kb0;
         kin_of(kb0, L.x2, L.q2, L.v, L.w, dt);
         T x2e[3], q2e[4];
@@ -3336,8 +3183,7 @@ struct LaneProgram {
                     for (int j = 0; j < 6; ++j) R.a[c * 36 + (i / 3) * 18 + (i % 3) * 6 + j] = (double)rhs[c][i][j];
         }
         wv.sync();
-        if (lu_form) gradient_columns_quad<1, true>(A, env, R, T(0), kb0, sp);
-        else gradient_columns_quad<1>(A, env, R, T(0), kb0, sp);
+        gradient_columns_quad<1>(A, env, R, T(0), kb0, sp);
     }
 
     // update_state!  src/bodies/set.jl:22-36: -> (x3, v25, q3, ω25) = the next maximal state of this body
@@ -3540,8 +3386,7 @@ constexpr int FAC_PER_LANE = 72;
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
         if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * 112 * wv.width() + lane; prog.lu_stride = wv.width(); }                \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \
-        if (A.ypark) { prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + ((lane >> 2) * 2 + (q & 1));  \
-                       prog.ypark_lane = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + lane; }                 \
+        if (A.ypark) prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + lane;                                \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \
     DJ_TSD_SETUP                                                                                                          \
     T zb[13], ue[6] = {0, 0, 0, 0, 0, 0};                                                                                 \

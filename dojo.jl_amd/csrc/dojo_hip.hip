@@ -87,7 +87,6 @@ struct DojoSim {
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping; explicit-inverse consumers only)
     void* d_lu = nullptr;               // the IFT kernel's LU-form factors between its phases (quad mapping)
-    double ift_lu_w = 0.0;              // threshold of the LU-form IFT sweeps (Globals::ift_lu_w): 0 = every workgroup (default), INFINITY = none
     void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
     void* d_ypark = nullptr;            // fp32 ABI, quad mapping: the IFT's forward-substituted right-hand sides between its two sweeps, in fp64
     int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
@@ -435,8 +434,6 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     dj::KernelArgs<TIO, T> A;
     const double rw_ = refine_threshold(s);
     A.G = dj::make_globals<T>(s->M, s->opts, s->grad_mode, rw_);
-    A.G.ift_lu_w = T(s->ift_lu_w);
-    { static const char* lw_ = std::getenv("DOJO_IFT_LU_W"); if (lw_) A.G.ift_lu_w = T(std::atof(lw_)); }   // experiments: threshold of the LU-form IFT sweeps
     A.nodes = (const dj::NodeP<T>*)s->d_nodes; A.contacts = (const dj::ContactP<T>*)s->d_contacts; A.B = nenv;
     A.z = off(z, 13 * Nb); A.u = off(u, nu); A.z_next = off(zn, 13 * Nb); A.fext = off(s->fext, 6 * Nb);
     A.status = status ? status + env0 : nullptr; A.iters = iters ? iters + env0 : nullptr;
@@ -467,13 +464,13 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
         if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * 112 * 64 * NW * sizeof(T)));
     }
-    // the explicit inverses travel only when somebody reads them: the refining IFT kernel, or explicit-inverse sweeps (ift_lu_w > 0)
-    const bool want_fac = A.G.refine_w < INFINITY || A.G.ift_lu_w > T(0);
+    // the explicit inverses of the Newton loop travel only when somebody reads them: the refining IFT kernel
+    const bool want_fac = A.G.refine_w < INFINITY;
     A.fac = (g && quad && want_fac) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
     A.lu = (g && quad) ? (T*)s->d_lu + wave0 * 112 * 64 * NW : nullptr;
     A.ypark = nullptr; A.ypark_stride = 0;
-    if (g && quad && sizeof(TIO) < sizeof(T) && dc == nullptr) {          // (DJ_YPARK: dojo_device.hpp, gradient_columns_quad)
-        const size_t batches = 2 * Nb + (nu + 5) / 6;
+    if (g && quad && sizeof(TIO) < sizeof(T)) {          // (dojo_device.hpp, gradient_columns_quad)
+        const size_t batches = std::max<size_t>(2 * Nb + (nu + 5) / 6, (size_t)s->M.Nc);     // state + control batches | contact batches (dojo_cgrad_kernel)
         A.ypark_stride = (long long)(batches * 18 * (64 * NW));      // all four roles park (LU-form sweeps)
         if (!s->d_ypark) HIPCHK(hipMalloc(&s->d_ypark, waves_total * (size_t)A.ypark_stride * sizeof(T)));
         A.ypark = (T*)s->d_ypark + wave0 * (size_t)A.ypark_stride;

@@ -147,7 +147,6 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
 template <class T> inline Globals<T> make_globals(const HostModel& M, const DojoSolverOptions& o, int grad_mode, double refine_w = INFINITY) {
     Globals<T> G;
     G.refine_w = T(refine_w);
-    G.ift_lu_w = T(0);             // LU-form IFT sweeps in every workgroup (the library / the emulator may override)
     G.dt = T(M.dt); G.idt2 = T(1.0 / (M.dt * M.dt)); G.input_scaling = T(M.input_scaling);
     for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
     G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);

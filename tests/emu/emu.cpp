@@ -102,7 +102,6 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
         ct(csg ? (size_t)B * (2 * dj::NCV) * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
     dj::KernelArgs<TIO, T> A;
     { const char* rw = std::getenv("EMU_REFINE_W"); A.G = dj::make_globals<T>(M, opts, grad_mode, rw ? std::atof(rw) : INFINITY); }
-    { const char* lw = std::getenv("EMU_IFT_LU_W"); if (lw) A.G.ift_lu_w = T(std::atof(lw)); }
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
     std::vector<dj::TraSD<T>> tsd;
     for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi); b.nlim = a.nlim; tsd.push_back(b); }
@@ -120,7 +119,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * 112 * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
     std::vector<T> yparkbuf; A.ypark = nullptr;
-    if (dz && QUAD && sizeof(TIO) < sizeof(T)) { A.ypark_stride = (long long)((2 * M.Nb + (M.nu + 5) / 6) * 18 * W); yparkbuf.resize((size_t)nwaves * A.ypark_stride); A.ypark = yparkbuf.data(); }
+    if (dz && QUAD && sizeof(TIO) < sizeof(T)) { A.ypark_stride = (long long)(std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 18 * W); yparkbuf.resize((size_t)nwaves * A.ypark_stride); A.ypark = yparkbuf.data(); }
     // the same two launches as the product: step kernel, then (when gradients are wanted) the IFT kernel
     // the product's launches: step kernel, refining step kernel (quad mapping; re-solves what the first deferred), IFT kernel,
     // refining IFT kernel

@@ -26,4 +26,12 @@ def test_headline_kernels_keep_their_register_footprint():
     assert scratch <= 256 and spills <= 45, ("step kernel: scratch %d B/lane, %d spilled VGPRs (was 256 / 39)" % (scratch, spills))
     assert lds <= 40960, lds                                  # four workgroups (one wave per SIMD) per CU
     scratch, spills, lds = res["dojo_grad_kernel"]
-    assert scratch <= 1200 and lds <= 40960, (scratch, lds)   # (its spills sit in the once-per-step prologue, not in the sweeps)
+    assert scratch <= 1500 and lds <= 40960, (scratch, lds)   # (its spills sit in the once-per-step prologue -- linearization, LU-form factorization, data blocks)
+    # ... and not in the pipelined sweeps: with one wave per SIMD nothing hides a scratch round trip (30 of them per pipeline step ran
+    # the sweeps at half speed).  tools/isa_loops.py lists the loops of the kernel with their instruction mix.
+    import ast
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_loops.py"), OBJ, "dojo_grad_kernel", "900"], capture_output=True, text=True, timeout=300).stdout
+    sweeps = [ast.literal_eval(ln[ln.index("{"):]) for ln in out.splitlines() if ln.startswith("loop")]
+    sweeps = [m for m in sweeps if 1000 <= m["n"] <= 2000 and m["dpp"] >= 100 and m["glob"] >= 10]          # the up- and the down-sweep step
+    assert len(sweeps) >= 2 and all(m["scratch"] == 0 for m in sweeps), sweeps
