@@ -92,6 +92,8 @@ def main():
     # environment that runs into max_iter = 50 (5x the mean iteration count, one wavefront) finishes in one group, the other
     # groups' kernels fill the GPU.  Asynchronous mode: consecutive steps chain per group, one dojo_join at the end.
     lib = api.lib()
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import build_info
     gm = api.BatchedMechanism(spec, B, dtype=args.io_dtype, device=local)
     if args.refine is not None:
         gm.set_refinement(args.refine)
@@ -163,6 +165,15 @@ def main():
         box = [None] * world
         dist.all_gather_object(box, "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(local)))
         rank_devices = box
+    # the same closed loop with a join of the environment groups into the caller's stream after EVERY step (what a policy over the
+    # whole batch needs: a barrier per step; the max_iter tail of a step is then not hidden behind the next step), outside the timed region
+    gm.set_async(False)
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(W, W + K):
+        one_step(k)
+    barrier()
+    el_sync = D.max_over_ranks(time.perf_counter() - t1, world, device=dev if args.backend == "nccl" else "cpu")
     ok_frac = float((status == 0).float().mean().item())
     mean_iters = float(iters.float().mean().item())
 
@@ -230,7 +241,10 @@ def main():
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
                        "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout)" % (world, NCH),
-                       "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters},
+                       "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters,
+                       "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,
+                       "sync_per_step_note": "the same %d steps with the environment groups joined into the caller's stream after every step (a barrier per step); `value` is the asynchronous rollout (one join at the end)" % K,
+                       "build": build_info()},
             "roofline": dominant,
         }
         if other is not None:
@@ -352,6 +366,20 @@ def measured_valu_utilization():
     return out
 
 
+def cpu_quota():
+    """CPU-time quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
     """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on the host's PHYSICAL cores: one
     persistent thread pinned to each core, every thread owns a copy of the mechanism (its workspaces and symbolic factorization
@@ -366,7 +394,9 @@ def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
     import dojo_amd as d
     import oracle as orc
     from oracle import Oracle
-    cores = orc.physical_cores() or (os.cpu_count() or 1)
+    physical = orc.physical_cores() or (os.cpu_count() or 1)
+    quota = cpu_quota()
+    cores = max(1, min(physical, int(quota))) if quota else physical      # a container's CPU-time quota (cgroup) caps what threads can use: more threads only get throttled
     o = Oracle(spec)
     o.set_refine_steps(0)
     per_thread = 128
@@ -394,8 +424,8 @@ def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
             "single_thread": out["sparse"]["single_thread"], "parallel_efficiency": out["sparse"]["parallel_efficiency"],
             "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],
             "dense": out["dense"]["value"], "dense_single_thread": out["dense"]["single_thread"], "dense_parallel_efficiency": out["dense"]["parallel_efficiency"],
-            "logical_cpus": os.cpu_count(), "sparse_lu_flops": la,
-            "sample": "%d Ant env-steps (fwd%s) per variant: %d synthetic environments per thread, one pinned thread on each of the %d physical cores (after one untimed "
+            "logical_cpus": os.cpu_count(), "physical_cores_of_the_host": physical, "cgroup_cpu_quota": quota, "sparse_lu_flops": la,
+            "sample": "%d Ant env-steps (fwd%s) per variant: %d synthetic environments per thread, one pinned thread per core on %d physical cores (= the container's CPU quota where there is one; after one untimed "
                       "step per thread); C++ oracle, fp64; value = block-sparse no-pivot LU in the mechanism graph's elimination order, dense = 206x206 partial-pivot LU"
                       % (nsample, "+grad" if grad else "", per_thread, cores)}
 
