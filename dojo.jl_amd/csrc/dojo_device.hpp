@@ -998,7 +998,8 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
 }
 
 // the NodeP fields the IFT column sweeps need, cached in registers (the sweeps' right-hand sides overlay NodeP in LDS)
-struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH], ncontact, contact[8]; };
+struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH], ncontact, contact[8];
+                unsigned long long sub_mask, ub_mask; };   // bodies in this supernode's subtree (itself included) | control / contact batches owned inside it
 
 // ================================================================================================
 // The lane program
@@ -1887,6 +1888,9 @@ struct LaneProgram {
         };
         // does column cI of batch b exist?  (padding columns of the last control batch / the sixth column of a contact batch)
         auto col_ok = [=](int b, int cI) -> bool { return b < nbs || (MODE == 0 ? NC * (b - nbs) + cI < ncol_u : cI < 5); };
+        // is this supernode's ỹ of batch b non-zero (sweep_masks)?  (b must be a valid batch index)
+        const unsigned long long sub_mask = sp.sub_mask, ub_mask = sp.ub_mask; const int par_k = has_parent ? sp.parent : -1;
+        auto y_nz = [=](int b) -> bool { return b < nbs ? (((sub_mask >> (b >> 1)) & 1ull) != 0 || ((b & 1) == 0 && par_k == (b >> 1))) : ((ub_mask >> (b - nbs)) & 1ull) != 0; };
         // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
         {
         TG Lm[3][12], mq[6][3];                                // L11 − I and the parent rows' multipliers m (load_lu_up)
@@ -1988,7 +1992,7 @@ struct LaneProgram {
                 if (valid) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? ua[cI][i] - (q == 0 ? p0_ : p1_) : TG(0); }
-                    if (col_ok(b, cI)) {
+                    if (col_ok(b, cI) && y_nz(b)) {
                         if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
                         else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
                     }
@@ -2013,7 +2017,7 @@ struct LaneProgram {
         typedef typename std::conditional<ypk, TG, TIO>::type TY;
         TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
-            const bool v_ = active && b_ >= 0 && b_ < NB;
+            const bool v_ = active && b_ >= 0 && b_ < NB && y_nz(b_ >= 0 ? b_ : 0);
             TIO* const cbn = colbase(v_ ? b_ : 0) + prk_off;
             const bool isS_ = b_ < nbs;
 #pragma unroll
@@ -2752,6 +2756,25 @@ struct LaneProgram {
         return status;
     }
 
+    // Which batches of the column sweeps reach this supernode with a non-zero right-hand side: the forward-substituted ỹ of a batch is
+    // non-zero only on the supernodes that carry a right-hand side (the owner body of the columns; for configuration columns its children
+    // too) and on their ancestors.  Everywhere else it is exactly zero and is neither parked nor fetched (more than half of the park's
+    // traffic for a tree like the Ant's).  MODE 0: second-kind batches = control batches (six input columns each); 1: contacts.
+    template <int MODE, class KA>
+    DJ_HD void sweep_masks(const KA& A, SweepP& sp) const {
+        unsigned long long sub = 0, ub = 0;
+        for (int j = 0; j < G.Nb; ++j) {
+            int a = j, guard = 0; bool in = false;
+            while (a >= 0 && guard++ < 64) { if (a == k) { in = true; break; } a = A.nodes[a].parent; }
+            if (!in) continue;
+            sub |= 1ull << j;
+            const NodeP<T>& Pj = A.nodes[j];
+            if (MODE == 0) { const int n = Pj.nu_t + Pj.nu_r; for (int c = 0; c < n; ++c) ub |= 1ull << ((Pj.u_off + c) / 6); }
+            else for (int c = 0; c < Pj.ncontact; ++c) ub |= 1ull << Pj.contact[c];
+        }
+        sp.sub_mask = active ? sub : 0ull; sp.ub_mask = active ? ub : 0ull;
+    }
+
     // the final linearization once more at the restored solution, factored in LU form and staged (quad mapping, IFT kernels)
     DJ_HD void lu_prepare() {
         if constexpr (QUAD) {
@@ -2954,6 +2977,7 @@ struct LaneProgram {
             for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
 #pragma unroll
             for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
+            sweep_masks<0>(A, sp);
             const bool lim = lim_on();
             const int ncon = P.ncontact;
             wv.sync();
@@ -3172,6 +3196,7 @@ struct LaneProgram {
         for (int c_ = 0; c_ < 8; ++c_) sp.contact[c_] = P.contact[c_];
 #pragma unroll
         for (int ci = 0; ci < MAXCH; ++ci) sp.child_lane0[ci] = base + stride * P.child[ci];
+        sweep_masks<1>(A, sp);
         wv.sync();
         ConRhs<MAXC>& R = *(ConRhs<MAXC>*)gb_lds;
         if (q == 0) {
