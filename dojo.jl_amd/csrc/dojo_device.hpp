@@ -1121,8 +1121,46 @@ struct LaneProgram {
 #define DJ_PB() ((void)0)
 #define DJ_PE(i) ((void)0)
 #endif
+    // Bodies with four or more contacts (Block, Atlas' feet; MAXC >= 4 builds of the quad mapping): the contacts are split over the four
+    // lanes of the quad -- lane q handles contacts q, q + 4, ... -- instead of every lane doing all of them.  What a contact contributes
+    // to the whole supernode (impulse on the body, its curvature term, the condensed right-hand side, its share of the centering sums) is
+    // added up inside the quad with two DPP steps; maxima / minima over contacts fold the same way; the per-contact cone variables
+    // live once per supernode in LDS (Lane::cs, cg), every lane updating its own contacts' entries.  With one contact per body nothing
+    // changes (the lane-local arrays have MAXC entries, cidx(i) = i).
+    static constexpr bool kSplitC = QUAD && MAXC >= 4;
+    static constexpr int CPL = kSplitC ? MAXC / 4 : MAXC;      // contact slots per lane
+    typedef Step<T, CPL> StepT;
+    typedef SolSnap<T, CPL> SnapT;
+    DJ_HD int cidx(int li) const { return kSplitC ? q + 4 * li : li; }      // contact (slot of the supernode) behind this lane's local slot li
+    template <int N> DJ_HD void quad_sum(T (&v)[N]) {
+        if constexpr (kSplitC) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) v[n] += T(wv.quad_xor(v[n], 1));
+#pragma unroll
+            for (int n = 0; n < N; ++n) v[n] += T(wv.quad_xor(v[n], 2));
+        }
+    }
+    DJ_HD T quad_maxv(T v) { if constexpr (kSplitC) { v = tmax(v, T(wv.quad_xor(v, 1))); v = tmax(v, T(wv.quad_xor(v, 2))); } return v; }
+    DJ_HD T quad_minv(T v) { if constexpr (kSplitC) { v = tmin(v, T(wv.quad_xor(v, 1))); v = tmin(v, T(wv.quad_xor(v, 2))); } return v; }
+    // SIMT emulator (its lanes are threads with private copies of what the GPU keeps once per supernode in LDS): after a lane has
+    // changed its own contacts' entries the other three lanes of the quad get them
+    DJ_HD void share_cone_state() {
+        if constexpr (kSplitC && !Wave::kLockstep) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+                for (int i = 0; i < NCV; ++i) { L.cs[c][i] = T(wv.quad_bcast(L.cs[c][i], c & 3)); L.cg[c][i] = T(wv.quad_bcast(L.cg[c][i], c & 3)); }
+        }
+    }
+    DJ_HD void share_contact_rows() {
+        if constexpr (kSplitC && !Wave::kLockstep) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) { ContactCold<T>& cc_ = ccold(c);
+                for (int i = 0; i < 18; ++i) { cc_.C134[i] = T(wv.quad_bcast(cc_.C134[i], c & 3)); cc_.G134[i] = T(wv.quad_bcast(cc_.G134[i], c & 3)); } }
+        }
+    }
     // residual pieces of the last evaluation
-    T rb[6], rj[6], theta, cres[MAXC][NCV];
+    T rb[6], rj[6], theta, cres[CPL][NCV];
     // Iterative refinement of the linear solves (DJ_REFINE, quad mapping).  `refine` is a per-environment flag (sticky once the
     // cones are stiff); the un-factored, contact-UNcondensed supernode rows of the last linearization live in global memory
     // (KernelArgs::blk, [workgroup][BLK_PER_LANE][lanes]: lane index fastest), written only while some environment of the
@@ -1195,23 +1233,40 @@ struct LaneProgram {
         // allocation is 1 % faster that way, same session).  joint_eval has zeroed / filled K by now.
         constexpr bool kEarly = MAXC > 1;
         ContactEval<T> CE[kEarly ? 1 : MAXC];
+        T dcon[6] = {0, 0, 0, 0, 0, 0}, dww[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // (split contacts: this lane's share of the contact impulses / curvature terms)
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int li = 0; li < CPL; ++li) {
+            const int c = cidx(li);
             if (c < P.ncontact) {
-                ContactEval<T>& CEc = CE[kEarly ? 0 : c];
+                ContactEval<T>& CEc = CE[kEarly ? 0 : li];
                 contact_eval<JAC>(CEc, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
-                for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i];
-                for (int i = 0; i < NCV; ++i) cres[c][i] = CEc.c[i];
-                if (!kLinear && G.contact_model == 1) cres[c][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
+                if constexpr (kSplitC) { for (int i = 0; i < 6; ++i) dcon[i] += CEc.imp[i]; } else { for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i]; }
+                for (int i = 0; i < NCV; ++i) cres[li][i] = CEc.c[i];
+                if (!kLinear && G.contact_model == 1) cres[li][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
                 if (JAC && kEarly) {
+                    if constexpr (kSplitC) { for (int i = 0; i < 9; ++i) dww[i] += CEc.Dww[i]; }
+                    else {
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CEc.Dww[3 * i + j]);
+                    }
                     ContactCold<T>& cc_ = ccold(c);
                     for (int i = 0; i < 18; ++i) { cc_.C134[i] = CEc.C134[i]; cc_.G134[i] = CEc.G134[i]; }
                 }
-            } else { for (int i = 0; i < NCV; ++i) cres[c][i] = T(0); }
+            } else { for (int i = 0; i < NCV; ++i) cres[li][i] = T(0); }
+        }
+        if constexpr (kSplitC) {
+            quad_sum(dcon);
+            for (int i = 0; i < 6; ++i) d[i] -= dcon[i];
+            if (JAC) {
+                quad_sum(dww);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -dww[3 * i + j]);
+                share_contact_rows();
+            }
         }
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
@@ -1270,8 +1325,9 @@ struct LaneProgram {
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rb[i]));
             for (int i = 0; i < 6; ++i) r = tmax(r, tabs(rj[i]));          // only the Nλ equality rows (padded slots are 0)
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                for (int i = 0; i < NCV; ++i) r = tmax(r, tabs(cres[c][i]));
+            for (int li = 0; li < CPL; ++li) if (cidx(li) < P.ncontact) {
+                const int c = cidx(li);
+                for (int i = 0; i < NCV; ++i) r = tmax(r, tabs(cres[li][i]));
                 const T* g = L.cg[c]; const T* s = L.cs[c];
                 b = tmax(b, tabs(g[0] * s[0]));
                 if constexpr (kLinear) { for (int i = 1; i < NCV; ++i) b = tmax(b, tabs(g[i] * s[i])); }      // complementarity.jl:16 (γ .* s)
@@ -1290,6 +1346,7 @@ struct LaneProgram {
                 if (kTrack && track_stiffness) { wq = tmax(wq, (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG))); wq = tmax(wq, (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG))); }
             }
         }
+        if constexpr (kSplitC) { r = quad_maxv(r); b = quad_maxv(b); if constexpr (kTrack) wq = quad_maxv(wq); }      // (the lanes of a quad looked at different contacts)
         if constexpr (QUAD && DJ_LDS_REDUCE) {
             if constexpr (kTrack) { T v3[3] = {r, b, wq}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v3[0]; bvio = v3[1]; wstiff = v3[2]; }
             else { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
@@ -1300,17 +1357,18 @@ struct LaneProgram {
     // ---------------------------------------------------------------- condensation of cone rows
     // comp-row right-hand sides (r1..r4 per contact, r_cu, r_cl for the limit) -> condensed rhs
     // additions for the parent (ra) and own (rbody) body rows; coefficients for the recovery.
-    struct ConeRhs { T cc[MAXC][NCV]; T lim[2]; };
+    struct ConeRhs { T cc[CPL][NCV]; T lim[2]; };      // (cc: this lane's contact slots)
 
     DJ_HD void cone_rhs_from_state(ConeRhs& R, T mu_asm) const {
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int li = 0; li < CPL; ++li) {
+            const int c = kSplitC ? (cidx(li) < MAXC ? cidx(li) : 0) : li;
             const T* g = L.cg[c]; const T* s = L.cs[c];
-            if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) R.cc[c][i] = -(g[i] * s[i] - mu_asm); continue; }   // complementarityμ: − μ·ones(6)
-            R.cc[c][0] = -(g[0] * s[0] - mu_asm);
-            R.cc[c][1] = -(g[1] * s[1] + g[2] * s[2] + g[3] * s[3] - mu_asm);
-            R.cc[c][2] = -(g[1] * s[2] + s[1] * g[2]);
-            R.cc[c][3] = -(g[1] * s[3] + s[1] * g[3]);
+            if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) R.cc[li][i] = -(g[i] * s[i] - mu_asm); continue; }   // complementarityμ: − μ·ones(6)
+            R.cc[li][0] = -(g[0] * s[0] - mu_asm);
+            R.cc[li][1] = -(g[1] * s[1] + g[2] * s[2] + g[3] * s[3] - mu_asm);
+            R.cc[li][2] = -(g[1] * s[2] + s[1] * g[2]);
+            R.cc[li][3] = -(g[1] * s[3] + s[1] * g[3]);
         }
         R.lim[0] = -(L.ls[0] * L.lg[0] - mu_asm);
         R.lim[1] = -(L.ls[1] * L.lg[1] - mu_asm);
@@ -2182,18 +2240,22 @@ struct LaneProgram {
     // Generic right-hand side: rk0 = rhs of the body (6) and joint-equality (6) rows, R = rhs of the
     // cone (complementarity) rows, rs = rhs of the two limit slack rows, r58 = rhs of the contact
     // constraint rows, upx = direct rhs contribution to the parent's body rows.
-    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, Step<T, MAXC>& D, T* dva_out = nullptr) {
+    DJ_HD void solve_rhs(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, StepT& D, T* dva_out = nullptr) {
         T rk[12], up[6];
         for (int i = 0; i < 12; ++i) rk[i] = rk0[i];
         for (int i = 0; i < 6; ++i) up[i] = upx[i];
-        CCoef Q[MAXC];
+        CCoef Q[CPL];
+        T rkc[6] = {0, 0, 0, 0, 0, 0};                            // (split contacts: this lane's share of the condensed right-hand side)
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int li = 0; li < CPL; ++li) {
+            const int c = cidx(li);
             if (c < P.ncontact) {
-                contact_coef(Q[c], c, R.cc[c], r58[c]);
-                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += ccold(c).G134[6 * a + i] * Q[c].k0[a];
+                contact_coef(Q[li], c, R.cc[li], r58[li]);
+                if constexpr (kSplitC) { for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rkc[i] += ccold(c).G134[6 * a + i] * Q[li].k0[a]; }
+                else { for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += ccold(c).G134[6 * a + i] * Q[li].k0[a]; }
             }
         }
+        if constexpr (kSplitC) { quad_sum(rkc); for (int i = 0; i < 6; ++i) rk[i] += rkc[i]; }
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0), isu = T(0), isl = T(0);
         if (lim_on()) {
             su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
@@ -2219,12 +2281,13 @@ struct LaneProgram {
             D.dlg[1] = (R.lim[1] - gl * D.dls[1]) * isl;
         } else { D.dls[0] = D.dls[1] = D.dlg[0] = D.dlg[1] = T(0); }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int li = 0; li < CPL; ++li) {
+            const int c = cidx(li);
             if (c < P.ncontact) {
                 const ContactP<T>& K = CP[P.contact[c]];
                 T cw[3];
                 for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += ccold(c).C134[6 * a + j] * D.dv[j] + ccold(c).C134[6 * a + 3 + j] * D.dw[j]; }
-                const CCoef& q = Q[c];
+                const CCoef& q = Q[li];
                 if constexpr (kLinear) {                               // recovery of the twelve LinearContact variables (see contact_coef)
                     const T n_ = cw[0], t1_ = cw[1], t2_ = cw[2];
                     const T dgam = q.a1 + q.b1 * n_, dpsi = q.kpsi + q.pn * n_ + q.p1 * t1_ + q.p2 * t2_;
@@ -2233,24 +2296,24 @@ struct LaneProgram {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const T db = q.le[i] - q.lw[i] * (ct[i] + dpsi);
-                        D.dcg[c][2 + i] = db; D.dcs[c][2 + i] = ct[i] + dpsi - r58[c][2 + i]; sb += db;
+                        D.dcg[li][2 + i] = db; D.dcs[li][2 + i] = ct[i] + dpsi - r58[li][2 + i]; sb += db;
                     }
-                    D.dcg[c][0] = dgam; D.dcs[c][0] = n_ - r58[c][0];
-                    D.dcg[c][1] = dpsi; D.dcs[c][1] = K.mu * dgam - sb - r58[c][1];
+                    D.dcg[li][0] = dgam; D.dcs[li][0] = n_ - r58[li][0];
+                    D.dcg[li][1] = dpsi; D.dcs[li][1] = K.mu * dgam - sb - r58[li][1];
                     continue;
                 }
-                T ds1 = cw[0] - r58[c][0], ds3 = cw[1] - r58[c][2], ds4 = cw[2] - r58[c][3];
+                T ds1 = cw[0] - r58[li][0], ds3 = cw[1] - r58[li][2], ds4 = cw[2] - r58[li][3];
                 T dg1 = q.a1 + q.b1 * cw[0];
-                T dg2 = K.mu * dg1 - r58[c][1];
+                T dg2 = K.mu * dg1 - r58[li][1];
                 T ih = trcp(q.h0);
-                T r2p = R.cc[c][1] - (q.h1 * R.cc[c][2] + q.h2 * R.cc[c][3]) * ih;
+                T r2p = R.cc[li][1] - (q.h1 * R.cc[li][2] + q.h2 * R.cc[li][3]) * ih;
                 T ds2 = (r2p - q.al3 * ds3 - q.al4 * ds4 - q.al2 * dg2) * trcp(q.den);
-                T dg3 = (R.cc[c][2] - q.g1 * ds2 - q.g0 * ds3 - q.h1 * dg2) * ih;
-                T dg4 = (R.cc[c][3] - q.g2 * ds2 - q.g0 * ds4 - q.h2 * dg2) * ih;
+                T dg3 = (R.cc[li][2] - q.g1 * ds2 - q.g0 * ds3 - q.h1 * dg2) * ih;
+                T dg4 = (R.cc[li][3] - q.g2 * ds2 - q.g0 * ds4 - q.h2 * dg2) * ih;
                 const T fz = G.contact_model == 1 ? T(0) : T(1);      // ImpactContact: the friction block stays at the neutral vector
-                D.dcs[c][0] = ds1; D.dcs[c][1] = fz * ds2; D.dcs[c][2] = fz * ds3; D.dcs[c][3] = fz * ds4;
-                D.dcg[c][0] = dg1; D.dcg[c][1] = fz * dg2; D.dcg[c][2] = fz * dg3; D.dcg[c][3] = fz * dg4;
-            } else { for (int i = 0; i < NCV; ++i) D.dcs[c][i] = D.dcg[c][i] = T(0); }
+                D.dcs[li][0] = ds1; D.dcs[li][1] = fz * ds2; D.dcs[li][2] = fz * ds3; D.dcs[li][3] = fz * ds4;
+                D.dcg[li][0] = dg1; D.dcg[li][1] = fz * dg2; D.dcg[li][2] = fz * dg3; D.dcg[li][3] = fz * dg4;
+            } else { for (int i = 0; i < NCV; ++i) D.dcs[li][i] = D.dcg[li][i] = T(0); }
         }
     }
 
@@ -2290,11 +2353,11 @@ struct LaneProgram {
     }
 
     // Newton right-hand side: −residual with the given cone-row right-hand sides
-    DJ_HD void solve(const ConeRhs& R, Step<T, MAXC>& D) {
-        T rk[12], rs[2] = {0, 0}, r58[MAXC][NCV], upx[6] = {0, 0, 0, 0, 0, 0};
+    DJ_HD void solve(const ConeRhs& R, StepT& D) {
+        T rk[12], rs[2] = {0, 0}, r58[CPL][NCV], upx[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) { rk[i] = -rb[i]; rk[6 + i] = -rj[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) r58[c][i] = -cres[c][i];
+        for (int c = 0; c < CPL; ++c) for (int i = 0; i < NCV; ++i) r58[c][i] = -cres[c][i];
         if (lim_on()) {
             rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
             rs[1] = -(L.ls[1] - (theta - lim_lo()));
@@ -2331,7 +2394,7 @@ struct LaneProgram {
             for (int j = 0; j < 6; ++j) { o[(size_t)(36 + 6 * i + j) * W] = T(K.U[i][j]); o[(size_t)(54 + 6 * i + j) * W] = T(K.L[j][i]); o[(size_t)(72 + 6 * i + j) * W] = T(K.D[i][j]); }
         }
     }
-    DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, Step<T, MAXC>& D, T* dva) {
+    DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, StepT& D, T* dva) {
         const T* bl = blk;
         const size_t W = (size_t)blk_stride;
         T xk[12];
@@ -2372,21 +2435,25 @@ struct LaneProgram {
         mail_post_node<6>(msg); mail_add_children_node<6>(acc, active, G.maxch);
         // contacts: −G Δγ₁₃₄ on the body rows; cone rows
         ConeRhs R2;
+        T accc[6] = {0, 0, 0, 0, 0, 0};                           // (this lane's contacts' share)
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int li = 0; li < CPL; ++li) {
+            const int c = cidx(li);
             if (c < P.ncontact) {
-                const T* gam = L.cg[c]; const T* s = L.cs[c]; const T* ds = D.dcs[c]; const T* dg = D.dcg[c];
+                const T* gam = L.cg[c]; const T* s = L.cs[c]; const T* ds = D.dcs[li]; const T* dg = D.dcg[li];
                 const ContactCold<T>& cc_ = ccold(c);
-                for (int i = 0; i < 6; ++i) acc[i] += cc_.G134[i] * dg[0] + cc_.G134[6 + i] * dg[2] + cc_.G134[12 + i] * dg[3];
+                for (int i = 0; i < 6; ++i) accc[i] += cc_.G134[i] * dg[0] + cc_.G134[6 + i] * dg[2] + cc_.G134[12 + i] * dg[3];
                 const T g1t = gam[0] + T(REG), s1t = s[0] + T(REG), g0 = gam[1] + T(REG), h0 = s[1] + T(REG);
-                R2.cc[c][0] = R.cc[c][0] - (g1t * ds[0] + s1t * dg[0]);
+                R2.cc[li][0] = R.cc[li][0] - (g1t * ds[0] + s1t * dg[0]);
                 if (G.contact_model == 0) {
-                    R2.cc[c][1] = R.cc[c][1] - (g0 * ds[1] + gam[2] * ds[2] + gam[3] * ds[3] + h0 * dg[1] + s[2] * dg[2] + s[3] * dg[3]);
-                    R2.cc[c][2] = R.cc[c][2] - (gam[2] * ds[1] + g0 * ds[2] + s[2] * dg[1] + h0 * dg[2]);
-                    R2.cc[c][3] = R.cc[c][3] - (gam[3] * ds[1] + g0 * ds[3] + s[3] * dg[1] + h0 * dg[3]);
-                } else { R2.cc[c][1] = R2.cc[c][2] = R2.cc[c][3] = T(0); }
-            } else { for (int i = 0; i < 4; ++i) R2.cc[c][i] = T(0); }
+                    R2.cc[li][1] = R.cc[li][1] - (g0 * ds[1] + gam[2] * ds[2] + gam[3] * ds[3] + h0 * dg[1] + s[2] * dg[2] + s[3] * dg[3]);
+                    R2.cc[li][2] = R.cc[li][2] - (gam[2] * ds[1] + g0 * ds[2] + s[2] * dg[1] + h0 * dg[2]);
+                    R2.cc[li][3] = R.cc[li][3] - (gam[3] * ds[1] + g0 * ds[3] + s[3] * dg[1] + h0 * dg[3]);
+                } else { R2.cc[li][1] = R2.cc[li][2] = R2.cc[li][3] = T(0); }
+            } else { for (int i = 0; i < 4; ++i) R2.cc[li][i] = T(0); }
         }
+        quad_sum(accc);
+        for (int i = 0; i < 6; ++i) acc[i] += accc[i];
         R2.lim[0] = R2.lim[1] = T(0);
         if (lim_on()) {
             R2.lim[0] = R.lim[0] - ((L.lg[0] + T(REG)) * D.dls[0] + (L.ls[0] + T(REG)) * D.dlg[0]);
@@ -2400,11 +2467,11 @@ struct LaneProgram {
             rk2[i] = q == 0 ? b0_ : T(0); rk2[3 + i] = q == 1 ? b1_ : T(0); rk2[6 + i] = q == 2 ? j0_ : T(0); rk2[9 + i] = q == 3 ? j1_ : T(0);
         }
         const T rs2[2] = {T(0), T(0)}, up2[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-        T r582[MAXC][4];
+        T r582[CPL][4];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) r582[c][i] = T(0);
+        for (int c = 0; c < CPL; ++c) for (int i = 0; i < 4; ++i) r582[c][i] = T(0);
         (void)rs; (void)r58;
-        Step<T, MAXC> D2;
+        StepT D2;
         T dva2[6];
         solve_rhs(rk2, R2, rs2, r582, up2, D2, dva2);
         for (int i = 0; i < 6; ++i) dva[i] += dva2[i];
@@ -2413,7 +2480,7 @@ struct LaneProgram {
             T m1 = 0, m2 = 0, mr = 0, mc = 0;
             for (int i = 0; i < 3; ++i) { m1 = tmax(m1, tmax(tabs(D.dv[i]), tabs(D.dw[i]))); m2 = tmax(m2, tmax(tabs(D2.dv[i]), tabs(D2.dw[i]))); }
             for (int i = 0; i < 12; ++i) mr = tmax(mr, tabs(rk2[i]));
-            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(R2.cc[c][i]));
+            for (int c = 0; c < CPL; ++c) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(R2.cc[c][i]));
             if (P.level == 1) std::printf("   node %d: m6 %.3e %.3e %.3e xk9-11 %.3e %.3e %.3e dls %.3e %.3e dlg %.3e %.3e ls %.3e %.3e lg %.3e %.3e Rlim %.3e %.3e\n", k, (double)m6[0], (double)m6[1], (double)m6[2], (double)xk[9], (double)xk[10], (double)xk[11],
                                          (double)D.dls[0], (double)D.dls[1], (double)D.dlg[0], (double)D.dlg[1], (double)L.ls[0], (double)L.ls[1], (double)L.lg[0], (double)L.lg[1], (double)R.lim[0], (double)R.lim[1]);
             if (k == 0) std::printf("   root: rk0 %.3e %.3e %.3e acc %.3e %.3e %.3e rho %.3e %.3e %.3e  dv %.3e %.3e %.3e\n", (double)rk0[0], (double)rk0[1], (double)rk0[2], (double)acc[0], (double)acc[1], (double)acc[2], (double)rho[0], (double)rho[1], (double)rho[2], (double)D.dv[0], (double)D.dv[1], (double)D.dv[2]);
@@ -2424,43 +2491,45 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) D.dlam[i] += D2.dlam[i];
         for (int i = 0; i < 2; ++i) { D.dls[i] += D2.dls[i]; D.dlg[i] += D2.dlg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { D.dcs[c][i] += D2.dcs[c][i]; D.dcg[c][i] += D2.dcg[c][i]; }
+        for (int c = 0; c < CPL; ++c) for (int i = 0; i < 4; ++i) { D.dcs[c][i] += D2.dcs[c][i]; D.dcg[c][i] += D2.dcg[c][i]; }
     }
 
     // cone_line_search!  src/solver/line_search.jl:36-96
-    DJ_HD T cone_line_search(const Step<T, MAXC>& D, T tort, T tsoc) {
+    DJ_HD T cone_line_search(const StepT& D, T tort, T tsoc) {
         T a = T(1);
         if (active) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
-                a = tmin(a, ort_step(L.cs[c][0], D.dcs[c][0], tort));
-                a = tmin(a, ort_step(L.cg[c][0], D.dcg[c][0], tort));
+            for (int li = 0; li < CPL; ++li) if (cidx(li) < P.ncontact) {
+                const int c = cidx(li);
+                a = tmin(a, ort_step(L.cs[c][0], D.dcs[li][0], tort));
+                a = tmin(a, ort_step(L.cg[c][0], D.dcg[li][0], tort));
                 if constexpr (kLinear) {                                   // line_search.jl:68-83: every pair on the positive orthant
-                    for (int i = 1; i < NCV; ++i) { a = tmin(a, ort_step(L.cs[c][i], D.dcs[c][i], tort)); a = tmin(a, ort_step(L.cg[c][i], D.dcg[c][i], tort)); }
+                    for (int i = 1; i < NCV; ++i) { a = tmin(a, ort_step(L.cs[c][i], D.dcs[li][i], tort)); a = tmin(a, ort_step(L.cg[c][i], D.dcg[li][i], tort)); }
                     continue;
                 }
-                a = tmin(a, soc_step(&L.cs[c][1], &D.dcs[c][1], tsoc));
-                a = tmin(a, soc_step(&L.cg[c][1], &D.dcg[c][1], tsoc));
+                a = tmin(a, soc_step(&L.cs[c][1], &D.dcs[li][1], tsoc));
+                a = tmin(a, soc_step(&L.cg[c][1], &D.dcg[li][1], tsoc));
             }
             if (lim_on()) for (int i = 0; i < 2; ++i) {
                 a = tmin(a, ort_step(L.ls[i], D.dls[i], tort));
                 a = tmin(a, ort_step(L.lg[i], D.dlg[i], tort));
             }
         }
+        a = quad_minv(a);
         if constexpr (QUAD && DJ_LDS_REDUCE) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
         else return env_min(wv, a, envl);
     }
 
     // candidate_step!  src/solver/line_search.jl:141-163: candidate = base + f Δ (base = the current iterate,
     // live only during the line search).  Returns 1 if ω stays beyond the error threshold after clipping.
-    DJ_HD void snapshot(SolSnap<T, MAXC>& B) const {
+    DJ_HD void snapshot(SnapT& B) const {
         for (int i = 0; i < 3; ++i) { B.v[i] = L.v[i]; B.w[i] = L.w[i]; }
         for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[i];
         for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[i]; B.lg[i] = L.lg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) { B.cs[c][i] = L.cs[c][i]; B.cg[c][i] = L.cg[c][i]; }
+        for (int li = 0; li < CPL; ++li) { const int c = kSplitC ? (cidx(li) < MAXC ? cidx(li) : 0) : li; for (int i = 0; i < NCV; ++i) { B.cs[li][i] = L.cs[c][i]; B.cg[li][i] = L.cg[c][i]; } }
     }
-    DJ_HD int candidate_step(const SolSnap<T, MAXC>& B, const Step<T, MAXC>& D, T f) {
+    DJ_HD int candidate_step(const SnapT& B, const StepT& D, T f) {
         int bad = 0;
         for (int i = 0; i < 3; ++i) { L.v[i] = B.v[i] + f * D.dv[i]; L.w[i] = B.w[i] + f * D.dw[i]; }
         T wmax = T(3.9) * G.idt2;
@@ -2470,7 +2539,8 @@ struct LaneProgram {
         for (int i = 0; i < 6; ++i) L.lam[i] = B.lam[i] + f * D.dlam[i];
         for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) for (int i = 0; i < NCV; ++i) { L.cs[c][i] = B.cs[c][i] + f * D.dcs[c][i]; L.cg[c][i] = B.cg[c][i] + f * D.dcg[c][i]; }
+        for (int li = 0; li < CPL; ++li) { const int c = cidx(li); if (!kSplitC || c < MAXC) for (int i = 0; i < NCV; ++i) { L.cs[c][i] = B.cs[li][i] + f * D.dcs[li][i]; L.cg[c][i] = B.cg[li][i] + f * D.dcg[li][i]; } }
+        share_cone_state();
         return bad;
     }
 
@@ -2600,7 +2670,7 @@ struct LaneProgram {
 
     // One Mehrotra direction (src/solver/mehrotra.jl:36-49 with the current factors): affine solve, centering!, correction!, corrected
     // solve; returns the cone step length alpha of the corrected direction D and the centering target mutarget.
-    DJ_HD T newton_direction(Step<T, MAXC>& D, T rvio, T bvio, T undercut, T& mutarget) {
+    DJ_HD T newton_direction(StepT& D, T rvio, T bvio, T undercut, T& mutarget) {
         ConeRhs R;
         cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
         DJ_PB();
@@ -2611,13 +2681,17 @@ struct LaneProgram {
         T p0 = T(0), p1 = T(0), p2 = T(0);
         if (active) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {
+            for (int li = 0; li < CPL; ++li) if (cidx(li) < P.ncontact) {
+                const int c = cidx(li);
                 // cone_degree: 2 for NonlinearContact (nonlinear.jl:101), N½ = 1 for ImpactContact (contact.jl:203), whose
                 // pinned friction variables do not take part
                 const int nv_ = kLinear ? NCV : (G.contact_model == 1 ? 1 : 4);
-                for (int i = 0; i < NCV; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[c][i]) * (L.cg[c][i] + aaff * D.dcg[c][i]); }
+                for (int i = 0; i < NCV; ++i) if (i < nv_) { p0 += L.cs[c][i] * L.cg[c][i]; p1 += (L.cs[c][i] + aaff * D.dcs[li][i]) * (L.cg[c][i] + aaff * D.dcg[li][i]); }
                 p2 += kLinear ? T(NCV) : (G.contact_model == 1 ? T(1) : T(2));      // (LinearContact: cone_degree = N½ = 6, contact.jl:203)
             }
+        }
+        if constexpr (kSplitC) { T pc_[3] = {p0, p1, p2}; quad_sum(pc_); p0 = pc_[0]; p1 = pc_[1]; p2 = pc_[2]; }   // (the limit terms below are the same on all four lanes)
+        if (active) {
             if (lim_on()) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
         }
         if constexpr (QUAD && DJ_LDS_REDUCE) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
@@ -2632,7 +2706,7 @@ struct LaneProgram {
         mutarget = munew;
         // correction!: cached residual += [−Δs∘Δγ + μ]   src/solver/correction.jl
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < CPL; ++c) {
             if constexpr (kLinear) { for (int i = 0; i < NCV; ++i) R.cc[c][i] += -D.dcs[c][i] * D.dcg[c][i] + mutarget; continue; }   // correction.jl:13-19
             R.cc[c][0] += -D.dcs[c][0] * D.dcg[c][0] + mutarget;
             R.cc[c][1] += -(D.dcs[c][1] * D.dcg[c][1] + D.dcs[c][2] * D.dcg[c][2] + D.dcs[c][3] * D.dcg[c][3]) + mutarget;
@@ -2676,8 +2750,8 @@ struct LaneProgram {
             // Lanes of finished environments keep executing (wave-uniform control flow, all lanes must
             // take part in the shuffles) but never change their state: their step factor is 0.
             if (!done) iters = n;
-            Step<T, MAXC> D_local;
-            Step<T, MAXC>& D = kLsInLds ? *(Step<T, MAXC>*)ls_lds : D_local;
+            StepT D_local;
+            StepT& D = kLsInLds ? *(StepT*)ls_lds : D_local;
             T alpha = newton_direction(D, rvio, bvio, undercut, mutarget);
             // line_search!  src/solver/line_search.jl:1-34 (halving; the last trial is taken if all are rejected)
             T rc = rvio, bc = bvio;
@@ -2685,8 +2759,8 @@ struct LaneProgram {
             {
                 bool searching = !done;
                 T f = done ? T(0) : alpha;
-                SolSnap<T, MAXC> base_local;
-                SolSnap<T, MAXC>& base_sol = kLsInLds ? *(SolSnap<T, MAXC>*)(ls_lds + sizeof(Step<T, MAXC>)) : base_local;
+                SnapT base_local;
+                SnapT& base_sol = kLsInLds ? *(SnapT*)(ls_lds + sizeof(StepT)) : base_local;
                 snapshot(base_sol);
                 DJ_PB();
                 // one trial: candidate, residual (with the Jacobian blocks when WITH_JAC), violations, accept / halve
@@ -2699,7 +2773,7 @@ struct LaneProgram {
                     if (trace && active && q == 0) {
                         T mb = 0, mj = 0, mc = 0;
                         for (int i = 0; i < 6; ++i) { mb = tmax(mb, tabs(rb[i])); mj = tmax(mj, tabs(rj[i])); }
-                        for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(cres[c][i]));
+                        for (int c = 0; c < CPL; ++c) for (int i = 0; i < 4; ++i) mc = tmax(mc, tabs(cres[c][i]));
                         if (tmax(mb, tmax(mj, mc)) > T(0.3) * r2) std::printf("   trial %d f %.3e node %d: body %.2e joint %.2e contact %.2e (rvio %.2e)\n", ls, (double)f, k, (double)mb, (double)mj, (double)mc, (double)r2);
                     }
 #endif
@@ -3035,13 +3109,21 @@ struct LaneProgram {
                 // the same column through the general solve (cone right-hand sides zero, slack rows (rs, −rs)) and refined
                 ConeRhs R0;
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) R0.cc[c][i] = T(0);
+                for (int c = 0; c < CPL; ++c) for (int i = 0; i < 4; ++i) R0.cc[c][i] = T(0);
                 R0.lim[0] = R0.lim[1] = T(0);
                 const T rs2[2] = {rs0, -rs0};
-                Step<T, MAXC> Dp; T dva[6];
-                solve_rhs(rk, R0, rs2, r58, upx, Dp, dva);
+                StepT Dp; T dva[6];
+                T r58l[CPL][4];                                   // this lane's contact slots of the contact-row right-hand sides (values first, then the select)
+#pragma unroll
+                for (int li = 0; li < CPL; ++li)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (kSplitC) { const T a0_ = r58[4 * li][i], a1_ = r58[4 * li + 1][i], a2_ = r58[4 * li + 2][i], a3_ = r58[4 * li + 3][i]; r58l[li][i] = q == 0 ? a0_ : q == 1 ? a1_ : q == 2 ? a2_ : a3_; }
+                        else r58l[li][i] = r58[li][i];
+                    }
+                solve_rhs(rk, R0, rs2, r58l, upx, Dp, dva);
 #pragma unroll 1
-                for (int rstep = 0; rstep < DJ_REFINE_STEPS; ++rstep) refine_solution(rk, R0, rs2, r58, upx, Dp, dva);
+                for (int rstep = 0; rstep < DJ_REFINE_STEPS; ++rstep) refine_solution(rk, R0, rs2, r58l, upx, Dp, dva);
                 for (int i = 0; i < 3; ++i) { D.dv[i] = Dp.dv[i]; D.dw[i] = Dp.dw[i]; }
                 return;
             }
