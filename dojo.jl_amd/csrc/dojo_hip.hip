@@ -682,7 +682,7 @@ int dojo_comm_init(DojoHandle s, int32_t rank, int32_t world, const void* id128)
     if (!s || !id128 || world < 1 || rank < 0 || rank >= world) { g_err = "dojo_comm_init: bad argument"; return DOJO_ERR_INVALID; }
     if (!rccl::load()) return DOJO_ERR_DEVICE;
     HIPCHK(hipSetDevice(s->device));
-    if (s->comm) { (void)rccl::comm_destroy(s->comm); s->comm = nullptr; }
+    if (s->comm) { HIPCHK(hipDeviceSynchronize()); (void)rccl::comm_destroy(s->comm); s->comm = nullptr; }     // (collectives of the old communicator may still be in flight)
     rccl::UniqueId id; std::memcpy(&id, id128, 128);
     int rc = rccl::comm_init_rank(&s->comm, world, id, rank);
     if (rc != 0) { s->comm = nullptr; g_err = std::string("ncclCommInitRank: ") + rccl::why(rc); return DOJO_ERR_DEVICE; }

@@ -279,8 +279,13 @@ end
 const HANDLES = IdDict{Dojo.Mechanism,BatchedMechanism{Float64}}()
 const OVERRIDE_WORLD = Ref{UInt}(0)
 
-"install the Dojo.mehrotra! method that dispatches enabled mechanisms to the library (done once, by the first enable!)"
+"""
+install the Dojo.mehrotra! method that dispatches enabled mechanisms to the library (done once, by the first enable!).
+UNVERIFIED (no Julia where this was written): the method is `@eval`ed at run time, so call `enable!` at top level before the first
+`step!` (a caller compiled earlier keeps dispatching to Dojo's own method until it returns to top level), and never while precompiling.
+"""
 function install_override!()
+    ccall(:jl_generating_output, Cint, ()) == 1 && error("DojoHIP.enable! must not run during precompilation")
     OVERRIDE_WORLD[] != 0 && return
     OVERRIDE_WORLD[] = Base.get_world_counter()           # the world in which Dojo's own method is still the one that runs
     @eval function Dojo.mehrotra!(mechanism::Dojo.Mechanism{T}; opts=Dojo.SolverOptions{T}()) where T

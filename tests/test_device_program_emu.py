@@ -436,3 +436,21 @@ def test_ift_hard_cases_lu_form():
         assert np.abs(r["dz"][b] - dz_o[b]).max() <= 1e-7 * max(1.0, np.abs(dz_o[b]).max())
         assert np.abs(r["du"][b] - du_o[b]).max() <= 1e-7 * max(1.0, np.abs(du_o[b]).max())
     assert n_cmp >= 7
+
+
+def test_ift_f32_abi_constraint_rows_in_double():
+    """fp32 ABI: the eight environments of the BASELINE Ant batch whose gradients were furthest off (tools/hunt_f32.py on the GPU: up to
+    1.4e-5 relative; tests/golden/hard_cases_ant_f32.npz).  The cause was the fp32 rounding of the IFT's right-hand sides on the JOINT rows
+    and the joint-limit slack rows (constraint rows: amplified by 1/dt and more on their way to the velocities); those blocks are double
+    now (QuadRhs::jd) and what is left is the rounding of the fp32 output, < 1e-7."""
+    G_ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_cases_ant_f32.npz"))
+    Z, U = G_["z"][:4], G_["u"][:4]
+    spec = d.baseline_config(3)
+    o = Oracle(spec)
+    Zo, st_o, it_o, dz_o, du_o = o.step_batch(d.fp32_abi_state(Z), U, with_grad=True, nthreads=4)
+    r = emu_step(spec, Z, U, grad=True, quad=True, dtype="f32")
+    assert np.array_equal(r["status"], st_o) and np.array_equal(r["iters"], it_o)
+    for b in range(len(Z)):
+        assert G_["eg"][b] > 2e-6                                   # (what the kernels of round 2 gave on this environment)
+        assert np.abs(r["dz"][b] - dz_o[b]).max() <= 1e-7 * max(1.0, np.abs(dz_o[b]).max())
+        assert np.abs(r["du"][b] - du_o[b]).max() <= 1e-7 * max(1.0, np.abs(du_o[b]).max())
