@@ -30,24 +30,8 @@
 #include <cstdlib>
 #endif
 
-#ifndef DJ_FUSE_LS
-#define DJ_FUSE_LS 0       // quad mapping: let the first line-search trial assemble the Jacobian blocks too and skip set_entries! when it is
-                           // accepted.  Measured: no gain (the saved residual evaluation is paid back in register pressure) -> off.
-#endif
-#ifndef DJ_FAST_RCP
-#define DJ_FAST_RCP 1       // Gauss-Jordan pivots: v_rcp_f64 + two Newton steps instead of the division expansion
-#endif
-#ifndef DJ_LDS_REDUCE
-#define DJ_LDS_REDUCE 1     // quad mapping: environment reductions through LDS (one slot per supernode) instead of shuffle butterflies
-#endif
 #ifndef DJ_TSD
 #define DJ_TSD 0           // 1: the kernels evaluate translational springs / dampers (KernelArgs::tsd); builds of their own
-#endif
-#ifndef DJ_PIVOT_ORDER
-#define DJ_PIVOT_ORDER 1   // quad Gauss-Jordan: 1 = pivot v, λ_t, ω, λ_r; 0 = v, ω, λ_t, λ_r (see factorize_quad)
-#endif
-#ifndef DJ_RHS_T
-#define DJ_RHS_T TIO       // quad mapping: type of the IFT right-hand-side blocks in LDS (the ABI type; double was measured: +25 % IFT kernel time, same error)
 #endif
 #ifndef DJ_REFINE
 #define DJ_REFINE 1        // quad mapping: iterative refinement of the Newton / IFT solves against the UNCONDENSED system for environments whose
@@ -57,12 +41,6 @@
 #ifndef DJ_REFINE_STEPS
 #define DJ_REFINE_STEPS 2  // rounds per solve (the contraction per round is ~ε·γ/s·cond of the un-stiff part; nearly redundant joint / contact rows need two)
 #endif
-#ifndef DJ_CONDENSE_OWN_ROWS
-#define DJ_CONDENSE_OWN_ROWS 1   // quad mapping: the contact condensation computes only the lane's own three body rows (108 instead of 648 multiply-adds per contact)
-#endif
-#ifndef DJ_SCHUR_LEAN
-#define DJ_SCHUR_LEAN 1      // quad factorization: Schur complement with 18 (not 54) gathered U entries and 18 (not 36) partial sums in flight: 49 -> 39 spilled VGPRs, +1.4 % (same session)
-#endif
 #ifndef DJ_LINEAR
 #define DJ_LINEAR 0         // 1: builds for LinearContact mechanisms (src/contacts/linear.jl: six cone pairs [γ ψ β1..β4] per contact, all on the positive
                             // orthant; forward only, like the reference) -- the step kernel alone, no refinement, no IFT
@@ -70,9 +48,6 @@
 #if DJ_LINEAR
 #undef DJ_REFINE
 #define DJ_REFINE 0
-#endif
-#ifndef DJ_LS_IN_LDS
-#define DJ_LS_IN_LDS 1     // quad mapping: Newton step + line-search base iterate once per supernode in LDS
 #endif
 
 namespace dj {
@@ -210,10 +185,6 @@ struct QuadBlocks {
     template <class V> DJ_HD void addL(int r, int c, V v) { if (c / 3 == q) L[r][c % 3] += T(v); }
     template <class V> DJ_HD void addD(int r, int c, V v) { if (r / 3 == q) D[r % 3][c] += T(v); }
 };
-
-struct NullQuad { template <class A, class B, class C> DJ_HD NullQuad(A&, B&, C&, int) {} };   // stands in for QuadBlocks in the lane mapping
-template <class T, bool QUAD> struct QuadKType { typedef QuadBlocks<T> type; };
-template <class T> struct QuadKType<T, false> { typedef NullQuad type; };
 
 // kinematic quantities of a body at the candidate velocity
 template <class T>
@@ -1091,7 +1062,7 @@ struct LaneProgram {
     ContactCold<T>* cpool = nullptr;   // contact rows: slot (supernode, c) [pool_by_id = false] or slot = contact index of the environment
     bool pool_by_id = false; int pool_base = 0;
     // Newton step + line-search base iterate once per supernode in LDS (single-wave quad mapping with one contact per body: there is room)
-    static constexpr bool kLsInLds = DJ_LS_IN_LDS && QUAD && Wave::kLockstep && Wave::kWaves == 1 && MAXC == 1;
+    static constexpr bool kLsInLds = QUAD && Wave::kLockstep && Wave::kWaves == 1 && MAXC == 1;
     char* ls_lds = nullptr;
     char* lane_slots = nullptr; int lane_slot_stride = 0;   // lock-step quad mapping: the Lane blocks of all supernodes of the workgroup (parents are read in place)
     DJ_HD const Lane<T, MAXC>& parent_state() const { return *(const Lane<T, MAXC>*)(lane_slots + (size_t)((has_parent ? base + stride * P.parent : qb) >> 2) * lane_slot_stride); }
@@ -1347,7 +1318,7 @@ struct LaneProgram {
             }
         }
         if constexpr (kSplitC) { r = quad_maxv(r); b = quad_maxv(b); if constexpr (kTrack) wq = quad_maxv(wq); }      // (the lanes of a quad looked at different contacts)
-        if constexpr (QUAD && DJ_LDS_REDUCE) {
+        if constexpr (QUAD) {
             if constexpr (kTrack) { T v3[3] = {r, b, wq}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v3[0]; bvio = v3[1]; wstiff = v3[2]; }
             else { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
         }
@@ -1443,7 +1414,6 @@ struct LaneProgram {
                 contact_coef(Q, c, rc, r58);
                 const ContactCold<T>& cc_ = ccold(c);
                 // body rows: −G134 Δγ134 = −G134 (k0 + coef C134 Δw)  ->  S[0:6,0:6] −= G134 coef C134
-#if DJ_CONDENSE_OWN_ROWS
                 if constexpr (QUAD) {
                     // quad mapping: only the two body-row roles hold such rows, three each -- M = coef C134 once (3 x 6), then
                     // the lane's rows G134[:, 3q + i]ᵀ M (the rows are picked by address in LDS, not by selects over six)
@@ -1463,7 +1433,6 @@ struct LaneProgram {
                     }
                     continue;
                 }
-#endif
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1571,23 +1540,19 @@ struct LaneProgram {
             // pivot only ever receives row operations afterwards, so the factor 1/pivot commutes to the end):
             // every row then takes the same update A −= fe·prow with fe = 0 on the pivot row itself.
             TL ipown[3] = {TL(1), TL(1), TL(1)};
-            // Pivot order v, λ_t, ω, λ_r (DJ_PIVOT_ORDER = 1) instead of v, ω, λ_t, λ_r: with the translational constraint rows eliminated
+            // Pivot order v, λ_t, ω, λ_r instead of v, ω, λ_t, λ_r: with the translational constraint rows eliminated
             // right after the linear velocity, the ω pivots are the inertia about the JOINT POINT (J + m r², ~1e-3) rather than about the
             // centre of mass (~1e-5 for an Ant foot), and the elimination's growth drops by that ratio -- without pivoting, the order
             // is all there is (numpy model of the tree elimination on the worst default-tolerance cases: 3e-5 -> 1e-8 relative).
 #pragma unroll
             for (int pp = 0; pp < 12; ++pp) {
-                const int p = DJ_PIVOT_ORDER ? (pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp) : pp;
+                const int p = pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp;
                 const int o = p / 3, ro = p % 3;
                 const bool own = (q == o);
                 TL prow[12];
 #pragma unroll
                 for (int c = 0; c < 12; ++c) prow[c] = wv.quad_bcast(A[ro][c], o);
-#if DJ_FAST_RCP
-                const TL ip = Wave::rcp(at ? prow[p] : TL(1));
-#else
-                const TL ip = TL(1) / (at ? prow[p] : TL(1));
-#endif
+                const TL ip = Wave::rcp(at ? prow[p] : TL(1));      // (GPU: v_rcp_f64 + two Newton steps = the IEEE quotient, tools/ubench/rcp_test.hip)
                 if (own) ipown[ro] = ip;
                 // the multiplier f/pivot is formed once per row (three products) instead of scaling the eleven
                 // broadcast pivot-row entries; lanes elsewhere get 0 and keep column p
@@ -1613,7 +1578,6 @@ struct LaneProgram {
             if (lev > 0) {   // level 0 = the roots of the trees: nothing to pass up (wave-uniform skip)
             // Schur complement onto the parent: Dup − L S⁻¹ U  (rows 0:3 of U are structurally zero -- except with a
             // translational damper, whose force on the child body depends on the parent's velocity: DJ_TSD builds)
-#if DJ_SCHUR_LEAN
             // Tq = S⁻¹(own rows) U gathered one source role at a time (18 values in flight instead of 54), then the 6x6 product
             // L Tq in two row halves (rows 0:3 end on role 0, rows 3:6 on role 1): 18 partial sums in flight instead of 36
             constexpr int U0 = DJ_TSD ? 0 : 1;
@@ -1654,46 +1618,6 @@ struct LaneProgram {
                         }
                 }
             }
-#else
-            TL Uf[12][6];
-            constexpr int U0 = DJ_TSD ? 0 : 1;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { Uf[0][j] = Uf[1][j] = Uf[2][j] = TL(0); }
-#pragma unroll
-            for (int o = U0; o < 4; ++o)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) Uf[3 * o + i][j] = wv.quad_bcast(F.Uq[i][j], o);
-            TL Tq[3][6], part[36];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    TL a_ = TL(0);
-#pragma unroll
-                    for (int m_ = 3 * U0; m_ < 12; ++m_) a_ += A[i][m_] * Uf[m_][j];
-                    Tq[i][j] = a_;
-                }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) part[6 * i + j] = F.Lq[i][0] * Tq[0][j] + F.Lq[i][1] * Tq[1][j] + F.Lq[i][2] * Tq[2][j];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) { part[i] += wv.quad_xor(part[i], 1); }
-#pragma unroll
-            for (int i = 0; i < 36; ++i) { part[i] += wv.quad_xor(part[i], 2); }
-            if (at && has_parent) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const TL pa0_ = part[6 * i + j], pa1_ = part[6 * (3 + i) + j];
-                        TL rowv = (q == 0) ? pa0_ : pa1_;
-                        up[i][j] = (q < 2) ? TL(K.D[i][j]) - rowv : TL(0);
-                    }
-            }
-#endif
             }
         }
     }
@@ -1717,8 +1641,8 @@ struct LaneProgram {
     // multiply-adds and 11 DPP broadcasts each way (the products with the explicit inverse: 36 + 18 and 12).  What waits between
     // the sweeps is ỹ, all twelve rows of it.
     struct QuadLU { TL Lm[3][12], Um[3][12], di[3]; };
-    static constexpr DJ_HD int lu_piv(int pp) { return DJ_PIVOT_ORDER ? (pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp) : pp; }   // pp-th pivot (an involution: also the position of column c)
-    static constexpr DJ_HD int lu_rolepos(int o) { return DJ_PIVOT_ORDER ? (o == 1 ? 2 : o == 2 ? 1 : o) : o; }                         // position of role o's rows in the pivot order
+    static constexpr DJ_HD int lu_piv(int pp) { return pp < 3 ? pp : pp < 6 ? pp + 3 : pp < 9 ? pp - 3 : pp; }   // pp-th pivot (an involution: also the position of column c)
+    static constexpr DJ_HD int lu_rolepos(int o) { return o == 1 ? 2 : o == 2 ? 1 : o; }                         // position of role o's rows in the pivot order
 
     // forward substitution with the unit lower factor for NCOLS right-hand sides at once (r[n] = the lane's three rows of column n):
     // the columns are independent chains, which is what hides the DPP and FMA latencies
@@ -2516,7 +2440,7 @@ struct LaneProgram {
             }
         }
         a = quad_minv(a);
-        if constexpr (QUAD && DJ_LDS_REDUCE) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
+        if constexpr (QUAD) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
         else return env_min(wv, a, envl);
     }
 
@@ -2694,7 +2618,7 @@ struct LaneProgram {
         if (active) {
             if (lim_on()) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
         }
-        if constexpr (QUAD && DJ_LDS_REDUCE) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
+        if constexpr (QUAD) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
         else { p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl); }
         T munew = G.btol / undercut;
         if (p2 > T(0)) {
@@ -2732,7 +2656,6 @@ struct LaneProgram {
         mu = T(0);
         if constexpr (kTrack) refine = T(1) > G.refine_w;        // reset! / initialize! leave every cone at γ/s = 1
         linearize();
-        typename QuadKType<TL, QUAD>::type Kq(F.Sq, F.Uq, F.Lq, q);   // quad mapping: the lane's rows, assembled in place in the factor storage
 #ifdef DJ_DEBUG
         if (dbg_on) { iters_out = 0; return 0; }   // wave-uniform early exit of the test hook
 #endif
@@ -2755,7 +2678,6 @@ struct LaneProgram {
             T alpha = newton_direction(D, rvio, bvio, undercut, mutarget);
             // line_search!  src/solver/line_search.jl:1-34 (halving; the last trial is taken if all are rejected)
             T rc = rvio, bc = bvio;
-            int lin_trials = 0;                                     // residual evaluations of this line search (1: the Jacobian blocks of trial 0 are those of the new iterate)
             {
                 bool searching = !done;
                 T f = done ? T(0) : alpha;
@@ -2763,10 +2685,10 @@ struct LaneProgram {
                 SnapT& base_sol = kLsInLds ? *(SnapT*)(ls_lds + sizeof(StepT)) : base_local;
                 snapshot(base_sol);
                 DJ_PB();
-                // one trial: candidate, residual (with the Jacobian blocks when WITH_JAC), violations, accept / halve
-                auto trial = [&](int ls, auto with_jac) {
+                // one trial: candidate, residual, violations, accept / halve
+                auto trial = [&](int ls) {
                     int bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
-                    if constexpr (decltype(with_jac)::value) evaluate<true>(Kq); else { NullBlocks nk; evaluate<false>(nk); }
+                    { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
 #ifdef DJ_DEBUG
@@ -2778,7 +2700,7 @@ struct LaneProgram {
                     }
 #endif
                     int anybad;
-                    if constexpr (QUAD && DJ_LDS_REDUCE) { T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)}; env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); anybad = vb[0] > T(0.5) ? 1 : 0; }
+                    if constexpr (QUAD) { T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)}; env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); anybad = vb[0] > T(0.5) ? 1 : 0; }
                     else anybad = env_or(wv, (active && searching) ? bad : 0, envl);
                     if (searching) {
                         excessive |= anybad;
@@ -2786,22 +2708,9 @@ struct LaneProgram {
                         if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
                     }
                 };
-                // Quad mapping: the first trial already assembles the Jacobian blocks (they do not depend on μ).  Most line
-                // searches accept it, and the set_entries! evaluation at the new iterate is then this one.
-                bool first_is_final = false;
-                if constexpr (QUAD && DJ_FUSE_LS) {
-                    if (G.max_ls > 0 && wv.any(active && searching)) {
-                        trial(0, std::true_type());
-                        first_is_final = !wv.any(active && searching) || G.max_ls == 1;
-                        lin_trials = 1;
-                    }
-                }
-                if (!first_is_final) {
-                    for (int ls = lin_trials; ls < G.max_ls; ++ls) {
-                        if (!wv.any(active && searching)) break;
-                        trial(ls, std::false_type());
-                        ++lin_trials;
-                    }
+                for (int ls = 0; ls < G.max_ls; ++ls) {
+                    if (!wv.any(active && searching)) break;
+                    trial(ls);
                 }
                 DJ_PE(3);
                 if (!done) {
@@ -2819,10 +2728,7 @@ struct LaneProgram {
                     if (!wv.any(active && !conv)) { if (!done) { status = DJ_STATUS_SUCCESS; done = true; } break; }
                 }
                 // set_entries! + factorization (cone rows now carry the new μ)
-                if constexpr (QUAD && DJ_FUSE_LS) {
-                    if (first_is_final && lin_trials == 1) { DJ_PB(); condense(Kq); DJ_PE(0); DJ_PB(); factorize_quad(Kq); DJ_PE(1); }
-                    else linearize();
-                } else linearize();
+                linearize();
             }
         }
         if (excessive && status != DJ_STATUS_DEFERRED) status = DJ_STATUS_EXCESSIVE_W;
@@ -3039,8 +2945,8 @@ struct LaneProgram {
         }
         // σ = wκ/(1 + wκ): the slack rows of a joint limit enter the Δκ row (see evaluate) as σ·(∂ slack row / ∂ data)
         if (lim_on()) { const T w_ = (L.lg[1] + T(REG)) / (L.ls[1] + T(REG)) + (L.lg[0] + T(REG)) / (L.ls[0] + T(REG)); wk = w_ / (T(1) + w_); }
-        // precision the IFT right-hand sides are kept in (DJ_RHS_T)
-        typedef typename KA::io_type TIO; typedef typename std::conditional<QUAD, DJ_RHS_T, TIO>::type TB;
+        // the body-row blocks of the IFT right-hand sides are kept in the ABI type (QuadRhs)
+        typedef typename KA::io_type TIO; typedef TIO TB;
         if constexpr (QUAD && !PRECISE) {
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
@@ -3428,10 +3334,10 @@ struct StepLds {
     // Newton step and the iterate at the start of the line search, once per supernode (step kernel, when there is room:
     // frees ~100 registers during the residual evaluations of the line search)
     static constexpr int ls_slot = (int)((sizeof(Step<T, MAXC>) + sizeof(SolSnap<T, MAXC>)) / 8 + (((sizeof(Step<T, MAXC>) + sizeof(SolSnap<T, MAXC>)) / 8) % 2 == 0 ? 1 : 0)) * 8;
-    static constexpr bool ls_in_lds = DJ_LS_IN_LDS && share && !GRAD && NW == 1 && MAXC == 1;                 // (must match LaneProgram::kLsInLds)
+    static constexpr bool ls_in_lds = share && !GRAD && NW == 1 && MAXC == 1;                 // (must match LaneProgram::kLsInLds)
     static constexpr int ls_off = pool_off + pool_bytes;
     static constexpr int a_end = ls_off + (ls_in_lds ? ls_slot * NSN : 0);
-    static constexpr int rhs_bytes = !QUAD ? 0 : GRAD == 1 ? (int)sizeof(QuadRhs<DJ_RHS_T>) * NSN : GRAD == 2 ? (int)sizeof(ConRhs<MAXC>) * NSN : 0;
+    static constexpr int rhs_bytes = !QUAD ? 0 : GRAD == 1 ? (int)sizeof(QuadRhs<TIO>) * NSN : GRAD == 2 ? (int)sizeof(ConRhs<MAXC>) * NSN : 0;
     static constexpr int mail_need = QUAD ? 2 * NSN * 20 * 8 : 0;
     static constexpr int rhs_off = 0;
     // (contact-data kernel: the mailbox keeps its own room behind the phase-A data; packed right behind the ConRhs blocks
@@ -3486,7 +3392,7 @@ constexpr int FAC_PER_LANE = 72;
     if (QUAD) {                                                                                                           \
         prog.cpool = (ContactCold<T>*)(lds + LY::pool_off); prog.pool_by_id = LY::pool_by_id;                             \
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
-        prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<DJ_RHS_T>*)lds) + lane / 4); \
+        prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
