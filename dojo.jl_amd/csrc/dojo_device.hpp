@@ -1492,14 +1492,29 @@ struct LaneProgram {
             gather_children<36>(wv, acc, up, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Sl[12 * i + j] += acc[6 * i + j];
-                for (int i = 0; i < 144; ++i) F.Sinv[i] = Sl[i];
-                gj_inverse<12>(F.Sinv);
-                if (has_parent) {
-                    mm<6, 12, 12>(F.W, Ll, F.Sinv);
-                    mm<12, 12, 6>(F.Z, F.Sinv, Ul);
-                    for (int i = 0; i < 36; ++i) up[i] = TL(Dup[i]);
-                    mm_sub<6, 12, 6>(up, Ll, F.Z);
+                // plain LU of [S U; L Dup] down to the parent's body rows, no pivoting (the host's elimination order makes every pivot
+                // the Schur complement of a well-conditioned block): Sinv <- unit-lower L11 \ U11 with the pivots' reciprocals on the
+                // diagonal, Z <- L11⁻¹ U, W <- L U11⁻¹, up <- Dup − W Z.  Triangular solves instead of products with an explicit S⁻¹:
+                // the explicit form loses cond(S) digits in y − Z Δv_parent.
+                if (has_parent) for (int i = 0; i < 36; ++i) up[i] = TL(Dup[i]);
+                for (int k = 0; k < 12; ++k) {
+                    const TL ip = TL(1) / Sl[13 * k];
+                    Sl[13 * k] = ip;
+                    for (int i = k + 1; i < 12; ++i) {
+                        const TL f = Sl[12 * i + k] * ip;
+                        Sl[12 * i + k] = f;
+                        for (int j = k + 1; j < 12; ++j) Sl[12 * i + j] -= f * Sl[12 * k + j];
+                        if (has_parent) for (int j = 0; j < 6; ++j) Ul[6 * i + j] -= f * Ul[6 * k + j];
+                    }
+                    if (has_parent) for (int i = 0; i < 6; ++i) {
+                        const TL f = Ll[12 * i + k] * ip;
+                        Ll[12 * i + k] = f;
+                        for (int j = k + 1; j < 12; ++j) Ll[12 * i + j] -= f * Sl[12 * k + j];
+                        for (int j = 0; j < 6; ++j) up[6 * i + j] -= f * Ul[6 * k + j];
+                    }
                 }
+                for (int i = 0; i < 144; ++i) F.Sinv[i] = Sl[i];
+                if (has_parent) for (int i = 0; i < 72; ++i) { F.W[i] = Ll[i]; F.Z[i] = Ul[i]; }
             }
         }
     }
@@ -2249,27 +2264,36 @@ struct LaneProgram {
             solve_quad(rk, up, dk, dva);
         } else {
         // forward: leaves -> root (factorization precision)
-        TL rl[12], y[12], send[6] = {0, 0, 0, 0, 0, 0};
+        TL rl[12], send[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             TL acc[6] = {0, 0, 0, 0, 0, 0};
             gather_children<6>(wv, acc, send, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) rl[i] += acc[i];
+                for (int k = 0; k < 12; ++k) for (int i = k + 1; i < 12; ++i) rl[i] -= F.Sinv[12 * i + k] * rl[k];      // y = L11⁻¹ r
                 if (has_parent) { TL t[6]; mv<6, 12>(t, F.W, rl); for (int i = 0; i < 6; ++i) send[i] = TL(up[i]) - t[i]; }
             }
         }
-        mv<12, 12>(y, F.Sinv, rl);
-        // backward: root -> leaves
+        // backward: root -> leaves, x = U11⁻¹ (y − Z Δv_parent)
+        auto back = [&](TL* x) {
+            for (int i = 11; i >= 0; --i) {
+                TL a = x[i];
+                for (int j = i + 1; j < 12; ++j) a -= F.Sinv[12 * i + j] * x[j];
+                x[i] = a * F.Sinv[13 * i];
+            }
+        };
         TL dkl[12];
-        for (int i = 0; i < 12; ++i) dkl[i] = y[i];
+        for (int i = 0; i < 12; ++i) dkl[i] = rl[i];
+        if (active && P.level == 0) back(dkl);
         for (int lev = 1; lev <= G.maxlevel; ++lev) {
             TL par[6];
             shfl_vec<6>(wv, par, dkl, plane);
             if (active && P.level == lev && has_parent) {
                 for (int i = 0; i < 6; ++i) dva[i] = T(par[i]);
                 TL t[12]; mv<12, 6>(t, F.Z, par);
-                for (int i = 0; i < 12; ++i) dkl[i] = y[i] - t[i];
+                for (int i = 0; i < 12; ++i) dkl[i] = rl[i] - t[i];
+                back(dkl);
             }
         }
         for (int i = 0; i < 12; ++i) dk[i] = T(dkl[i]);

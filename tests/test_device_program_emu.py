@@ -454,3 +454,29 @@ def test_ift_f32_abi_constraint_rows_in_double():
         assert G_["eg"][b] > 2e-6                                   # (what the kernels of round 2 gave on this environment)
         assert np.abs(r["dz"][b] - dz_o[b]).max() <= 1e-7 * max(1.0, np.abs(dz_o[b]).max())
         assert np.abs(r["du"][b] - du_o[b]).max() <= 1e-7 * max(1.0, np.abs(du_o[b]).max())
+
+
+@pytest.mark.parametrize("seed,nb", [(3052, 36), (5015, 33), (5018, 40)])
+def test_lane_per_supernode_mapping_lu_form(seed, nb):
+    """Mechanisms above 32 bodies run one lane per supernode.  With products by an explicitly inverted 12x12 supernode block that
+    mapping took up to twice the oracle's iterations on about one random tree in ten and ran out of iterations on some at 1e-9
+    (a GPU sweep found seed 3052; 5015 and 5018 are from the emulator survey); with the supernode blocks LU-factorized and
+    triangular solves (LaneProgram::factorize / core_solve) iteration counts and states are the oracle's at 1e-9, and the gradients
+    at the reference's default tolerances (this mapping has no refining kernels: at 1e-9 its IFT keeps the ~1e-6 of the condensed
+    cone rows)."""
+    from random_mechanisms import random_mechanism
+    spec, z0, u0 = random_mechanism(seed, nb=nb, contact_type="nonlinear", translational=False, tra_limits=False)
+    rng = np.random.default_rng(seed)
+    Z = np.tile(z0, (2, 1)); U = np.tile(u0, (2, 1)) + rng.normal(size=(2, spec.nu)) * 0.2
+    for tol in (1e-9, None):
+        opts = d.SolverOptions(rtol=tol, btol=tol) if tol else d.SolverOptions()
+        o = Oracle(spec, opts=opts)
+        r = emu_step(spec, Z, U, opts=opts, quad=False, grad=tol is None)
+        for b in range(2):
+            zo, info = o.step(Z[b], U[b])
+            assert info["status"] == 0 and r["status"][b] == 0 and r["iters"][b] == info["iters"]
+            assert np.abs(r["z_next"][b] - zo).max() < 1e-9
+            if tol is None:
+                dz, du = o.gradients(mode=0)
+                assert np.abs(r["dz"][b] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max())
+                assert np.abs(r["du"][b] - du).max() < 1e-7 * max(1.0, np.abs(du).max())

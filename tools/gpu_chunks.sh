@@ -1,8 +1,7 @@
 #!/bin/bash
-# bench.py over the number of independent environment groups (same session, same box): gpurun_out/chunks.txt
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-make -C oracle > /dev/null 2>&1
-: > gpurun_out/chunks.txt
-for rep in 1 2; do for c in ${CHUNKS:-8 16 24 32 64}; do
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --chunks $c 2>&1 | tail -1 | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('chunks $c', round(b['value']), b['ms_per_step'], b['roofline']['avg_kernel_ms'], b['roofline_second_kernel']['avg_kernel_ms'])" | tee -a gpurun_out/chunks.txt
-done; done
+# environment groups of dojo_step_dev against throughput: asynchronous rollout (`value`) and a join after every step (`sync_per_step_value`)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for c in 1 2 3 4 6 8 16 32; do
+  timeout 600 python bench.py --steps 20 --warmup 3 --no-parity --no-cpu-baseline --chunks $c 2>&1 | tail -1 | python -c "
+import sys, json; r = json.loads(sys.stdin.readline()); print('chunks $c: async %.0f  sync-per-step %.0f  (ms/step %.3f / %.3f)' % (r['value'], r['config']['sync_per_step_value'], r['ms_per_step'], r['config']['sync_per_step_ms']))"
+done

@@ -1,5 +1,6 @@
-#!/bin/bash
-# random-mechanism sweep on the GPU (tools/random_sweep.py): gpurun_out/sweep.txt
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-make -C oracle > /dev/null 2>&1
-SWEEP_TRA=${SWEEP_TRA:-1} timeout 1500 python tools/random_sweep.py ${S0:-2000} ${CNT:-300} 2>&1 | tee gpurun_out/sweep.txt | tail -40
+# GPU regression sweep: random tree mechanisms against the oracle (tools/random_sweep.py), then the whole GPU tier.
+cd $GRAFT_REPO_ROOT; make -C oracle >/dev/null 2>&1
+echo "== sweep, solver tolerance 1e-9"; timeout 900 python tools/random_sweep.py 3000 200 2>&1 | tail -8
+echo "== sweep, solver tolerance 1e-6"; SWEEP_TOL=1e-6 timeout 900 python tools/random_sweep.py 3000 200 2>&1 | tail -8
+echo "== translational features, 1e-9"; SWEEP_TRA=1 timeout 900 python tools/random_sweep.py 4000 150 2>&1 | tail -8
+echo "== gpu tier"; timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -6
