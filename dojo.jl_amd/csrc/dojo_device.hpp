@@ -1892,9 +1892,12 @@ struct LaneProgram {
         {
         TG Lm[3][12], mq[6][3];                                // L11 − I and the parent rows' multipliers m (load_lu_up)
         load_lu_up(Lm, mq);
-        TG send3[NC][3];
+        // a supernode's messages to its parent are posted at the END of the step that produced them and read at the top of the next one
+        // (no message registers live across the substitution); before the first step: zeros
+        wv.sync();
+        if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
-        for (int n = 0; n < NC; ++n) send3[n][0] = send3[n][1] = send3[n][2] = TG(0);
+            for (int i = 0; i < 3 * NC; ++i) ms_[i] = 0.0; }
         for (int t = 0; t < NB + G.maxlevel; ++t) {
             const int b = t - (G.maxlevel - lvl);
             const bool valid = active && b >= 0 && b < NB;
@@ -1906,10 +1909,6 @@ struct LaneProgram {
             unsigned long long tg0 = wv.clock();
 #endif
             {   // children -> parent through the mailbox (only the body-row roles carry anything)
-                wv.sync();
-                if (q < 2) { double* ms_ = mail_slot(qb, q);
-#pragma unroll
-                    for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)send3[n][i]; }
                 wv.sync();
 #pragma unroll
                 for (int ci = 0; ci < MAXCH; ++ci) {
@@ -1951,34 +1950,41 @@ struct LaneProgram {
             }
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the six columns of the batch together: right-hand sides, one forward substitution of all six, then the messages
-            TG r3a[NC][3], ua[NC][3];
+            TG r3a[NC][3];
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
-                TG r_[3], u_[3];
+                TG r_[3];
                 if constexpr (MODE == 0) {
                     const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
-                    const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0)), um = isS ? um_s : rm;
-                    const int ir = (isS || uok) ? r_off + cI : 0, iu = (isS || uok) ? u_off_ + cI : 0, ij = isS ? j_off + cI : 0;
+                    const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0));
+                    const int ir = (isS || uok) ? r_off + cI : 0, ij = isS ? j_off + cI : 0;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]), av_ = TG(R.a[ir + i * 6]), jv_ = TG(R.jd[ij + i * 6]);
                         r_[i] = od ? dv_ : rm * (q < 2 ? av_ : jv_);
-                        u_[i] = um * TG(R.a[iu + i * 6]);
                     }
                     r_[2] += wkm * TG(R.jd[sl_off + cI]);
                 } else {
                     const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { r_[i] = rm * TG(R.a[r_off + i * 6 + cI]); u_[i] = TG(0); }
+                    for (int i = 0; i < 3; ++i) r_[i] = rm * TG(R.a[r_off + i * 6 + cI]);
                 }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0); ua[cI][i] = u_[i]; }
+                for (int i = 0; i < 3; ++i) r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0);
             }
             lu_forward_quad<NC>(Lm, r3a);                         // ỹ = L11⁻¹ r
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
                 const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
                 const TG (&yy)[3] = r3a[cI];
+                TG ua[3] = {TG(0), TG(0), TG(0)};                 // the direct right-hand side of the parent's body rows (read here: not live across the substitution)
+                if constexpr (MODE == 0) {
+                    const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
+                    const TG um = isS ? um_s : (uok ? TG(1) : TG(0));
+                    const int iu = (isS || uok) ? u_off_ + cI : 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) ua[i] = um * TG(R.a[iu + i * 6]);
+                }
                 TG part[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) part[i] = mq[i][0] * yy[0] + mq[i][1] * yy[1] + mq[i][2] * yy[2];
@@ -1986,9 +1992,13 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 1);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) part[i] += wv.quad_xor(part[i], 2);
-                if (valid) {
+                // the message to the parent's body rows, posted at once (an invalid step posts zeros: its batch is out of range for the
+                // parent's next step as well)
+                if (cI == 0) wv.sync();                             // (every supernode has read its children's messages of the previous step)
+                if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; send3[cI][i] = (has_parent && q < 2) ? ua[cI][i] - (q == 0 ? p0_ : p1_) : TG(0); }
+                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; ms_[3 * cI + i] = (double)((valid && has_parent) ? ua[i] - (q == 0 ? p0_ : p1_) : TG(0)); } }
+                if (valid) {
                     if (col_ok(b, cI) && y_nz(b)) {
                         if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
                         else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
@@ -2003,9 +2013,11 @@ struct LaneProgram {
         // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
         TG Um[3][12], Tq[3][6], di[3];                          // D⁻¹U11 − I, T = L11⁻¹U and the reciprocal pivots (load_lu_down)
         load_lu_down(Um, Tq, di);
-        TG d3[NC][3];
+        // (as in the up-sweep: Δv, Δω of a batch are posted at the end of the step that solved them)
+        wv.sync();
+        if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
-        for (int n = 0; n < NC; ++n) d3[n][0] = d3[n][1] = d3[n][2] = TG(0);
+            for (int i = 0; i < 3 * NC; ++i) ms_[i] = 0.0; }
         // the parked ỹ of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
         // away and nothing else hides it with one wave per SIMD)
         T Mq[9];
@@ -2044,38 +2056,38 @@ struct LaneProgram {
             TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the parent finished this batch in the previous step: its two body-row roles posted Δv, Δω of the six columns
             wv.sync();
-            if (q < 2) { double* ms_ = mail_slot(qb, q);
-#pragma unroll
-                for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)d3[n][i]; }
-            wv.sync();
-            TG pall[NC][6];
+            // x = U11⁻¹ (ỹ − T x_parent) of the six columns (T = 0 on the roots: store_lu)
+            TG x3[NC][3];
             {
                 const double* p0 = mail_slot(pb, 0); const double* p1 = mail_slot(pb, 1);
 #pragma unroll
-                for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) { pall[n][i] = TG(p0[3 * n + i]); pall[n][3 + i] = TG(p1[3 * n + i]); }
-            }
-            // x = U11⁻¹ (ỹ − T x_parent) of the six columns (T = 0 on the roots: store_lu)
-            TG x3[NC][3];
+                for (int n = 0; n < NC; ++n) {
+                    const bool ok_ = valid && col_ok(b, n);
+                    TG pall[6];
 #pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                const bool ok_ = valid && col_ok(b, n);
+                    for (int i = 0; i < 3; ++i) { pall[i] = TG(p0[3 * n + i]); pall[3 + i] = TG(p1[3 * n + i]); }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { TG a_ = ok_ ? TG(ycur[n][i]) : TG(0);
+                    for (int i = 0; i < 3; ++i) { TG a_ = ok_ ? TG(ycur[n][i]) : TG(0);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) a_ -= Tq[i][j] * pall[n][j];
-                    x3[n][i] = a_; }
+                        for (int j = 0; j < 6; ++j) a_ -= Tq[i][j] * pall[j];
+                        x3[n][i] = a_; }
+                }
             }
             lu_backward_quad<NC>(Um, di, x3);
+            wv.sync();                                            // (every supernode has read its parent's Δv, Δω of the previous step)
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
-                if (valid) {
+                // posted at once (an invalid step posts zeros: its batch is out of range for the children's next step as well)
+                TG d3[1][3];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) d3[n][i] = x3[n][i];
-                }
+                for (int i = 0; i < 3; ++i) d3[0][i] = valid ? x3[n][i] : TG(0);
+                if (q < 2) { double* ms_ = mail_slot(qb, q);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)d3[0][i]; }
                 if (valid && q < 2 && col_ok(b, n)) {
                     // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows)
                     TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
-                    T d_[3] = {T(d3[n][0]), T(d3[n][1]), T(d3[n][2])};
+                    T d_[3] = {T(d3[0][0]), T(d3[0][1]), T(d3[0][2])};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         T x = Mq[3 * i] * d_[0] + Mq[3 * i + 1] * d_[1] + Mq[3 * i + 2] * d_[2];

@@ -11,6 +11,17 @@ _lib = None
 _lib_lin = None
 
 
+def _build(so, src, flags=()):
+    """compile once, whoever comes first (pytest-xdist workers race here): under a file lock, into a temporary name, renamed into place"""
+    import fcntl
+    with open(so + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(so) or any(os.path.getmtime(s_) > os.path.getmtime(so) for s_ in src):
+            tmp = "%s.%d.tmp" % (so, os.getpid())
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", *flags, "-o", tmp, src[0]])
+            os.replace(tmp, so)
+
+
 def lib_linear():
     """the emulator compiled with -DDJ_LINEAR=1 (LinearContact builds of the device source: six cone pairs per contact)"""
     global _lib_lin
@@ -18,8 +29,7 @@ def lib_linear():
         so = os.path.join(_HERE, "emu", "libemu_lin.so")
         src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
                                                          for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DDJ_LINEAR=1", "-o", so, src[0]])
+        _build(so, src, ("-DDJ_LINEAR=1",))
         _lib_lin = C.CDLL(so)
         _lib_lin.emu_step.restype = C.c_int
     return _lib_lin
@@ -34,8 +44,7 @@ def lib():
         so = os.path.join(_HERE, "emu", "libemu.so")
         src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
                                                          for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src[0]])
+        _build(so, src)
         _lib = C.CDLL(so)
         _lib.emu_step.restype = C.c_int
     return _lib
