@@ -34,7 +34,10 @@ struct Barrier {
 
 struct Shared {
     int W; Barrier bar; std::vector<double> slot; std::vector<int> islot; std::vector<double> lds;
-    explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(160 * 1024 / 8) {}
+    // "LDS" of the emulated workgroup.  The emulator's lanes are not in lock step, so Cold / the contact pool are per LANE here
+    // (StepLds, LOCKSTEP = false): the MAXC = 8 layout needs 167 KB -- more than the GPU's 160 KB, which the lock-step layouts fit.
+    static constexpr size_t kLdsBytes = 256 * 1024;
+    explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(kLdsBytes / 8) {}
 };
 
 template <int NW, bool RF = false>
@@ -125,6 +128,8 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     // refining IFT kernel
     std::vector<int> flagbuf(B, 0); A.flag = (QUAD && A.G.refine_w < INFINITY) ? flagbuf.data() : nullptr;
     if (!A.flag) A.blk = nullptr;
+    static_assert((size_t)dj::step_lds_bytes<TIO, T, MAXC, 0, QUAD, false, NW>() <= Shared::kLdsBytes && (size_t)dj::step_lds_bytes<TIO, T, MAXC, 1, QUAD, false, NW>() <= Shared::kLdsBytes
+                  && (size_t)dj::step_lds_bytes<TIO, T, MAXC, 2, QUAD, false, NW>() <= Shared::kLdsBytes, "the emulated LDS block is too small for this layout");
     for (int pass = 0; pass < 4; ++pass) {
         if ((pass == 1 || pass == 3) && !A.flag) continue;
         if (pass >= 2 && !(dz && !dbg)) continue;
