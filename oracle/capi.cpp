@@ -82,6 +82,22 @@ struct OracleT : IOracle {
             for (int i = 0; i < 3; ++i) out[i] = (double)d[i];
             return 3;
         }
+        if (what >= 9) {
+            // dampers of the joint half at the states in = [xa qa xb qb | p(3, unused) | va ωa vb ωb] (candidate velocities: vsol[2], ωsol[2]):
+            //   what 9 / 10: damper_impulses(:parent / :child, ...) = timestep * damper_force(...; rotate = true, unitary = false) -> 6
+            //                (rotational/dampers.jl:4-30, translational/dampers.jl:5-37)
+            //   what 11..14: damper_jacobian_configuration(relative, jacobian, ...) -> 6x6, (relative, jacobian) = pp, pc, cp, cc
+            //   what 15..18: damper_jacobian_velocity(relative, jacobian, ...)      -> 6x6     (dampers.jl:36-84 / :70-123)
+            orc::State<T> pa, ch;
+            pa.x2 = xa; pa.q2 = qa; ch.x2 = xb; ch.q2 = qb;
+            pa.vsol[1] = M::vec({(T)in[17], (T)in[18], (T)in[19]}); pa.wsol[1] = M::vec({(T)in[20], (T)in[21], (T)in[22]});
+            ch.vsol[1] = M::vec({(T)in[23], (T)in[24], (T)in[25]}); ch.wsol[1] = M::vec({(T)in[26], (T)in[27], (T)in[28]});
+            if (what <= 10) { M r = m.half_damper_impulses(what == 9, J, h, pa, ch, false); for (int i = 0; i < 6; ++i) out[i] = (double)r[i]; return 6; }
+            const int k = (what - 11) % 4; const bool rel_parent = k < 2, jac_parent = (k % 2) == 0;
+            M Jm = what <= 14 ? m.half_damper_jacobian_configuration(rel_parent, jac_parent, J, h, pa, ch) : m.half_damper_jacobian_velocity(rel_parent, jac_parent, J, h, pa, ch);
+            for (int i = 0; i < 36; ++i) out[i] = (double)Jm.a[i];
+            return 36;
+        }
         if (what >= 3) {
             // what 3 / 4: impulse_transform(:parent / :child, ...) * p -> 6 (joints/impulses.jl:4-8), p = in[14:17]
             // what 5..8: impulse_transform_jacobian(relative, jacobian, ..., p) -> 6x6, (relative, jacobian) = (parent,parent), (parent,child),

@@ -92,3 +92,39 @@ def test_impulse_transform_jacobians(name, kw, joint, half):
             return o.joint_unit(joint, half, 3 if rel_parent else 4, xa, qa, z[:3], z[3:], p0)
         att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
         assert np.abs(J0 - _fd(f, np.concatenate([x, q])) @ att).max() < 1e-6
+
+
+JOINT_TYPES = ["Fixed", "Prismatic", "Planar", "FixedOrientation", "Revolute", "Cylindrical", "PlanarAxis", "FreeRevolute", "Orbital",
+               "PrismaticOrbital", "PlanarOrbital", "FreeOrbital", "Spherical", "CylindricalFree", "PlanarFree"]
+
+
+@pytest.mark.parametrize("joint_type", JOINT_TYPES)
+def test_damper_jacobians(joint_type):
+    """test/damper.jl:1-104 ("rotational damper jacobian"): for the joint between the two links of a snake with dampers 0.3, each of the
+    fifteen joint prototypes: damper_jacobian_configuration(relative, jacobian, ...) against the derivative of
+    timestep * damper_force(relative, ...; rotate = true, unitary = false) w.r.t. (x, q) of the `jacobian` body times the attitude Jacobian,
+    and damper_jacobian_velocity against its derivative w.r.t. (v, ω), all four (relative, jacobian) pairs, 1e-8 like the reference --
+    at random configurations and velocities instead of the end of a controlled rollout, and for the translational half as well (the
+    reference's test covers the rotational one)."""
+    import dojo_amd as d
+    spec = d.get_mechanism("snake", gravity=0.0, num_bodies=2, dampers=0.3, joint_type=joint_type)
+    o = oracle.Oracle(spec)
+    rng = np.random.default_rng(11)
+    xa, xb, qa, qb = rng.normal(size=3), rng.normal(size=3), _rand_quat(rng), _rand_quat(rng)
+    vel = rng.normal(size=12)
+    for half in (1, 0):
+        for k, (rel_parent, jac_parent) in enumerate(((True, True), (True, False), (False, True), (False, False))):
+            x, q = (xa, qa) if jac_parent else (xb, qb)
+            def force_cfg(z):
+                if jac_parent:
+                    return o.joint_unit(1, half, 9 if rel_parent else 10, z[:3], z[3:], xb, qb, vel=vel)
+                return o.joint_unit(1, half, 9 if rel_parent else 10, xa, qa, z[:3], z[3:], vel=vel)
+            def force_vel(w):
+                v2 = vel.copy(); v2[0 if jac_parent else 6:6 if jac_parent else 12] = w
+                return o.joint_unit(1, half, 9 if rel_parent else 10, xa, qa, xb, qb, vel=v2)
+            att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
+            Jc = o.joint_unit(1, half, 11 + k, xa, qa, xb, qb, vel=vel).reshape(6, 6)
+            Jv = o.joint_unit(1, half, 15 + k, xa, qa, xb, qb, vel=vel).reshape(6, 6)
+            ec = np.abs(Jc - _fd(force_cfg, np.concatenate([x, q])) @ att).max()
+            ev = np.abs(Jv - _fd(force_vel, vel[0 if jac_parent else 6:6 if jac_parent else 12])).max()
+            assert ec < 1e-8 and ev < 1e-8, (joint_type, half, rel_parent, jac_parent, ec, ev)
