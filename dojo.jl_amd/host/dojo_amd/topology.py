@@ -35,7 +35,8 @@ class CJoint(C.Structure):
 
 class CContact(C.Structure):
     _fields_ = [("body", C.c_int32), ("model", C.c_int32), ("friction_coefficient", C.c_double),
-                ("normal", d3), ("tangent", d6), ("origin", d3), ("radius", C.c_double), ("offset", d3)]
+                ("normal", d3), ("tangent", d6), ("origin", d3), ("radius", C.c_double), ("offset", d3),
+                ("collision", C.c_int32), ("child_body", C.c_int32), ("child_origin", d3), ("child_radius", C.c_double)]
 
 
 class CTopology(C.Structure):
@@ -148,6 +149,10 @@ class ContactSpec:
     radius: float = 0.0
     offset: np.ndarray = field(default_factory=lambda: np.zeros(3))
     model: int = 0                 # 0: NonlinearContact, 1: ImpactContact (src/contacts/impact.jl)
+    collision: int = 0             # 0: SphereHalfSpaceCollision (child = origin), 1: SphereSphereCollision (src/contacts/collisions/sphere_sphere.jl)
+    child_body: int = -1           # collision 1: the contact's child body (its joint hangs on `body`); (origin, radius) = the parent's sphere
+    child_origin: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    child_radius: float = 0.0
 
 
 @dataclass
@@ -232,6 +237,8 @@ class MechanismSpec:
             K[i].origin = d3(*c.origin)
             K[i].radius = float(c.radius)
             K[i].offset = d3(*c.offset)
+            K[i].collision, K[i].child_body = int(c.collision), int(c.child_body)
+            K[i].child_origin = d3(*c.child_origin); K[i].child_radius = float(c.child_radius)
         T = CTopology(nb, nj, nc, 0, float(self.timestep), float(self.input_scaling), d3(*self.gravity),
                       C.cast(B, C.POINTER(CBody)), C.cast(J, C.POINTER(CJoint)), C.cast(K, C.POINTER(CContact)))
         return T, (B, J, K)

@@ -49,6 +49,7 @@ struct IOracle {
     virtual long long sparse_solve_flops() = 0;
     virtual void ls_stats(long long* out) = 0;
     virtual int joint_unit(int joint, int half, int what, const double* in, double* out) = 0;
+    virtual int contact_unit(int contact, int what, const double* in, double* out) = 0;
     virtual void input_impulses(const double* z, const double* u, double* jf) = 0;
     virtual void maximal_to_minimal(const double* z, double* x) = 0;
     virtual void minimal_to_maximal(const double* x, double* z) = 0;
@@ -113,6 +114,39 @@ struct OracleT : IOracle {
         M XQ = orc::hcat(X, Qm);
         for (int i = 0; i < 18; ++i) out[i] = (double)XQ.a[i];
         return 18;
+    }
+    // unit functions of one body-body contact's collision at given configurations in = [xp(3) qp(4) xc(3) qc(4)]
+    // (src/contacts/collisions/{collision,sphere_sphere}.jl; what test/collisions.jl:59-170 differentiates):
+    //   0 distance -> 1    1 / 2 contact_point(:parent / :child) -> 3    3 contact_normal -> 3    4 contact_tangent -> 2x3
+    //   10 / 11 ∂distance∂x(:parent / :child) -> 1x3        12 / 13 ∂distance∂q -> 1x4
+    //   14..17 ∂contact_point∂x(relative, jacobian) -> 3x3, (relative, jacobian) = pp, pc, cp, cc      18..21 ∂contact_point∂q -> 3x4
+    //   22 / 23 ∂contact_normal_transpose∂x -> 3x3          24 / 25 ∂contact_normal_transpose∂q -> 3x4
+    //   26 / 27, 28 / 29 ∂contact_tangent_one / two_transpose∂x -> 3x3      30 / 31, 32 / 33 ... ∂q -> 3x4
+    int contact_unit(int contact, int what, const double* in, double* out) override {
+        using M = orc::SM<T>; using Q = orc::Quat<T>;
+        const orc::Contact<T>& c = m.contacts[contact];
+        if (c.kind != 1) return -1;
+        typename orc::Mechanism<T>::SS k{M::vec({(T)in[0], (T)in[1], (T)in[2]}), M::vec({(T)in[7], (T)in[8], (T)in[9]}),
+                                         Q((T)in[3], (T)in[4], (T)in[5], (T)in[6]), Q((T)in[10], (T)in[11], (T)in[12], (T)in[13])};
+        auto put = [&](const M& a) { for (int i = 0; i < a.r * a.c; ++i) out[i] = (double)a.a[i]; return a.r * a.c; };
+        const bool jp = (what % 2) == 0;
+        switch (what) {
+            case 0: out[0] = (double)m.ss_distance(c, k); return 1;
+            case 1: case 2: return put(m.ss_contact_point(what == 1, c, k));
+            case 3: return put(m.ss_normal(c, k));
+            case 4: return put(m.ss_tangent(c, k));
+            case 10: case 11: return put(m.ss_dd_dx(jp, c, k));
+            case 12: case 13: return put(m.ss_dd_dq(jp, c, k));
+            case 14: case 15: case 16: case 17: return put(m.ss_dcp_dx(what < 16, jp, c, k));
+            case 18: case 19: case 20: case 21: return put(m.ss_dcp_dq(what < 20, jp, c, k));
+            case 22: case 23: return put(m.ss_dnT_dx(jp, c, k));
+            case 24: case 25: return put(m.ss_dnT_dq(jp, c, k));
+            case 26: case 27: return put(m.ss_dt1T_dx(jp, c, k));
+            case 28: case 29: return put(m.ss_dt2T_dx(jp, c, k));
+            case 30: case 31: return put(m.ss_dt1T_dq(jp, c, k));
+            case 32: case 33: return put(m.ss_dt2T_dq(jp, c, k));
+        }
+        return -1;
     }
     void maximal_to_minimal(const double* z, double* x) override {
         int nz = 13 * (int)m.bodies.size(), nm = 2 * m.nu();
@@ -387,6 +421,7 @@ double orc_time_batch(void* h, int B, const double* z, const double* u, int with
 //   4 mrp(q[4]) -> 3     5 dmrpdq(q) -> 3x4     6 axis(q) -> 3     7 daxisdq(q) -> 3x4      src/orientation/mrp.jl
 //   8 rotation_vector(q) -> 3     9 drotation_vectordq(q) -> 3x4                              mrp.jl:61-78
 int orc_joint_unit(void* h, int joint, int half, int what, const double* in, double* out) { return ((IOracle*)h)->joint_unit(joint, half, what, in, out); }
+int orc_contact_unit(void* h, int contact, int what, const double* in, double* out) { return ((IOracle*)h)->contact_unit(contact, what, in, out); }
 int orc_unit(int what, const double* in, double* out) {
     using M = orc::SM<double>; using Q = orc::Quat<double>;
     auto put = [&](const M& m) { for (int i = 0; i < m.r * m.c; ++i) out[i] = m.a[i]; };

@@ -82,6 +82,9 @@ struct Contact {
     int nh() const { return model == 1 ? 1 : model == 2 ? 6 : 4; }     // N½: γ and s each (LinearContact: [γ ψ β1..β4])
     T mu = 0;                      // friction_coefficient
     M normal, tangent, origin, offset; T radius = 0;   // 1x3, 2x3, 3, 3
+    // SphereSphereCollision (kind 1, sphere_sphere.jl:11-16): `body` = parent_id with (origin, radius) = (origin_parent, radius_parent),
+    // body2 = child_id with (origin_c, radius_c)
+    int kind = 0; int body2 = -1; M origin_c = M(3, 1); T radius_c = 0;
     M gam[2] = {M(4, 1), M(4, 1)}; // impulses       (γ)
     M s[2] = {M(4, 1), M(4, 1)};   // impulses_dual  (s)
 };
@@ -177,6 +180,8 @@ struct Mechanism {
             c.normal = M(1, 3); c.tangent = M(2, 3); c.origin = M(3, 1); c.offset = M(3, 1);
             for (int k = 0; k < 3; ++k) { c.normal.a[k] = T(s.normal[k]); c.origin[k] = T(s.origin[k]); c.offset[k] = T(s.offset[k]); }
             for (int k = 0; k < 6; ++k) c.tangent.a[k] = T(s.tangent[k]);
+            c.kind = s.collision; c.body2 = s.collision == 1 ? s.child_body : -1; c.radius_c = T(s.child_radius);
+            for (int k = 0; k < 3; ++k) c.origin_c[k] = T(s.child_origin[k]);
             contacts.push_back(c);
         }
         verbose = std::getenv("ORC_VERBOSE") != nullptr;
@@ -782,6 +787,170 @@ struct Mechanism {
         Qq += drotation_matrix_dq(qi, skew(r) * (X * lam)) * Tmat<T>();
         return vcat(hcat(Xx, Xq), hcat(Qx, Qq));
     }
+    // =====================================================================
+    // BODY-BODY CONTACT: SphereSphereCollision between c.body (parent) and c.body2 (child)
+    // src/contacts/collisions/{collision,sphere_sphere}.jl, src/contacts/{contact,velocity}.jl for two bodies.
+    // The reference RETURNS FiniteDiff approximations from ∂distance∂x/∂q and ∂contact_point∂x/∂q (sphere_sphere.jl:57-63,84-92,
+    // 144-152,186-196) right after computing the analytic expressions; this restatement returns the analytic ones.
+    // =====================================================================
+    static M normalize_(const M& x) { return (T(1) / norm2(x)) * x; }
+    static M dnormalize_dx(const M& x) {                                  // utilities/normalize.jl:10-19
+        T mag = norm2(x);
+        if (!(mag > T(0))) return M::eye(3);
+        return (T(1) / mag) * M::eye(3) - (T(1) / (mag * mag * mag)) * (x * x.t());
+    }
+    struct SS { M xp, xc; Q qp, qc; };
+    SS ss_next(const Contact<T>& c) const { const State<T>& a = bodies[c.body].st; const State<T>& b = bodies[c.body2].st; return SS{x3(a), x3(b), q3(a), q3(b)}; }
+    M ss_cop(const Contact<T>& c, const SS& k) const { return k.xp + vector_rotate(c.origin, k.qp); }      // contact_point_origin  collision.jl:9-11
+    M ss_coc(const Contact<T>& c, const SS& k) const { return k.xc + vector_rotate(c.origin_c, k.qc); }
+    T ss_distance(const Contact<T>& c, const SS& k) const { return norm2(ss_cop(c, k) - ss_coc(c, k)) - (c.radius + c.radius_c); }   // sphere_sphere.jl:28-38
+    M ss_contact_point(bool rel_parent, const Contact<T>& c, const SS& k) const {                         // :96-111
+        M cop = ss_cop(c, k), coc = ss_coc(c, k); M dir = normalize_(cop - coc);
+        return rel_parent ? cop - c.radius * dir : coc + c.radius_c * dir;
+    }
+    M ss_dd_dx(bool jac_parent, const Contact<T>& c, const SS& k) const {                                 // :40-66 (the analytic D)
+        M dn = (T(1) / norm2(ss_cop(c, k) - ss_coc(c, k))) * (ss_cop(c, k) - ss_coc(c, k)).t();         // ∂norm∂x
+        return jac_parent ? dn : T(-1) * dn;
+    }
+    M ss_dd_dq(bool jac_parent, const Contact<T>& c, const SS& k) const {                                 // :68-93
+        M dn = (T(1) / norm2(ss_cop(c, k) - ss_coc(c, k))) * (ss_cop(c, k) - ss_coc(c, k)).t();
+        return jac_parent ? dn * dvector_rotate_dq(c.origin, k.qp) : T(-1) * (dn * dvector_rotate_dq(c.origin_c, k.qc));
+    }
+    M ss_dcp_dx(bool rel_parent, bool jac_parent, const Contact<T>& c, const SS& k) const {               // :113-153 (the analytic X)
+        M N = dnormalize_dx(ss_cop(c, k) - ss_coc(c, k));
+        if (rel_parent) return jac_parent ? M::eye(3) - c.radius * N : c.radius * N;
+        return jac_parent ? c.radius_c * N : M::eye(3) - c.radius_c * N;
+    }
+    M ss_dcp_dq(bool rel_parent, bool jac_parent, const Contact<T>& c, const SS& k) const {               // :155-199 (the analytic Q)
+        M N = dnormalize_dx(ss_cop(c, k) - ss_coc(c, k));
+        M dp = dvector_rotate_dq(c.origin, k.qp), dc = dvector_rotate_dq(c.origin_c, k.qc);
+        if (rel_parent) return jac_parent ? dp - c.radius * (N * dp) : c.radius * (N * dc);
+        return jac_parent ? c.radius_c * (N * dp) : dc - c.radius_c * (N * dc);
+    }
+    // contact_normal (1x3, child -> parent, flipped in penetration)  collision.jl:27-45
+    M ss_normal(const Contact<T>& c, const SS& k) const {
+        M dir = ss_contact_point(true, c, k) - ss_contact_point(false, c, k);
+        M n = normalize_(dir).t();
+        return ss_distance(c, k) >= T(0) ? n : T(-1) * n;
+    }
+    M ss_dnT_dx(bool jac_parent, const Contact<T>& c, const SS& k) const {                                // collision.jl:47-68
+        M dir = ss_contact_point(true, c, k) - ss_contact_point(false, c, k);
+        M X = dnormalize_dx(dir) * (ss_dcp_dx(true, jac_parent, c, k) - ss_dcp_dx(false, jac_parent, c, k));
+        return ss_distance(c, k) >= T(0) ? X : T(-1) * X;
+    }
+    M ss_dnT_dq(bool jac_parent, const Contact<T>& c, const SS& k) const {                                // collision.jl:70-100
+        M dir = ss_contact_point(true, c, k) - ss_contact_point(false, c, k);
+        M X = dnormalize_dx(dir) * (ss_dcp_dq(true, jac_parent, c, k) - ss_dcp_dq(false, jac_parent, c, k));
+        return ss_distance(c, k) >= T(0) ? X : T(-1) * X;
+    }
+    // the candidate axis of the first tangent (collision.jl:102-116; the Jacobians test 1e-5 instead of 1e-6, :160-167)
+    M ss_w(const Contact<T>& c, const SS& k, T tol) const {
+        M n = ss_normal(c, k); M w = M::vec({1, 0, 0});
+        if (!(norm2(skew(w) * n.t()) > tol)) w = M::vec({0, 1, 0});
+        return w;
+    }
+    M ss_t1(const Contact<T>& c, const SS& k) const { return (skew(ss_w(c, k, T(1e-6))) * ss_normal(c, k).t()).t(); }    // 1x3, not normalized
+    M ss_t2(const Contact<T>& c, const SS& k) const { return (skew(ss_t1(c, k).t()) * ss_normal(c, k).t()).t(); }          // collision.jl:118-129
+    M ss_tangent(const Contact<T>& c, const SS& k) const { return vcat(ss_t1(c, k), ss_t2(c, k)); }                       // 2x3
+    M ss_dt1T_dx(bool jp, const Contact<T>& c, const SS& k) const { return skew(ss_w(c, k, T(1e-5))) * ss_dnT_dx(jp, c, k); }   // :149-174
+    M ss_dt2T_dx(bool jp, const Contact<T>& c, const SS& k) const {                                                          // :176-194
+        return skew(ss_t1(c, k).t()) * ss_dnT_dx(jp, c, k) + skew(T(-1) * ss_normal(c, k).t()) * ss_dt1T_dx(jp, c, k);
+    }
+    // ∂contact_tangent_one_transpose∂q multiplies by skew(t1) where the ∂x version has skew(w) (collision.jl:207): literal
+    M ss_dt1T_dq(bool jp, const Contact<T>& c, const SS& k) const {
+        M w = ss_w(c, k, T(1e-5)); M t1 = skew(w) * ss_normal(c, k).t();
+        return skew(t1) * ss_dnT_dq(jp, c, k);
+    }
+    M ss_dt2T_dq(bool jp, const Contact<T>& c, const SS& k) const {                                                          // :222-247
+        M w = ss_w(c, k, T(1e-5)); M t1 = skew(w) * ss_normal(c, k).t();
+        M dt1 = skew(w) * ss_dnT_dq(jp, c, k);
+        return skew(t1) * ss_dnT_dq(jp, c, k) + skew(T(-1) * ss_normal(c, k).t()) * dt1;
+    }
+    // contact point velocities and Δv = vp − vc  velocity.jl:2-38
+    struct SSV { M cp, cc, vp, vc, dv; };
+    SSV ss_velocities(const Contact<T>& c, const SS& k) const {
+        const State<T>& a = bodies[c.body].st; const State<T>& b = bodies[c.body2].st;
+        SSV r; r.cp = ss_contact_point(true, c, k); r.cc = ss_contact_point(false, c, k);
+        r.vp = a.vsol[1] + skew(vector_rotate(a.wsol[1], k.qp)) * (r.cp - k.xp);
+        r.vc = b.vsol[1] + skew(vector_rotate(b.wsol[1], k.qc)) * (r.cc - k.xc);
+        r.dv = r.vp - r.vc;
+        return r;
+    }
+    M ss_vt(const Contact<T>& c, const SS& k) const { return ss_tangent(c, k) * ss_velocities(c, k).dv; }
+    // ∂relative_tangential_velocity∂x / ∂q / ∂v / ∂ω (jacobian = :parent | :child)  velocity.jl:40-143
+    M ss_dvt_dx(bool jp, const Contact<T>& c, const SS& k) const {
+        const State<T>& a = bodies[c.body].st; const State<T>& b = bodies[c.body2].st;
+        SSV v = ss_velocities(c, k); M Tm = ss_tangent(c, k);
+        M Sp = skew(vector_rotate(a.wsol[1], k.qp)), Sc = skew(vector_rotate(b.wsol[1], k.qc));     // ∂cpv∂c; ∂cpv∂x = −that
+        M X;
+        if (jp) { X = Tm * (T(-1) * Sp); X += Tm * Sp * ss_dcp_dx(true, true, c, k); X -= Tm * Sc * ss_dcp_dx(false, true, c, k); }
+        else    { X = Tm * Sp * ss_dcp_dx(true, false, c, k); X -= Tm * (T(-1) * Sc); X -= Tm * Sc * ss_dcp_dx(false, false, c, k); }
+        X += vcat(v.dv.t() * ss_dt1T_dx(jp, c, k), v.dv.t() * ss_dt2T_dx(jp, c, k));
+        return X;
+    }
+    M ss_dvt_dq(bool jp, const Contact<T>& c, const SS& k) const {
+        const State<T>& a = bodies[c.body].st; const State<T>& b = bodies[c.body2].st;
+        SSV v = ss_velocities(c, k); M Tm = ss_tangent(c, k);
+        M Sp = skew(vector_rotate(a.wsol[1], k.qp)), Sc = skew(vector_rotate(b.wsol[1], k.qc));
+        M X;
+        if (jp) { X = Tm * ((T(-1) * skew(v.cp - k.xp)) * dvector_rotate_dq(a.wsol[1], k.qp)); X += Tm * Sp * ss_dcp_dq(true, true, c, k); X -= Tm * Sc * ss_dcp_dq(false, true, c, k); }
+        else    { X = Tm * Sp * ss_dcp_dq(true, false, c, k); X -= Tm * ((T(-1) * skew(v.cc - k.xc)) * dvector_rotate_dq(b.wsol[1], k.qc)); X -= Tm * Sc * ss_dcp_dq(false, false, c, k); }
+        X += vcat(v.dv.t() * ss_dt1T_dq(jp, c, k), v.dv.t() * ss_dt2T_dq(jp, c, k));
+        return X;
+    }
+    M ss_dvt_dv(bool jp, const Contact<T>& c, const SS& k) const { return jp ? ss_tangent(c, k) : T(-1) * ss_tangent(c, k); }
+    M ss_dvt_dw(bool jp, const Contact<T>& c, const SS& k) const {
+        SSV v = ss_velocities(c, k); M Tm = ss_tangent(c, k);
+        return jp ? Tm * ((T(-1) * skew(v.cp - k.xp)) * rotation_matrix(k.qp)) : T(-1) * (Tm * ((T(-1) * skew(v.cc - k.xc)) * rotation_matrix(k.qc)));
+    }
+    // constraint(mechanism, contact)  nonlinear.jl:50-76 / impact.jl:41-54 with a two-body collision
+    M ss_constraint(const Contact<T>& c) const {
+        SS k = ss_next(c); T d = ss_distance(c, k);
+        const M& g = c.gam[1]; const M& s = c.s[1];
+        if (c.model == 1) return M::vec({d - s[0]});
+        M vt = ss_vt(c, k);
+        return M::vec({d - s[0], c.mu * g[0] - g[1], vt[0] - s[2], vt[1] - s[3]});
+    }
+    // constraint_jacobian_velocity(relative, model, ...)  contact.jl:37-77 (impact.jl:76-104)
+    M ss_constraint_jacobian_velocity(bool rel_parent, const Contact<T>& c) const {
+        SS k = ss_next(c); const State<T>& st = bodies[rel_parent ? c.body : c.body2].st;
+        M dd_dx = ss_dd_dx(rel_parent, c, k), dd_dq = ss_dd_dq(rel_parent, c, k);
+        // "recover current orientation": next_orientation(q3, −ω, Δt) and the integrator Jacobian there
+        Q q = next_orientation(rel_parent ? k.qp : k.qc, T(-1) * st.wsol[1], dt);
+        M dq_dw = rotational_integrator_jacobian_velocity(q, st.wsol[1], dt);
+        if (c.model == 1) return hcat(dt * dd_dx, dd_dq * dq_dw);
+        M V = vcat(vcat(dt * dd_dx, M(1, 3)), ss_dvt_dv(rel_parent, c, k));
+        M Om = vcat(vcat(dd_dq * dq_dw, M(1, 3)), ss_dvt_dw(rel_parent, c, k) + ss_dvt_dq(rel_parent, c, k) * dq_dw);
+        return hcat(V, Om);
+    }
+    // force_mapping(relative, model, ...)  contact.jl:141-154
+    M ss_force_mapping(bool rel_parent, const Contact<T>& c, const SS& k) const {
+        M X = c.model == 1 ? ss_normal(c, k).t() : hcat(hcat(ss_normal(c, k).t(), M(3, 1)), ss_tangent(c, k).t());
+        return rel_parent ? X : T(-1) * X;
+    }
+    // impulse_map(relative, model, pbody, cbody, timestep)  contact.jl:79-100
+    M ss_impulse_map(bool rel_parent, const Contact<T>& c) const {
+        SS k = ss_next(c);
+        M X = ss_force_mapping(rel_parent, c, k);
+        M r = ss_contact_point(rel_parent, c, k) - (rel_parent ? k.xp : k.xc);
+        return vcat(X, rotation_matrix(inv(rel_parent ? k.qp : k.qc)) * skew(r) * X);
+    }
+    // impulse_map_jacobian(relative, jacobian = relative, model, pbody, cbody, λ, timestep): 6x7  contact.jl:102-138
+    M ss_impulse_map_jacobian(bool rel_parent, const Contact<T>& c) const {
+        SS k = ss_next(c); const M& lam = c.gam[1]; const bool jp = rel_parent;
+        M X = ss_force_mapping(rel_parent, c, k);
+        M Xx = lam[0] * ss_dnT_dx(jp, c, k), Xq = lam[0] * ss_dnT_dq(jp, c, k);                         // ∂force_mapping_jvp∂x / ∂q  :157-199
+        if (c.model != 1) { Xx += lam[2] * ss_dt1T_dx(jp, c, k) + lam[3] * ss_dt2T_dx(jp, c, k); Xq += lam[2] * ss_dt1T_dq(jp, c, k) + lam[3] * ss_dt2T_dq(jp, c, k); }
+        if (!rel_parent) { Xx = T(-1) * Xx; Xq = T(-1) * Xq; }
+        M r = ss_contact_point(rel_parent, c, k) - (rel_parent ? k.xp : k.xc); Q qi = inv(rel_parent ? k.qp : k.qc);
+        M Qx = rotation_matrix(qi) * skew(r) * Xx;
+        Qx -= rotation_matrix(qi) * skew(X * lam) * (ss_dcp_dx(rel_parent, jp, c, k) - M::eye(3));
+        M Qq = rotation_matrix(qi) * skew(r) * Xq;
+        Qq -= rotation_matrix(qi) * skew(X * lam) * ss_dcp_dq(rel_parent, jp, c, k);
+        Qq += drotation_matrix_dq(qi, skew(r) * (X * lam)) * Tmat<T>();
+        return vcat(hcat(Xx, Xq), hcat(Qx, Qq));
+    }
+
     void reset_contact(Contact<T>& c) {   // contacts/constraints.jl:79-86, neutral_vector nonlinear.jl:99
         M nv = c.model == 1 ? M::vec({1}) : c.model == 2 ? M::vec({1, 1, 1, 1, 1, 1}) : M::vec({1, 1, 0, 0});       // neutral_vector: contact.jl:202 (ones(N½)) / nonlinear.jl:99
         c.gam[0] = nv; c.gam[1] = nv; c.s[0] = nv; c.s[1] = nv;
@@ -835,7 +1004,10 @@ struct Mechanism {
             if (J.spring) d -= joint_spring_impulses(J, parent, false);
             if (J.damper) d -= joint_damper_impulses(J, parent, false);
         }
-        for (auto& c : contacts) if (c.body == ib) d -= contact_impulse_map(c) * c.gam[1];
+        for (auto& c : contacts) {
+            if (c.kind == 1) { if (c.body == ib || c.body2 == ib) d -= ss_impulse_map(c.body == ib, c) * c.gam[1]; continue; }
+            if (c.body == ib) d -= contact_impulse_map(c) * c.gam[1];
+        }
         s.d = d;
         return d;
     }
@@ -861,7 +1033,10 @@ struct Mechanism {
                 D -= half_damper_jacobian_velocity(parent, parent, J, J.rot, pa, ch);
             }
         }
-        for (auto& c : contacts) if (c.body == ib) D -= contact_impulse_map_jacobian(c) * ijv;
+        for (auto& c : contacts) {
+            if (c.kind == 1) { if (c.body == ib || c.body2 == ib) D -= ss_impulse_map_jacobian(c.body == ib, c) * ijv; continue; }
+            if (c.body == ib) D -= contact_impulse_map_jacobian(c) * ijv;
+        }
         s.D = D;
         return D;
     }
@@ -909,6 +1084,15 @@ struct Mechanism {
             put(coff[k], coff[k], contact_constraint_jacobian(c));
             M comp = contact_complementarity(c); comp[0] -= mu; if (c.model == 0) comp[1] -= mu;   // complementarityμ: − μ·neutral_vector
             if (c.model == 2) for (int i = 1; i < 6; ++i) comp[i] -= mu;
+            if (c.kind == 1) {      // two bodies: contacts/constraints.jl:60-70 for the parent and for the child (no body-body entry: system.jl:33-40)
+                putv(coff[k], vcat(-comp, -ss_constraint(c)));
+                for (int side = 0; side < 2; ++side) {
+                    const int ib = side == 0 ? c.body : c.body2;
+                    put(boff[ib], coff[k], hcat(M(6, c.nh()), -ss_impulse_map(side == 0, c)));
+                    put(coff[k], boff[ib], vcat(M(c.nh(), 6), ss_constraint_jacobian_velocity(side == 0, c)));
+                }
+                continue;
+            }
             putv(coff[k], vcat(-comp, -contact_constraint(c)));
             put(boff[c.body], coff[k], hcat(M(6, c.nh()), -contact_impulse_map(c)));
             put(coff[k], boff[c.body], vcat(M(c.nh(), 6), contact_constraint_jacobian_velocity(c)));
@@ -929,7 +1113,7 @@ struct Mechanism {
             for (int i = 0; i < J.rot.nl; ++i) v = std::fmax(v, std::fabs(res[o + i]));
         }
         for (size_t i = 0; i < bodies.size(); ++i) v = std::fmax(v, body_constraint((int)i).norm_inf());
-        for (auto& c : contacts) v = std::fmax(v, contact_constraint(c).norm_inf());
+        for (auto& c : contacts) v = std::fmax(v, (c.kind == 1 ? ss_constraint(c) : contact_constraint(c)).norm_inf());
         return v;
     }
     T bilinear_violation() {

@@ -41,7 +41,7 @@ def lib():
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
         _lib.orc_ls_stats.restype = None
-        _lib.orc_unit.restype = C.c_int; _lib.orc_joint_unit.restype = C.c_int
+        _lib.orc_unit.restype = C.c_int; _lib.orc_joint_unit.restype = C.c_int; _lib.orc_contact_unit.restype = C.c_int
         _lib.orc_input_impulses.restype = None
         _lib.orc_maximal_to_minimal.restype = None; _lib.orc_minimal_to_maximal.restype = None
         _lib.orc_step.restype = C.c_int
@@ -226,6 +226,14 @@ class Oracle:
         (15..18) Jacobians at the velocities vel = [va ωa vb ωb], of one joint half (0 translational, 1 rotational); see oracle/capi.cpp"""
         inp = np.concatenate([xa, qa, xb, qb, np.zeros(3) if p is None else p, np.zeros(12) if vel is None else vel]).astype(np.float64); out = np.zeros(36)
         n = lib().orc_joint_unit(self.h, int(joint), int(half), int(what), _p(inp), _p(out))
+        return out[:n].copy()
+
+    def contact_unit(self, contact, what, xp, qp, xc, qc):
+        """collision functions of a body-body contact at given configurations (see oracle/capi.cpp: contact_unit)"""
+        inp = np.concatenate([xp, qp, xc, qc]).astype(np.float64); out = np.zeros(16)
+        n = lib().orc_contact_unit(self.h, int(contact), int(what), _p(inp), _p(out))
+        if n < 0:
+            raise ValueError("contact_unit: contact %d / what %d" % (contact, what))
         return out[:n].copy()
 
     def sparse_flops(self):
