@@ -50,6 +50,11 @@
 #define DJ_REFINE 0
 #endif
 
+#ifndef DJ_SS
+#define DJ_SS 0             // 1: builds that carry body-body contacts (SphereSphereCollision between a body and its tree child, src/contacts/collisions/
+                            // sphere_sphere.jl; forward only): ContactCold holds the parent-side rows as well
+#endif
+
 namespace dj {
 
 constexpr int MAXCH = 4;          // children per body supported by the lane program
@@ -89,7 +94,7 @@ struct NodeP {
     T spring_r, damper_r, spring_off_r[3], lim_lo, lim_hi;
 };
 template <class T>
-struct ContactP { T n[3], t[6], o[3], off[3], r, mu; };
+struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2; int kind; };   // kind 1: SphereSphereCollision, r = radius_parent, r2 = radius_child (origins zero), parent = the owner's tree parent
 
 // ------------------------------------------------------------------------------------------------
 // Lane-local dynamic state
@@ -249,7 +254,11 @@ struct Cold {
     T pad_[((sizeof(JointCfg<T>) / sizeof(T)) % 2 == 0) ? 1 : 2];       // odd stride in 8-byte words
 };
 template <class T>
-struct ContactCold { T C134[18], G134[18]; };
+struct ContactCold { T C134[18], G134[18];
+#if DJ_SS
+                     T Cp134[18], Gp134[18];      // body-body contact: the rows of the contact's PARENT body (the owner's tree parent); zero otherwise
+#endif
+};
 
 // IFT data-Jacobian blocks of one supernode (datamat = −∂residual/∂θ, src/gradients/data.jl), stored
 // once per supernode (per quad) in the precision of the ABI buffers
@@ -921,6 +930,100 @@ DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& k
     }
 }
 
+// Body-body contact: SphereSphereCollision between the owner's tree parent (the contact's parent_id, sphere radius K.r about its centre
+// of mass) and the owner (child_id, K.r2).  src/contacts/collisions/{collision,sphere_sphere}.jl, src/contacts/{contact,velocity}.jl in
+// closed form for origin_parent = origin_child = 0 (the analytic expressions; the reference returns FiniteDiff values of the same):
+//   n = (x_p − x_c)/|x_p − x_c| (child -> parent), N = ∂n/∂x_p = (I − n nᵀ)/|x_p − x_c| = −∂n/∂x_c,  t1 = w × n (w = e_x, or e_y when
+//   |e_x × n| <= 1e-6), t2 = t1 × n (neither normalized: collision.jl:102-129),  levers l_p = −r n, l_c = r2 n,
+//   force on the parent F = n γ1 + t1 γ3 + t2 γ4, on the child −F  (force_mapping, contact.jl:141-154)
+// `kb` / `ka`: the owner's and the parent's kinematics at the candidate velocities.
+template <class T>
+struct ContactEvalSS { T imp_p[6]; T Cp134[18], Gp134[18]; T Sxx[9], Swx[9], Pwx[9], Pww[9]; };   // parent-side rows; −∂(impulse)/∂v blocks: own (v,v), (ω,v); parent (ω,v), (ω,ω)
+template <bool JAC, class T>
+DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const ContactP<T>& K, const Kin<T>& kb, const Kin<T>& ka,
+                           const T* v, const T* w, const T* va, const T* wa, const T* s, const T* gam, T dt, bool impact) {
+    T dx[3], n[3], t1[3], t2[3], wax[3] = {T(1), T(0), T(0)};
+    for (int i = 0; i < 3; ++i) dx[i] = ka.x3[i] - kb.x3[i];
+    const T dist = tsqrt(v3dot(dx, dx)), id = trcp(dist);
+    for (int i = 0; i < 3; ++i) n[i] = dx[i] * id;
+    v3cross(t1, wax, n);
+    if (!(tsqrt(v3dot(t1, t1)) > T(1e-6))) { wax[0] = T(0); wax[1] = T(1); v3cross(t1, wax, n); }
+    v3cross(t2, t1, n);
+    if (impact) for (int i = 0; i < 3; ++i) t1[i] = t2[i] = T(0);      // ImpactContact (impact.jl:106-118): the normal alone; the friction block stays at the neutral vector
+    T lp[3], lc[3], Rwp[3], Rwc[3], cp_[3], cc_[3], dv[3];
+    for (int i = 0; i < 3; ++i) { lp[i] = -K.r * n[i]; lc[i] = K.r2 * n[i]; }
+    m3vec(Rwp, ka.R3, wa); m3vec(Rwc, kb.R3, w);
+    v3cross(cp_, Rwp, lp); v3cross(cc_, Rwc, lc);
+    for (int i = 0; i < 3; ++i) dv[i] = (va[i] + cp_[i]) - (v[i] + cc_[i]);           // contact point velocities, velocity.jl:2-38
+    E.c[0] = (dist - (K.r + K.r2)) - s[0];                                               // distance, sphere_sphere.jl:28-38
+    E.c[1] = K.mu * gam[0] - gam[1];
+    E.c[2] = v3dot(t1, dv) - s[2];
+    E.c[3] = v3dot(t2, dv) - s[3];
+    T F[3], lxF[3], tau[3];
+    for (int i = 0; i < 3; ++i) F[i] = n[i] * gam[0] + t1[i] * gam[2] + t2[i] * gam[3];
+    v3cross(lxF, lp, F); m3tvec(tau, ka.R3, lxF);
+    for (int i = 0; i < 3; ++i) { P2.imp_p[i] = F[i]; P2.imp_p[3 + i] = tau[i]; }                                // impulse_map(:parent) γ
+    T Fc[3] = {-F[0], -F[1], -F[2]}, tauc[3];
+    v3cross(lxF, lc, Fc); m3tvec(tauc, kb.R3, lxF);
+    for (int i = 0; i < 3; ++i) { E.imp[i] = Fc[i]; E.imp[3 + i] = tauc[i]; }                                    // impulse_map(:child) γ
+    if (JAC) {
+        const T* dirs[3] = {n, t1, t2};
+        for (int d = 0; d < 3; ++d) {
+            T lx[3], g3[3];
+            v3cross(lx, lp, dirs[d]); m3tvec(g3, ka.R3, lx);
+            for (int i = 0; i < 3; ++i) { P2.Gp134[6 * d + i] = dirs[d][i]; P2.Gp134[6 * d + 3 + i] = g3[i]; }
+            v3cross(lx, lc, dirs[d]); m3tvec(g3, kb.R3, lx);
+            for (int i = 0; i < 3; ++i) { E.G134[6 * d + i] = -dirs[d][i]; E.G134[6 * d + 3 + i] = -g3[i]; }
+        }
+        // constraint_jacobian_velocity(:parent | :child)  contact.jl:37-77: row 1 = [±Δt n | 0] (∂distance∂q = 0 about the centres of mass);
+        // rows 3, 4 = ±[t_i | t_i(−[l]x R + 2 [l]x R [ω]x Φ)]  (∂vt∂v, ∂vt∂ω + ∂vt∂q ∂q∂ω; the position dependence of vt is not in V, as in the reference)
+        for (int side = 0; side < 2; ++side) {
+            const Kin<T>& kk = side == 0 ? ka : kb; const T* l = side == 0 ? lp : lc; const T* ww = side == 0 ? wa : w;
+            const T sg = side == 0 ? T(1) : T(-1);
+            T* Cx = side == 0 ? P2.Cp134 : E.C134;
+            T Sl[9], SlR[9], Sw[9], B1[9], BPhi[9];
+            m3skew(Sl, l); m3mul(SlR, Sl, kk.R3); m3skew(Sw, ww); m3mul(B1, SlR, Sw);
+            for (int i = 0; i < 9; ++i) B1[i] *= T(2);
+            m3mul(BPhi, B1, kk.Phi);
+            for (int j = 0; j < 3; ++j) { Cx[j] = sg * dt * n[j]; Cx[3 + j] = T(0); }
+            for (int r = 0; r < 2; ++r) {
+                const T* tt = r == 0 ? t1 : t2;
+                for (int j = 0; j < 3; ++j) {
+                    Cx[6 * (1 + r) + j] = sg * tt[j];
+                    const T a = -(tt[0] * SlR[j] + tt[1] * SlR[3 + j] + tt[2] * SlR[6 + j]);
+                    const T b = tt[0] * BPhi[j] + tt[1] * BPhi[3 + j] + tt[2] * BPhi[6 + j];
+                    Cx[6 * (1 + r) + 3 + j] = sg * (a + b);
+                }
+            }
+        }
+        // impulse_map_jacobian(relative, relative, ..., γ) · integrator_jacobian_velocity  contact.jl:102-138:
+        //   Xx = K N for both bodies, K = γ1 I + γ3 [w]x + γ4 ([t1]x − [n]x [w]x);  Xq = 0
+        //   Qx(rel) = R_relᵀ([l_rel]x K N + r_rel [F_rel]x N)      (∂contact_point∂x − I = −r_rel N);  Qq ∂q∂ω = 2 [τ_rel]x Φ_rel
+        T N[9], Kw[9], Sn[9], Swx_[9], St1[9], SnSw[9], KN[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = ((i == j ? T(1) : T(0)) - n[i] * n[j]) * id;
+        m3skew(Sn, n); m3skew(Swx_, wax); m3skew(St1, t1); m3mul(SnSw, Sn, Swx_);
+        for (int i = 0; i < 9; ++i) Kw[i] = gam[2] * Swx_[i] + gam[3] * (St1[i] - SnSw[i]);
+        for (int i = 0; i < 3; ++i) Kw[4 * i] += gam[0];
+        m3mul(KN, Kw, N);
+        for (int i = 0; i < 9; ++i) P2.Sxx[i] = dt * KN[i];
+        for (int side = 0; side < 2; ++side) {
+            const Kin<T>& kk = side == 0 ? ka : kb; const T* l = side == 0 ? lp : lc; const T* Fs = side == 0 ? F : Fc;
+            const T rr = side == 0 ? K.r : K.r2; const T* tb = side == 0 ? tau : tauc;
+            T Sl[9], SF[9], A1[9], A2[9], W[9];
+            m3skew(Sl, l); m3skew(SF, Fs); m3mul(A1, Sl, KN); m3mul(A2, SF, N);
+            for (int i = 0; i < 9; ++i) W[i] = A1[i] + rr * A2[i];
+            T* Qx = side == 0 ? P2.Pwx : P2.Swx;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Qx[3 * i + j] = dt * (kk.R3[i] * W[j] + kk.R3[3 + i] * W[3 + j] + kk.R3[6 + i] * W[6 + j]);   // Rᵀ W
+            T St[9], Q2[9];
+            m3skew(St, tb);
+            for (int i = 0; i < 9; ++i) Q2[i] = T(2) * St[i];
+            if (side == 0) m3mul(P2.Pww, Q2, kk.Phi); else { m3mul(E.Dww, Q2, kk.Phi); for (int i = 0; i < 9; ++i) E.Qraw[i] = Q2[i]; }
+        }
+        for (int j = 0; j < 3; ++j) E.c1p[j] = T(0);
+        for (int j = 0; j < 6; ++j) E.c34p[j] = T(0);
+    }
+}
+
 // second-order-cone helpers: src/contacts/cone.jl, src/solver/line_search.jl:98-139
 template <class T> DJ_HD T ort_step(T lam, T dl, T tau) { return dl < T(0) ? tmin(T(1), -tau * lam * trcp(dl)) : T(1); }
 template <class T> DJ_HD T soc_step(const T* l, const T* d, T tau) {
@@ -1098,6 +1201,7 @@ struct LaneProgram {
     // added up inside the quad with two DPP steps; maxima / minima over contacts fold the same way; the per-contact cone variables
     // live once per supernode in LDS (Lane::cs, cg), every lane updating its own contacts' entries.  With one contact per body nothing
     // changes (the lane-local arrays have MAXC entries, cidx(i) = i).
+    static constexpr bool kSS = DJ_SS != 0 && QUAD && MAXC == 1;   // body-body contacts: the single-contact quad builds (the host refuses them elsewhere)
     static constexpr bool kSplitC = QUAD && MAXC >= 4;
     static constexpr int CPL = kSplitC ? MAXC / 4 : MAXC;      // contact slots per lane
     typedef Step<T, CPL> StepT;
@@ -1204,12 +1308,22 @@ struct LaneProgram {
         // allocation is 1 % faster that way, same session).  joint_eval has zeroed / filled K by now.
         constexpr bool kEarly = MAXC > 1;
         ContactEval<T> CE[kEarly ? 1 : MAXC];
+#if DJ_SS
+        ContactEvalSS<T> CS[MAXC];                               // body-body contacts: the rows of the contact's parent body
+        T upc[6] = {0, 0, 0, 0, 0, 0};                           // ... and what they apply to it
+#endif
         T dcon[6] = {0, 0, 0, 0, 0, 0}, dww[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // (split contacts: this lane's share of the contact impulses / curvature terms)
 #pragma unroll
         for (int li = 0; li < CPL; ++li) {
             const int c = cidx(li);
             if (c < P.ncontact) {
                 ContactEval<T>& CEc = CE[kEarly ? 0 : li];
+#if DJ_SS
+                if (kSS && CP[P.contact[c]].kind == 1) {
+                    contact_eval_ss<JAC>(CEc, CS[li], CP[P.contact[c]], kb, ka, L.v, L.w, va, wa, L.cs[c], L.cg[c], dt, G.contact_model == 1);
+                    for (int i = 0; i < 6; ++i) upc[i] += CS[li].imp_p[i];
+                } else
+#endif
                 contact_eval<JAC>(CEc, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
                 if constexpr (kSplitC) { for (int i = 0; i < 6; ++i) dcon[i] += CEc.imp[i]; } else { for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i]; }
                 for (int i = 0; i < NCV; ++i) cres[li][i] = CEc.c[i];
@@ -1242,6 +1356,9 @@ struct LaneProgram {
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -E.imp_a[i] : T(0);
+#if DJ_SS
+        for (int i = 0; i < 6; ++i) up[i] -= has_parent ? upc[i] : T(0);
+#endif
         if constexpr (QUAD) { mail_post_node<6>(up); mail_add_children_node<6>(d, active, G.maxch); }
         else gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
@@ -1276,6 +1393,22 @@ struct LaneProgram {
 #pragma unroll
                             for (int j = 0; j < 3; ++j) K.addS(3 + i, 3 + j, -CE[c].Dww[3 * i + j]);
                         { ContactCold<T>& cc_ = ccold(c); for (int i = 0; i < 18; ++i) { cc_.C134[i] = CE[c].C134[i]; cc_.G134[i] = CE[c].G134[i]; } }
+#if DJ_SS
+                        if constexpr (kSS) {   // body-body contact: −∂(impulses)/∂(v, ω) of both bodies (contacts/constraints.jl:54-57) and the parent-side rows
+                            const bool ss_ = CP[P.contact[c]].kind == 1;
+                            ContactCold<T>& cc_ = ccold(c);
+                            for (int i = 0; i < 18; ++i) { cc_.Cp134[i] = ss_ ? CS[c].Cp134[i] : T(0); cc_.Gp134[i] = ss_ ? CS[c].Gp134[i] : T(0); }
+                            if (ss_) {
+#pragma unroll
+                                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                                    for (int j = 0; j < 3; ++j) {
+                                        K.addS(i, j, -CS[c].Sxx[3 * i + j]); K.addS(3 + i, j, -CS[c].Swx[3 * i + j]);
+                                        K.addD(i, j, -CS[c].Sxx[3 * i + j]); K.addD(3 + i, j, -CS[c].Pwx[3 * i + j]); K.addD(3 + i, 3 + j, -CS[c].Pww[3 * i + j]);
+                                    }
+                            }
+                        }
+#endif
                     }
                 }
             }
@@ -1430,6 +1563,33 @@ struct LaneProgram {
 #pragma unroll
                             for (int j = 0; j < 6; ++j) K.S[i][j] -= TL(g0 * Mc[0][j] + g1 * Mc[1][j] + g2 * Mc[2][j]);
                         }
+#if DJ_SS
+                        // body-body contact: Δγ134 = k0 + coef (C134 Δw + Cp134 Δw_parent); the parent's body rows carry −Gp134 Δγ134:
+                        //   U −= G134ᵀ coef Cp134,   L −= Gp134ᵀ coef C134,   Dup −= Gp134ᵀ coef Cp134     (all zero for a half-space contact)
+                        if constexpr (kSS) {
+                        T Mp[3][6];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) Mp[a][j] = Q.coef[3 * a] * cc_.Cp134[j] + Q.coef[3 * a + 1] * cc_.Cp134[6 + j] + Q.coef[3 * a + 2] * cc_.Cp134[12 + j];
+                        const T* pq = cc_.Gp134 + 3 * q;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const T g0 = gq[i], g1 = gq[6 + i], g2 = gq[12 + i], p0 = pq[i], p1 = pq[6 + i], p2 = pq[12 + i];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) {
+                                K.U[i][j] -= TL(g0 * Mp[0][j] + g1 * Mp[1][j] + g2 * Mp[2][j]);
+                                K.D[i][j] -= TL(p0 * Mp[0][j] + p1 * Mp[1][j] + p2 * Mp[2][j]);
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            const T p0 = cc_.Gp134[r], p1 = cc_.Gp134[6 + r], p2 = cc_.Gp134[12 + r];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) K.L[r][i] -= TL(p0 * Mc[0][3 * q + i] + p1 * Mc[1][3 * q + i] + p2 * Mc[2][3 * q + i]);
+                        }
+                        }
+#endif
                     }
                     continue;
                 }
@@ -1595,7 +1755,7 @@ struct LaneProgram {
             // translational damper, whose force on the child body depends on the parent's velocity: DJ_TSD builds)
             // Tq = S⁻¹(own rows) U gathered one source role at a time (18 values in flight instead of 54), then the 6x6 product
             // L Tq in two row halves (rows 0:3 end on role 0, rows 3:6 on role 1): 18 partial sums in flight instead of 36
-            constexpr int U0 = DJ_TSD ? 0 : 1;
+            constexpr int U0 = (DJ_TSD || DJ_SS) ? 0 : 1;     // (a body-body contact fills them too: the force on the child depends on the velocity of the parent)
             TL Tq[3][6];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -2204,6 +2364,9 @@ struct LaneProgram {
                 contact_coef(Q[li], c, R.cc[li], r58[li]);
                 if constexpr (kSplitC) { for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rkc[i] += ccold(c).G134[6 * a + i] * Q[li].k0[a]; }
                 else { for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) rk[i] += ccold(c).G134[6 * a + i] * Q[li].k0[a]; }
+#if DJ_SS
+                if constexpr (kSS) { for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) up[i] += ccold(c).Gp134[6 * a + i] * Q[li].k0[a]; }      // (zero rows for a half-space contact)
+#endif
             }
         }
         if constexpr (kSplitC) { quad_sum(rkc); for (int i = 0; i < 6; ++i) rk[i] += rkc[i]; }
@@ -2238,6 +2401,9 @@ struct LaneProgram {
                 const ContactP<T>& K = CP[P.contact[c]];
                 T cw[3];
                 for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += ccold(c).C134[6 * a + j] * D.dv[j] + ccold(c).C134[6 * a + 3 + j] * D.dw[j]; }
+#if DJ_SS
+                if constexpr (kSS) { for (int a = 0; a < 3; ++a) for (int j = 0; j < 6; ++j) cw[a] += ccold(c).Cp134[6 * a + j] * dva[j]; }
+#endif
                 const CCoef& q = Q[li];
                 if constexpr (kLinear) {                               // recovery of the twelve LinearContact variables (see contact_coef)
                     const T n_ = cw[0], t1_ = cw[1], t2_ = cw[2];
@@ -3252,8 +3418,12 @@ struct LaneProgram {
 //   D2 − D1 = [m(v25 + v15); ½Δt(c25 Jω25 + ω25×Jω25) + ½Δt(c15 Jω15 − ω15×Jω15)].
 // zb = the body's 13 state values the step was solved at, v/w = its solution (v25, ω25), csg = [s(4); γ(4)] per contact
 // of the environment, rb = the body's six residual rows.  Shared by the HIP storage kernel and the SIMT emulator.
-template <class T, class TC>
-DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb, const T* fe = nullptr) {
+// Body-body contacts (ContactP::kind 1) need the other body: `other(body index, zb[13], v[3], w[3])` loads its state and solution and
+// `nodes` is the node table (null: the mechanism has none).
+struct NoOtherBody { template <class T> DJ_HD void operator()(int, T*, T*, T*) const {} };
+template <class T, class TC, class OTHER = NoOtherBody>
+DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb, const T* fe = nullptr,
+                       const NodeP<T>* nodes = nullptr, OTHER other = OTHER()) {
     const T x2[3] = {zb[0], zb[1], zb[2]}, v15[3] = {zb[3], zb[4], zb[5]}, q2[4] = {zb[6], zb[7], zb[8], zb[9]}, w15[3] = {zb[10], zb[11], zb[12]};
     Kin<T> kb;
     kin_of(kb, x2, q2, v, w, dt);
@@ -3270,8 +3440,27 @@ DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, c
         T cs[4], cg[4];
         for (int i = 0; i < 4; ++i) { cs[i] = T(csg[8 * id + i]); cg[i] = T(csg[8 * id + 4 + i]); }
         ContactEval<T> CE;
-        contact_eval<false>(CE, CP[id], kb, v, w, cs, cg, dt);
+        if (CP[id].kind == 1 && nodes != nullptr) {              // this body is the child of a body-body contact: its parent's state at the same step
+            T zo[13], vo[3], wo[3]; other(P.parent, zo, vo, wo);
+            Kin<T> ka; kin_of(ka, zo, zo + 6, vo, wo, dt);
+            ContactEvalSS<T> CS;
+            contact_eval_ss<false>(CE, CS, CP[id], kb, ka, v, w, vo, wo, cs, cg, dt, false);
+        } else contact_eval<false>(CE, CP[id], kb, v, w, cs, cg, dt);
         for (int i = 0; i < 6; ++i) p[i] += CE.imp[i];
+    }
+    if (nodes != nullptr) for (int ci = 0; ci < P.nchild; ++ci) {      // ... and the parent of its children's body-body contacts
+        const NodeP<T>& Pc = nodes[P.child[ci]];
+        for (int c = 0; c < Pc.ncontact; ++c) {
+            const int id = Pc.contact[c];
+            if (CP[id].kind != 1) continue;
+            T cs[4], cg[4], zo[13], vo[3], wo[3];
+            for (int i = 0; i < 4; ++i) { cs[i] = T(csg[8 * id + i]); cg[i] = T(csg[8 * id + 4 + i]); }
+            other(P.child[ci], zo, vo, wo);
+            Kin<T> kc; kin_of(kc, zo, zo + 6, vo, wo, dt);
+            ContactEval<T> CE; ContactEvalSS<T> CS;
+            contact_eval_ss<false>(CE, CS, CP[id], kc, kb, vo, wo, v, w, cs, cg, dt, false);
+            for (int i = 0; i < 6; ++i) p[i] += CS.imp_p[i];
+        }
     }
     for (int i = 0; i < 6; ++i) p[i] *= T(0.5);
     // simulate! clears the external force before it records (simulate.jl:29-31): momentum's D2 is evaluated without it

@@ -45,6 +45,7 @@ DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_laun
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
 DJ_DECL(dojo_launch_lin_float_1_1) DJ_DECL(dojo_launch_lin_float_4_1) DJ_DECL(dojo_launch_lin_double_1_1) DJ_DECL(dojo_launch_lin_double_4_1)     // LinearContact builds
+DJ_DECL(dojo_launch_ss_float_1_1) DJ_DECL(dojo_launch_ss_double_1_1)     // body-body contacts (-DDJ_SS=1): single-wavefront quad mapping, <= 1 contact per body, forward only
 #define DJ_CDECL(n) int n(const void*, int, void*);
 DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
 DJ_CDECL(dojo_launch_cgrad_double_1_1) DJ_CDECL(dojo_launch_cgrad_double_4_1) DJ_CDECL(dojo_launch_cgrad_double_8_1)
@@ -195,7 +196,11 @@ __global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double
     for (int i = 0; i < 13; ++i) zb[i] = (double)z[env * 13 * Nb + 13 * k + i];
     for (int i = 0; i < 3; ++i) { v[i] = (double)vel[env * 6 * Nb + 6 * k + i]; w[i] = (double)vel[env * 6 * Nb + 6 * k + 3 + i]; }
     for (int i = 0; i < 6; ++i) rb[i] = (double)res[env * 6 * Nb + 6 * k + i];
-    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb, fext ? fe : (const double*)nullptr);
+    auto other = [=](int b, double* zo, double* vo, double* wo) {            // (body-body contacts: the contact partner's state and solution)
+        for (int i = 0; i < 13; ++i) zo[i] = (double)z[env * 13 * Nb + 13 * b + i];
+        for (int i = 0; i < 3; ++i) { vo[i] = (double)vel[env * 6 * Nb + 6 * b + i]; wo[i] = (double)vel[env * 6 * Nb + 6 * b + 3 + i]; }
+    };
+    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb, fext ? fe : (const double*)nullptr, nodes, other);
     TIO* o = storage + (env * Nb + k) * 25;
     for (int i = 0; i < 25; ++i) o[i] = (TIO)row[i];
 }
@@ -390,6 +395,7 @@ int acquire_slot(DojoSim* s, int* idx) {
 // (rtol 1e-6, btol 1e-4) are met by the plain solves; tighter ones enable the refining kernels.
 double refine_threshold(const DojoSim* s) {
     if (s->M.contact_model == 2) return (double)INFINITY;       // LinearContact builds carry no refining kernels
+    if (s->M.has_ss) return (double)INFINITY;                   // ... nor do the body-body contact builds
     return s->refine_w >= 0.0 ? s->refine_w : ((s->opts.rtol <= 1e-7 || s->opts.btol <= 1e-6) ? DOJO_DEFAULT_REFINE_STIFFNESS : (double)INFINITY);
 }
 // scalars per contact in the exported [s; gamma] block: 8 (NonlinearContact; ImpactContact uses the first of each four), 12 (LinearContact)
@@ -454,6 +460,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     int slot = -1;
     if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = (dz != nullptr) || (dc != nullptr);
+    if (g && s->M.has_ss) { g_err = "gradients are not available for mechanisms with a body-body contact"; return DOJO_ERR_UNSUPPORTED; }
     if (g && s->M.contact_model != 0) {   // the reference has no data Jacobians for ImpactContact / LinearContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
         g_err = "gradients are not available for ImpactContact / LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
     }
@@ -500,7 +507,8 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         return DOJO_OK;
     }
     launcher_t fn;
-    if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
+    if (s->M.has_ss) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
+    else if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
     else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
                                           : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
     else if (NW == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_2 : dojo_launch_double_1_2) : (f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2);
@@ -588,6 +596,9 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
     if (s->M.has_tsd && (mapping_waves(s->M) != 1 || s->M.maxc > 4)) {
         g_err = "translational springs/dampers need the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    }
+    if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd || s->M.contact_model == 2)) {
+        g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     if (s->M.contact_model == 2 && (mapping_waves(s->M) != 1 || s->M.maxc > 4 || s->M.has_tsd)) {
         g_err = "LinearContact needs the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body, no translational springs / dampers / limits)"; delete s; return DOJO_ERR_UNSUPPORTED;

@@ -18,6 +18,7 @@ struct HostModel {
     std::vector<ContactP<double>> contacts;
     std::vector<TraSD<double>> tsd;   // [Nb + 1] translational springs / dampers per supernode (+ the idle slot's zero entry)
     bool has_tsd = false;
+    bool has_ss = false;          // a body-body contact (SphereSphereCollision): the DJ_SS kernels, forward only
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
     std::string error;
 };
@@ -105,7 +106,17 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     for (int c = 0; c < M.Nc; ++c) {
         const DojoContact& K = tp.contacts[c];
         if (K.body < 0 || K.body >= M.Nb) { M.error = "contact with invalid body index"; return DOJO_ERR_INVALID; }
-        NodeP<double>& P = M.nodes[K.body];
+        // a body-body contact (SphereSphereCollision) belongs to the supernode of its CHILD body, next to the joint that ties it to the parent
+        int owner = K.body;
+        if (K.collision == 1) {
+            if (K.child_body < 0 || K.child_body >= M.Nb || M.nodes[K.child_body].parent != K.body) {
+                M.error = "body-body contact: child_body must be a body whose joint hangs on `body` (the contact has to be an edge of the tree)"; return DOJO_ERR_UNSUPPORTED; }
+            for (int i = 0; i < 3; ++i) if (K.origin[i] != 0.0 || K.child_origin[i] != 0.0) {
+                M.error = "body-body contact: only spheres about the centres of mass (origin_parent = origin_child = 0)"; return DOJO_ERR_UNSUPPORTED; }
+            if (K.model == 2) { M.error = "body-body contact with LinearContact is not supported"; return DOJO_ERR_UNSUPPORTED; }
+            owner = K.child_body; M.has_ss = true;
+        } else if (K.collision != 0) { M.error = "unknown collision (0 = SphereHalfSpaceCollision, 1 = SphereSphereCollision)"; return DOJO_ERR_UNSUPPORTED; }
+        NodeP<double>& P = M.nodes[owner];
         if (P.ncontact >= 8) { M.error = "more than 8 contacts on one body is not supported"; return DOJO_ERR_UNSUPPORTED; }
         P.contact[P.ncontact++] = c;
         if (P.ncontact > M.maxc) M.maxc = P.ncontact;
@@ -118,6 +129,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         // no friction coefficient, and the device pins the friction variables at the neutral vector
         for (int i = 0; i < 6; ++i) Q.t[i] = K.model == 1 ? 0.0 : K.tangent[i];
         Q.r = K.radius; Q.mu = K.model == 1 ? 0.0 : K.friction_coefficient;
+        Q.kind = K.collision; Q.r2 = K.collision == 1 ? K.child_radius : 0.0;
     }
     return DOJO_OK;
 }
@@ -139,7 +151,7 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
     ContactP<T> b;
     for (int i = 0; i < 3; ++i) { b.n[i] = T(a.n[i]); b.o[i] = T(a.o[i]); b.off[i] = T(a.off[i]); }
     for (int i = 0; i < 6; ++i) b.t[i] = T(a.t[i]);
-    b.r = T(a.r); b.mu = T(a.mu);
+    b.r = T(a.r); b.mu = T(a.mu); b.r2 = T(a.r2); b.kind = a.kind;
     return b;
 }
 // refine_w: stiffness (max γ/s over the cones of an environment) beyond which the device refines its linear solves against

@@ -159,6 +159,8 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
 #if DJ_LINEAR   // LinearContact builds: the step kernel alone (forward only, like the reference; no refinement, no IFT)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_lin_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#elif DJ_SS     // builds with body-body contacts: the step kernel alone (forward only)
+#define DJ_LAUNCHER DJ_CAT(dojo_launch_ss_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #elif DJ_TSD    // builds that evaluate translational springs / dampers (KernelArgs::tsd)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_tsd_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #define DJ_CLAUNCHER DJ_CAT(dojo_launch_cgrad_tsd_, DJ_TIO, DJ_MAXC, DJ_QUAD)
@@ -172,11 +174,11 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, v
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
     constexpr int NW = DJ_QUAD == 2 ? 2 : 1;
     hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
-#if DJ_QUAD != 0 && DJ_REFINE
+#if DJ_QUAD != 0 && DJ_REFINE && !DJ_SS
     if (A.flag != nullptr) hipLaunchKernelGGL((dojo_stepp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
 #endif
     if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
-#if DJ_LINEAR
+#if DJ_LINEAR || DJ_SS
     (void)grad;
     return (int)hipGetLastError();
 #else
@@ -188,7 +190,7 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, v
 #endif
 }
 
-#if DJ_QUAD != 0 && !DJ_LINEAR
+#if DJ_QUAD != 0 && !DJ_LINEAR && !DJ_SS
 // the contact-data IFT kernel alone (the step kernel of the same inputs must have run with its hand-off enabled)
 extern "C" int DJ_CLAUNCHER(const void* args, int grid, void* stream) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;

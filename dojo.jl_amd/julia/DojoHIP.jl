@@ -42,6 +42,7 @@ end
 struct CContact
     body::Int32; model::Int32; friction_coefficient::Cdouble
     normal::NTuple{3,Cdouble}; tangent::NTuple{6,Cdouble}; origin::NTuple{3,Cdouble}; radius::Cdouble; offset::NTuple{3,Cdouble}
+    collision::Int32; child_body::Int32; child_origin::NTuple{3,Cdouble}; child_radius::Cdouble      # SphereSphereCollision (collision = 1)
 end
 struct CTopology
     n_bodies::Int32; n_joints::Int32; n_contacts::Int32; reserved::Int32
@@ -75,11 +76,24 @@ function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
         (c.model isa Dojo.NonlinearContact || c.model isa Dojo.ImpactContact || c.model isa Dojo.LinearContact) || error("DojoHIP: unknown contact model")
         impact = c.model isa Dojo.ImpactContact
         col = c.model.collision
-        col isa Dojo.SphereHalfSpaceCollision || error("DojoHIP: only SphereHalfSpaceCollision is supported")
+        if col isa Dojo.SphereSphereCollision
+            # body-body contact (src/contacts/collisions/sphere_sphere.jl): forward only, spheres about the centres of mass, and the child body's
+            # joint must hang on the parent body.  A child body WITHOUT a joint (test/collisions.jl:2-58) gets a Floating joint to the parent here:
+            # no rows; its six inputs come last in the library's u and must stay zero (pad u accordingly).
+            cb = bidx(c.child_id)
+            if !any(j -> j.child == cb, joints)
+                free = CJointHalf(0, 0, ntuple(_ -> 0.0, 9), rowmajor([1.0 0 0; 0 1 0; 0 0 1]), 0.0, 0.0, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3))
+                push!(joints, CJoint(bidx(c.parent_id), cb, Int32(0), Int32(0), ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3), (1.0, 0.0, 0.0, 0.0), free, free))
+            end
+            push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : 0, impact ? 0.0 : c.model.friction_coefficient, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 6),
+                                     pad(col.origin_parent, 3), col.radius_parent, ntuple(_ -> 0.0, 3), Int32(1), cb, pad(col.origin_child, 3), col.radius_child))
+            continue
+        end
+        col isa Dojo.SphereHalfSpaceCollision || error("DojoHIP: only SphereHalfSpaceCollision and SphereSphereCollision are supported")
         # (LinearContact: the library has the reference's friction_parameterization [0 1; 0 -1; 1 0; -1 0] built in, src/contacts/linear.jl:33-38)
         push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : (c.model isa Dojo.LinearContact ? 2 : 0), impact ? 0.0 : c.model.friction_coefficient, pad(col.contact_normal', 3),
                                  impact ? ntuple(_ -> 0.0, 6) : pad(vec(permutedims(Matrix(col.contact_tangent))), 6), pad(col.contact_origin, 3),
-                                 col.contact_radius, pad(col.contact_offset, 3)))
+                                 col.contact_radius, pad(col.contact_offset, 3), Int32(0), Int32(-1), ntuple(_ -> 0.0, 3), 0.0))
     end
     return bodies, joints, contacts
 end

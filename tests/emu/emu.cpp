@@ -6,6 +6,7 @@
 // It is not a product path: libdojo_hip.so has no CPU fallback.
 #define DJ_DEBUG 1
 #define DJ_TSD 1        // the emulator always carries the translational spring / damper code (KernelArgs::tsd decides)
+#define DJ_SS 1         // ... and the body-body contact code (ContactP::kind decides)
 #include "../../dojo.jl_amd/csrc/dojo_host.hpp"
 #include <thread>
 #include <mutex>
@@ -35,8 +36,8 @@ struct Barrier {
 struct Shared {
     int W; Barrier bar; std::vector<double> slot; std::vector<int> islot; std::vector<double> lds;
     // "LDS" of the emulated workgroup.  The emulator's lanes are not in lock step, so Cold / the contact pool are per LANE here
-    // (StepLds, LOCKSTEP = false): the MAXC = 8 layout needs 167 KB -- more than the GPU's 160 KB, which the lock-step layouts fit.
-    static constexpr size_t kLdsBytes = 256 * 1024;
+    // (StepLds, LOCKSTEP = false): the MAXC = 8 layout needs 167 KB (twice that with the body-body contact rows of DJ_SS) -- more than the GPU's 160 KB, which the lock-step layouts fit.
+    static constexpr size_t kLdsBytes = 512 * 1024;
     explicit Shared(int w) : W(w), bar(w), slot(w), islot(w), lds(kLdsBytes / 8) {}
 };
 
@@ -164,7 +165,11 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
             for (int i = 0; i < 13; ++i) zb[i] = T(zt[(size_t)e * nz + 13 * k + i]);
             for (int i = 0; i < 3; ++i) { v[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + i]); w[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * k + 3 + i]); }
             for (int i = 0; i < 6; ++i) rb[i] = T(rest[(size_t)e * 6 * M.Nb + 6 * k + i]);
-            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr);
+            auto other = [&](int b, T* zo, T* vo, T* wo) {
+                for (int i = 0; i < 13; ++i) zo[i] = T(zt[(size_t)e * nz + 13 * b + i]);
+                for (int i = 0; i < 3; ++i) { vo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + i]); wo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + 3 + i]); }
+            };
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr, nodes.data(), other);
             for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
         }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
@@ -184,6 +189,8 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
     if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || M.contact_model == 2 || dz != nullptr)) {       // (as dojo_create / launch)
+        if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();

@@ -480,3 +480,77 @@ def test_lane_per_supernode_mapping_lu_form(seed, nb):
                 dz, du = o.gradients(mode=0)
                 assert np.abs(r["dz"][b] - dz).max() < 1e-7 * max(1.0, np.abs(dz).max())
                 assert np.abs(r["du"][b] - du).max() < 1e-7 * max(1.0, np.abs(du).max())
+
+
+def _two_sphere_state(x1, x2, v2, w2=(0, 0, 0), v1=(0, 0, 0)):
+    z = np.zeros((2, 13)); z[:, 6] = 1.0
+    z[0, 0:3] = x1; z[0, 3:6] = v1; z[1, 0:3] = x2; z[1, 3:6] = v2; z[1, 10:13] = w2
+    return z.reshape(-1)
+
+
+SS_CASES = [(-9.81, "Fixed", [0, 0, 2.0], [0, 0, 0], (0, 0, 0)), (0.0, "Fixed", [0, 0, 2.0], [0, 0, -5.0], (0, 0, 0)), (0.0, "Floating", [0, 0, 2.0], [0, 0, -5.0], (0, 0, 0)),
+            (0.0, "Fixed", [2.0, 0, 0], [-5.0, 0, 0], (0, 0, 0)), (-9.81, "Floating", [0.3, 0.1, 1.5], [0.5, 0.2, -1.0], (1.0, -2.0, 0.5))]
+
+
+@pytest.mark.parametrize("friction_type", ["nonlinear", "impact"])
+def test_body_body_contact_matches_oracle(friction_type):
+    """SphereSphereCollision between a body and its tree child (src/contacts/collisions/sphere_sphere.jl; the two-sphere mechanism of
+    test/collisions.jl:2-58): the rollouts of the reference's test -- resting under gravity, thrown at the fixed sphere, at a floating one,
+    along x -- and a spinning off-axis landing on a floating sphere.  Same Newton iterates as the oracle: equal iteration counts, states
+    and contact variables to round-off (the contact rows couple the child's supernode to its parent's: U, L and Dup blocks)."""
+    for g, joint, x2, v2, w2 in SS_CASES:
+        spec = d.get_two_spheres(friction_type=friction_type, gravity=g, joint_world_body1=joint)
+        o = Oracle(spec)
+        z = _two_sphere_state([0, 0, 0], x2, v2, w2)
+        for k in range(20):
+            zo, info = o.step(z, np.zeros(spec.nu))
+            r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=True)
+            assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+            nh = 1 if friction_type == "impact" else 4
+            sg = o.get_solution()[-2 * nh:]
+            csg = r["contact_sg"][0].reshape(1, 8)
+            assert np.abs(csg[0, 0:nh] - sg[:nh]).max() < 1e-8 and np.abs(csg[0, 4:4 + nh] - sg[nh:]).max() < 1e-8
+            z = zo
+
+
+def test_body_body_contact_storage_rows():
+    """save_to_storage! with a body-body contact: the momenta of BOTH bodies need the contact impulse (dj::storage_row evaluates the
+    contact from either side with the partner's state); against the oracle's momentum.jl restatement, in contact"""
+    spec = d.get_two_spheres(friction_type="nonlinear", gravity=-9.81, joint_world_body1="Floating")
+    opts = d.SolverOptions()
+    o = Oracle(spec, opts=opts)
+    z = _two_sphere_state([0, 0, 0], [0.2, 0.1, 1.05], [0.3, 0.0, -2.0], (0.5, 1.0, 0.0))
+    hit = False
+    for k in range(6):
+        S, st = o.simulate_storage(z, np.zeros((1, spec.nu)))
+        r = emu_step(spec, z[None], np.zeros((1, spec.nu)), opts=opts, quad=True)
+        assert st[0] == 0 and r["status"][0] == 0
+        assert np.abs(r["storage"][0] - S[0]).max() < 1e-9 * max(1.0, np.abs(S[0]).max())
+        hit = hit or o.get_solution()[-4] > 1e-3
+        z, _ = o.step(z, np.zeros(spec.nu))
+    assert hit
+
+
+def test_body_body_contact_in_a_chain_with_a_half_space_contact():
+    """a pendulum bob (Revolute to the world) carrying a free sphere that also touches the floor plane through a half-space contact of its
+    own... the free sphere owns the body-body contact, the bob a half-space contact: both kinds in one mechanism, one contact per body"""
+    from dojo_amd.mechanisms import BodySpec, MechanismSpec, Revolute, Floating, sphere_inertia, contact_constraint, sphere_sphere_contact
+    bodies = [BodySpec("bob", 2.0, sphere_inertia(0.3, 2.0)), BodySpec("ball", 0.5, sphere_inertia(0.2, 0.5))]
+    joints = [Revolute("pin", -1, 0, np.array([1.0, 0, 0]), child_vertex=np.array([0, 0, 0.8])), Floating("free", 0, 1)]
+    contacts = [contact_constraint("floor", 0, np.array([0, 0, 1.0]), 0.6, contact_radius=0.3, contact_offset=np.array([0, 0, -1.2])),
+                sphere_sphere_contact("touch", 0, 1, 0.3, 0.2, 0.4)]
+    spec = MechanismSpec("bob_and_ball", bodies, joints, contacts, 0.02, None, np.array([0.0, 0.0, -9.81]))
+    o = Oracle(spec)
+    z = np.zeros((2, 13)); z[:, 6] = 1.0
+    z[0, 0:3] = [0, 0, -0.8]; z[1, 0:3] = [0.05, 0.1, -0.25]; z[1, 3:6] = [0, 0.3, -0.5]; z[0, 10:13] = [0.4, 0, 0]
+    z = z.reshape(-1)
+    touched = False
+    for k in range(40):
+        zo, info = o.step(z, np.zeros(spec.nu))
+        r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=True)
+        assert info["status"] == 0 and r["status"][0] == 0 and abs(int(r["iters"][0]) - info["iters"]) == 0
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+        touched = touched or o.get_solution()[-4] > 1e-4
+        z = zo
+    assert touched
