@@ -187,6 +187,11 @@ struct OracleT : IOracle {
     void set_solution(const double* sol) override { auto s = cast(sol, m.n); m.set_solution(s.data()); }
     void gradients(int mode, double* dz, double* du) override {
         int nx = 12 * (int)m.bodies.size(), nu = m.nu();
+        for (auto& c : m.contacts) if (c.kind == 1) {          // body-body contacts are forward only (no data Jacobians restated): NaN, not numbers
+            for (size_t i = 0; i < (size_t)nx * nx; ++i) dz[i] = std::numeric_limits<double>::quiet_NaN();
+            for (size_t i = 0; i < (size_t)nx * nu; ++i) du[i] = std::numeric_limits<double>::quiet_NaN();
+            return;
+        }
         std::vector<T> a((size_t)nx * nx), b((size_t)nx * std::max(nu, 1));
         std::vector<T> solmat = m.A;   // un-factored matrix of the last set_entries! (mehrotra.jl:69)
         if (mode == DOJO_GRAD_CONSISTENT && pre.size() == m.bodies.size()) {
