@@ -35,6 +35,22 @@ def lib_linear():
     return _lib_lin
 
 
+_lib_ss = None
+
+
+def lib_ss():
+    """the emulator compiled like the GPU's body-body contact builds (-DDJ_TSD=0 with DJ_SS=1)"""
+    global _lib_ss
+    if _lib_ss is None:
+        so = os.path.join(_HERE, "emu", "libemu_ss.so")
+        src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
+                                                         for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
+        _build(so, src, ("-DDJ_TSD=0",))
+        _lib_ss = C.CDLL(so)
+        _lib_ss.emu_step.restype = C.c_int
+    return _lib_ss
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -76,7 +92,8 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     stor = np.zeros((B, spec.Nb, 25))
     fext = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(B, 6 * spec.Nb))
     err = C.create_string_buffer(256)
-    rc = (lib_linear() if linear else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
+    ss = any(getattr(c, "collision", 0) == 1 for c in spec.contacts)          # body-body contacts: the emulator built with the GPU builds' flags
+    rc = (lib_linear() if linear else lib_ss() if ss else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:
         raise RuntimeError("emu_step: %d %s" % (rc, err.value.decode()))
