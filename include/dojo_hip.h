@@ -342,7 +342,11 @@ int  dojo_minimal_gradients_dev(DojoHandle h, const void* x, const void* u, void
                                 void* jx, void* ju, void* stream);
 
 /* timing helper for bench.py: average duration in ms of the last `n` launches of the
- * step kernel measured with hipEvents on the launch stream (roofline.achieved) */
+ * step kernel measured with hipEvents on the launch stream (roofline.achieved).
+ * With environment groups (dojo_set_groups / the library's default for B >= 512) every group is a launch of its own with its own
+ * event pair: dojo_last_kernel_ms / dojo_last_kernel_times then report the LAST GROUP's kernels (1/groups of the batch), and
+ * dojo_kernel_time_totals sums intervals that overlap in time and counts `groups` launches per step.  For the duration of a kernel
+ * over the whole batch call dojo_set_groups(h, 1) first (what bench.py does for its roofline leg). */
 int  dojo_last_kernel_ms(DojoHandle h, double* ms);
 /* the same, split by kernel: the step kernel (Newton loop: step!/mehrotra!) and the IFT kernel (the
  * back-solves of get_maximal_gradients!, src/gradients/state.jl:78-126; 0 when not requested) */

@@ -17,6 +17,7 @@ if what in ("all", "sweep"):
         for grad in (False, True):
             Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
             gm = api.BatchedMechanism(spec, B, dtype="f32")
+            gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
             z = Z.astype(np.float32)
             ms = []
             for k in range(4):
@@ -72,6 +73,7 @@ if what == "phases":
     B = 4096
     Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
     gm = api.BatchedMechanism(spec, B, dtype="f32")
+    gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
     z = Z.astype(np.float32)
     for grad in (False, True):
         for k in range(3):
@@ -98,6 +100,7 @@ if what == "stragglers":
     Z = np.tile(Z0, (B // 64, 1)); mask = (np.abs(np.tile(U0, (B // 64, 1))) > 0)
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000]))
     gm = api.BatchedMechanism(spec, B, dtype="f64")
+    gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
     z = Z.copy(); dumps = []; hist = np.zeros(52, int)
     for k in range(23):
         U = 0.5 * rng.standard_normal((B, spec.nu)) * mask
@@ -137,6 +140,7 @@ if what == "rollout":
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000]))
     Uh = 0.5 * rng.standard_normal((H, B, spec.nu)) * mask
     gm = api.BatchedMechanism(spec, B, dtype="f32")
+    gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
     for rep in range(3):
         t0 = time.perf_counter()
         traj, st = gm.rollout(Z.astype(np.float32), Uh.astype(np.float32), record=False)
@@ -166,6 +170,7 @@ if what == "pcie":
     Z0, U0 = d.synthetic_inputs(spec, 64)
     Z = np.tile(Z0, (B // 64, 1)).astype(np.float32); U = np.tile(U0, (B // 64, 1)).astype(np.float32)
     gm = api.BatchedMechanism(spec, B, dtype="f32")
+    gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
     for grad in (False, True):
         ts = []
         for k in range(4):
