@@ -956,11 +956,20 @@ DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const Contac
     v3cross(cp_, Rwp, lp); v3cross(cc_, Rwc, lc);
     for (int i = 0; i < 3; ++i) dv[i] = (va[i] + cp_[i]) - (v[i] + cc_[i]);           // contact point velocities, velocity.jl:2-38
     E.c[0] = (dist - (K.r + K.r2)) - s[0];                                               // distance, sphere_sphere.jl:28-38
-    E.c[1] = K.mu * gam[0] - gam[1];
-    E.c[2] = v3dot(t1, dv) - s[2];
-    E.c[3] = v3dot(t2, dv) - s[3];
+    T gt1, gt2;                                                                          // the tangential impulse along t1, t2 (Pᵀβ for the LinearContact pyramid)
+    if constexpr (kLinear) {                                                             // linear.jl:71-102, as contact_eval
+        const T vt1 = v3dot(t1, dv), vt2 = v3dot(t2, dv), psi = gam[1];
+        E.c[1] = K.mu * gam[0] - (gam[2] + gam[3] + gam[4] + gam[5]) - s[1];
+        E.c[2] = vt2 + psi - s[2]; E.c[3] = -vt2 + psi - s[3]; E.c[4] = vt1 + psi - s[4]; E.c[5] = -vt1 + psi - s[5];
+        gt1 = gam[4] - gam[5]; gt2 = gam[2] - gam[3];
+    } else {
+        E.c[1] = K.mu * gam[0] - gam[1];
+        E.c[2] = v3dot(t1, dv) - s[2];
+        E.c[3] = v3dot(t2, dv) - s[3];
+        gt1 = gam[2]; gt2 = gam[3];
+    }
     T F[3], lxF[3], tau[3];
-    for (int i = 0; i < 3; ++i) F[i] = n[i] * gam[0] + t1[i] * gam[2] + t2[i] * gam[3];
+    for (int i = 0; i < 3; ++i) F[i] = n[i] * gam[0] + t1[i] * gt1 + t2[i] * gt2;
     v3cross(lxF, lp, F); m3tvec(tau, ka.R3, lxF);
     for (int i = 0; i < 3; ++i) { P2.imp_p[i] = F[i]; P2.imp_p[3 + i] = tau[i]; }                                // impulse_map(:parent) γ
     T Fc[3] = {-F[0], -F[1], -F[2]}, tauc[3];
@@ -997,12 +1006,12 @@ DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const Contac
             }
         }
         // impulse_map_jacobian(relative, relative, ..., γ) · integrator_jacobian_velocity  contact.jl:102-138:
-        //   Xx = K N for both bodies, K = γ1 I + γ3 [w]x + γ4 ([t1]x − [n]x [w]x);  Xq = 0
+        //   Xx = K N for both bodies, K = γ1 I + g1 [w]x + g2 ([t1]x − [n]x [w]x) with (g1, g2) the tangential impulse;  Xq = 0
         //   Qx(rel) = R_relᵀ([l_rel]x K N + r_rel [F_rel]x N)      (∂contact_point∂x − I = −r_rel N);  Qq ∂q∂ω = 2 [τ_rel]x Φ_rel
         T N[9], Kw[9], Sn[9], Swx_[9], St1[9], SnSw[9], KN[9];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = ((i == j ? T(1) : T(0)) - n[i] * n[j]) * id;
         m3skew(Sn, n); m3skew(Swx_, wax); m3skew(St1, t1); m3mul(SnSw, Sn, Swx_);
-        for (int i = 0; i < 9; ++i) Kw[i] = gam[2] * Swx_[i] + gam[3] * (St1[i] - SnSw[i]);
+        for (int i = 0; i < 9; ++i) Kw[i] = gt1 * Swx_[i] + gt2 * (St1[i] - SnSw[i]);
         for (int i = 0; i < 3; ++i) Kw[4 * i] += gam[0];
         m3mul(KN, Kw, N);
         for (int i = 0; i < 9; ++i) P2.Sxx[i] = dt * KN[i];

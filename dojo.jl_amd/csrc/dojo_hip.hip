@@ -507,7 +507,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         return DOJO_OK;
     }
     launcher_t fn;
-    if (s->M.has_ss) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
+    if (s->M.has_ss && s->M.contact_model != 2) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
     else if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
     else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
                                           : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
@@ -597,7 +597,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (s->M.has_tsd && (mapping_waves(s->M) != 1 || s->M.maxc > 4)) {
         g_err = "translational springs/dampers need the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
-    if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd || s->M.contact_model == 2)) {
+    if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
         g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     if (s->M.contact_model == 2 && (mapping_waves(s->M) != 1 || s->M.maxc > 4 || s->M.has_tsd)) {

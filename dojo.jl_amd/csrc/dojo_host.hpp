@@ -113,7 +113,6 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
                 M.error = "body-body contact: child_body must be a body whose joint hangs on `body` (the contact has to be an edge of the tree)"; return DOJO_ERR_UNSUPPORTED; }
             for (int i = 0; i < 3; ++i) if (K.origin[i] != 0.0 || K.child_origin[i] != 0.0) {
                 M.error = "body-body contact: only spheres about the centres of mass (origin_parent = origin_child = 0)"; return DOJO_ERR_UNSUPPORTED; }
-            if (K.model == 2) { M.error = "body-body contact with LinearContact is not supported"; return DOJO_ERR_UNSUPPORTED; }
             owner = K.child_body; M.has_ss = true;
         } else if (K.collision != 0) { M.error = "unknown collision (0 = SphereHalfSpaceCollision, 1 = SphereSphereCollision)"; return DOJO_ERR_UNSUPPORTED; }
         NodeP<double>& P = M.nodes[owner];

@@ -85,7 +85,7 @@ function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
                 free = CJointHalf(0, 0, ntuple(_ -> 0.0, 9), rowmajor([1.0 0 0; 0 1 0; 0 0 1]), 0.0, 0.0, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3))
                 push!(joints, CJoint(bidx(c.parent_id), cb, Int32(0), Int32(0), ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3), (1.0, 0.0, 0.0, 0.0), free, free))
             end
-            push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : 0, impact ? 0.0 : c.model.friction_coefficient, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 6),
+            push!(contacts, CContact(bidx(c.parent_id), impact ? 1 : (c.model isa Dojo.LinearContact ? 2 : 0), impact ? 0.0 : c.model.friction_coefficient, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 6),
                                      pad(col.origin_parent, 3), col.radius_parent, ntuple(_ -> 0.0, 3), Int32(1), cb, pad(col.origin_child, 3), col.radius_child))
             continue
         end

@@ -128,7 +128,7 @@ typedef struct DojoContact {
     double  origin[3];            /* collision.contact_origin                              */
     double  radius;               /* collision.contact_radius                              */
     double  offset[3];            /* collision.contact_offset                              */
-    /* body-body contact (src/contacts/collisions/sphere_sphere.jl:11-16; forward only): `body` is the contact's parent_id, its sphere is
+    /* body-body contact (src/contacts/collisions/sphere_sphere.jl:11-16; forward only; any of the three contact models): `body` is the contact's parent_id, its sphere is
      * (origin, radius); the child sphere sits on child_body, which must be a body whose joint hangs on `body` (the contact is an edge of
      * the tree next to that joint; the reference's test mechanism has no joint there at all: give the child a Floating joint to `body`).
      * Both origins must be zero (spheres about the centres of mass, what test/collisions.jl builds); normal / tangent / offset are unused. */

@@ -909,6 +909,11 @@ struct Mechanism {
         const M& g = c.gam[1]; const M& s = c.s[1];
         if (c.model == 1) return M::vec({d - s[0]});
         M vt = ss_vt(c, k);
+        if (c.model == 2) {                                               // linear.jl:71-102
+            M pv = friction_parameterization() * vt;
+            return M::vec({d - s[0], c.mu * g[0] - (g[2] + g[3] + g[4] + g[5]) - s[1],
+                           pv[0] + g[1] - s[2], pv[1] + g[1] - s[3], pv[2] + g[1] - s[4], pv[3] + g[1] - s[5]});
+        }
         return M::vec({d - s[0], c.mu * g[0] - g[1], vt[0] - s[2], vt[1] - s[3]});
     }
     // constraint_jacobian_velocity(relative, model, ...)  contact.jl:37-77 (impact.jl:76-104)
@@ -919,13 +924,14 @@ struct Mechanism {
         Q q = next_orientation(rel_parent ? k.qp : k.qc, T(-1) * st.wsol[1], dt);
         M dq_dw = rotational_integrator_jacobian_velocity(q, st.wsol[1], dt);
         if (c.model == 1) return hcat(dt * dd_dx, dd_dq * dq_dw);
-        M V = vcat(vcat(dt * dd_dx, M(1, 3)), ss_dvt_dv(rel_parent, c, k));
-        M Om = vcat(vcat(dd_dq * dq_dw, M(1, 3)), ss_dvt_dw(rel_parent, c, k) + ss_dvt_dq(rel_parent, c, k) * dq_dw);
+        M Pm = c.model == 2 ? friction_parameterization() : M::eye(2);
+        M V = vcat(vcat(dt * dd_dx, M(1, 3)), Pm * ss_dvt_dv(rel_parent, c, k));
+        M Om = vcat(vcat(dd_dq * dq_dw, M(1, 3)), Pm * (ss_dvt_dw(rel_parent, c, k) + ss_dvt_dq(rel_parent, c, k) * dq_dw));
         return hcat(V, Om);
     }
     // force_mapping(relative, model, ...)  contact.jl:141-154
     M ss_force_mapping(bool rel_parent, const Contact<T>& c, const SS& k) const {
-        M X = c.model == 1 ? ss_normal(c, k).t() : hcat(hcat(ss_normal(c, k).t(), M(3, 1)), ss_tangent(c, k).t());
+        M X = c.model == 1 ? ss_normal(c, k).t() : hcat(hcat(ss_normal(c, k).t(), M(3, 1)), c.model == 2 ? ss_tangent(c, k).t() * friction_parameterization().t() : ss_tangent(c, k).t());
         return rel_parent ? X : T(-1) * X;
     }
     // impulse_map(relative, model, pbody, cbody, timestep)  contact.jl:79-100
@@ -940,7 +946,11 @@ struct Mechanism {
         SS k = ss_next(c); const M& lam = c.gam[1]; const bool jp = rel_parent;
         M X = ss_force_mapping(rel_parent, c, k);
         M Xx = lam[0] * ss_dnT_dx(jp, c, k), Xq = lam[0] * ss_dnT_dq(jp, c, k);                         // ∂force_mapping_jvp∂x / ∂q  :157-199
-        if (c.model != 1) { Xx += lam[2] * ss_dt1T_dx(jp, c, k) + lam[3] * ss_dt2T_dx(jp, c, k); Xq += lam[2] * ss_dt1T_dq(jp, c, k) + lam[3] * ss_dt2T_dq(jp, c, k); }
+        if (c.model != 1) {
+            // λ_tangent = friction_parameterization' * λ[3:end]  (contact.jl:165,188): (β3 − β4, β1 − β2) for the LinearContact pyramid
+            const T l1 = c.model == 2 ? lam[4] - lam[5] : lam[2], l2 = c.model == 2 ? lam[2] - lam[3] : lam[3];
+            Xx += l1 * ss_dt1T_dx(jp, c, k) + l2 * ss_dt2T_dx(jp, c, k); Xq += l1 * ss_dt1T_dq(jp, c, k) + l2 * ss_dt2T_dq(jp, c, k);
+        }
         if (!rel_parent) { Xx = T(-1) * Xx; Xq = T(-1) * Xq; }
         M r = ss_contact_point(rel_parent, c, k) - (rel_parent ? k.xp : k.xc); Q qi = inv(rel_parent ? k.qp : k.qc);
         M Qx = rotation_matrix(qi) * skew(r) * Xx;

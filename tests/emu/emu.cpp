@@ -193,7 +193,7 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
     if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
-    if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || M.contact_model == 2 || dz != nullptr)) {       // (as dojo_create / launch)
+    if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || dz != nullptr)) {       // (as dojo_create / launch)
         if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);

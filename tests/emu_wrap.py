@@ -29,7 +29,7 @@ def lib_linear():
         so = os.path.join(_HERE, "emu", "libemu_lin.so")
         src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
                                                          for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
-        _build(so, src, ("-DDJ_LINEAR=1",))
+        _build(so, src, ("-DDJ_LINEAR=1", "-DDJ_TSD=0"))      # (the flag set of the GPU's LinearContact builds)
         _lib_lin = C.CDLL(so)
         _lib_lin.emu_step.restype = C.c_int
     return _lib_lin

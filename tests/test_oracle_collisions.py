@@ -2,7 +2,7 @@
 src/contacts/collisions/{collision,sphere_sphere}.jl, src/contacts/{contact,velocity}.jl for a contact between two bodies).
 The collision's Jacobians against finite differences of the functions they differentiate (`test_jacobians`, :59-170), the geometry of
 the two-sphere mechanism, and the rollouts: the free sphere comes to rest on the fixed one, bounces off without gravity, pushes a
-floating one away.  NonlinearContact and ImpactContact (no LinearContact body-body contact here)."""
+floating one away.  For all three friction types of the reference's loop (:nonlinear, :linear, :impact)."""
 import numpy as np
 import pytest
 import dojo_amd as d
@@ -56,7 +56,7 @@ def check_jacobians(o, xp, qp, xc, qc):
 Q1 = np.array([1.0, 0, 0, 0])
 
 
-@pytest.mark.parametrize("friction_type", ["nonlinear", "impact"])
+@pytest.mark.parametrize("friction_type", ["nonlinear", "linear", "impact"])
 def test_geometry_and_jacobians(friction_type):
     """:172-216: distance 1, contact points (0, 0, 0.5) and (0, 0, 1.5), normal (0, 0, -1) (child -> parent), tangents e_y and -e_x; the
     Jacobians there, at a generic pair of poses and in penetration"""
@@ -84,7 +84,7 @@ def rollout(spec, z0, steps, opts=None):
     return np.array(Z).reshape(len(Z), 2, 13), o
 
 
-@pytest.mark.parametrize("friction_type", ["nonlinear", "impact"])
+@pytest.mark.parametrize("friction_type", ["nonlinear", "linear", "impact"])
 def test_rollouts(friction_type):
     """:218-330: 2 s at timestep 0.1.  Under gravity the free sphere ends resting on the fixed one (z = 1 to 1e-4); without gravity, thrown
     at it with 5 m/s, it does not pass (z > 1: the contact is inelastic); a floating first sphere is pushed away (both move down,
@@ -127,7 +127,7 @@ def test_friction_between_the_spheres():
 
 # ---- the HIP path (GPU tier): the same mechanism through the C-ABI ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("friction_type,dtype", [("nonlinear", "f64"), ("impact", "f64"), ("nonlinear", "f32")])
+@pytest.mark.parametrize("friction_type,dtype", [("nonlinear", "f64"), ("impact", "f64"), ("linear", "f64"), ("nonlinear", "f32")])
 def test_body_body_contact_on_the_device(friction_type, dtype):
     """the two-sphere mechanism on the GPU: a batch of 256 environments whose free sphere starts at random places above / beside the other
     one with random velocities and spins, stepped 25 times next to the oracle: equal iteration counts and states within 1e-6 on the environments both sides solve
@@ -168,6 +168,14 @@ def test_body_body_contact_on_the_device(friction_type, dtype):
     spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81)
     gm = api.BatchedMechanism(spec, 4, dtype=dtype)
     z0 = _state(spec, [0, 0, 0], [0, 0, 2.0], [0, 0, 0])
-    Zs, S, st = gm.simulate(np.tile(z0, (4, 1)), np.zeros((20, 4, spec.nu)), steps=20)
+    if friction_type == "linear":                        # (no Storage rows for LinearContact mechanisms: step by step)
+        z = np.tile(z0, (4, 1))
+        for _ in range(20):
+            z, st, _it = gm.step(z, np.zeros((4, spec.nu))); assert (st == 0).all()
+        zend = z[0]
+    else:
+        Zs, S, st = gm.simulate(np.tile(z0, (4, 1)), np.zeros((20, 4, spec.nu)), steps=20)
+        assert (st == 0).all()
+        zend = Zs[-1, 0]
     gm.close()
-    assert (st == 0).all() and np.abs(Zs[-1, 0].astype(np.float64).reshape(2, 13)[1, 0:3] - [0, 0, 1.0]).max() < (1e-4 if dtype == "f64" else 2e-4)      # test/collisions.jl:226
+    assert np.abs(zend.astype(np.float64).reshape(2, 13)[1, 0:3] - [0, 0, 1.0]).max() < (1e-4 if dtype == "f64" else 2e-4)      # test/collisions.jl:226
