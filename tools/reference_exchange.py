@@ -28,6 +28,26 @@ import dojo_amd as d
 # the reference-side constructor calls that build the same five mechanisms (DojoEnvironments/src/mechanisms/*/mechanism.jl)
 BUILDERS = {1: ("pendulum", ""), 2: ("block", "contact_corners=4"), 3: ("ant", "contact_body=false"), 4: ("quadruped", "contact_body=false"), 5: ("atlas", "contact_body=false")}
 TOL = 1e-8
+# config 6 (forward only): the two-sphere mechanism of test/collisions.jl:2-58 with a body-body (SphereSphereCollision) contact, built inline
+# by tools/reference_golden.jl; reference-default tolerances (its Newton matrix is inexact for such a contact: DESIGN.md section 9)
+TWO_SPHERES = 6
+TWO_SPHERES_KW = dict(friction_type="nonlinear", joint_world_body1="Floating", gravity=-9.81)
+
+
+def spec_of(cfg):
+    return d.get_two_spheres(**TWO_SPHERES_KW) if cfg == TWO_SPHERES else d.baseline_config(cfg)
+
+
+def two_spheres_inputs():
+    """seeded states of the two-sphere mechanism: the second sphere approaching / touching / resting on the first from random directions"""
+    rng = np.random.default_rng(606)
+    C = 12
+    Z = np.zeros((C, 2, 13)); Z[:, :, 6] = 1.0
+    dirs = rng.normal(size=(C, 3)); dirs[:, 2] = np.abs(dirs[:, 2]) + 0.3; dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    Z[:, 1, 0:3] = dirs * rng.uniform(1.0005, 1.3, size=(C, 1))
+    Z[:, 1, 3:6] = -dirs * rng.uniform(0.0, 3.0, size=(C, 1)) + 0.3 * rng.normal(size=(C, 3))
+    Z[:, 1, 10:13] = rng.normal(size=(C, 3)); Z[:, 0, 3:6] = 0.2 * rng.normal(size=(C, 3))
+    return Z.reshape(C, 26), np.zeros((C, 12))
 
 
 def fmt(v):
@@ -51,6 +71,15 @@ def export():
                     if sl.stop > sl.start:
                         f.write("u %d %s %s\n" % (c, j.name, fmt(U[c, sl])))
         print("wrote", os.path.join(out, "config%d.txt" % cfg))
+    spec = spec_of(TWO_SPHERES); Z, _ = two_spheres_inputs()
+    with open(os.path.join(out, "config%d.txt" % TWO_SPHERES), "w") as f:
+        f.write("config %d two_spheres %s\n" % (TWO_SPHERES, " ".join("%s=%s" % kv for kv in TWO_SPHERES_KW.items())))
+        f.write("options %r %r\n" % (1e-6, 1e-4))
+        for c in range(len(Z)):
+            f.write("case %d\n" % c)
+            for i, b in enumerate(spec.bodies):
+                f.write("z %d %s %s\n" % (c, b.name, fmt(Z[c, 13 * i:13 * i + 13])))
+    print("wrote", os.path.join(out, "config%d.txt" % TWO_SPHERES))
 
 
 def load_outputs(cfg, directory=None):
@@ -58,7 +87,7 @@ def load_outputs(cfg, directory=None):
     path = os.path.join(directory or os.path.join(ROOT, "tests", "golden", "reference_outputs"), "config%d.txt" % cfg)
     if not os.path.exists(path):
         return None
-    spec = d.baseline_config(cfg)
+    spec = spec_of(cfg)
     bi = {b.name: i for i, b in enumerate(spec.bodies)}
     recs = [ln.split() for ln in open(path) if ln.strip()]
     C = 1 + max(int(r[1]) for r in recs if r[0] in ("zn", "status"))

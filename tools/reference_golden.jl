@@ -28,12 +28,34 @@ parse_kw(s) = begin
     kw = Dict{Symbol,Any}()
     for item in split(s)
         k, v = split(item, "=")
-        kw[Symbol(k)] = v == "true" ? true : v == "false" ? false : (occursin(".", v) ? parse(Float64, v) : parse(Int, v))
+        kw[Symbol(k)] = v == "true" ? true : v == "false" ? false : tryparse(Float64, v) === nothing ? String(v) : (occursin(".", v) ? parse(Float64, v) : parse(Int, v))
     end
     kw
 end
 
+# get_two_body of test/collisions.jl:2-58 with named bodies: a sphere on a joint to the world and a free second sphere that touches it
+# through a SphereSphereCollision contact (forward only: the reference has no data Jacobians for it)
+function two_spheres(; friction_type="nonlinear", joint_world_body1="Floating", gravity=-9.81, timestep=0.1, radius=0.5, mass=1.0, friction_coefficient=0.5)
+    origin = Dojo.Origin{Float64}()
+    pbody = Dojo.Sphere(radius, mass; name=:sphere1)
+    cbody = Dojo.Sphere(radius, mass; name=:sphere2)
+    joint = Dojo.JointConstraint((joint_world_body1 == "Fixed" ? Dojo.Fixed : Dojo.Floating)(origin, pbody); name=:joint)
+    if friction_type == "impact"
+        collision = Dojo.SphereSphereCollision{Float64,0,3,0}(zeros(3), zeros(3), radius, radius)
+        model = Dojo.ImpactContact{Float64,2}(zeros(Float64, 0, 2), collision)
+    elseif friction_type == "linear"
+        collision = Dojo.SphereSphereCollision{Float64,2,3,6}(zeros(3), zeros(3), radius, radius)
+        model = Dojo.LinearContact{Float64,12}(friction_coefficient, [0.0 1.0; 0.0 -1.0; 1.0 0.0; -1.0 0.0], collision)
+    else
+        collision = Dojo.SphereSphereCollision{Float64,2,3,6}(zeros(3), zeros(3), radius, radius)
+        model = Dojo.NonlinearContact{Float64,8}(friction_coefficient, [1.0 0.0; 0.0 1.0], collision)
+    end
+    contacts = [Dojo.ContactConstraint((model, pbody.id, cbody.id), name=:body_body)]
+    return Dojo.Mechanism(origin, [pbody, cbody], [joint], contacts; gravity=gravity, timestep=timestep)
+end
+
 function build(name::AbstractString, kw::Dict{Symbol,Any})
+    name == "two_spheres" && return two_spheres(; Dict(k => (v isa Number ? v : String(v)) for (k, v) in kw)...)
     corners = pop!(kw, :contact_corners, nothing)           # not a keyword of the reference's get_block: it always builds 8 corners
     mech = DojoEnvironments.get_mechanism(Symbol(name); kw...)
     if corners !== nothing
@@ -78,7 +100,8 @@ function run_config(path::AbstractString)
                 r = single_joint ? (1:nu) : joff[String(l[3])]
                 u[r] = parse.(Float64, l[4:3+length(r)])
             end
-            jz, ju = get_maximal_gradients!(mech, z, u; opts=opts)       # step! + IFT (the step is repeated below for the status)
+            forward_only = name == "two_spheres"
+            jz, ju = forward_only ? (zeros(12Nb, 12Nb), zeros(12Nb, max(nu, 1))) : get_maximal_gradients!(mech, z, u; opts=opts)       # step! + IFT (the step is repeated below for the status)
             set_maximal_state!(mech, z); set_input!(mech, u)
             status = Dojo.mehrotra!(mech; opts=opts)
             for body in mech.bodies
