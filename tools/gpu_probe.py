@@ -68,9 +68,10 @@ if what in ("all", "grad"):
 if what == "phases":
     # needs the instrumented library: DOJO_HIP_LIB=dojo.jl_amd/csrc/libdojo_hip_prof.so (tools/build_variant.sh prof -DDJ_PROF);
     # the step kernel then reports per-phase cycle counts of every wave through the `vel` export
-    spec = d.baseline_config(3)
+    cfg = int(os.environ.get("PHASES_CFG", "3"))              # 3: Ant (libdojo_hip_prof.so of the default variant); 5: Atlas (VMAXC=4 VQUAD=2 tools/build_variant.sh prof -DDJ_PROF)
+    spec = d.baseline_config(cfg)
     Z0, U0 = d.synthetic_inputs(spec, 64)
-    B = 4096
+    B = 4096 if cfg == 3 else 2048
     Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
     gm = api.BatchedMechanism(spec, B, dtype="f32")
     gm.set_groups(1)        # (last_kernel_ms: one launch of the whole batch per kernel; with groups it reports the last group's, include/dojo_hip.h)
