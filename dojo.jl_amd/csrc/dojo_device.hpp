@@ -3427,12 +3427,49 @@ struct LaneProgram {
 //   D2 − D1 = [m(v25 + v15); ½Δt(c25 Jω25 + ω25×Jω25) + ½Δt(c15 Jω15 − ω15×Jω15)].
 // zb = the body's 13 state values the step was solved at, v/w = its solution (v25, ω25), csg = [s(4); γ(4)] per contact
 // of the environment, rb = the body's six residual rows.  Shared by the HIP storage kernel and the SIMT emulator.
+// The impulse one contact applies to its body (and, for a body-body contact, to the contact's parent body): impulse_map γ of
+// src/contacts/contact.jl:79-100 for either collision and any of the three contact models, from the exported cone variables
+// (gam = γ: [γ ψ β1 β2] NonlinearContact / ImpactContact, [γ ψ β1..β4] LinearContact, linear.jl:33-38).  Runtime switches: the Storage
+// kernel is compiled once for all mechanisms.  ka = the parent body's kinematics (body-body contacts only).
+template <class T>
+DJ_HD void contact_impulses(T* imp, T* imp_par, const ContactP<T>& K, int model, const Kin<T>& kb, const Kin<T>* ka, const T* gam) {
+    T n[3], t1[3], t2[3], l[3], lp[3] = {0, 0, 0};
+    if (K.kind == 1) {
+        T dx[3], wax[3] = {T(1), T(0), T(0)};
+        for (int i = 0; i < 3; ++i) dx[i] = ka->x3[i] - kb.x3[i];
+        const T id = trcp(tsqrt(v3dot(dx, dx)));
+        for (int i = 0; i < 3; ++i) n[i] = dx[i] * id;
+        v3cross(t1, wax, n);
+        if (!(tsqrt(v3dot(t1, t1)) > T(1e-6))) { wax[0] = T(0); wax[1] = T(1); v3cross(t1, wax, n); }
+        v3cross(t2, t1, n);
+        for (int i = 0; i < 3; ++i) { l[i] = K.r2 * n[i]; lp[i] = -K.r * n[i]; }
+    } else {
+        T Ro[3];
+        m3vec(Ro, kb.R3, K.o);
+        for (int i = 0; i < 3; ++i) { n[i] = K.n[i]; t1[i] = K.t[i]; t2[i] = K.t[3 + i]; l[i] = Ro[i] - K.off[i] - K.n[i] * K.r; }
+    }
+    const T g1 = model == 1 ? T(0) : model == 2 ? gam[4] - gam[5] : gam[2], g2 = model == 1 ? T(0) : model == 2 ? gam[2] - gam[3] : gam[3];
+    T F[3], lxF[3];
+    const T sg = K.kind == 1 ? T(-1) : T(1);                      // (the owner of a body-body contact is its CHILD: −X γ)
+    for (int i = 0; i < 3; ++i) F[i] = sg * (n[i] * gam[0] + t1[i] * g1 + t2[i] * g2);
+    v3cross(lxF, l, F);
+    m3tvec(imp + 3, kb.R3, lxF);
+    for (int i = 0; i < 3; ++i) imp[i] = F[i];
+    if (K.kind == 1 && imp_par != nullptr) {
+        T Fp[3] = {-F[0], -F[1], -F[2]};
+        v3cross(lxF, lp, Fp);
+        m3tvec(imp_par + 3, ka->R3, lxF);
+        for (int i = 0; i < 3; ++i) imp_par[i] = Fp[i];
+    }
+}
+
 // Body-body contacts (ContactP::kind 1) need the other body: `other(body index, zb[13], v[3], w[3])` loads its state and solution and
-// `nodes` is the node table (null: the mechanism has none).
+// `nodes` is the node table (null: the mechanism has none).  model / cper: Globals::contact_model and the scalars per contact in csg
+// (8, LinearContact 12).
 struct NoOtherBody { template <class T> DJ_HD void operator()(int, T*, T*, T*) const {} };
 template <class T, class TC, class OTHER = NoOtherBody>
 DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb, const T* fe = nullptr,
-                       const NodeP<T>* nodes = nullptr, OTHER other = OTHER()) {
+                       const NodeP<T>* nodes = nullptr, OTHER other = OTHER(), int model = 0, int cper = 8) {
     const T x2[3] = {zb[0], zb[1], zb[2]}, v15[3] = {zb[3], zb[4], zb[5]}, q2[4] = {zb[6], zb[7], zb[8], zb[9]}, w15[3] = {zb[10], zb[11], zb[12]};
     Kin<T> kb;
     kin_of(kb, x2, q2, v, w, dt);
@@ -3444,31 +3481,30 @@ DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, c
         p[i] = P.m * (v[i] + v15[i]) + rb[i];
         p[3 + i] = T(0.5) * dt * (kb.c * J25[i] + x25[i] + c15 * J15[i] - x15[i]) + rb[3 + i];
     }
+    const int nh = cper / 2;
     for (int c = 0; c < P.ncontact; ++c) {
         const int id = P.contact[c];
-        T cs[4], cg[4];
-        for (int i = 0; i < 4; ++i) { cs[i] = T(csg[8 * id + i]); cg[i] = T(csg[8 * id + 4 + i]); }
-        ContactEval<T> CE;
-        if (CP[id].kind == 1 && nodes != nullptr) {              // this body is the child of a body-body contact: its parent's state at the same step
+        T cg[6] = {0, 0, 0, 0, 0, 0}, imp[6];
+        for (int i = 0; i < nh; ++i) cg[i] = T(csg[cper * id + nh + i]);
+        if (CP[id].kind == 1) {                                  // this body is the child of a body-body contact: its parent's state at the same step
+            if (nodes == nullptr) continue;
             T zo[13], vo[3], wo[3]; other(P.parent, zo, vo, wo);
             Kin<T> ka; kin_of(ka, zo, zo + 6, vo, wo, dt);
-            ContactEvalSS<T> CS;
-            contact_eval_ss<false>(CE, CS, CP[id], kb, ka, v, w, vo, wo, cs, cg, dt, false);
-        } else contact_eval<false>(CE, CP[id], kb, v, w, cs, cg, dt);
-        for (int i = 0; i < 6; ++i) p[i] += CE.imp[i];
+            contact_impulses<T>(imp, nullptr, CP[id], model, kb, &ka, cg);
+        } else contact_impulses<T>(imp, nullptr, CP[id], model, kb, nullptr, cg);
+        for (int i = 0; i < 6; ++i) p[i] += imp[i];
     }
     if (nodes != nullptr) for (int ci = 0; ci < P.nchild; ++ci) {      // ... and the parent of its children's body-body contacts
         const NodeP<T>& Pc = nodes[P.child[ci]];
         for (int c = 0; c < Pc.ncontact; ++c) {
             const int id = Pc.contact[c];
             if (CP[id].kind != 1) continue;
-            T cs[4], cg[4], zo[13], vo[3], wo[3];
-            for (int i = 0; i < 4; ++i) { cs[i] = T(csg[8 * id + i]); cg[i] = T(csg[8 * id + 4 + i]); }
+            T cg[6] = {0, 0, 0, 0, 0, 0}, zo[13], vo[3], wo[3], imp[6], impp[6];
+            for (int i = 0; i < nh; ++i) cg[i] = T(csg[cper * id + nh + i]);
             other(P.child[ci], zo, vo, wo);
             Kin<T> kc; kin_of(kc, zo, zo + 6, vo, wo, dt);
-            ContactEval<T> CE; ContactEvalSS<T> CS;
-            contact_eval_ss<false>(CE, CS, CP[id], kc, kb, vo, wo, v, w, cs, cg, dt, false);
-            for (int i = 0; i < 6; ++i) p[i] += CS.imp_p[i];
+            contact_impulses<T>(imp, impp, CP[id], model, kc, &kb, cg);
+            for (int i = 0; i < 6; ++i) p[i] += impp[i];
         }
     }
     for (int i = 0; i < 6; ++i) p[i] *= T(0.5);

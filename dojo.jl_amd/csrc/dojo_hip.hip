@@ -185,7 +185,7 @@ __global__ void contact_obs_kernel(int Nc, int B, const TIO* csg, TIO* obs, int 
 // save_to_storage! (src/simulation/storage.jl:50-67): one thread per (environment, body); inputs are the state the step
 // was solved at and what the step kernel left behind (solution velocities, cone variables, body residual rows)
 template <class TIO>
-__global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double>* contacts, int Nb, int Nc, double dt, int env0, int nenv,
+__global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double>* contacts, int Nb, int Nc, int model, int cper, double dt, int env0, int nenv,
                                const TIO* z, const TIO* vel, const TIO* csg, const TIO* res, const TIO* fext, TIO* storage) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / Nb, k = tid % Nb;
@@ -200,7 +200,7 @@ __global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double
         for (int i = 0; i < 13; ++i) zo[i] = (double)z[env * 13 * Nb + 13 * b + i];
         for (int i = 0; i < 3; ++i) { vo[i] = (double)vel[env * 6 * Nb + 6 * b + i]; wo[i] = (double)vel[env * 6 * Nb + 6 * b + 3 + i]; }
     };
-    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * 8 * Nc, rb, fext ? fe : (const double*)nullptr, nodes, other);
+    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * (size_t)cper * Nc, rb, fext ? fe : (const double*)nullptr, nodes, other, model, cper);
     TIO* o = storage + (env * Nb + k) * 25;
     for (int i = 0; i < 25; ++i) o[i] = (TIO)row[i];
 }
@@ -524,7 +524,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (storage) {                         // record: the Storage rows of the environments of this launch
         const long long n = (long long)nenv * Nb; const int T_ = 128;
         hipLaunchKernelGGL((ckern::storage_kernel<TIO>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, st, (const dj::NodeP<double>*)s->d_nodes,
-                           (const dj::ContactP<double>*)s->d_contacts, (int)Nb, s->M.Nc, s->M.dt, (int)env0, nenv,
+                           (const dj::ContactP<double>*)s->d_contacts, (int)Nb, s->M.Nc, s->M.contact_model, (int)csg_per(s), s->M.dt, (int)env0, nenv,
                            (const TIO*)z, (const TIO*)vel, (const TIO*)csg, (const TIO*)s->d_res, (const TIO*)s->fext, (TIO*)storage);
         HIPCHK(hipGetLastError());
     }
@@ -920,7 +920,6 @@ int dojo_gradients(DojoHandle s, void* dz, void* du) {
 // internal next state; storage != null records save_to_storage! rows [H][B][Nb][25] of every solved step
 static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, void* Z, int32_t* status, void* storage, void* stream) {
     if (!s || !z0 || H < 1) { g_err = "dojo_rollout_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (storage && s->M.contact_model == 2) { g_err = "dojo_simulate: Storage rows are not available for LinearContact mechanisms (use dojo_rollout)"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb, nu = s->M.nu;
     int rc;

@@ -173,7 +173,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
                 for (int i = 0; i < 13; ++i) zo[i] = T(zt[(size_t)e * nz + 13 * b + i]);
                 for (int i = 0; i < 3; ++i) { vo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + i]); wo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + 3 + i]); }
             };
-            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr, nodes.data(), other);
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr, nodes.data(), other, M.contact_model, 2 * dj::NCV);
             for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
         }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];

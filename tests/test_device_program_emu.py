@@ -514,6 +514,25 @@ def test_body_body_contact_matches_oracle(friction_type):
             z = zo
 
 
+@pytest.mark.parametrize("contact_type", ["linear", "impact"])
+def test_storage_rows_with_the_other_contact_models(contact_type):
+    """save_to_storage! for LinearContact and ImpactContact mechanisms: dj::storage_row takes the contact impulses from the exported cone
+    variables with the model's own force mapping (contact_impulses); a block sliding on the floor, against the oracle's momentum.jl restatement"""
+    spec = d.get_block(contact_type=contact_type, contact_corners=4, friction_coefficient=0.3)
+    o = Oracle(spec)
+    z = d.initialize(spec, position=[0, 0, 0.02], velocity=[1.2, 0.9, -0.3], angular_velocity=[0.3, -0.2, 0.5])
+    pressed = False
+    for k in range(8):
+        S, st = o.simulate_storage(z, np.zeros((1, spec.nu)))
+        r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=True)
+        assert st[0] == 0 and r["status"][0] == 0
+        assert np.abs(r["storage"][0] - S[0]).max() < 1e-8 * max(1.0, np.abs(S[0]).max())
+        nh = 6 if contact_type == "linear" else 1
+        pressed = pressed or o.get_solution()[6:].reshape(4, 2 * nh)[:, nh].max() > 1e-3
+        z, _ = o.step(z, np.zeros(spec.nu))
+    assert pressed
+
+
 def test_body_body_contact_storage_rows():
     """save_to_storage! with a body-body contact: the momenta of BOTH bodies need the contact impulse (dj::storage_row evaluates the
     contact from either side with the partner's state); against the oracle's momentum.jl restatement, in contact"""

@@ -171,14 +171,10 @@ def test_body_body_contact_on_the_device(friction_type, dtype):
     spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81)
     gm = api.BatchedMechanism(spec, 4, dtype=dtype)
     z0 = _state(spec, [0, 0, 0], [0, 0, 2.0], [0, 0, 0])
-    if friction_type == "linear":                        # (no Storage rows for LinearContact mechanisms: step by step)
-        z = np.tile(z0, (4, 1))
-        for _ in range(20):
-            z, st, _it = gm.step(z, np.zeros((4, spec.nu))); assert (st == 0).all()
-        zend = z[0]
-    else:
-        Zs, S, st = gm.simulate(np.tile(z0, (4, 1)), np.zeros((20, 4, spec.nu)), steps=20)
-        assert (st == 0).all()
-        zend = Zs[-1, 0]
+    Zs, S, st = gm.simulate(np.tile(z0, (4, 1)), np.zeros((20, 4, spec.nu)), steps=20)
     gm.close()
+    assert (st == 0).all()
+    zend = Zs[-1, 0]
+    rows, st_o = Oracle(spec).simulate_storage(z0, np.zeros((20, spec.nu)))            # the Storage rows (momenta with the contact impulse on both spheres)
+    assert np.abs(S[:, 0].astype(np.float64) - rows).max() < (1e-6 if dtype == "f64" else 1e-4)
     assert np.abs(zend.astype(np.float64).reshape(2, 13)[1, 0:3] - [0, 0, 1.0]).max() < (1e-4 if dtype == "f64" else 2e-4)      # test/collisions.jl:226

@@ -65,3 +65,21 @@ def test_environments(name):
     torch.cuda.synchronize()
     assert torch.isfinite(x1).all() and (env.status == 0).all()
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("contact_type", ["linear", "impact"])
+def test_simulate_storage_with_the_other_contact_models(contact_type):
+    """dojo_simulate's Storage rows for LinearContact / ImpactContact mechanisms (the momenta take the contact impulses from the exported
+    cone variables with the model's own force mapping): a block thrown along the floor, 30 steps, against the oracle's save_to_storage!"""
+    from dojo_amd import api
+    spec = d.get_block(contact_type=contact_type, contact_corners=4, friction_coefficient=0.3)
+    z0 = d.initialize(spec, position=[0, 0, 0.02], velocity=[1.2, 0.9, -0.3], angular_velocity=[0.3, -0.2, 0.5])
+    B, H = 8, 30
+    gm = api.BatchedMechanism(spec, B, dtype="f64")
+    Z, S, st = gm.simulate(np.tile(z0, (B, 1)), np.zeros((H, B, spec.nu)), steps=H)
+    gm.close()
+    rows, st_o = Oracle(spec).simulate_storage(z0, np.zeros((H, spec.nu)))
+    assert (st == 0).all() and all(s == 0 for s in st_o)
+    assert np.abs(S[:, 0] - rows).max() < 1e-6 * max(1.0, np.abs(rows).max())
+    assert np.array_equal(S[:, 0], S[:, B - 1])
