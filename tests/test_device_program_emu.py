@@ -573,3 +573,30 @@ def test_body_body_contact_in_a_chain_with_a_half_space_contact():
         touched = touched or o.get_solution()[-4] > 1e-4
         z = zo
     assert touched
+
+
+def test_body_body_contacts_in_a_stack_of_three_spheres():
+    """a chain of body-body contacts: three spheres, the lowest on the floor (half-space contact), each next one touching the one below through a
+    SphereSphereCollision contact and hanging in the tree on it; dropped slightly off-axis, the stack settles and then topples.  Equal Newton
+    iteration counts with the oracle on every step (the state error grows with the toppling: 2e-6 at the end)"""
+    from dojo_amd.mechanisms import BodySpec, MechanismSpec, Floating, sphere_inertia, contact_constraint, sphere_sphere_contact
+    r = 0.3
+    bodies = [BodySpec("s%d" % i, 1.0, sphere_inertia(r, 1.0)) for i in range(3)]
+    joints = [Floating("j0", -1, 0), Floating("j1", 0, 1), Floating("j2", 1, 2)]
+    contacts = [contact_constraint("floor", 0, np.array([0, 0, 1.0]), 0.8, contact_radius=r),
+                sphere_sphere_contact("c01", 0, 1, r, r, 0.8), sphere_sphere_contact("c12", 1, 2, r, r, 0.8)]
+    spec = MechanismSpec("stack", bodies, joints, contacts, 0.02, None, np.array([0.0, 0.0, -9.81]))
+    o = Oracle(spec)
+    z = np.zeros((3, 13)); z[:, 6] = 1.0
+    z[0, 0:3] = [0, 0, r + 0.05]; z[1, 0:3] = [0.01, 0.0, 3 * r + 0.1]; z[2, 0:3] = [0.0, 0.01, 5 * r + 0.15]
+    z = z.reshape(-1)
+    carried = False
+    for k in range(40):
+        zo, info = o.step(z, np.zeros(spec.nu))
+        rr = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=True)
+        assert info["status"] == 0 and rr["status"][0] == 0 and rr["iters"][0] == info["iters"]
+        assert np.abs(rr["z_next"][0] - zo).max() < 1e-5
+        g = o.get_solution()[-24:].reshape(3, 8)[:, 4]
+        carried = carried or (g[1] > 0.05 and g[2] > 0.05)          # both upper contacts loaded at the same time
+        z = zo
+    assert carried
