@@ -94,7 +94,7 @@ struct NodeP {
     T spring_r, damper_r, spring_off_r[3], lim_lo, lim_hi;
 };
 template <class T>
-struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2; int kind; };   // kind 1: SphereSphereCollision, r = radius_parent, r2 = radius_child (origins zero), parent = the owner's tree parent
+struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2, o2[3]; int kind; };   // kind 1: SphereSphereCollision: (o, r) = (origin_parent, radius_parent), (o2, r2) = the child's; parent = the owner's tree parent
 
 // ------------------------------------------------------------------------------------------------
 // Lane-local dynamic state
@@ -930,20 +930,23 @@ DJ_HD void contact_eval(ContactEval<T>& E, const ContactP<T>& K, const Kin<T>& k
     }
 }
 
-// Body-body contact: SphereSphereCollision between the owner's tree parent (the contact's parent_id, sphere radius K.r about its centre
-// of mass) and the owner (child_id, K.r2).  src/contacts/collisions/{collision,sphere_sphere}.jl, src/contacts/{contact,velocity}.jl in
-// closed form for origin_parent = origin_child = 0 (the analytic expressions; the reference returns FiniteDiff values of the same):
-//   n = (x_p − x_c)/|x_p − x_c| (child -> parent), N = ∂n/∂x_p = (I − n nᵀ)/|x_p − x_c| = −∂n/∂x_c,  t1 = w × n (w = e_x, or e_y when
-//   |e_x × n| <= 1e-6), t2 = t1 × n (neither normalized: collision.jl:102-129),  levers l_p = −r n, l_c = r2 n,
-//   force on the parent F = n γ1 + t1 γ3 + t2 γ4, on the child −F  (force_mapping, contact.jl:141-154)
+// Body-body contact: SphereSphereCollision between the owner's tree parent (the contact's parent_id: sphere of radius K.r about the point
+// K.o of that body) and the owner (child_id: K.r2 about K.o2).  src/contacts/collisions/{collision,sphere_sphere}.jl,
+// src/contacts/{contact,velocity}.jl in closed form (the analytic expressions; the reference returns FiniteDiff values of the same).  With
+// c_p = x_p + R_p o_p, c_c = x_c + R_c o_c:
+//   n = (c_p − c_c)/|c_p − c_c| (child -> parent), N = ∂n/∂c_p = (I − n nᵀ)/|c_p − c_c| = −∂n/∂c_c,  t1 = w × n (w = e_x, or e_y when
+//   |e_x × n| <= 1e-6), t2 = t1 × n (neither normalized: collision.jl:102-129),  levers l_p = R_p o_p − r n, l_c = R_c o_c + r2 n,
+//   force on the parent F = n γ1 + t1 g1 + t2 g2, on the child −F  (force_mapping, contact.jl:141-154),
+//   E_s = ∂(R_s o_s)/∂q_s ∂q_s/∂ω_s = −2 R_s [o_s]x Φ_s   (the sphere centres move with the bodies' rotations; zero for centred spheres).
 // `kb` / `ka`: the owner's and the parent's kinematics at the candidate velocities.
 template <class T>
-struct ContactEvalSS { T imp_p[6]; T Cp134[18], Gp134[18]; T Sxx[9], Swx[9], Pwx[9], Pww[9]; };   // parent-side rows; −∂(impulse)/∂v blocks: own (v,v), (ω,v); parent (ω,v), (ω,ω)
+struct ContactEvalSS { T imp_p[6]; T Cp134[18], Gp134[18]; T Sxx[9], Sxw[9], Swx[9], Pxw[9], Pwx[9], Pww[9]; };   // parent-side rows; −∂(impulse)/∂(v, ω) blocks: own (v,v) [= parent's], (v,ω), (ω,v); parent (v,ω), (ω,v), (ω,ω)
 template <bool JAC, class T>
 DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const ContactP<T>& K, const Kin<T>& kb, const Kin<T>& ka,
                            const T* v, const T* w, const T* va, const T* wa, const T* s, const T* gam, T dt, bool impact) {
-    T dx[3], n[3], t1[3], t2[3], wax[3] = {T(1), T(0), T(0)};
-    for (int i = 0; i < 3; ++i) dx[i] = ka.x3[i] - kb.x3[i];
+    T dx[3], n[3], t1[3], t2[3], wax[3] = {T(1), T(0), T(0)}, Rop[3], Roc[3];
+    m3vec(Rop, ka.R3, K.o); m3vec(Roc, kb.R3, K.o2);
+    for (int i = 0; i < 3; ++i) dx[i] = (ka.x3[i] + Rop[i]) - (kb.x3[i] + Roc[i]);
     const T dist = tsqrt(v3dot(dx, dx)), id = trcp(dist);
     for (int i = 0; i < 3; ++i) n[i] = dx[i] * id;
     v3cross(t1, wax, n);
@@ -951,7 +954,7 @@ DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const Contac
     v3cross(t2, t1, n);
     if (impact) for (int i = 0; i < 3; ++i) t1[i] = t2[i] = T(0);      // ImpactContact (impact.jl:106-118): the normal alone; the friction block stays at the neutral vector
     T lp[3], lc[3], Rwp[3], Rwc[3], cp_[3], cc_[3], dv[3];
-    for (int i = 0; i < 3; ++i) { lp[i] = -K.r * n[i]; lc[i] = K.r2 * n[i]; }
+    for (int i = 0; i < 3; ++i) { lp[i] = Rop[i] - K.r * n[i]; lc[i] = Roc[i] + K.r2 * n[i]; }
     m3vec(Rwp, ka.R3, wa); m3vec(Rwc, kb.R3, w);
     v3cross(cp_, Rwp, lp); v3cross(cc_, Rwc, lc);
     for (int i = 0; i < 3; ++i) dv[i] = (va[i] + cp_[i]) - (v[i] + cc_[i]);           // contact point velocities, velocity.jl:2-38
@@ -984,8 +987,24 @@ DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const Contac
             v3cross(lx, lc, dirs[d]); m3tvec(g3, kb.R3, lx);
             for (int i = 0; i < 3; ++i) { E.G134[6 * d + i] = -dirs[d][i]; E.G134[6 * d + 3 + i] = -g3[i]; }
         }
-        // constraint_jacobian_velocity(:parent | :child)  contact.jl:37-77: row 1 = [±Δt n | 0] (∂distance∂q = 0 about the centres of mass);
-        // rows 3, 4 = ±[t_i | t_i(−[l]x R + 2 [l]x R [ω]x Φ)]  (∂vt∂v, ∂vt∂ω + ∂vt∂q ∂q∂ω; the position dependence of vt is not in V, as in the reference)
+        T N[9], Sn[9], Swx_[9], St1[9], SnSw[9], T2m[9], NE[2][9], Es[2][9], Swp[9], Swc[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = ((i == j ? T(1) : T(0)) - n[i] * n[j]) * id;
+        m3skew(Sn, n); m3skew(Swx_, wax); m3skew(St1, t1); m3mul(SnSw, Sn, Swx_);
+        for (int i = 0; i < 9; ++i) T2m[i] = St1[i] - SnSw[i];                          // ∂t2/∂n = [t1]x − [n]x [w]x
+        m3skew(Swp, Rwp); m3skew(Swc, Rwc);
+        for (int side = 0; side < 2; ++side) {                                          // E_s and N E_s
+            const Kin<T>& kk = side == 0 ? ka : kb;
+            T So[9], RSo[9];
+            m3skew(So, side == 0 ? K.o : K.o2); m3mul(RSo, kk.R3, So);
+            for (int i = 0; i < 9; ++i) RSo[i] *= T(-2);
+            m3mul(Es[side], RSo, kk.Phi);
+            m3mul(NE[side], N, Es[side]);
+        }
+        // constraint_jacobian_velocity(:parent | :child)  contact.jl:37-77.  Row 1 = ±[Δt n | nᵀ E_s].  Rows 3, 4: the v columns ±t_i (the position
+        // dependence of vt is not in V, as in the reference); the ω columns ∂vt∂ω + ∂vt∂q ∂q∂ω (velocity.jl:71-143):
+        //   ±t_i(−[l_s]x R_s + 2 [l_s]x R_s [ω_s]x Φ_s)  +  t_i([R_p ω_p]x ∂c_p'/∂ω_s − [R_c ω_c]x ∂c_c'/∂ω_s)  +  Δvᵀ ∂t_iᵀ/∂q_s ∂q_s/∂ω_s
+        // with the contact points c_p' = c_p − r n, c_c' = c_c + r2 n, and ∂t1ᵀ/∂q = [t1]x ∂nᵀ/∂q -- the reference's literal form (collision.jl:207;
+        // the ∂x version has [w]x there) -- , ∂t2ᵀ/∂q = ([t1]x − [n]x [w]x) ∂nᵀ/∂q.
         for (int side = 0; side < 2; ++side) {
             const Kin<T>& kk = side == 0 ? ka : kb; const T* l = side == 0 ? lp : lc; const T* ww = side == 0 ? wa : w;
             const T sg = side == 0 ? T(1) : T(-1);
@@ -994,39 +1013,53 @@ DJ_HD void contact_eval_ss(ContactEval<T>& E, ContactEvalSS<T>& P2, const Contac
             m3skew(Sl, l); m3mul(SlR, Sl, kk.R3); m3skew(Sw, ww); m3mul(B1, SlR, Sw);
             for (int i = 0; i < 9; ++i) B1[i] *= T(2);
             m3mul(BPhi, B1, kk.Phi);
-            for (int j = 0; j < 3; ++j) { Cx[j] = sg * dt * n[j]; Cx[3 + j] = T(0); }
+            // M = [R_p ω_p]x ∂c_p'/∂ω_s − [R_c ω_c]x ∂c_c'/∂ω_s;  ∂c_s'/∂ω_s = E_s − r_s N E_s, the other point's: r_other N E_s
+            T Dp[9], Dc[9], M1[9], M2[9], Q1[9], Q2[9];
+            for (int i = 0; i < 9; ++i) { Dp[i] = side == 0 ? Es[0][i] - K.r * NE[0][i] : K.r * NE[1][i]; Dc[i] = side == 0 ? K.r2 * NE[0][i] : Es[1][i] - K.r2 * NE[1][i]; }
+            m3mul(M1, Swp, Dp); m3mul(M2, Swc, Dc);
+            m3mul(Q1, St1, NE[side]); m3mul(Q2, T2m, NE[side]);                        // (∂n/∂ω_s = ±N E_s: the sign is sg)
+            for (int j = 0; j < 3; ++j) { Cx[j] = sg * dt * n[j]; Cx[3 + j] = sg * (n[0] * Es[side][j] + n[1] * Es[side][3 + j] + n[2] * Es[side][6 + j]); }
             for (int r = 0; r < 2; ++r) {
-                const T* tt = r == 0 ? t1 : t2;
+                const T* tt = r == 0 ? t1 : t2; const T* Qr = r == 0 ? Q1 : Q2;
                 for (int j = 0; j < 3; ++j) {
                     Cx[6 * (1 + r) + j] = sg * tt[j];
                     const T a = -(tt[0] * SlR[j] + tt[1] * SlR[3 + j] + tt[2] * SlR[6 + j]);
                     const T b = tt[0] * BPhi[j] + tt[1] * BPhi[3 + j] + tt[2] * BPhi[6 + j];
-                    Cx[6 * (1 + r) + 3 + j] = sg * (a + b);
+                    const T m_ = tt[0] * (M1[j] - M2[j]) + tt[1] * (M1[3 + j] - M2[3 + j]) + tt[2] * (M1[6 + j] - M2[6 + j]);
+                    const T q_ = impact ? T(0) : sg * (dv[0] * Qr[j] + dv[1] * Qr[3 + j] + dv[2] * Qr[6 + j]);
+                    Cx[6 * (1 + r) + 3 + j] = sg * (a + b) + m_ + q_;
                 }
             }
         }
-        // impulse_map_jacobian(relative, relative, ..., γ) · integrator_jacobian_velocity  contact.jl:102-138:
-        //   Xx = K N for both bodies, K = γ1 I + g1 [w]x + g2 ([t1]x − [n]x [w]x) with (g1, g2) the tangential impulse;  Xq = 0
-        //   Qx(rel) = R_relᵀ([l_rel]x K N + r_rel [F_rel]x N)      (∂contact_point∂x − I = −r_rel N);  Qq ∂q∂ω = 2 [τ_rel]x Φ_rel
-        T N[9], Kw[9], Sn[9], Swx_[9], St1[9], SnSw[9], KN[9];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = ((i == j ? T(1) : T(0)) - n[i] * n[j]) * id;
-        m3skew(Sn, n); m3skew(Swx_, wax); m3skew(St1, t1); m3mul(SnSw, Sn, Swx_);
-        for (int i = 0; i < 9; ++i) Kw[i] = gt1 * Swx_[i] + gt2 * (St1[i] - SnSw[i]);
-        for (int i = 0; i < 3; ++i) Kw[4 * i] += gam[0];
+        // impulse_map_jacobian(relative, relative, ..., γ) · integrator_jacobian_velocity  contact.jl:102-138, for both bodies:
+        //   Xx = K N,  K = γ1 I + g1 [w]x + g2 ([t1]x − [n]x [w]x);   Xq ∂q∂ω = Kq N E_s,  Kq = γ1 I + g1 [t1]x + g2 ([t1]x − [n]x [w]x)  (literal ∂t1ᵀ/∂q)
+        //   Qx = R_sᵀ([l_s]x K N + r_s [F_s]x N)      (∂c_s'/∂x_s − I = −r_s N)
+        //   Qq ∂q∂ω = R_sᵀ([l_s]x Kq N E_s − [F_s]x (E_s − r_s N E_s)) + 2 [τ_s]x Φ_s
+        T Kw[9], Kq[9], KN[9];
+        for (int i = 0; i < 9; ++i) { Kw[i] = gt1 * Swx_[i] + gt2 * T2m[i]; Kq[i] = gt1 * St1[i] + gt2 * T2m[i]; }
+        for (int i = 0; i < 3; ++i) { Kw[4 * i] += gam[0]; Kq[4 * i] += gam[0]; }
         m3mul(KN, Kw, N);
         for (int i = 0; i < 9; ++i) P2.Sxx[i] = dt * KN[i];
         for (int side = 0; side < 2; ++side) {
             const Kin<T>& kk = side == 0 ? ka : kb; const T* l = side == 0 ? lp : lc; const T* Fs = side == 0 ? F : Fc;
             const T rr = side == 0 ? K.r : K.r2; const T* tb = side == 0 ? tau : tauc;
-            T Sl[9], SF[9], A1[9], A2[9], W[9];
+            T Sl[9], SF[9], A1[9], A2[9], W[9], Xw[9], B3[9], B4[9], Dd[9];
             m3skew(Sl, l); m3skew(SF, Fs); m3mul(A1, Sl, KN); m3mul(A2, SF, N);
             for (int i = 0; i < 9; ++i) W[i] = A1[i] + rr * A2[i];
             T* Qx = side == 0 ? P2.Pwx : P2.Swx;
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Qx[3 * i + j] = dt * (kk.R3[i] * W[j] + kk.R3[3 + i] * W[3 + j] + kk.R3[6 + i] * W[6 + j]);   // Rᵀ W
-            T St[9], Q2[9];
+            m3mul(Xw, Kq, NE[side]);                                                   // Xq ∂q∂ω
+            T* Xo = side == 0 ? P2.Pxw : P2.Sxw;
+            for (int i = 0; i < 9; ++i) { Xo[i] = Xw[i]; Dd[i] = Es[side][i] - rr * NE[side][i]; }
+            m3mul(B3, Sl, Xw); m3mul(B4, SF, Dd);
+            for (int i = 0; i < 9; ++i) B3[i] -= B4[i];
+            T St[9], Q2[9], QP[9];
             m3skew(St, tb);
             for (int i = 0; i < 9; ++i) Q2[i] = T(2) * St[i];
-            if (side == 0) m3mul(P2.Pww, Q2, kk.Phi); else { m3mul(E.Dww, Q2, kk.Phi); for (int i = 0; i < 9; ++i) E.Qraw[i] = Q2[i]; }
+            m3mul(QP, Q2, kk.Phi);
+            T* Dw = side == 0 ? P2.Pww : E.Dww;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Dw[3 * i + j] = QP[3 * i + j] + (kk.R3[i] * B3[j] + kk.R3[3 + i] * B3[3 + j] + kk.R3[6 + i] * B3[6 + j]);
+            if (side == 1) for (int i = 0; i < 9; ++i) E.Qraw[i] = Q2[i];
         }
         for (int j = 0; j < 3; ++j) E.c1p[j] = T(0);
         for (int j = 0; j < 6; ++j) E.c34p[j] = T(0);
@@ -1412,8 +1445,8 @@ struct LaneProgram {
                                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                                     for (int j = 0; j < 3; ++j) {
-                                        K.addS(i, j, -CS[c].Sxx[3 * i + j]); K.addS(3 + i, j, -CS[c].Swx[3 * i + j]);
-                                        K.addD(i, j, -CS[c].Sxx[3 * i + j]); K.addD(3 + i, j, -CS[c].Pwx[3 * i + j]); K.addD(3 + i, 3 + j, -CS[c].Pww[3 * i + j]);
+                                        K.addS(i, j, -CS[c].Sxx[3 * i + j]); K.addS(i, 3 + j, -CS[c].Sxw[3 * i + j]); K.addS(3 + i, j, -CS[c].Swx[3 * i + j]);
+                                        K.addD(i, j, -CS[c].Sxx[3 * i + j]); K.addD(i, 3 + j, -CS[c].Pxw[3 * i + j]); K.addD(3 + i, j, -CS[c].Pwx[3 * i + j]); K.addD(3 + i, 3 + j, -CS[c].Pww[3 * i + j]);
                                     }
                             }
                         }
@@ -3435,14 +3468,15 @@ template <class T>
 DJ_HD void contact_impulses(T* imp, T* imp_par, const ContactP<T>& K, int model, const Kin<T>& kb, const Kin<T>* ka, const T* gam) {
     T n[3], t1[3], t2[3], l[3], lp[3] = {0, 0, 0};
     if (K.kind == 1) {
-        T dx[3], wax[3] = {T(1), T(0), T(0)};
-        for (int i = 0; i < 3; ++i) dx[i] = ka->x3[i] - kb.x3[i];
+        T dx[3], wax[3] = {T(1), T(0), T(0)}, Rop[3], Roc[3];
+        m3vec(Rop, ka->R3, K.o); m3vec(Roc, kb.R3, K.o2);
+        for (int i = 0; i < 3; ++i) dx[i] = (ka->x3[i] + Rop[i]) - (kb.x3[i] + Roc[i]);
         const T id = trcp(tsqrt(v3dot(dx, dx)));
         for (int i = 0; i < 3; ++i) n[i] = dx[i] * id;
         v3cross(t1, wax, n);
         if (!(tsqrt(v3dot(t1, t1)) > T(1e-6))) { wax[0] = T(0); wax[1] = T(1); v3cross(t1, wax, n); }
         v3cross(t2, t1, n);
-        for (int i = 0; i < 3; ++i) { l[i] = K.r2 * n[i]; lp[i] = -K.r * n[i]; }
+        for (int i = 0; i < 3; ++i) { l[i] = Roc[i] + K.r2 * n[i]; lp[i] = Rop[i] - K.r * n[i]; }
     } else {
         T Ro[3];
         m3vec(Ro, kb.R3, K.o);

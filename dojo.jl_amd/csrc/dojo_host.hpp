@@ -111,8 +111,6 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         if (K.collision == 1) {
             if (K.child_body < 0 || K.child_body >= M.Nb || M.nodes[K.child_body].parent != K.body) {
                 M.error = "body-body contact: child_body must be a body whose joint hangs on `body` (the contact has to be an edge of the tree)"; return DOJO_ERR_UNSUPPORTED; }
-            for (int i = 0; i < 3; ++i) if (K.origin[i] != 0.0 || K.child_origin[i] != 0.0) {
-                M.error = "body-body contact: only spheres about the centres of mass (origin_parent = origin_child = 0)"; return DOJO_ERR_UNSUPPORTED; }
             owner = K.child_body; M.has_ss = true;
         } else if (K.collision != 0) { M.error = "unknown collision (0 = SphereHalfSpaceCollision, 1 = SphereSphereCollision)"; return DOJO_ERR_UNSUPPORTED; }
         NodeP<double>& P = M.nodes[owner];
@@ -129,6 +127,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         for (int i = 0; i < 6; ++i) Q.t[i] = K.model == 1 ? 0.0 : K.tangent[i];
         Q.r = K.radius; Q.mu = K.model == 1 ? 0.0 : K.friction_coefficient;
         Q.kind = K.collision; Q.r2 = K.collision == 1 ? K.child_radius : 0.0;
+        for (int i = 0; i < 3; ++i) Q.o2[i] = K.collision == 1 ? K.child_origin[i] : 0.0;
     }
     return DOJO_OK;
 }
@@ -151,6 +150,7 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
     for (int i = 0; i < 3; ++i) { b.n[i] = T(a.n[i]); b.o[i] = T(a.o[i]); b.off[i] = T(a.off[i]); }
     for (int i = 0; i < 6; ++i) b.t[i] = T(a.t[i]);
     b.r = T(a.r); b.mu = T(a.mu); b.r2 = T(a.r2); b.kind = a.kind;
+    for (int i = 0; i < 3; ++i) b.o2[i] = T(a.o2[i]);
     return b;
 }
 // refine_w: stiffness (max γ/s over the cones of an environment) beyond which the device refines its linear solves against

@@ -95,12 +95,13 @@ def contact_constraint(name, body, normal, friction_coefficient=1.0, contact_ori
                        CONTACT_MODELS[contact_type])
 
 
-def sphere_sphere_contact(name, parent_body, child_body, radius_parent, radius_child, friction_coefficient=0.5, contact_type="nonlinear"):
-    """ContactConstraint((NonlinearContact | ImpactContact with SphereSphereCollision(0, 0, r_parent, r_child), parent_id, child_id))
-    src/contacts/collisions/sphere_sphere.jl:11-16, as test/collisions.jl:19-52 builds it: spheres about the two centres of mass.
-    Forward only; `child_body`'s joint must hang on `parent_body`."""
-    return ContactSpec(name, parent_body, float(friction_coefficient), np.zeros(3), np.zeros((2, 3)), np.zeros(3), float(radius_parent), np.zeros(3),
-                       CONTACT_MODELS[contact_type], collision=1, child_body=child_body, child_origin=np.zeros(3), child_radius=float(radius_child))
+def sphere_sphere_contact(name, parent_body, child_body, radius_parent, radius_child, friction_coefficient=0.5, contact_type="nonlinear",
+                          origin_parent=np.zeros(3), origin_child=np.zeros(3)):
+    """ContactConstraint((NonlinearContact | LinearContact | ImpactContact with SphereSphereCollision(origin_parent, origin_child, r_parent,
+    r_child), parent_id, child_id))  src/contacts/collisions/sphere_sphere.jl:11-16; test/collisions.jl:19-52 builds it with the spheres about
+    the two centres of mass.  Forward only; `child_body`'s joint must hang on `parent_body`."""
+    return ContactSpec(name, parent_body, float(friction_coefficient), np.zeros(3), np.zeros((2, 3)), np.array(origin_parent, float), float(radius_parent), np.zeros(3),
+                       CONTACT_MODELS[contact_type], collision=1, child_body=child_body, child_origin=np.array(origin_child, float), child_radius=float(radius_child))
 
 
 def get_two_spheres(timestep=0.1, input_scaling=None, gravity=-9.81, radius_body1=0.5, radius_body2=0.5, mass_body1=1.0, mass_body2=1.0,

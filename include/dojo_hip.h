@@ -131,7 +131,7 @@ typedef struct DojoContact {
     /* body-body contact (src/contacts/collisions/sphere_sphere.jl:11-16; forward only; any of the three contact models): `body` is the contact's parent_id, its sphere is
      * (origin, radius); the child sphere sits on child_body, which must be a body whose joint hangs on `body` (the contact is an edge of
      * the tree next to that joint; the reference's test mechanism has no joint there at all: give the child a Floating joint to `body`).
-     * Both origins must be zero (spheres about the centres of mass, what test/collisions.jl builds); normal / tangent / offset are unused. */
+     * normal / tangent / offset are unused. */
     int32_t collision;            /* 0: SphereHalfSpaceCollision (child = origin), 1: SphereSphereCollision */
     int32_t child_body;           /* collision 1: child_id as index into bodies[]; else ignored */
     double  child_origin[3];      /* collision 1: collision.origin_child                    */

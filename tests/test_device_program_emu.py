@@ -600,3 +600,53 @@ def test_body_body_contacts_in_a_stack_of_three_spheres():
         carried = carried or (g[1] > 0.05 and g[2] > 0.05)          # both upper contacts loaded at the same time
         z = zo
     assert carried
+
+
+def _rotm(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def off_centre_pair(friction_type, joint):
+    """two boxes carrying contact spheres OFF their centres of mass (origin_parent, origin_child != 0: the sphere centres move with the bodies'
+    rotations), the first on a Floating or Revolute joint to the world; the second approaches with spin, 0.02 from touching"""
+    from dojo_amd.mechanisms import BodySpec, MechanismSpec, Floating, Revolute, box_inertia, sphere_sphere_contact
+    op, oc = np.array([0.15, -0.05, 0.1]), np.array([-0.1, 0.05, -0.15])
+    bodies = [BodySpec("a", 2.0, box_inertia(0.6, 0.4, 0.3, 2.0)), BodySpec("b", 0.7, box_inertia(0.3, 0.3, 0.5, 0.7))]
+    j0 = Floating("j0", -1, 0) if joint == "Floating" else Revolute("j0", -1, 0, np.array([0, 1.0, 0]), child_vertex=np.array([0, 0, 0.4]))
+    contacts = [sphere_sphere_contact("touch", 0, 1, 0.25, 0.2, 0.5, friction_type, origin_parent=op, origin_child=oc)]
+    spec = MechanismSpec("off_centre", bodies, [j0, Floating("free", 0, 1)], contacts, 0.02, None, np.array([0.0, 0.0, -9.81]))
+    rng = np.random.default_rng(3)
+    z = np.zeros((2, 13)); z[:, 6] = 1.0
+    qa = rng.normal(size=4); qa /= np.linalg.norm(qa); qb = rng.normal(size=4); qb /= np.linalg.norm(qb)
+    z[0, 0:3] = [0, 0, -0.4] if joint == "Revolute" else [0, 0, 0]
+    if joint == "Floating":
+        z[0, 6:10] = qa
+    z[1, 6:10] = qb
+    dirv = np.array([0.3, -0.2, 1.0]); dirv /= np.linalg.norm(dirv)
+    z[1, 0:3] = z[0, 0:3] + _rotm(z[0, 6:10]) @ op + dirv * 0.47 - _rotm(qb) @ oc
+    z[1, 3:6] = -dirv + [0.2, 0.1, 0]; z[1, 10:13] = [1.0, -2.0, 0.5]; z[0, 10:13] = [0.3, 0.5, -0.2] if joint == "Floating" else [0, 0.4, 0]
+    return spec, z.reshape(-1)
+
+
+@pytest.mark.parametrize("friction_type", ["nonlinear", "impact", "linear"])
+@pytest.mark.parametrize("joint", ["Floating", "Revolute"])
+def test_body_body_contact_off_the_centres_of_mass(friction_type, joint):
+    """SphereSphereCollision with origin_parent, origin_child != 0 (sphere_sphere.jl:11-16): the distance, the normal, the tangents and the contact
+    points depend on both orientations -- the ω columns of the contact rows, the (v, ω) blocks of −∂(impulse)/∂(v, ω) and the reference's literal
+    ∂t1ᵀ/∂q (collision.jl:207) come into play.  Equal Newton iterates with the oracle through approach, impact and sliding; Storage rows too."""
+    spec, z = off_centre_pair(friction_type, joint)
+    o = Oracle(spec)
+    nh = {"impact": 1, "nonlinear": 4, "linear": 6}[friction_type]
+    hit = False
+    for k in range(15):
+        S, st = o.simulate_storage(z, np.zeros((1, spec.nu)))
+        zo, info = o.step(z, np.zeros(spec.nu))
+        r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=True)
+        assert info["status"] == 0 and r["status"][0] == 0 and r["iters"][0] == info["iters"]
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-8
+        assert np.abs(r["storage"][0] - S[0]).max() < 1e-8 * max(1.0, np.abs(S[0]).max())
+        hit = hit or o.get_solution()[-nh] > 1e-3
+        z = zo
+    assert hit
