@@ -650,3 +650,32 @@ def test_body_body_contact_off_the_centres_of_mass(friction_type, joint):
         hit = hit or o.get_solution()[-nh] > 1e-3
         z = zo
     assert hit
+
+
+def test_body_body_contact_inside_the_ant():
+    """a body-body contact inside a BASELINE mechanism: a ball dropped on the Ant's front left leg link (fourteen bodies, the ball hangs in the tree
+    on the link; the four foot contacts stay half-space contacts).  Status and Newton iteration counts equal to the oracle's on every step --
+    including the steps where the reference's algorithm runs into max_iter on this contact on both sides -- and states to 1e-7 where it converges"""
+    import copy
+    from dojo_amd.mechanisms import BodySpec, Floating, sphere_inertia, sphere_sphere_contact
+    base = d.baseline_config(3)
+    spec = copy.deepcopy(base)
+    link = 1                                                    # front_left_leg
+    spec.bodies.append(BodySpec("ball", 0.3, sphere_inertia(0.1, 0.3)))
+    spec.joints.append(Floating("ball_free", link, spec.Nb - 1))
+    spec.contacts.append(sphere_sphere_contact("ball_on_leg", link, spec.Nb - 1, 0.1, 0.1, 0.6))
+    Z0, U0 = d.synthetic_inputs(base, 1)
+    zb = np.zeros(13); zb[6] = 1.0
+    zb[0:3] = Z0[0][13 * link:13 * link + 3] + np.array([0.02, 0.01, 0.21]); zb[3:6] = Z0[0][13 * link + 3:13 * link + 6]
+    z = np.concatenate([Z0[0], zb]); u = np.concatenate([U0[0], np.zeros(6)])
+    o = Oracle(spec)
+    loaded = False
+    for k in range(10):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z[None], u[None], quad=True)
+        assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"]
+        if info["status"] == 0:
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-7
+        loaded = loaded or o.get_solution()[-4] > 1e-2
+        z = zo
+    assert loaded
