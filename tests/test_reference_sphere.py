@@ -31,6 +31,7 @@ REF_FILE = "/root/reference/examples/system_identification/data/datasets/synthet
 # the bound of the contract (BASELINE.json north_star) and what is asserted for the fp64 paths: the achieved figures are
 # 4e-14 (oracle), 1e-13 (device program), so a change of the iterate path (>= 1e-8 at these tolerances) cannot hide below it
 CONTRACT = 1e-6
+CONTRACT_F32 = 1e-3
 PINNED = 1e-10
 
 
@@ -129,8 +130,8 @@ def test_device_program_equals_the_reference_rows():
 # ---------------------------------------------------------------------------------------------------------------- GPU tier
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,bound", [("f64", PINNED), ("f32", 1e-5)])
-def test_hip_step_equals_the_reference_rows(dtype, bound):
+@pytest.mark.parametrize("dtype,bound,contract", [("f64", PINNED, CONTRACT), ("f32", 1e-5, CONTRACT_F32)])
+def test_hip_step_equals_the_reference_rows(dtype, bound, contract):
     """990 environments = the 990 reference pairs, one launch through dojo_step"""
     z0, z1, _ = pairs()
     gm = api.BatchedMechanism(sphere(), len(z0), dtype=dtype)
@@ -139,7 +140,7 @@ def test_hip_step_equals_the_reference_rows(dtype, bound):
     e = np.abs(zn.astype(np.float64) - z1).max(axis=1)
     print("HIP %s vs reference Storage rows: max %.3g over %d pairs; iterations %s" % (dtype, e.max(), len(e), np.bincount(it)))
     assert (st == 0).all()
-    assert e.max() <= bound <= CONTRACT, e.max()
+    assert e.max() <= bound <= contract, e.max()
 
 
 @pytest.mark.gpu
