@@ -123,7 +123,8 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
     std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
-    std::vector<T> facbuf((dz && QUAD) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
+    // (as the product's launch(): the explicit inverses of the Newton loop travel only when the refining IFT kernel will read them)
+    std::vector<T> facbuf((dz && QUAD && A.G.refine_w < INFINITY) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
     std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * 112 * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
     std::vector<T> yparkbuf; A.ypark = nullptr;
