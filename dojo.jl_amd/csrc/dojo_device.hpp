@@ -1115,7 +1115,14 @@ template <int N, class Wave, class T, class NP> DJ_HD void gather_children(Wave&
 
 // the NodeP fields the IFT column sweeps need, cached in registers (the sweeps' right-hand sides overlay NodeP in LDS)
 struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[MAXCH], ncontact, contact[8];
-                unsigned long long sub_mask, ub_mask; };   // bodies in this supernode's subtree (itself included) | control / contact batches owned inside it
+                unsigned long long sub_mask, ub_mask,      // bodies in this supernode's subtree (itself included) | control / contact batches owned inside it
+                                   sub_t, ub_t; };         // ... the same for every slot with k < Nb, whether its environment exists or not (topology)
+
+// What the IFT column sweeps publish per supernode in LDS (quad mapping): the up-sweep's root phase reads other supernodes' entries
+// (any quad of the environment forward-substitutes a batch on a root's behalf, gradient_columns_quad).  bm = the batches whose
+// forward-substituted right-hand side is non-zero on this supernode (bit b; topology only); topid = rank of a level-1 supernode
+// among the level-1 supernodes of the environment.
+struct SweepInfo { int level, parent, u_off, myu, nlim_r, ncontact, nchild, topid; int child[MAXCH]; unsigned char contact[8]; double wk; unsigned long long bm[2]; };
 
 // ================================================================================================
 // The lane program
@@ -1141,6 +1148,8 @@ struct LaneProgram {
     enum { MAIL_N = 18, MAIL_STRIDE = 20 };
     double* mail = nullptr;
     double* qred = nullptr;            // [3][supernode slots]: reduction scratch (quad mapping)
+    SweepInfo* sinfo = nullptr;        // [supernode slots of the workgroup] (IFT kernels, quad mapping)
+    T* msg = nullptr;                  // this ENVIRONMENT's block of KernelArgs::msg (IFT kernels, quad mapping)
     DJ_HD double* mail_slot(int supernode_lane0, int role) const { return mail + (size_t)((supernode_lane0 >> 2) * 2 + role) * MAIL_STRIDE; }
     // Reduction over the supernodes of this lane's environment of NV values that the four lanes of a supernode hold
     // identically (quad mapping): one LDS write per supernode, then every lane folds the S values of its environment --
@@ -2038,6 +2047,58 @@ struct LaneProgram {
         }
     }
 
+    // The right-hand sides of one batch (NC columns, this lane's role: three rows each) of the supernode `idk` -- the executing lane's own
+    // supernode, or a root on whose behalf it works (up-sweep, root phase) -- from that supernode's block Rn, plus what its children sent:
+    //   body roles (ABI-type block a):   own batch: own_cfg (configuration columns, double) | ROWNV (velocity columns);
+    //                                    parent's configuration batch: RPARB;  control batch: UB on the owner (child body of the joint)
+    //   joint roles (double block jd):   own configuration batch: ROWNJ;  parent's configuration batch: RPARJ
+    // MODE 1: contact batch b − nbs = contact index of the environment, five columns, on the body rows of the contact's supernode.
+    template <int MODE, int NC, class RH, class TG>
+    DJ_HD void sweep_rhs(TG (&r3a)[NC][3], const RH& Rn, int idk, int idparent, bool idhasp, int idu_off, int idmyu, int idnlim, TG idwk,
+                         int idncontact, const int* idcontact, int b, int nbs, bool valid, const TG* acc) const {
+        const int qh = q & 1;
+        const bool isS = b < nbs;
+        const int kk = b >> 1, typ = b & 1;
+        const bool mine = valid && isS && (idk == kk), par = valid && isS && typ == 0 && idhasp && (idparent == kk);
+        const int cu0 = NC * (b - nbs) - idu_off;             // control batch: local input index of column 0
+        int r_off = 0, j_off = 0, sl_off = 0, cl = -1;
+        bool od = false; TG rm_s = TG(0), wkm = TG(0);
+        if constexpr (MODE == 0) {
+            r_off = isS ? (mine ? RH::ROWNV : RH::RPARB) + qh * 18 : RH::UB + qh * 18 + cu0;
+            j_off = (mine ? RH::ROWNJ : RH::RPARJ) + qh * 18;
+            od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
+            rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0);
+            // joint-limit condensation: the slack rows (rs, −rs) enter the Δκ row (row 2 of role 3; role 2 for a translational limit) as σ rs
+            wkm = (idnlim > 0 && q == ((DJ_TSD && idnlim == 2) ? 2 : 3) && (mine || par) && typ == 0) ? idwk : TG(0);
+            sl_off = mine ? RH::SLO : RH::SLP;
+        } else {
+#pragma unroll
+            for (int c_ = 0; c_ < MAXC; ++c_) if (c_ < idncontact && idcontact[c_] == b - nbs) cl = c_;
+            r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18;
+        }
+#pragma unroll
+        for (int cI = 0; cI < NC; ++cI) {
+            TG r_[3];
+            if constexpr (MODE == 0) {
+                const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < idmyu;
+                const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0));
+                const int ir = (isS || uok) ? r_off + cI : 0, ij = isS ? j_off + cI : 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const TG dv_ = TG(Rn.own_cfg[qh * 18 + i * 6 + cI]), av_ = TG(Rn.a[ir + i * 6]), jv_ = TG(Rn.jd[ij + i * 6]);
+                    r_[i] = od ? dv_ : rm * (q < 2 ? av_ : jv_);
+                }
+                r_[2] += wkm * TG(Rn.jd[sl_off + cI]);
+            } else {
+                const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r_[i] = rm * TG(Rn.a[r_off + i * 6 + cI]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0);
+        }
+    }
+
     // quad mapping: IFT column solves  X = solmat⁻¹ · datamat  (DESIGN.md §5).
     // Columns travel through the tree six at a time ("batches") and the two sweeps are software-
     // pipelined over the batches: in step t of the up-sweep a supernode at level l works on batch
@@ -2078,11 +2139,12 @@ struct LaneProgram {
         // state batches: column cI sits at index cI (+3 for cI >= 3: the batch holds x2|φ2 or v15|ω15)
         TIO* const dz_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? A.dz : A.dc);
         TIO* const du_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? (nbu > 0 ? A.du : A.dz) : A.dc);
-        const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * ncol_u, row0 = (size_t)(12 * k + 6 * q), nxs = (size_t)nx;
+        const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * ncol_u, nxs = (size_t)nx;
         const int ucols = MODE == 0 ? NC : 5;                  // columns a control / contact batch owns in the output buffer
-        auto colbase = [=](int b) -> TIO* {
-            TIO* pz = dz_p + (env_dz + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nxs + row0;
-            TIO* pu = du_p + (env_du + (size_t)(ucols * (b - nbs))) * nxs + row0;
+        auto colbase = [=](int b, int kx) -> TIO* {               // kx: the supernode whose rows are addressed (this lane's own; a root's in the up-sweep's root phase)
+            const size_t rowx = (size_t)(12 * kx + 6 * q);
+            TIO* pz = dz_p + (env_dz + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nxs + rowx;
+            TIO* pu = du_p + (env_du + (size_t)(ucols * (b - nbs))) * nxs + rowx;
             return b < nbs ? pz : pu;
         };
         // does column cI of batch b exist?  (padding columns of the last control batch / the sixth column of a contact batch)
@@ -2090,7 +2152,55 @@ struct LaneProgram {
         // is this supernode's ỹ of batch b non-zero (sweep_masks)?  (b must be a valid batch index)
         const unsigned long long sub_mask = sp.sub_mask, ub_mask = sp.ub_mask; const int par_k = has_parent ? sp.parent : -1;
         auto y_nz = [=](int b) -> bool { return b < nbs ? (((sub_mask >> (b >> 1)) & 1ull) != 0 || ((b & 1) == 0 && par_k == (b >> 1))) : ((ub_mask >> (b - nbs)) & 1ull) != 0; };
-        // ---------------- up-sweep (leaves -> root), pipelined over the batches ----------------
+        // ---------------- up-sweep (leaves -> root): branches in parallel, then the roots ----------------
+        // ỹ of a batch is non-zero only on the supernodes that carry one of its right-hand sides and on their ancestors (sweep_masks):
+        // for a tree like the Ant's a quarter of the (supernode, batch) pairs.  Marching every batch through every supernode (rounds
+        // 1-3: NB + depth pipeline steps) spends the rest on zeros, and cannot skip them -- the quads of a wavefront run in lock step,
+        // each on a different batch.  So the sweep is scheduled by BRANCH (a child of a root and its subtree):
+        //   phase 1  every branch marches only ITS batches (those that are non-zero somewhere in it, in batch order) through its own
+        //            supernodes, all branches at once: a supernode at level l >= 1 works on the i-th batch of its branch in step
+        //            i + (maxlevel − l); the level-1 supernodes leave their messages to the root's body rows in KernelArgs::msg;
+        //   phase 2  the roots' forward substitutions -- every batch reaches a root -- are dealt out over ALL quads of the environment
+        //            (idle supernode slots included): quad s takes batches s, s + S, ... on the root's behalf, with the root's factors,
+        //            right-hand sides (its QuadRhs block in LDS) and the messages of phase 1, and parks ỹ where the root would have.
+        // Steps: max over branches of their batch count + maxlevel − 1, plus ceil(NB / S) root rounds (Ant: 8 + 2 + 2 instead of 32).
+        // The arithmetic of every (supernode, batch) pair is what it was: the same operations in the same order.
+        {
+        // -- what every supernode publishes (topology only: identical in every environment of the workgroup)
+        SweepInfo* const inf = sinfo + (base >> 2);              // this environment's entries, indexed by supernode
+        unsigned long long bm0 = 0ull, bm1 = 0ull;
+        {
+            const unsigned long long sub_t = sp.sub_t, ub_t = sp.ub_t; const int par_t = sp.parent;
+            if (k < G.Nb) for (int b_ = 0; b_ < NB; ++b_) {
+                const bool nz_ = b_ < nbs ? (((sub_t >> (b_ >> 1)) & 1ull) != 0 || ((b_ & 1) == 0 && par_t == (b_ >> 1))) : ((ub_t >> (b_ - nbs)) & 1ull) != 0;
+                if (nz_) { if (b_ < 64) bm0 |= 1ull << b_; else bm1 |= 1ull << (b_ - 64); }
+            }
+        }
+        wv.sync();
+        if (q == 0) {
+            SweepInfo& me = inf[k];
+            me.level = k < G.Nb ? lvl : -1; me.parent = sp.parent; me.u_off = sp.u_off; me.myu = sp.myu; me.nlim_r = sp.nlim_r; me.ncontact = sp.ncontact; me.nchild = k < G.Nb ? sp.nchild : 0;
+#pragma unroll
+            for (int ci = 0; ci < MAXCH; ++ci) me.child[ci] = (sp.child_lane0[ci] - base) >> 2;
+#pragma unroll
+            for (int c_ = 0; c_ < 8; ++c_) me.contact[c_] = (unsigned char)sp.contact[c_];
+            me.wk = (double)wk; me.bm[0] = bm0; me.bm[1] = bm1; me.topid = 0;
+        }
+        wv.sync();
+        // -- this supernode's branch: its level-1 ancestor, the batches of that branch, its rank among the level-1 supernodes
+        int top = k, topid = 0, maxn = 0;
+        if (k < G.Nb && lvl >= 1) { int guard = 0; while (inf[top].level > 1 && guard++ < 64) top = inf[top].parent; }
+        unsigned long long rem0 = 0ull, rem1 = 0ull;
+        if (k < G.Nb && lvl >= 1) { rem0 = inf[top].bm[0]; rem1 = inf[top].bm[1]; }
+        for (int a = 0; a < G.Nb; ++a) if (inf[a].level == 1) {
+            if (a < top) ++topid;
+            const int n_ = __builtin_popcountll(inf[a].bm[0]) + __builtin_popcountll(inf[a].bm[1]);
+            maxn = n_ > maxn ? n_ : maxn;
+        }
+        if (q == 0 && k < G.Nb && lvl == 1) inf[k].topid = topid;
+        wv.sync();
+        T* const msg_top = msg + (size_t)topid * (size_t)NB * 36 + (size_t)(q & 1) * 18;      // (+ 36 per branch-local batch position)
+        // ---- phase 1 ----
         {
         TG Lm[3][12], mq[6][3];                                // L11 − I and the parent rows' multipliers m (load_lu_up)
         load_lu_up(Lm, mq);
@@ -2100,9 +2210,13 @@ struct LaneProgram {
         if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
             for (int i = 0; i < 3 * NC; ++i) ms_[i] = 0.0; }
-        for (int t = 0; t < NB + G.maxlevel; ++t) {
-            const int b = t - (G.maxlevel - lvl);
-            const bool valid = active && b >= 0 && b < NB;
+        const int nsteps1 = G.maxlevel >= 1 ? maxn + G.maxlevel - 1 : 0;
+        for (int t = 0; t < nsteps1; ++t) {
+            const int ib = t - (G.maxlevel - lvl);                // position of this step's batch in the branch's list
+            const bool have = k < G.Nb && lvl >= 1 && ib >= 0 && (rem0 | rem1) != 0ull;
+            int b = 0;
+            if (have) { if (rem0 != 0ull) { b = __builtin_ctzll(rem0); rem0 &= rem0 - 1ull; } else { b = 64 + __builtin_ctzll(rem1); rem1 &= rem1 - 1ull; } }
+            const bool valid = active && have;
             // the children finished this batch in the previous step
             TG acc[3 * NC];
 #pragma unroll
@@ -2127,54 +2241,19 @@ struct LaneProgram {
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
             const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (sp.parent == kk);
-            // where this lane's rows of the batch's right-hand sides live in the supernode's QuadRhs (all blocks are [.][3][6]):
-            //   body roles (ABI-type block a):   own batch: own_cfg (configuration columns, double) | ROWNV (velocity columns);
-            //                                    parent's configuration batch: RPARB;  control batch: UB on the owner (child body of the joint)
-            //   joint roles (double block jd):   own configuration batch: ROWNJ;  parent's configuration batch: RPARJ
-            //   parent-row parts (roles 0, 1):   UOWN / UPAR / UA
             const int cu0 = NC * (b - nbs) - sp.u_off;            // control batch: local input index of column 0
-            int r_off = 0, j_off = 0, u_off_ = 0, sl_off = 0, cl = -1;
-            bool od = false; TG rm_s = TG(0), um_s = TG(0), wkm = TG(0);
+            int u_off_ = 0; TG um_s = TG(0);
             if constexpr (MODE == 0) {
-                r_off = isS ? (mine ? RH::ROWNV : RH::RPARB) + qh * 18 : RH::UB + qh * 18 + cu0;
-                j_off = (mine ? RH::ROWNJ : RH::RPARJ) + qh * 18;
                 u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
-                od = mine && typ == 0 && q < 2;                     // the folded owner rows come from the double block
-                rm_s = (mine ? ((q < 2) == (typ == 1)) : par) ? TG(1) : TG(0); um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
-                // joint-limit condensation: the slack rows (rs, −rs) enter the Δκ row (row 2 of role 3; role 2 for a translational limit) as σ rs
-                wkm = (sp.nlim_r > 0 && q == ((DJ_TSD && sp.nlim_r == 2) ? 2 : 3) && (mine || par) && typ == 0) ? TG(wk) : TG(0);
-                sl_off = mine ? RH::SLO : RH::SLP;
-            } else {
-                // contact batch b - nbs = contact index of the environment; cl = its slot on this supernode (or -1)
-#pragma unroll
-                for (int c_ = 0; c_ < MAXC; ++c_) if (c_ < sp.ncontact && sp.contact[c_] == b - nbs) cl = c_;
-                r_off = (cl < 0 ? 0 : cl) * 36 + qh * 18;
+                um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
             }
-            TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            TIO* const cb = colbase(valid ? b : 0, k);            // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the six columns of the batch together: right-hand sides, one forward substitution of all six, then the messages
             TG r3a[NC][3];
-#pragma unroll
-            for (int cI = 0; cI < NC; ++cI) {
-                TG r_[3];
-                if constexpr (MODE == 0) {
-                    const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < myu;
-                    const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0));
-                    const int ir = (isS || uok) ? r_off + cI : 0, ij = isS ? j_off + cI : 0;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const TG dv_ = TG(R.own_cfg[qh * 18 + i * 6 + cI]), av_ = TG(R.a[ir + i * 6]), jv_ = TG(R.jd[ij + i * 6]);
-                        r_[i] = od ? dv_ : rm * (q < 2 ? av_ : jv_);
-                    }
-                    r_[2] += wkm * TG(R.jd[sl_off + cI]);
-                } else {
-                    const TG rm = (valid && q < 2 && cl >= 0 && cI < 5) ? TG(1) : TG(0);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) r_[i] = rm * TG(R.a[r_off + i * 6 + cI]);
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) r3a[cI][i] = valid ? TG(r_[i]) + acc[3 * cI + i] : TG(0);
-            }
+            sweep_rhs<MODE, NC>(r3a, R, k, sp.parent, has_parent, sp.u_off, myu, sp.nlim_r, TG(wk), sp.ncontact, sp.contact, b, nbs, valid, acc);
             lu_forward_quad<NC>(Lm, r3a);                         // ỹ = L11⁻¹ r
+            T* const mg = msg_top + (size_t)(ib > 0 ? ib : 0) * 36;
+            const bool to_root = valid && lvl == 1 && q < 2;      // the parent is a root: it reads the message in phase 2
 #pragma unroll
             for (int cI = 0; cI < NC; ++cI) {
                 const int cx = (isS && cI >= 3) ? cI + 3 : cI;      // column index inside the batch's block of the output buffer
@@ -2197,9 +2276,13 @@ struct LaneProgram {
                 // the message to the parent's body rows, posted at once (an invalid step posts zeros: its batch is out of range for the
                 // parent's next step as well)
                 if (cI == 0) wv.sync();                             // (every supernode has read its children's messages of the previous step)
+                TG ms3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; ms3[i] = (valid && has_parent) ? ua[i] - (q == 0 ? p0_ : p1_) : TG(0); }
                 if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { const TG p0_ = part[i], p1_ = part[3 + i]; ms_[3 * cI + i] = (double)((valid && has_parent) ? ua[i] - (q == 0 ? p0_ : p1_) : TG(0)); } }
+                    for (int i = 0; i < 3; ++i) ms_[3 * cI + i] = (double)ms3[i]; }
+                if (to_root) { mg[3 * cI] = T(ms3[0]); mg[3 * cI + 1] = T(ms3[1]); mg[3 * cI + 2] = T(ms3[2]); }
                 if (valid) {
                     if (col_ok(b, cI) && y_nz(b)) {
                         if constexpr (ypk) { T* yo = yp0 + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
@@ -2208,6 +2291,64 @@ struct LaneProgram {
                 }
             }
         }
+        }
+        // ---- phase 2: the roots ----
+        wv.sync_mem();                                            // (the messages of phase 1 and the staged factors are read by other lanes)
+        {
+        const int nrounds = (NB + G.S - 1) / G.S;
+        const bool env_ok = (env < A.B);
+        for (int a = 0; a < G.Nb; ++a) {
+            if (inf[a].level != 0) continue;                      // (uniform: the tables are the same in every environment)
+            const int dl = base + 4 * a + q - wv.lane();          // from this lane to the root's lane of the same role
+            TG Lm[3][12];
+            { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int j = 0; j < 12; ++j) Lm[i][j] = TL(o[(size_t)(LU_LM + 12 * i + j) * S_]); }
+            const RH& Rr = *((const RH*)&R + (a - k));             // the root's right-hand-side block
+            const SweepInfo& ri = inf[a];
+            int rcontact[8];
+#pragma unroll
+            for (int c_ = 0; c_ < 8; ++c_) rcontact[c_] = ri.contact[c_];
+            for (int rd = 0; rd < nrounds; ++rd) {
+                const int b = rd * G.S + k;
+                const bool inb = b < NB;
+                const bool valid = env_ok && inb && (((b < 64 ? ri.bm[0] >> (b < 64 ? b : 0) : ri.bm[1] >> (b >= 64 ? b - 64 : 0)) & 1ull) != 0);
+                TG acc[3 * NC];
+#pragma unroll
+                for (int i = 0; i < 3 * NC; ++i) acc[i] = TG(0);
+                for (int ci = 0; ci < ri.nchild; ++ci) {
+                    const SweepInfo& cinf = inf[ri.child[ci]];
+                    const unsigned long long c0 = cinf.bm[0], c1 = cinf.bm[1];
+                    const bool cnz = valid && q < 2 && (((b < 64 ? c0 >> (b < 64 ? b : 0) : c1 >> (b >= 64 ? b - 64 : 0)) & 1ull) != 0);
+                    // position of b among the child's batches = the slot its phase-1 step wrote
+                    const int pos = b < 64 ? __builtin_popcountll(c0 & ((1ull << (b < 64 ? b : 0)) - 1ull))
+                                           : __builtin_popcountll(c0) + __builtin_popcountll(c1 & ((1ull << (b >= 64 ? b - 64 : 0)) - 1ull));
+                    const T* mg = msg + ((size_t)cinf.topid * (size_t)NB + (size_t)(cnz ? pos : 0)) * 36 + (size_t)(q & 1) * 18;
+                    if (cnz) {
+#pragma unroll
+                        for (int i = 0; i < 3 * NC; ++i) acc[i] += TG(mg[i]);
+                    }
+                }
+                TG r3a[NC][3];
+                sweep_rhs<MODE, NC>(r3a, Rr, a, -1, false, ri.u_off, ri.myu, ri.nlim_r, TG(ri.wk), ri.ncontact, rcontact, inb ? b : 0, nbs, valid, acc);
+                lu_forward_quad<NC>(Lm, r3a);
+                if (valid) {
+                    const bool isS = b < nbs;
+                    TIO* const cb = colbase(b, a);
+#pragma unroll
+                    for (int cI = 0; cI < NC; ++cI) if (col_ok(b, cI)) {
+                        const int cx = (isS && cI >= 3) ? cI + 3 : cI;
+                        const TG (&yy)[3] = r3a[cI];
+                        if constexpr (ypk) { T* yo = yp0 + dl + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
+                        else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
+                    }
+                }
+            }
+        }
+        }
+        wv.sync_mem();                                            // (the roots fetch the ỹ other lanes parked for them)
         }
 #ifdef DJ_PROF
         unsigned long long td0 = wv.clock();
@@ -2229,7 +2370,7 @@ struct LaneProgram {
         TY ynext[NC][3];
         auto fetch_y = [&](int b_) {
             const bool v_ = active && b_ >= 0 && b_ < NB && y_nz(b_ >= 0 ? b_ : 0);
-            TIO* const cbn = colbase(v_ ? b_ : 0) + prk_off;
+            TIO* const cbn = colbase(v_ ? b_ : 0, k) + prk_off;
             const bool isS_ = b_ < nbs;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
@@ -2255,7 +2396,7 @@ struct LaneProgram {
             fetch_y(b + 1);
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
-            TIO* const cb = colbase(valid ? b : 0);               // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            TIO* const cb = colbase(valid ? b : 0, k);            // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the parent finished this batch in the previous step: its two body-row roles posted Δv, Δω of the six columns
             wv.sync();
             // x = U11⁻¹ (ỹ − T x_parent) of the six columns (T = 0 on the roots: store_lu)
@@ -2997,6 +3138,7 @@ struct LaneProgram {
             else for (int c = 0; c < Pj.ncontact; ++c) ub |= 1ull << Pj.contact[c];
         }
         sp.sub_mask = active ? sub : 0ull; sp.ub_mask = active ? ub : 0ull;
+        sp.sub_t = k < G.Nb ? sub : 0ull; sp.ub_t = k < G.Nb ? ub : 0ull;
     }
 
     // the final linearization once more at the restored solution, factored in LU form and staged (quad mapping, IFT kernels)
@@ -3593,6 +3735,8 @@ struct KernelArgs {
     long long ypark_stride = 0;    // elements per workgroup of ypark
     T* ypark = nullptr;            // [workgroups][batches][6][3][lanes / 2] quad mapping, ABI type narrower than the arithmetic: the IFT's forward-substituted
                                    // right-hand sides in full precision between the two sweeps (or null: they wait in the output buffer, in the ABI type)
+    T* msg = nullptr;              // [B][level-1 supernodes][batches][2 roles][18] quad mapping: what the children of a root post to its body rows during the
+    long long msg_stride = 0;      // up-sweep (read back by the root phase, gradient_columns_quad); msg_stride = elements per environment
     int* flag = nullptr;           // [B] 1: the plain step kernel deferred this environment to the refining kernels (DJ_REFINE; or null)
     T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
     T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
@@ -3651,7 +3795,8 @@ struct StepLds {
     static constexpr int mail_off = (QUAD && GRAD == 2) ? a_end : (QUAD && GRAD) ? lds_imax(a_end, rhs_off + rhs_bytes) : a_end;
     static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
     static constexpr int qred_off = red_off + 64;                    // per-supernode values of the environment reductions (3 at a time)
-    static constexpr int bytes = qred_off + (QUAD ? 3 * NSN * 8 : 0);
+    static constexpr int info_off = qred_off + (QUAD ? 3 * NSN * 8 : 0);   // SweepInfo per supernode (IFT kernels)
+    static constexpr int bytes = info_off + ((QUAD && GRAD) ? NSN * (int)sizeof(SweepInfo) : 0);
 };
 template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
@@ -3699,6 +3844,8 @@ constexpr int FAC_PER_LANE = 72;
         prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
         prog.mail = (double*)(lds + LY::mail_off);                                                                        \
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
+        if (GRAD_LAYOUT) prog.sinfo = (SweepInfo*)(lds + LY::info_off);                                                   \
+        if (A.msg) prog.msg = DJ_GLOBAL_PTR(T, A.msg) + (size_t)(env < A.B ? env : 0) * (size_t)A.msg_stride;                 \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
         if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * 112 * wv.width() + lane; prog.lu_stride = wv.width(); }                \

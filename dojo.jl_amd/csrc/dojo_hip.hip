@@ -89,6 +89,7 @@ struct DojoSim {
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping; explicit-inverse consumers only)
     void* d_lu = nullptr;               // the IFT kernel's LU-form factors between its phases (quad mapping)
     void* d_blk = nullptr;              // un-factored supernode rows of the environments whose solves are refined (quad mapping, DJ_REFINE)
+    void* d_msg = nullptr;              // quad mapping: messages of the IFT up-sweep to the roots (KernelArgs::msg)
     void* d_ypark = nullptr;            // fp32 ABI, quad mapping: the IFT's forward-substituted right-hand sides between its two sweeps, in fp64
     int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
     double refine_w = -1.0;             // refine once max γ/s of an environment exceeds this (dojo_set_refinement); < 0: chosen from the tolerances
@@ -482,6 +483,16 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (!s->d_ypark) HIPCHK(hipMalloc(&s->d_ypark, waves_total * (size_t)A.ypark_stride * sizeof(T)));
         A.ypark = (T*)s->d_ypark + wave0 * (size_t)A.ypark_stride;
     }
+    A.msg = nullptr; A.msg_stride = 0;
+    if (g && quad) {                                       // (dojo_device.hpp, gradient_columns_quad: what the children of a root post to its body rows)
+        size_t ntops = 0; for (auto& n_ : s->M.nodes) if (n_.level == 1) ++ntops;
+        const size_t batches = std::max<size_t>(2 * Nb + (nu + 5) / 6, (size_t)s->M.Nc);
+        A.msg_stride = (long long)(ntops * batches * 36);
+        if (A.msg_stride > 0) {
+            if (!s->d_msg) HIPCHK(hipMalloc(&s->d_msg, (size_t)s->B * (size_t)A.msg_stride * sizeof(T)));
+            A.msg = (T*)s->d_msg + env0 * (size_t)A.msg_stride;
+        }
+    }
     A.blk = nullptr; A.flag = nullptr;
     if (quad && A.G.refine_w < INFINITY) {                  // the refining kernels follow the plain ones (dojo_kernels.hip)
         if (!s->d_blk) HIPCHK(hipMalloc(&s->d_blk, waves_total * 90 * 64 * NW * sizeof(T)));
@@ -615,7 +626,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);

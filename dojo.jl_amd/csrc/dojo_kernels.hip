@@ -38,6 +38,12 @@ struct GpuWave {
         if (NW == 1) __asm__ volatile("" ::: "memory");
         else __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    // ... and when lanes read GLOBAL memory other lanes of the workgroup wrote: this wave's stores have left it (vmcnt(0)); the vector L1 is
+    // shared by the wavefronts of a workgroup, so no invalidation is needed at workgroup scope
+    __device__ __forceinline__ void sync_mem() const {
+        if (NW == 1) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }              // lane index inside the workgroup
     __device__ __forceinline__ int width() const { return 64 * NW; }
     __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }

@@ -57,6 +57,7 @@ struct EmuWaveT {
     int width() const { return sh->W; }
     void* lds() const { return (void*)sh->lds.data(); }
     void sync() { sh->bar.wait(); }
+    void sync_mem() { sh->bar.wait(); }
     template <class T> T shfl(T v, int src) {
         sh->slot[l] = (double)v;
         sh->bar.wait();
@@ -127,6 +128,10 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<T> facbuf((dz && QUAD && A.G.refine_w < INFINITY) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
     std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * 112 * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
+    // the up-sweep's messages to the roots (as the product's launch())
+    int ntops = 0; for (auto& n : M.nodes) if (n.level == 1) ++ntops;
+    std::vector<T> msgbuf; A.msg = nullptr; A.msg_stride = (long long)ntops * std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 36;
+    if (dz && QUAD && A.msg_stride > 0) { msgbuf.resize((size_t)B * A.msg_stride); A.msg = msgbuf.data(); }
     std::vector<T> yparkbuf; A.ypark = nullptr;
     if (dz && QUAD && sizeof(TIO) < sizeof(T)) { A.ypark_stride = (long long)(std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 18 * W); yparkbuf.resize((size_t)nwaves * A.ypark_stride); A.ypark = yparkbuf.data(); }
     // the same two launches as the product: step kernel, then (when gradients are wanted) the IFT kernel
