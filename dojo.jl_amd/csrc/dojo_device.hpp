@@ -25,6 +25,7 @@
 #pragma once
 #include "dojo_math.hpp"
 #include <type_traits>
+#include <cstddef>
 #ifdef DJ_DEBUG
 #include <cstdio>
 #include <cstdlib>
@@ -1118,6 +1119,18 @@ struct SweepP { int level, parent, pb, u_off, myu, nlim_r, nchild, child_lane0[M
                 unsigned long long sub_mask, ub_mask,      // bodies in this supernode's subtree (itself included) | control / contact batches owned inside it
                                    sub_t, ub_t; };         // ... the same for every slot with k < Nb, whether its environment exists or not (topology)
 
+// 8 bytes at p read as a double, or their first 4 as a float (isd false) -- without a branch: two 32-bit reads and a select
+template <bool ALWAYS_DOUBLE> DJ_HD double lds_read_as_double(const char* p, bool isd) {
+    if constexpr (ALWAYS_DOUBLE) { double v; __builtin_memcpy(&v, p, 8); return v; }
+    else {
+        unsigned lo, hi; __builtin_memcpy(&lo, p, 4); __builtin_memcpy(&hi, p + 4, 4);
+        float f; __builtin_memcpy(&f, &lo, 4);
+        const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+        double d; __builtin_memcpy(&d, &u, 8);
+        return isd ? d : (double)f;
+    }
+}
+
 // What the IFT column sweeps publish per supernode in LDS (quad mapping): the up-sweep's root phase reads other supernodes' entries
 // (any quad of the environment forward-substitutes a batch on a root's behalf, gradient_columns_quad).  bm = the batches whose
 // forward-substituted right-hand side is non-zero on this supernode (bit b; topology only); topid = rank of a level-1 supernode
@@ -2083,10 +2096,18 @@ struct LaneProgram {
                 const bool uok = !isS && valid && q < 2 && (cu0 + cI) >= 0 && (cu0 + cI) < idmyu;
                 const TG rm = isS ? rm_s : (uok ? TG(1) : TG(0));
                 const int ir = (isS || uok) ? r_off + cI : 0, ij = isS ? j_off + cI : 0;
+                // ONE read per value, at a lane-dependent byte offset into the block: the body roles' ABI-type block a, or the double blocks
+                // own_cfg / jd.  (Reading all three and selecting made the compiler put every read behind a branch of its own: 18 x
+                // [branch, three reads, two waits] per step, each exposing the LDS latency to the one wave of the SIMD.)
+                typedef typename std::remove_reference<decltype(Rn.a[0])>::type TBv;
+                const char* const Rb = (const char*)&Rn;
+                const bool isd = sizeof(TBv) == 8 || q >= 2 || od;
+                const TG sc = od ? TG(1) : rm;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const TG dv_ = TG(Rn.own_cfg[qh * 18 + i * 6 + cI]), av_ = TG(Rn.a[ir + i * 6]), jv_ = TG(Rn.jd[ij + i * 6]);
-                    r_[i] = od ? dv_ : rm * (q < 2 ? av_ : jv_);
+                    const int ob = q < 2 ? (od ? (int)offsetof(RH, own_cfg) + 8 * (qh * 18 + i * 6 + cI) : (int)sizeof(TBv) * (ir + i * 6))
+                                         : (int)offsetof(RH, jd) + 8 * (ij + i * 6);
+                    r_[i] = sc * TG(lds_read_as_double<sizeof(TBv) == 8>(Rb + ob, isd));
                 }
                 r_[2] += wkm * TG(Rn.jd[sl_off + cI]);
             } else {
@@ -2141,8 +2162,8 @@ struct LaneProgram {
         TIO* const du_p = DJ_GLOBAL_PTR(TIO, MODE == 0 ? (nbu > 0 ? A.du : A.dz) : A.dc);
         const size_t env_dz = (size_t)env * nx, env_du = (size_t)env * ncol_u, nxs = (size_t)nx;
         const int ucols = MODE == 0 ? NC : 5;                  // columns a control / contact batch owns in the output buffer
-        auto colbase = [=](int b, int kx) -> TIO* {               // kx: the supernode whose rows are addressed (this lane's own; a root's in the up-sweep's root phase)
-            const size_t rowx = (size_t)(12 * kx + 6 * q);
+        auto colbase = [=](int b, int kx, int role) -> TIO* {     // kx: the supernode whose rows are addressed (this lane's own; a root's in the root phase), role: whose six rows
+            const size_t rowx = (size_t)(12 * kx + 6 * role);
             TIO* pz = dz_p + (env_dz + (size_t)(12 * (b >> 1) + 3 * (b & 1))) * nxs + rowx;
             TIO* pu = du_p + (env_du + (size_t)(ucols * (b - nbs))) * nxs + rowx;
             return b < nbs ? pz : pu;
@@ -2165,7 +2186,6 @@ struct LaneProgram {
         //            right-hand sides (its QuadRhs block in LDS) and the messages of phase 1, and parks ỹ where the root would have.
         // Steps: max over branches of their batch count + maxlevel − 1, plus ceil(NB / S) root rounds (Ant: 8 + 2 + 2 instead of 32).
         // The arithmetic of every (supernode, batch) pair is what it was: the same operations in the same order.
-        {
         // -- what every supernode publishes (topology only: identical in every environment of the workgroup)
         SweepInfo* const inf = sinfo + (base >> 2);              // this environment's entries, indexed by supernode
         unsigned long long bm0 = 0ull, bm1 = 0ull;
@@ -2190,8 +2210,16 @@ struct LaneProgram {
         // -- this supernode's branch: its level-1 ancestor, the batches of that branch, its rank among the level-1 supernodes
         int top = k, topid = 0, maxn = 0;
         if (k < G.Nb && lvl >= 1) { int guard = 0; while (inf[top].level > 1 && guard++ < 64) top = inf[top].parent; }
-        unsigned long long rem0 = 0ull, rem1 = 0ull;
-        if (k < G.Nb && lvl >= 1) { rem0 = inf[top].bm[0]; rem1 = inf[top].bm[1]; }
+        unsigned long long tbm0 = 0ull, tbm1 = 0ull;              // the batches of this supernode's branch (none for a root)
+        if (k < G.Nb && lvl >= 1) { tbm0 = inf[top].bm[0]; tbm1 = inf[top].bm[1]; }
+        unsigned long long rem0 = tbm0, rem1 = tbm1;
+        int rootk = k < G.Nb ? k : 0, rootrank = 0, ntops = 0;  // this supernode's root, its rank among the roots; level-1 supernodes of the environment
+        if (k < G.Nb && lvl >= 1) rootk = inf[top].parent;
+        int nroots = 0;
+        for (int a = 0; a < G.Nb; ++a) { if (inf[a].level == 0) { ++nroots; if (a < rootk) ++rootrank; } if (inf[a].level == 1) ++ntops; }
+        // x of the roots' body rows (Δv, Δω of every batch), posted by the root phase for everybody: behind the messages in KernelArgs::msg
+        T* const xr_mine = msg + (size_t)(ntops + rootrank) * (size_t)NB * 36;
+        TIO* const trash = (TIO*)(msg + (size_t)(ntops + nroots) * (size_t)NB * 36);   // where the stores of columns that do not exist go (and their loads come from)
         for (int a = 0; a < G.Nb; ++a) if (inf[a].level == 1) {
             if (a < top) ++topid;
             const int n_ = __builtin_popcountll(inf[a].bm[0]) + __builtin_popcountll(inf[a].bm[1]);
@@ -2201,6 +2229,9 @@ struct LaneProgram {
         wv.sync();
         T* const msg_top = msg + (size_t)topid * (size_t)NB * 36 + (size_t)(q & 1) * 18;      // (+ 36 per branch-local batch position)
         // ---- phase 1 ----
+#ifdef DJ_PROF
+        unsigned long long tp1 = wv.clock();
+#endif
         {
         TG Lm[3][12], mq[6][3];                                // L11 − I and the parent rows' multipliers m (load_lu_up)
         load_lu_up(Lm, mq);
@@ -2221,23 +2252,18 @@ struct LaneProgram {
             TG acc[3 * NC];
 #pragma unroll
             for (int i = 0; i < 3 * NC; ++i) acc[i] = TG(0);
-#ifdef DJ_PROF
-            unsigned long long tg0 = wv.clock();
-#endif
             {   // children -> parent through the mailbox (only the body-row roles carry anything)
                 wv.sync();
+                // (no branches: a slot without a child reads the quad's own, finite post and adds 0 times it)
 #pragma unroll
-                for (int ci = 0; ci < MAXCH; ++ci) {
-                    if (valid && q < 2 && ci < sp.nchild) {
-                        const double* cs_ = mail_slot(sp.child_lane0[ci], q);
+                for (int ci = 0; ci < MAXCH; ++ci) if (ci < G.maxch) {   // (unrolled: a run-time index would put sp.child_lane0 into scratch; the test is uniform)
+                    const bool use = valid && q < 2 && ci < sp.nchild;
+                    const double* cs_ = mail_slot(use ? sp.child_lane0[ci] : qb, q & 1);
+                    const TG uf = use ? TG(1) : TG(0);
 #pragma unroll
-                        for (int i = 0; i < 3 * NC; ++i) acc[i] += TG(cs_[i]);
-                    }
+                    for (int i = 0; i < 3 * NC; ++i) acc[i] += uf * TG(cs_[i]);
                 }
             }
-#ifdef DJ_PROF
-            pc[2] += wv.clock() - tg0;
-#endif
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
             const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (sp.parent == kk);
@@ -2247,7 +2273,7 @@ struct LaneProgram {
                 u_off_ = isS ? (mine ? RH::UOWN : RH::UPAR) + qh * 18 : RH::UA + qh * 18 + cu0;
                 um_s = ((mine || par) && typ == 0 && q < 2) ? TG(1) : TG(0);
             }
-            TIO* const cb = colbase(valid ? b : 0, k);            // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            TIO* const cb = colbase(valid ? b : 0, k, q);            // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the six columns of the batch together: right-hand sides, one forward substitution of all six, then the messages
             TG r3a[NC][3];
             sweep_rhs<MODE, NC>(r3a, R, k, sp.parent, has_parent, sp.u_off, myu, sp.nlim_r, TG(wk), sp.ncontact, sp.contact, b, nbs, valid, acc);
@@ -2292,11 +2318,15 @@ struct LaneProgram {
             }
         }
         }
+#ifdef DJ_PROF
+        pc[3] += wv.clock() - tp1; tp1 = wv.clock();
+#endif
         // ---- phase 2: the roots ----
         wv.sync_mem();                                            // (the messages of phase 1 and the staged factors are read by other lanes)
         {
         const int nrounds = (NB + G.S - 1) / G.S;
         const bool env_ok = (env < A.B);
+        int rrank = 0;                                            // rank of the root at hand among the roots
         for (int a = 0; a < G.Nb; ++a) {
             if (inf[a].level != 0) continue;                      // (uniform: the tables are the same in every environment)
             const int dl = base + 4 * a + q - wv.lane();          // from this lane to the root's lane of the same role
@@ -2336,7 +2366,7 @@ struct LaneProgram {
                 lu_forward_quad<NC>(Lm, r3a);
                 if (valid) {
                     const bool isS = b < nbs;
-                    TIO* const cb = colbase(b, a);
+                    TIO* const cb = colbase(b, a, q);
 #pragma unroll
                     for (int cI = 0; cI < NC; ++cI) if (col_ok(b, cI)) {
                         const int cx = (isS && cI >= 3) ? cI + 3 : cI;
@@ -2346,31 +2376,131 @@ struct LaneProgram {
                     }
                 }
             }
+            // ... and at once its backward substitution of the same batches, x = U11⁻¹ ỹ (a root has no parent term), by the same quads
+            // (every lane reads back what it parked itself); Δv, Δω of the root go to xr for the whole tree
+            {
+                TG Um[3][12], di[3];
+                { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+                  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                      for (int j = 0; j < 12; ++j) Um[i][j] = TL(o[(size_t)(LU_UM + 12 * i + j) * S_]);
+                      di[i] = TL(o[(size_t)(LU_DI + i) * S_]); } }
+                T* const xr_root = msg + (size_t)(ntops + rrank) * (size_t)NB * 36;
+                for (int rd = 0; rd < nrounds; ++rd) {
+                    const int b = rd * G.S + k;
+                    const bool inb = b < NB;
+                    const bool valid = env_ok && inb && (((b < 64 ? ri.bm[0] >> (b < 64 ? b : 0) : ri.bm[1] >> (b >= 64 ? b - 64 : 0)) & 1ull) != 0);
+                    const bool isS = b < nbs;
+                    TIO* const cb = colbase(valid ? b : 0, a, q);
+                    TG x3[NC][3];
+#pragma unroll
+                    for (int cI = 0; cI < NC; ++cI) {
+                        const bool ok_ = valid && col_ok(b, cI);
+                        const int cx = (isS && cI >= 3) ? cI + 3 : cI;
+                        if constexpr (ypk) { const T* yi = yp0 + dl + (size_t)(((valid ? b : 0) * NC + cI) * 3) * yW;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) x3[cI][i] = ok_ ? TG(yi[i * yW]) : TG(0); }
+                        else { const TIO* o = cb + (size_t)cx * nx + prk_off;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) x3[cI][i] = ok_ ? TG(o[i]) : TG(0); }
+                    }
+                    lu_backward_quad<NC>(Um, di, x3);
+                    if (valid && q < 2) {
+                        T* xo = xr_root + (size_t)b * 36 + 18 * q;
+#pragma unroll
+                        for (int cI = 0; cI < NC; ++cI)
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) xo[3 * cI + i] = T(x3[cI][i]);
+                    }
+                }
+            }
+            ++rrank;
         }
         }
-        wv.sync_mem();                                            // (the roots fetch the ỹ other lanes parked for them)
-        }
+        wv.sync_mem();                                            // (what the root phase left in global memory is read by other lanes)
 #ifdef DJ_PROF
+        pc[7] += wv.clock() - tp1;
         unsigned long long td0 = wv.clock();
 #endif
-        // ---------------- down-sweep (root -> leaves), pipelined over the batches ----------------
+        // ---------------- down-sweep (roots -> leaves) ----------------
+        // x = U11⁻¹ (ỹ − T x_parent).  The roots are done (root phase above); x is dense, but where ỹ vanishes in a whole branch -- every batch
+        // that is not one of the branch's own -- the body rows (Δv, Δω) of a supernode are a fixed linear map of its root's:
+        //   x_body = P x_body(parent),  P = body rows of −U11⁻¹ T;   Q = P Q(parent) down the tree,   x_body = Q x_body(root).
+        // So:  phase A  every branch marches its OWN batches through its supernodes with the full backward substitution, all branches at
+        //               once (the mirror image of the up-sweep's phase 1; the level-1 supernodes take x of their root from xr);
+        //      phase B  every supernode (the roots too: Q = I) writes its rows of all other batches as Q times xr -- 36 multiply-adds per
+        //               column and body instead of a substitution step, no exchange, no dependency chain.
+        static_assert(NC == 6, "the Q maps are built as one batch of six columns");
         TG Um[3][12], Tq[3][6], di[3];                          // D⁻¹U11 − I, T = L11⁻¹U and the reciprocal pivots (load_lu_down)
         load_lu_down(Um, Tq, di);
+        TG Qr[3][6];                                            // roles 0 / 1: this lane's rows (Δv / Δω) of Q
+        {
+            TG w3[NC][3];
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w3[n][i] = -Tq[i][n];
+            lu_backward_quad<NC>(Um, di, w3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int n = 0; n < NC; ++n) Qr[i][n] = lvl == 0 ? ((n == 3 * q + i) ? TG(1) : TG(0)) : w3[n][i];
+        }
+        // Q = U11⁻¹(−T Q(parent)), level by level: the substitution is applied to T Q(parent) -- the product (U11⁻¹ T) Q(parent) of explicitly
+        // formed factors loses the digits of a stiff supernode (measured on tests/golden/hard_cases_ant.npz: 5e-7 instead of 1e-8 relative)
+        for (int lev = 2; lev <= G.maxlevel; ++lev) {
+            TG qf[18];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) qf[6 * i + j] = Qr[i][j];
+            mail_post_roles<18>(qf);
+            const double* p0 = mail_slot(pb, 0); const double* p1 = mail_slot(pb, 1);
+            TG w3[NC][3];
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    TG a_ = TG(0);
+#pragma unroll
+                    for (int m_ = 0; m_ < 3; ++m_) a_ -= Tq[i][m_] * TG(p0[6 * m_ + n]) + Tq[i][3 + m_] * TG(p1[6 * m_ + n]);
+                    w3[n][i] = a_;
+                }
+            lu_backward_quad<NC>(Um, di, w3);
+            const bool at = lvl == lev;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Qr[i][j] = at ? w3[j][i] : Qr[i][j];
+        }
+        // ---- phase A: the branches' own batches ----
         // (as in the up-sweep: Δv, Δω of a batch are posted at the end of the step that solved them)
         wv.sync();
         if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
             for (int i = 0; i < 3 * NC; ++i) ms_[i] = 0.0; }
-        // the parked ỹ of the NEXT step's batch is fetched while this step computes (the loads are one HBM / L2 round trip
-        // away and nothing else hides it with one wave per SIMD)
         T Mq[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Mq[i] = q == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
+        for (int i = 0; i < 9; ++i) Mq[i] = (q & 1) == 0 ? ((i % 4 == 0) ? dt : T(0)) : kb0.Phi[i];
+        {
+        // the parked ỹ of the NEXT step's batch, and (level 1) this lane's quarter of its root's x, are fetched while this step computes (the
+        // loads are one HBM / L2 round trip away and nothing else hides it with one wave per SIMD)
         typedef typename std::conditional<ypk, TG, TIO>::type TY;
         TY ynext[NC][3];
-        auto fetch_y = [&](int b_) {
-            const bool v_ = active && b_ >= 0 && b_ < NB && y_nz(b_ >= 0 ? b_ : 0);
-            TIO* const cbn = colbase(v_ ? b_ : 0, k) + prk_off;
+        T xnext[9];
+        double* const stage = (double*)gb_lds;                  // [2 roles][18]: the root's Δv, Δω of the current batch (level 1; the right-hand sides are dead)
+        unsigned long long rem0 = tbm0, rem1 = tbm1;
+        int bnxt = -1;
+        auto advance = [&](int tn) {                              // pops the batch of step tn into bnxt and fetches what it needs
+            const int in_ = tn - (lvl - 1);
+            bnxt = -1;
+            if (k < G.Nb && lvl >= 1 && in_ >= 0 && (rem0 | rem1) != 0ull) {
+                if (rem0 != 0ull) { bnxt = __builtin_ctzll(rem0); rem0 &= rem0 - 1ull; } else { bnxt = 64 + __builtin_ctzll(rem1); rem1 &= rem1 - 1ull; }
+            }
+            const int b_ = bnxt;
+            const bool v_ = active && b_ >= 0 && y_nz(b_ >= 0 ? b_ : 0);
+            TIO* const cbn = colbase(v_ ? b_ : 0, k, q) + prk_off;
             const bool isS_ = b_ < nbs;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
@@ -2385,24 +2515,37 @@ struct LaneProgram {
                     for (int i = 0; i < 3; ++i) ynext[n][i] = ok_ ? o_[i] : TIO(0);
                 }
             }
+            const bool x_ = active && lvl == 1 && b_ >= 0;
+            const T* xs = xr_mine + (size_t)(x_ ? b_ : 0) * 36 + 9 * q;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) xnext[j] = x_ ? xs[j] : T(0);
         };
-        fetch_y(0 - lvl);
-        for (int t = 0; t < NB + G.maxlevel; ++t) {
-            const int b = t - lvl;
-            const bool valid = active && b >= 0 && b < NB;
+        advance(0);
+        const int nstepsA = G.maxlevel >= 1 ? maxn + G.maxlevel - 1 : 0;
+        for (int t = 0; t < nstepsA; ++t) {
+            const int b = bnxt < 0 ? 0 : bnxt;
+            const bool valid = active && bnxt >= 0;
             TY ycur[NC][3];
 #pragma unroll
             for (int n = 0; n < NC; ++n) for (int i = 0; i < 3; ++i) ycur[n][i] = ynext[n][i];
-            fetch_y(b + 1);
+            T xcur[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) xcur[j] = xnext[j];
+            advance(t + 1);
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
-            TIO* const cb = colbase(valid ? b : 0, k);            // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
+            TIO* const cb = colbase(b, k, q);                     // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
             // the parent finished this batch in the previous step: its two body-row roles posted Δv, Δω of the six columns
             wv.sync();
-            // x = U11⁻¹ (ỹ − T x_parent) of the six columns (T = 0 on the roots: store_lu)
+            if (lvl == 1) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) stage[9 * q + j] = (double)xcur[j];
+            }
+            wv.sync();
+            // x = U11⁻¹ (ỹ − T x_parent) of the six columns
             TG x3[NC][3];
             {
-                const double* p0 = mail_slot(pb, 0); const double* p1 = mail_slot(pb, 1);
+                const double* p0 = lvl == 1 ? stage : mail_slot(pb, 0); const double* p1 = lvl == 1 ? stage + 18 : mail_slot(pb, 1);
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     const bool ok_ = valid && col_ok(b, n);
@@ -2427,9 +2570,10 @@ struct LaneProgram {
                 if (q < 2) { double* ms_ = mail_slot(qb, q);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) ms_[3 * n + i] = (double)d3[0][i]; }
-                if (valid && q < 2 && col_ok(b, n)) {
-                    // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows)
-                    TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
+                {
+                    // one code path for both body-row roles: rows [Mq d (+ identity term); d] with Mq = Δt I (role 0: x3 rows) or Φ (role 1: φ3 rows);
+                    // the joint roles, idle steps and columns that do not exist store to the trash slot (no branch around the stores)
+                    TIO* const o = (valid && q < 2 && col_ok(b, n)) ? cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx : trash;
                     T d_[3] = {T(d3[0][0]), T(d3[0][1]), T(d3[0][2])};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
@@ -2441,8 +2585,71 @@ struct LaneProgram {
                 }
             }
         }
+        }
+        // ---- phase B: everybody's rows of the batches of the OTHER branches (a root: of all its batches) ----
 #ifdef DJ_PROF
-        pc[4] += wv.clock() - td0;
+        unsigned long long tpb = wv.clock();
+#endif
+        {
+            const int rq = q & 1, half = q >> 1;                  // lanes 2, 3 work as roles 0, 1 on every other batch
+            TG Qb[3][6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const TG o_ = wv.quad_xor(Qr[i][j], 2); Qb[i][j] = q < 2 ? Qr[i][j] : o_; }
+            unsigned long long f0 = 0ull, f1 = 0ull;            // the root's batches that are not this branch's own
+            if (active) { f0 = inf[rootk].bm[0] & ~tbm0; f1 = inf[rootk].bm[1] & ~tbm1; }
+            int cnt = 0;
+            auto pop = [&]() -> int {                             // this lane's next batch: every other one of the set
+                while ((f0 | f1) != 0ull) {
+                    int b_;
+                    if (f0 != 0ull) { b_ = __builtin_ctzll(f0); f0 &= f0 - 1ull; } else { b_ = 64 + __builtin_ctzll(f1); f1 &= f1 - 1ull; }
+                    if (((cnt++) & 1) == half) return b_;
+                }
+                return -1;
+            };
+            // Software pipeline: the root's x of the NEXT batch is loaded while this one is computed, and every load and store of an iteration
+            // is issued unconditionally (columns that do not exist go to a trash slot behind xr): the waits then count instructions instead of
+            // draining the memory pipeline (vmcnt(0)), which with one wave per SIMD cost a full round trip per batch
+            T xc[36];
+            int bc = pop();
+            { const T* xb = xr_mine + (size_t)(bc >= 0 ? bc : 0) * 36;
+#pragma unroll
+              for (int j = 0; j < 36; ++j) xc[j] = xb[j]; }
+            while (bc >= 0) {
+                const int b = bc;
+                const int bn = pop();
+                T xn[36];
+                { const T* xb = xr_mine + (size_t)(bn >= 0 ? bn : 0) * 36;
+#pragma unroll
+                  for (int j = 0; j < 36; ++j) xn[j] = xb[j]; }
+                const bool isS = b < nbs;
+                const bool own = isS && (k == (b >> 1)) && ((b & 1) == 0);     // (a root's own configuration batch: the identity terms)
+                TIO* const cb = colbase(b, k, rq);
+#pragma unroll
+                for (int n = 0; n < NC; ++n) {
+                    T d_[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { TG a_ = TG(0);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) a_ += Qb[i][j] * TG(xc[3 * n + j]) + Qb[i][3 + j] * TG(xc[18 + 3 * n + j]);
+                        d_[i] = T(a_); }
+                    TIO* const o = col_ok(b, n) ? cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx : trash;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        T x = Mq[3 * i] * d_[0] + Mq[3 * i + 1] * d_[1] + Mq[3 * i + 2] * d_[2];
+                        const T idt = rq == 0 ? (n == i ? T(1) : T(0)) : (n >= 3 ? kb0.Xi[3 * i + (n >= 3 ? n - 3 : 0)] : T(0));
+                        if (own) x += idt;
+                        o[i] = TIO(x); o[3 + i] = TIO(d_[i]);
+                    }
+                }
+                bc = bn;
+#pragma unroll
+                for (int j = 0; j < 36; ++j) xc[j] = xn[j];
+            }
+        }
+#ifdef DJ_PROF
+        pc[4] += wv.clock() - td0; pc[2] = wv.clock() - tpb;
 #endif
     }
 
@@ -3934,7 +4141,7 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     }
     else if constexpr (QUAD) prog.gradients_contact(A, env);
 #ifdef DJ_PROF
-    if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); }
+    if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); vo[7] = TIO((double)prog.pc[3]); vo[8] = TIO((double)prog.pc[7]); }
 #endif
 }
 

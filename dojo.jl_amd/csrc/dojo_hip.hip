@@ -485,9 +485,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     }
     A.msg = nullptr; A.msg_stride = 0;
     if (g && quad) {                                       // (dojo_device.hpp, gradient_columns_quad: what the children of a root post to its body rows)
-        size_t ntops = 0; for (auto& n_ : s->M.nodes) if (n_.level == 1) ++ntops;
+        size_t ntops = 0; for (auto& n_ : s->M.nodes) if (n_.level <= 1) ++ntops;      // one block per level-1 supernode (messages) and per root (its Δv, Δω)
         const size_t batches = std::max<size_t>(2 * Nb + (nu + 5) / 6, (size_t)s->M.Nc);
-        A.msg_stride = (long long)(ntops * batches * 36);
+        A.msg_stride = (long long)(ntops * batches * 36 + 8);      // (+ a trash slot for the stores of columns that do not exist)
         if (A.msg_stride > 0) {
             if (!s->d_msg) HIPCHK(hipMalloc(&s->d_msg, (size_t)s->B * (size_t)A.msg_stride * sizeof(T)));
             A.msg = (T*)s->d_msg + env0 * (size_t)A.msg_stride;

@@ -129,8 +129,8 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * 112 * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
     // the up-sweep's messages to the roots (as the product's launch())
-    int ntops = 0; for (auto& n : M.nodes) if (n.level == 1) ++ntops;
-    std::vector<T> msgbuf; A.msg = nullptr; A.msg_stride = (long long)ntops * std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 36;
+    int ntops = 0; for (auto& n : M.nodes) if (n.level <= 1) ++ntops;       // one block per level-1 supernode (messages) and per root (its body rows' x)
+    std::vector<T> msgbuf; A.msg = nullptr; A.msg_stride = (long long)ntops * std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 36 + 8;
     if (dz && QUAD && A.msg_stride > 0) { msgbuf.resize((size_t)B * A.msg_stride); A.msg = msgbuf.data(); }
     std::vector<T> yparkbuf; A.ypark = nullptr;
     if (dz && QUAD && sizeof(TIO) < sizeof(T)) { A.ypark_stride = (long long)(std::max(2 * M.Nb + (M.nu + 5) / 6, M.Nc) * 18 * W); yparkbuf.resize((size_t)nwaves * A.ypark_stride); A.ypark = yparkbuf.data(); }

@@ -87,8 +87,8 @@ if what == "phases":
             print("   %-20s %10.0f cycles  %5.1f%%" % (n, v, 100 * v / tot.mean()))
         print("   %-20s %10.0f cycles  %5.1f%%" % ("other", tot.mean() - ph.mean(axis=0).sum(), 100 * (1 - ph.mean(axis=0).sum() / tot.mean())))
         if grad:
-            g = vel[:, 12:19].astype(np.float64).mean(axis=0)
-            print("   IFT kernel: total %.0f cycles/wave = linearize %.0f + %.0f, data blocks %.0f, sweeps %.0f (down-sweep %.0f; gathers of the up-sweep %.0f)" % (g[4], g[0], g[1], g[2], g[3], g[5], g[6]))
+            g = vel[:, 12:21].astype(np.float64).mean(axis=0)
+            print("   IFT kernel: total %.0f cycles/wave = linearize %.0f + LU %.0f, data blocks %.0f, sweeps %.0f = up-sweep phase 1 %.0f + root phase %.0f + down-sweep %.0f (of which phase B %.0f)" % (g[4], g[0], g[1], g[2], g[3], g[7], g[8], g[5], g[6]))
         json.dump(dict(total=tot.tolist(), iters=iters.tolist()), open(os.path.join(out, "phase_hist_grad%d.json" % grad), "w"))
     gm.close()
 
