@@ -382,10 +382,20 @@ static std::vector<int> physical_cpus() {
 }
 int orc_physical_cores(void) { return (int)physical_cpus().size(); }
 
-// Large blocks stay in the per-thread malloc arenas (no mmap / munmap per call: those serialize a multi-threaded batch in the kernel)
-namespace { struct MallocTuning { MallocTuning() { mallopt(M_MMAP_THRESHOLD, 512 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); } } malloc_tuning_; }
+// Timing runs only (orc_time_batch): blocks up to glibc's limit for this knob (HEAP_MAX_SIZE / 2 = 32 MiB on 64-bit; larger requests are
+// rejected) stay in the per-thread malloc arenas, and freed memory is not trimmed back to the kernel between passes -- mmap / munmap per
+// call serialize a multi-threaded batch in the kernel.  Applied when a timing run starts, not when the library is loaded: the setting is
+// process-wide, and pytest / torch processes that only load the checker are left alone.
+static void malloc_tuning_for_timing() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (!mallopt(M_MMAP_THRESHOLD, 32 << 20)) std::fprintf(stderr, "oracle: mallopt(M_MMAP_THRESHOLD) rejected\n");
+    if (!mallopt(M_TRIM_THRESHOLD, 1 << 30)) std::fprintf(stderr, "oracle: mallopt(M_TRIM_THRESHOLD) rejected\n");
+}
 
 double orc_time_batch(void* h, int B, const double* z, const double* u, int with_grad, int grad_mode, int nthreads, int rounds) {
+    malloc_tuning_for_timing();
     const std::vector<int> cpus = physical_cpus();
     IOracle* base = (IOracle*)h; int d[7]; base->dims(d);
     const int nz = 13 * d[4], nu = d[1], nx = 12 * d[4];

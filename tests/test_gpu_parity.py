@@ -66,11 +66,11 @@ def _rollout_compare(cfg, batch, steps, dtype, opts, check_residual=True):
     return np.concatenate(errs), float(np.mean(conv)), np.concatenate(itg), np.concatenate(ito), nstat
 
 
-# Parity criterion.  With the refined linear solves the device follows the oracle's Newton iterate path: equal
-# iteration counts, equal status, and the north-star bound 1e-6 holds as a MAXIMUM over every converged environment-step whose
-# solve is regular (<= REGULAR_ITERS Newton iterations, twice the typical count).  A solve that stalls beyond that wanders at
-# mu <= 1e-12, where cond(KKT) eps > 1e-4: no two fp64 implementations agree there better than ~1e-5 (measured on 28 672
-# Ant environment-steps at rtol = btol = 1e-8: one such step, 1.8e-6).
+# Parity criterion, ONE for every test of this file (_split_by_state): the north-star bound holds as a MAXIMUM over every
+# environment-step that converges on both sides and ends at the same point, long solves included.  A solve may end APART from the oracle's
+# only if it is long (> REGULAR_ITERS Newton iterations, twice the typical count: it wanders at mu <= 1e-12 where cond(KKT) eps > 1e-5, and
+# no two fp64 implementations stop at the same point there), and never further than APART_CEILING.  Equality of the Newton iteration
+# COUNTS is asserted on the regular solves (the device follows the oracle's iterate path).
 REGULAR_ITERS = 20
 
 
@@ -79,10 +79,8 @@ def test_forward_parity_fp64(cfg, batch, steps):
     errs, conv, itg, ito, nstat = _rollout_compare(cfg, batch, steps, "f64", TIGHT)
     assert conv > 0.9, conv
     assert nstat == 0, nstat
-    reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
-    assert np.array_equal(itg[reg], ito[reg]), int((itg[reg] != ito[reg]).sum())
-    assert errs[reg].max() <= 1e-6, errs[reg].max()
-    assert errs.max() <= 1e-5, errs.max()
+    same, apart = _split_by_state(errs, itg, ito, 1e-6, "cfg %d" % cfg)
+    assert apart.sum() <= 1 and np.array_equal(itg[same], ito[same]), (int(apart.sum()), int((itg[same] != ito[same]).sum()))
 
 
 def test_forward_parity_fp64_default_options():
@@ -119,24 +117,48 @@ def _grad_errors(spec, Z, U, opts, mode=0, dtype="f64", refine=None):
     ez = np.array([np.abs(dz[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
     eu = np.array([np.abs(du[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok]) if spec.nu else np.zeros(len(ok))
     es = np.abs(zn[ok].astype(np.float64) - Zo[ok]).max(axis=1)
+    ea = np.array([max(np.abs(dz[b] - dz_o[b]).max(), np.abs(du[b] - du_o[b]).max() if spec.nu else 0.0) for b in ok])     # absolute inf-norm
+    _grad_errors.last_abs = ea                     # (next to the relative figures; _full_batch_bound asserts it too)
     return ok, ez, eu, es, it[ok], it_o[ok], int((st != st_o).sum())
 
 
-def _full_batch_bound(label, ok, ez, eu, es, itg, ito, nstat, B, state_bound, grad_bound, min_ok=0.99, max_apart=2e-3):
-    """The north-star bound as a MAXIMUM over EVERY environment that converged on both sides -- long solves included -- whose two
-    solves ended at the same point (states within `state_bound`).  The few that ended apart (both within the solver's tolerances,
-    at different points: solves that wander at mu ~ 1e-12, where cond(KKT) eps > 1e-5) are counted, printed and bounded in number;
-    their Jacobians are Jacobians of different points."""
-    eg = np.maximum(ez, eu)
+def _split_by_state(es, itg, ito, state_bound, label=""):
+    """ONE criterion for every parity test: environments whose two solves ended at the same point (states within
+    `state_bound`) are compared, all of them, long solves included.  An environment may only end APART if its solve was a long one
+    (> REGULAR_ITERS Newton iterations on either side: it wanders at mu ~ 1e-12 where cond(KKT) eps > 1e-5, and two fp64 implementations
+    stop at different points, both within the solver's tolerances) and even then no further than APART_CEILING: a divergence of a regular
+    solve, or a gross one, fails here instead of hiding among the excluded."""
     apart = es > state_bound
-    same = ~apart
-    print("\n%s: converged on both sides %d of %d, status mismatches %d, iteration mismatches %d | state max (same point) %.2e | gradient q50 %.2e q99 %.2e MAX %.2e | ended apart: %d %s"
-          % (label, len(ok), B, nstat, int((itg != ito).sum()), es[same].max(), np.quantile(eg[same], 0.5), np.quantile(eg[same], 0.99), eg[same].max(), int(apart.sum()),
+    for i in np.nonzero(apart)[0]:
+        assert max(itg[i], ito[i]) > REGULAR_ITERS, "%s: a regular solve (%d / %d iterations) ended %.2e apart" % (label, itg[i], ito[i], es[i])
+        assert es[i] <= APART_CEILING, "%s: solves ended %.2e apart" % (label, es[i])
+    return ~apart, apart
+
+
+APART_CEILING = 1e-2        # measured: 1e-5 .. 2.4e-3 on 36 864 Ant environment-steps (three solves of 34-44 iterations)
+
+
+def _full_batch_bound(label, ok, ez, eu, es, itg, ito, nstat, B, state_bound, grad_bound, min_ok=0.99, max_apart=2e-3, max_stat=2, max_iter_mismatch=2,
+                      abs_bound=None):
+    """The north-star bound as a MAXIMUM over EVERY environment that converged on both sides -- long solves included -- whose two
+    solves ended at the same point (_split_by_state).  Status and iteration counts: equal but for a small ABSOLUTE number of
+    environments at the max_iter edge.  The gradient bound is asserted in the relative norm |dJ|_inf / max(1, |J|_inf) per environment
+    and, with `abs_bound`, in the absolute inf-norm as well (|J|_inf reaches 2e3 on the Ant batch)."""
+    eg = np.maximum(ez, eu)
+    same, apart = _split_by_state(es, itg, ito, state_bound, label)
+    ea = getattr(_grad_errors, "last_abs", None)
+    assert same.any(), "%s: no environment to compare" % label
+    print("\n%s: converged on both sides %d of %d, status mismatches %d, iteration mismatches %d | state max (same point) %.2e | gradient q50 %.2e q99 %.2e MAX %.2e (absolute %.2e; unfiltered %.2e) | ended apart: %d %s"
+          % (label, len(ok), B, nstat, int((itg != ito).sum()), es[same].max(), np.quantile(eg[same], 0.5), np.quantile(eg[same], 0.99), eg[same].max(),
+             ea[same].max() if ea is not None and len(ea) == len(eg) else float("nan"), eg.max(), int(apart.sum()),
              [(int(ok[i]), int(itg[i]), int(ito[i]), float("%.1e" % es[i]), float("%.1e" % eg[i])) for i in np.nonzero(apart)[0][:8]]))
-    assert len(ok) >= min_ok * B and nstat <= (1 - min_ok) * B, (len(ok), nstat)
+    assert len(ok) >= min_ok * B, len(ok)
+    assert nstat <= max_stat, nstat
     assert apart.mean() <= max_apart, int(apart.sum())
-    assert (itg[same] != ito[same]).mean() <= 1e-3
+    assert int((itg[same] != ito[same]).sum()) <= max_iter_mismatch, int((itg[same] != ito[same]).sum())
     assert eg[same].max() <= grad_bound, eg[same].max()
+    if abs_bound is not None and ea is not None and len(ea) == len(eg):
+        assert ea[same].max() <= abs_bound, ea[same].max()
     return eg[same].max()
 
 
@@ -159,8 +181,10 @@ def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
     if f32:
         Z = Z.astype(np.float32).astype(np.float64); U = U.astype(np.float32).astype(np.float64)   # what the fp32 buffers hold
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions(), dtype=dtype)
+    # (Atlas: 6 % of these synthetic states sit at the max_iter edge on both sides -- four coplanar contacts per foot -- where one side may
+    #  converge in its 50th iteration and the other not: the status / iteration allowances are counts of such environments)
     _full_batch_bound("BASELINE cfg %d B %d %s ABI" % (cfg, B, dtype), ok, ez, eu, es, itg, ito, nstat, B, 1e-5 if f32 else 1e-6, 1e-5 if f32 else 1e-6,
-                      min_ok=0.9 if cfg == 5 else 0.99, max_apart=1e-2 if cfg == 5 else 2e-3)
+                      min_ok=0.9 if cfg == 5 else 0.99, max_apart=1e-2 if cfg == 5 else 2e-3, max_stat=40 if cfg == 5 else 4, max_iter_mismatch=20 if cfg == 5 else 4)
 
 
 def test_solution_export_matches_oracle():
@@ -194,10 +218,9 @@ def test_gradient_parity_fp64(cfg, batch, pre_steps, mode, tol):
         Z, st, it, _, _ = o.step_batch(Z, U, nthreads=16)
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, opts, mode)
     assert len(ok) > 0.8 * batch and nstat == 0
-    reg = (itg <= REGULAR_ITERS) & (ito <= REGULAR_ITERS)
-    assert np.array_equal(itg[reg], ito[reg])
-    assert es[reg].max() <= 1e-6, es[reg].max()
-    assert ez[reg].max() <= 1e-6 and eu[reg].max() <= 1e-6, (ez[reg].max(), eu[reg].max())
+    same, apart = _split_by_state(es, itg, ito, 1e-6, "cfg %d tol %g" % (cfg, tol))
+    assert same.sum() >= len(ok) - 1 and np.array_equal(itg[same], ito[same])
+    assert ez[same].max() <= 1e-6 and eu[same].max() <= 1e-6, (ez[same].max(), eu[same].max())
 
 
 def test_parity_at_the_baseline_batch_distinct_seeds():
@@ -206,8 +229,9 @@ def test_parity_at_the_baseline_batch_distinct_seeds():
     LU-form IFT sweeps), reference-default options.
     fp64 ABI: state and gradient MAX <= 1e-6 over every environment that converged on both sides and ended at the same point
     (the north-star bound; measured 5e-8).  fp32 ABI, what bench.py times (the oracle steps the state the fp32 buffer stands for):
-    state <= 1e-5 (output rounding), gradient max <= 1e-6.
-    rtol = btol = 1e-8 (refining kernels): the same bound."""
+    state <= 1e-5 (output rounding), gradient max <= 1e-6.  Next to the relative gradient norm the ABSOLUTE inf-norm is asserted (5e-6 /
+    2e-4).  Status and iteration counts: equal but for at most two environments.  With every solve refined: the same bounds.
+    rtol = btol = 1e-8 (refining kernels): gradient max <= 1e-4, at most 0.1 % of the environments above 1e-6 (see below)."""
     spec = d.baseline_config(3)
     B = 4096
     Z, U = d.synthetic_inputs(spec, B)
@@ -216,12 +240,20 @@ def test_parity_at_the_baseline_batch_distinct_seeds():
         Z, st, it = gm.step(Z, U)
     gm.close()
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions())
-    _full_batch_bound("Ant B 4096 f64 ABI, default options", ok, ez, eu, es, itg, ito, nstat, B, 1e-6, 1e-6)
+    _full_batch_bound("Ant B 4096 f64 ABI, default options", ok, ez, eu, es, itg, ito, nstat, B, 1e-6, 1e-6, abs_bound=5e-6)     # (measured: relative 3.3e-8, absolute 1.3e-6 at |J| <= 2e3)
     Zf = Z.astype(np.float32).astype(np.float64); Uf = U.astype(np.float32).astype(np.float64)
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Zf, Uf, d.SolverOptions(), dtype="f32")
-    _full_batch_bound("Ant B 4096 f32 ABI, default options", ok, ez, eu, es, itg, ito, nstat, B, 1e-5, 1e-6)
+    _full_batch_bound("Ant B 4096 f32 ABI, default options", ok, ez, eu, es, itg, ito, nstat, B, 1e-5, 1e-6, abs_bound=2e-4)     # (measured: 9.0e-8 / 6.1e-5: output rounding of |J| <= 2e3)
+    # every linear solve of every environment refined against the uncondensed blocks (dojo_set_refinement(h, 0)), default tolerances
+    ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions(), refine=0.0)
+    _full_batch_bound("Ant B 4096 f64 ABI, default options, all solves refined", ok, ez, eu, es, itg, ito, nstat, B, 1e-6, 1e-6, abs_bound=2e-5)
+    # rtol = btol = 1e-8 (the library's policy then refines stiff environments): the iteration drives mu far below btol, Jacobian entries of
+    # contacts about to switch reach 1e4 .. 1e5 and amplify the 1e-9 state agreement -- measured ten of 28 672 environment-steps above 1e-6
+    # (nine <= 4e-5): asserted as 1e-4 with at most 0.1 % above 1e-6
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, TIGHT)
-    _full_batch_bound("Ant B 4096 f64 ABI, rtol = btol = 1e-8 (refining kernels)", ok, ez, eu, es, itg, ito, nstat, B, 1e-6, 1e-4)
+    _full_batch_bound("Ant B 4096 f64 ABI, rtol = btol = 1e-8 (refining kernels)", ok, ez, eu, es, itg, ito, nstat, B, 1e-6, 1e-4, max_stat=8, max_iter_mismatch=8)
+    same, _ = _split_by_state(es, itg, ito, 1e-6, "tight")
+    assert (np.maximum(ez, eu)[same] > 1e-6).mean() <= 1e-3
 
 
 def test_gradient_parity_f32_io():
@@ -780,9 +812,12 @@ def test_linear_contact_parity_and_properties(name, kw, dtype):
         zg, st, it = gm.step(z.astype(gm.np_dtype), U.astype(gm.np_dtype))
         zo, st_o, it_o, _, _ = o.step_batch(d.fp32_abi_state(z) if dtype == "f32" else z, U, nthreads=16)
         reg = (it <= REGULAR_ITERS) & (it_o <= REGULAR_ITERS)
-        assert np.array_equal(st[reg], st_o[reg]) and np.array_equal(it[reg], it_o[reg]) and reg.mean() > 0.8
-        assert np.abs(zg[reg].astype(np.float64) - zo[reg]).max() < (1e-8 if dtype == "f64" else 1e-5)
-        nconv += int(((st == 0) & reg).sum())
+        assert np.array_equal(st[reg], st_o[reg]) and np.array_equal(it[reg], it_o[reg]) and reg.mean() > 0.8      # iterate path of the regular solves
+        both = (st == 0) & (st_o == 0)
+        e_ = np.abs(zg[both].astype(np.float64) - zo[both]).max(axis=1)
+        same, apart = _split_by_state(e_, it[both], it_o[both], 1e-8 if dtype == "f64" else 1e-5, "linear contact step %d" % k)
+        assert apart.sum() <= 1
+        nconv += int(both.sum())
         z = zo.astype(np.float32).astype(np.float64) if dtype == "f32" else zo
     assert nconv > 0.8 * 20 * B
     _, _, sg = gm.get_solution()
@@ -1113,8 +1148,12 @@ def test_reference_mechanisms_rollout_gpu(name, kw):
         zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=last, grad_mode=0, nthreads=8)
         ok = np.nonzero((st == 0) & (st_o == 0))[0]
         assert len(ok) >= 0.7 * B, (k, len(ok))
-        ok = ok[(it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)]          # (stalled solves: see test_forward_parity_fp64)
-        assert np.array_equal(it[ok], it_o[ok])
+        e_ = np.abs(zg[ok] - zo[ok]).max(axis=1)
+        same_, apart_ = _split_by_state(e_, it[ok], it_o[ok], 1e-6, "step %d" % k)
+        assert apart_.sum() <= 1
+        ok = ok[same_]
+        reg_ = (it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)
+        assert np.array_equal(it[ok][reg_], it_o[ok][reg_])
         es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
         if last:
             dzg, dug = gm.gradients()

@@ -130,8 +130,8 @@ def test_friction_between_the_spheres():
 @pytest.mark.parametrize("friction_type,dtype", [("nonlinear", "f64"), ("impact", "f64"), ("linear", "f64"), ("nonlinear", "f32")])
 def test_body_body_contact_on_the_device(friction_type, dtype):
     """the two-sphere mechanism on the GPU: a batch of 256 environments whose free sphere starts at random places above / beside the other
-    one with random velocities and spins, stepped 25 times next to the oracle: equal iteration counts and states within 1e-6 (but for a handful of long solves per 6400 environment-steps, see below) on the
-    environments both sides solve (fp64 ABI; the fp32 ABI, whose states are rounded between the steps); then the reference's resting case through dojo_simulate"""
+    one with random velocities and spins, stepped 25 times next to the oracle: every environment-step both sides solve ends within 1e-6 of the oracle's state, equal iteration counts on every
+    regular solve; only a long solve (> 20 iterations) may end apart (see below) (fp64 ABI; the fp32 ABI, whose states are rounded between the steps); then the reference's resting case through dojo_simulate"""
     from dojo_amd import api
     B = 256
     rng = np.random.default_rng(17)
@@ -146,25 +146,30 @@ def test_body_body_contact_on_the_device(friction_type, dtype):
         gm = api.BatchedMechanism(spec, B, dtype=dtype)
         o = Oracle(spec)
         z = Z.astype(np.float32).astype(np.float64) if dtype == "f32" else Z.copy()
-        contact_seen = 0; n_apart = 0; n_above = 0
+        contact_seen = 0; n_apart = 0; n_stat = 0
+        bound = 1e-6 if dtype == "f64" else 1e-4                  # (fp32 ABI: the states are rounded to fp32 between the steps)
         for k in range(25):
             zg, st, it = gm.step(z, np.zeros((B, spec.nu)))
             zin = d.fp32_abi_state(z) if dtype == "f32" else z
             Zo, st_o, it_o = o.step_batch(zin, np.zeros((B, spec.nu)), nthreads=8)[:3]
-            # the same Newton path wherever the linear systems are well conditioned; a solve that misses rtol by a hair on one side runs on into
-            # complementarities of 1e-8 and below, where the (inexact: contact.jl:37-77 leaves ∂vt/∂x out) Newton matrix is singular to working
-            # precision and the two linear solvers part -- seen on about one environment-step in a thousand, as with half-space contacts
-            same = (st == 0) & (st_o == 0) & ((it == it_o) if dtype == "f64" else (np.abs(it - it_o) <= 2))
-            n_apart += int(((st != st_o) | ((st == 0) & (st_o == 0) & ~same)).sum())
-            e_same = np.abs(zg[same] - Zo[same]).max(axis=1)       # (median 1e-13; a handful of long solves per run 1e-8 .. 1e-6: rounding differences
-            n_above += int((e_same > 1e-6).sum())                  #  amplified by the near-singular matrix of their last iterations)
-            assert e_same.max() < 1e-4, (joint, k, e_same.max())
+            # The criterion of DESIGN.md section 7, as a BOUND: every environment-step that converges on both sides ends within `bound` of the
+            # oracle's state -- unless its solve is a long one (> 20 Newton iterations on either side: a solve that misses rtol by a hair runs on
+            # into complementarities of 1e-8 and below, where the Newton matrix -- inexact by construction: contact.jl:37-77 leaves dvt/dx out --
+            # is singular to working precision and two linear solvers part), and then no further than 1e-3.  The oracle is a host-independent
+            # build (oracle/Makefile: no FMA contraction, baseline x86-64), so this does not depend on the box.
             both = (st == 0) & (st_o == 0)
-            assert np.abs(zg[both] - Zo[both]).max() < 1e-3
+            e = np.abs(zg[both].astype(np.float64) - Zo[both]).max(axis=1)
+            long_ = (it[both] > 20) | (it_o[both] > 20)
+            apart = e > bound
+            assert long_[apart].all(), (joint, k, e[apart & ~long_].max(), it[both][apart & ~long_], it_o[both][apart & ~long_])
+            assert e.max() < 1e-3, (joint, k, e.max())
+            if dtype == "f64":
+                assert np.array_equal(it[both][~long_], it_o[both][~long_])        # the same Newton path on every regular solve
+            n_apart += int(apart.sum()); n_stat += int((st != st_o).sum())
             contact_seen += int((np.linalg.norm(Zo[:, 13:16] - Zo[:, 0:3], axis=1) < 1.0 + 1e-3).sum())
             z = zg.astype(np.float64)
-        assert contact_seen > B and n_apart <= 0.01 * 25 * B, n_apart
-        assert dtype == "f32" or n_above <= 8, n_above             # of 6400 environment-steps (seen: 0 .. 1; the fp32 ABI's states carry their rounding: bounded by 1e-4 above)
+        print("%s %s %s: long solves that ended apart %d, status mismatches %d of %d environment-steps" % (friction_type, dtype, joint, n_apart, n_stat, 25 * B))
+        assert contact_seen > B and n_stat <= 0.01 * 25 * B and n_apart <= 8, (n_apart, n_stat)
         with pytest.raises(Exception):
             gm.step(z, np.zeros((B, spec.nu)), with_gradient=True)          # forward only, like the reference's data Jacobians
         gm.close()
