@@ -1923,7 +1923,28 @@ struct LaneProgram {
     // wave per SIMD cannot hide: the sweeps ran at half speed).
     enum { LU_LM = 0, LU_M = 36, LU_UM = 54, LU_T = 90, LU_DI = 108, LU_PER_LANE = 112 };
     T* lu = nullptr; int lu_stride = 0;
-    DJ_HD void store_lu(const QuadLU& W) {
+    // A supernode's rows of the in-place factors (F.Sq) stay as its own level left them -- on every other level its updates have a zero
+    // multiplier -- so the split into the zero-filled triangles the substitutions read happens here, once, after the last level (kept
+    // inside the level loop, the 75 values were loop-carried state next to the 90 of the factorization itself: past the 256 architectural
+    // registers, every pivot step paid for it in v_accvgpr moves).  Idle supernode slots store an identity system: their lanes run the sweeps too.
+    DJ_HD void store_lu() {
+        QuadLU W;
+        const int rq = lu_rolepos(q);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int pos = 3 * rq + r;                          // this row's place in the pivot order
+            TL dg = TL(1);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) { const TL a_ = F.Sq[r][c]; dg = (active && lu_piv(c) == pos) ? a_ : dg; }
+            const TL di_ = Wave::rcp(dg);
+            W.di[r] = di_;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const TL a_ = F.Sq[r][c];
+                W.Lm[r][c] = (active && lu_piv(c) < pos) ? a_ : TL(0);
+                W.Um[r][c] = (active && lu_piv(c) > pos) ? a_ * di_ : TL(0);
+            }
+        }
         T* o = lu; const size_t S_ = (size_t)lu_stride;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -1958,18 +1979,14 @@ struct LaneProgram {
 
     // Rows stay distributed as in factorize_quad: role q owns rows 3q .. 3q+2 of S and U, columns 3q .. 3q+2 of L, roles 0 / 1
     // rows 0:3 / 3:6 of Dup.  On lanes that are not at the current level every update has a zero multiplier.
-    DJ_HD void factorize_quad_lu(QuadBlocks<TL>& K, QuadLU& W) {
+    DJ_HD void factorize_quad_lu(QuadBlocks<TL>& K) {
         TL up[3][6];
         TL (&A)[3][12] = F.Sq;
         const int rq = lu_rolepos(q);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            W.di[i] = TL(1);                                       // (idle supernode slots: an identity system; their lanes run the sweeps too)
-#pragma unroll
-            for (int j = 0; j < 12; ++j) { W.Lm[i][j] = TL(0); W.Um[i][j] = TL(0); }
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) up[i][j] = TL(0);
-        }
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             const bool at = active && P.level == lev;
             TL acc[18], upf[18];
@@ -2030,24 +2047,6 @@ struct LaneProgram {
                         const TL mm = (at && q < 2) ? (q == 0 ? m0_ : m1_) : TL(0);
 #pragma unroll
                         for (int j = 0; j < 6; ++j) K.D[i][j] -= mm * pU[j];
-                    }
-                }
-            }
-            if (at) {
-                // this supernode is done: split its in-place factors into the zero-filled triangles the substitutions read
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int pos = 3 * rq + r;                  // this row's place in the pivot order
-                    TL dg = TL(1);
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) { const TL a_ = A[r][c]; dg = (lu_piv(c) == pos) ? a_ : dg; }
-                    const TL di_ = Wave::rcp(dg);
-                    W.di[r] = di_;
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) {
-                        const TL a_ = A[r][c];
-                        W.Lm[r][c] = (lu_piv(c) < pos) ? a_ : TL(0);
-                        W.Um[r][c] = (lu_piv(c) > pos) ? a_ * di_ : TL(0);
                     }
                 }
             }
@@ -2336,6 +2335,14 @@ struct LaneProgram {
               for (int i = 0; i < 3; ++i)
 #pragma unroll
                   for (int j = 0; j < 12; ++j) Lm[i][j] = TL(o[(size_t)(LU_LM + 12 * i + j) * S_]); }
+            TG Um[3][12], di[3];
+            { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                  for (int j = 0; j < 12; ++j) Um[i][j] = TL(o[(size_t)(LU_UM + 12 * i + j) * S_]);
+                  di[i] = TL(o[(size_t)(LU_DI + i) * S_]); } }
+            T* const xr_root = msg + (size_t)(ntops + rrank) * (size_t)NB * 36;
             const RH& Rr = *((const RH*)&R + (a - k));             // the root's right-hand-side block
             const SweepInfo& ri = inf[a];
             int rcontact[8];
@@ -2363,56 +2370,19 @@ struct LaneProgram {
                 }
                 TG r3a[NC][3];
                 sweep_rhs<MODE, NC>(r3a, Rr, a, -1, false, ri.u_off, ri.myu, ri.nlim_r, TG(ri.wk), ri.ncontact, rcontact, inb ? b : 0, nbs, valid, acc);
-                lu_forward_quad<NC>(Lm, r3a);
-                if (valid) {
-                    const bool isS = b < nbs;
-                    TIO* const cb = colbase(b, a, q);
+                lu_forward_quad<NC>(Lm, r3a);                     // ỹ of the root ...
+                // ... and at once x = U11⁻¹ ỹ (a root has no parent term): ỹ never leaves the registers; Δv, Δω of the root go to xr for the whole tree
 #pragma unroll
-                    for (int cI = 0; cI < NC; ++cI) if (col_ok(b, cI)) {
-                        const int cx = (isS && cI >= 3) ? cI + 3 : cI;
-                        const TG (&yy)[3] = r3a[cI];
-                        if constexpr (ypk) { T* yo = yp0 + dl + (size_t)((b * NC + cI) * 3) * yW; yo[0] = T(yy[0]); yo[yW] = T(yy[1]); yo[2 * yW] = T(yy[2]); }
-                        else { TIO* o = cb + (size_t)cx * nx + prk_off; o[0] = TIO(yy[0]); o[1] = TIO(yy[1]); o[2] = TIO(yy[2]); }
-                    }
-                }
-            }
-            // ... and at once its backward substitution of the same batches, x = U11⁻¹ ỹ (a root has no parent term), by the same quads
-            // (every lane reads back what it parked itself); Δv, Δω of the root go to xr for the whole tree
-            {
-                TG Um[3][12], di[3];
-                { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+                for (int cI = 0; cI < NC; ++cI) { const bool ok_ = valid && col_ok(b, cI);
 #pragma unroll
-                  for (int i = 0; i < 3; ++i) {
+                    for (int i = 0; i < 3; ++i) r3a[cI][i] = ok_ ? r3a[cI][i] : TG(0); }
+                lu_backward_quad<NC>(Um, di, r3a);
+                if (valid && q < 2) {
+                    T* xo = xr_root + (size_t)b * 36 + 18 * q;
 #pragma unroll
-                      for (int j = 0; j < 12; ++j) Um[i][j] = TL(o[(size_t)(LU_UM + 12 * i + j) * S_]);
-                      di[i] = TL(o[(size_t)(LU_DI + i) * S_]); } }
-                T* const xr_root = msg + (size_t)(ntops + rrank) * (size_t)NB * 36;
-                for (int rd = 0; rd < nrounds; ++rd) {
-                    const int b = rd * G.S + k;
-                    const bool inb = b < NB;
-                    const bool valid = env_ok && inb && (((b < 64 ? ri.bm[0] >> (b < 64 ? b : 0) : ri.bm[1] >> (b >= 64 ? b - 64 : 0)) & 1ull) != 0);
-                    const bool isS = b < nbs;
-                    TIO* const cb = colbase(valid ? b : 0, a, q);
-                    TG x3[NC][3];
+                    for (int cI = 0; cI < NC; ++cI)
 #pragma unroll
-                    for (int cI = 0; cI < NC; ++cI) {
-                        const bool ok_ = valid && col_ok(b, cI);
-                        const int cx = (isS && cI >= 3) ? cI + 3 : cI;
-                        if constexpr (ypk) { const T* yi = yp0 + dl + (size_t)(((valid ? b : 0) * NC + cI) * 3) * yW;
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) x3[cI][i] = ok_ ? TG(yi[i * yW]) : TG(0); }
-                        else { const TIO* o = cb + (size_t)cx * nx + prk_off;
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) x3[cI][i] = ok_ ? TG(o[i]) : TG(0); }
-                    }
-                    lu_backward_quad<NC>(Um, di, x3);
-                    if (valid && q < 2) {
-                        T* xo = xr_root + (size_t)b * 36 + 18 * q;
-#pragma unroll
-                        for (int cI = 0; cI < NC; ++cI)
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) xo[3 * cI + i] = T(x3[cI][i]);
-                    }
+                        for (int i = 0; i < 3; ++i) xo[3 * cI + i] = T(r3a[cI][i]);
                 }
             }
             ++rrank;
@@ -3368,9 +3338,8 @@ struct LaneProgram {
 #endif
         // (a root's joint hangs on the origin, whose "velocity" is no unknown: its U block was assembled like any other, but the
         //  down-sweep must not apply it -- store_lu writes T = 0 for the roots)
-        QuadLU W;
-        factorize_quad_lu(K, W);
-        store_lu(W);
+        factorize_quad_lu(K);
+        store_lu();
         DJ_PE(1); DJ_PB();
         }
     }
