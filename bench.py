@@ -332,7 +332,7 @@ def parity_vs_cpu(spec, B, device):
         if not same.any():
             out[name] = {"converged_both": int(ok.sum()), "error": "no environment converged on both sides to the same point"}
             continue
-        gb, ab = (1e-6, 5e-6) if dt == np.float64 else (1e-3, 1e-3)           # north-star bounds (relative norm; the absolute norm asserted next to it for fp64: |J|_inf <= 2e3 here)
+        gb, ab = (1e-6, 1e-5) if dt == np.float64 else (1e-3, 1e-3)           # north-star bounds (relative norm; the absolute norm asserted next to it for fp64: |J|_inf <= 2e3 here)
         out[name] = {"converged_both": int(ok.sum()), "status_mismatch": int((st != st_o).sum()), "iters_mismatch": int((it[ok] != it_o[ok]).sum()),
                      "state_inf_err_max": float(ez[same].max()), "state_inf_err_max_unfiltered": float(ez.max()), "n_state_err_above_bound": int(apart.sum()), "state_bound": tol_s,
                      "grad_inf_err_max": float(eg[same].max()), "grad_abs_inf_err_max": float(ea[same].max()), "grad_inf_err_max_unfiltered": float(eg.max()),
