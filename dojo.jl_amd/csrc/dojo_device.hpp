@@ -59,6 +59,7 @@
 namespace dj {
 
 constexpr int MAXCH = 4;          // children per body supported by the lane program
+constexpr int LU_PER_LANE = 112;  // values per lane of the IFT kernel's LU-form factors between its phases (KernelArgs::lu; layout: LaneProgram::LU_LM .. LU_DI)
 constexpr bool kLinear = DJ_LINEAR != 0;
 constexpr int NCV = kLinear ? 6 : 4;      // cone variable pairs (s, γ) per contact: NonlinearContact 4 (ImpactContact uses the first), LinearContact 6
 constexpr double REG = 1e-10;     // src/Dojo.jl:4
@@ -1921,13 +1922,14 @@ struct LaneProgram {
     // are assembled, and each sweep loads only its half: L11, m for the up-sweep, U11, T, D⁻¹ for the down-sweep -- 54 / 57 values
     // per lane in registers instead of 111 (all of them resident cost the sweeps ~30 scratch accesses per pipeline step, which one
     // wave per SIMD cannot hide: the sweeps ran at half speed).
-    enum { LU_LM = 0, LU_M = 36, LU_UM = 54, LU_T = 90, LU_DI = 108, LU_PER_LANE = 112 };
+    enum { LU_LM = 0, LU_M = 36, LU_UM = 54, LU_T = 90, LU_DI = 108, LU_END = 111 };            // (dj::LU_PER_LANE values per lane, static_assert in store_lu)
     T* lu = nullptr; int lu_stride = 0;
     // A supernode's rows of the in-place factors (F.Sq) stay as its own level left them -- on every other level its updates have a zero
     // multiplier -- so the split into the zero-filled triangles the substitutions read happens here, once, after the last level (kept
     // inside the level loop, the 75 values were loop-carried state next to the 90 of the factorization itself: past the 256 architectural
     // registers, every pivot step paid for it in v_accvgpr moves).  Idle supernode slots store an identity system: their lanes run the sweeps too.
     DJ_HD void store_lu() {
+        static_assert(LU_END < LU_PER_LANE, "the staged factors must fit dj::LU_PER_LANE");
         QuadLU W;
         const int rq = lu_rolepos(q);
 #pragma unroll
@@ -3906,7 +3908,7 @@ struct KernelArgs {
     TIO* res;                      // [B,6Nb] or null          body residual rows at the solution (for the Storage kernel)
     T* sol;                        // [B][S][sol_record<MAXC>] converged solution in state precision: step kernel -> IFT kernel (or null)
     T* fac;                        // [waves][72][64] quad mapping: the final supernode factors of every lane (explicit inverses; or null: nobody reads them)
-    T* lu = nullptr;               // [workgroups][LU_PER_LANE = 112][lanes] quad mapping: the IFT kernel's own LU-form factors between its phases (or null)
+    T* lu = nullptr;               // [workgroups][dj::LU_PER_LANE][lanes] quad mapping: the IFT kernel's own LU-form factors between its phases (or null)
     T* blk = nullptr;              // [workgroups][90][lanes] quad mapping: un-factored supernode rows of refining environments (DJ_REFINE; or null)
     long long ypark_stride = 0;    // elements per workgroup of ypark
     T* ypark = nullptr;            // [workgroups][batches][6][3][lanes / 2] quad mapping, ABI type narrower than the arithmetic: the IFT's forward-substituted
@@ -4024,7 +4026,7 @@ constexpr int FAC_PER_LANE = 72;
         if (A.msg) prog.msg = DJ_GLOBAL_PTR(T, A.msg) + (size_t)(env < A.B ? env : 0) * (size_t)A.msg_stride;                 \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
-        if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * 112 * wv.width() + lane; prog.lu_stride = wv.width(); }                \
+        if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * LU_PER_LANE * wv.width() + lane; prog.lu_stride = wv.width(); }                \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \
         if (A.ypark) prog.ypark = DJ_GLOBAL_PTR(T, A.ypark) + (size_t)wave_index * (size_t)A.ypark_stride + lane;                                \
     } else { prog.cpool = pool_local; prog.pool_by_id = false; prog.pool_base = 0; }                                      \

@@ -458,24 +458,28 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     int E = 64 * (quad ? NW : 1) / (s->M.S * (quad ? 4 : 1));
     dim3 grid((nenv + E - 1) / E);
     const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;        // workgroups, each 64 * NW lanes
-    int slot = -1;
-    if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     const int g = (dz != nullptr) || (dc != nullptr);
+    // (refusals first: a timing slot taken before them would never be marked used)
     if (g && s->M.has_ss) { g_err = "gradients are not available for mechanisms with a body-body contact"; return DOJO_ERR_UNSUPPORTED; }
     if (g && s->M.contact_model != 0) {   // the reference has no data Jacobians for ImpactContact / LinearContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
         g_err = "gradients are not available for ImpactContact / LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
     }
+    if (dc != nullptr && s->M.Nc > 64) {  // the sweeps' batch masks hold one bit per contact of the environment (dojo_device.hpp, sweep_masks)
+        g_err = "contact-data gradients support at most 64 contacts per environment"; return DOJO_ERR_UNSUPPORTED;
+    }
+    int slot = -1;
+    if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
     A.sol = nullptr;
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
         A.sol = (T*)s->d_sol + env0 * s->M.S * dj::sol_record<8>();          // any record size <= sol_record<8> fits this spacing
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
-        if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * 112 * 64 * NW * sizeof(T)));
+        if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * dj::LU_PER_LANE * 64 * NW * sizeof(T)));
     }
     // the explicit inverses of the Newton loop travel only when somebody reads them: the refining IFT kernel
     const bool want_fac = A.G.refine_w < INFINITY;
     A.fac = (g && quad && want_fac) ? (T*)s->d_fac + wave0 * dj::FAC_PER_LANE * 64 * NW : nullptr;
-    A.lu = (g && quad) ? (T*)s->d_lu + wave0 * 112 * 64 * NW : nullptr;
+    A.lu = (g && quad) ? (T*)s->d_lu + wave0 * dj::LU_PER_LANE * 64 * NW : nullptr;
     A.ypark = nullptr; A.ypark_stride = 0;
     if (g && quad && sizeof(TIO) < sizeof(T)) {          // (dojo_device.hpp, gradient_columns_quad)
         const size_t batches = std::max<size_t>(2 * Nb + (nu + 5) / 6, (size_t)s->M.Nc);     // state + control batches | contact batches (dojo_cgrad_kernel)

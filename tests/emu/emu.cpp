@@ -126,7 +126,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
     // (as the product's launch(): the explicit inverses of the Newton loop travel only when the refining IFT kernel will read them)
     std::vector<T> facbuf((dz && QUAD && A.G.refine_w < INFINITY) ? (size_t)nwaves * dj::FAC_PER_LANE * W : 0); A.fac = facbuf.empty() ? nullptr : facbuf.data();
-    std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * 112 * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
+    std::vector<T> lubuf((dz && QUAD) ? (size_t)nwaves * dj::LU_PER_LANE * W : 0); A.lu = lubuf.empty() ? nullptr : lubuf.data();
     std::vector<T> blkbuf(QUAD ? (size_t)nwaves * 90 * W : 0); A.blk = blkbuf.empty() ? nullptr : blkbuf.data();
     // the up-sweep's messages to the roots (as the product's launch())
     int ntops = 0; for (auto& n : M.nodes) if (n.level <= 1) ++ntops;       // one block per level-1 supernode (messages) and per root (its body rows' x)
