@@ -7,7 +7,15 @@
 // The reference is 100 % Julia and Julia is not installed in the build container, so
 // the reference itself cannot be executed here ("oracle/_ref" does not exist).  This
 // file follows the reference function by function; every routine cites the
-// /root/reference file:line it restates.  It is pinned by re-stating the reference's
+// /root/reference file:line it restates.
+// PINNED against reference-COMPUTED numbers on one contact configuration: the ten 100-step
+// Storage trajectories of the reference's own simulate! that it ships in
+// examples/system_identification/data/datasets/synthetic_sphere.jld2 (one body, NonlinearContact
+// + SphereHalfSpaceCollision, default SolverOptions): step!(row k) == row k+1 to 3.8e-14 over
+// all 990 pairs, equal Newton iteration counts (tests/test_reference_sphere.py,
+// tests/golden/reference_sphere.npz, tools/jld2_reader.py).  For joints, limits, springs /
+// dampers and the IFT gradients no reference-computed numbers exist in the tree (PARITY
+// UNPINNED there in the strict sense); they are pinned by re-stating the reference's
 // own property tests (tests/test_oracle_*.py):
 //   * test/jacobian.jl:1-64     FD(residual wrt solution) == -full_matrix(system)
 //   * test/data.jl:82-126       FD(residual wrt data)·attjac == jacobian_data!
