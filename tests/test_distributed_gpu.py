@@ -85,6 +85,24 @@ def test_bench_two_ranks_plumbing():
     assert "torch.distributed" in res["config"]["final_gather"]
 
 
+def test_bench_strong_scaling_line():
+    """BASELINE configs[3] in the form it is quoted in -- a FIXED total batch sharded over the ranks: `bench.py --config 4 --batch-total T --gpus 2`
+    gives every rank T / 2 environments (contiguous slices), reports "scaling": "strong", the per-rank and the total batch, and value = T K / time
+    (two ranks on the one GPU of the box, gloo).  A total that the ranks do not divide is refused."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "4", "--batch-total", "512",
+                        "--backend", "gloo", "--no-parity", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["per_rank_batch"] == 256 and res["config"]["total_batch"] == 512
+    assert abs(res["value"] - 512 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--config", "4", "--batch-total", "511", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "not a multiple" in (r.stderr + r.stdout)
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT a launcher: bench.py re-executes itself as two ranks (torch.distributed.run on 127.0.0.1)
     and rank 0 prints the one JSON line with n_gpus = 2 and the device of every rank (gloo: the two ranks share the one GPU)."""
