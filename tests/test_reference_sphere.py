@@ -172,3 +172,38 @@ def test_hip_iterate_path_equals_the_oracles_on_the_reference_rows():
         sol = o.get_solution()               # [joint impulses (0); v25 ω25; s γ]
         assert np.abs(sol[:6] - vel[b]).max() <= PINNED
         assert np.abs(sol[6:] - cs[b]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_system_identification_on_the_reference_dataset():
+    """The reference's own use of these trajectories (examples/system_identification/synthetic_sphere.jl:45-100, utilities.jl) on the device:
+    three-step prediction cost over the ten trajectories as ONE batch, gradient and Gauss-Newton Hessian through dojo_contact_gradients
+    (get_contact_gradients, src/gradients/contact.jl:1-55) chained over the steps.  The cost vanishes at the parameters the reference generated
+    the data with; the chained analytic gradient is the derivative of the cost (central differences, tight tolerances); and the example's quasi-Newton loop recovers
+    friction_coefficient = 0.2, contact_radius = 0.5 from its guess [0, 1]."""
+    sys.path.insert(0, os.path.join(HERE, "..", "examples"))
+    import sphere_system_identification_device as ex
+    Z = ex.dataset()
+    f0 = lambda th: ex.loss(np.concatenate([th, np.zeros(3)]), Z)
+    fgH0 = lambda th: ex.loss(np.concatenate([th, np.zeros(3)]), Z, derivatives=True)
+    assert f0(np.array([0.2, 0.5])) < 1e-20                      # (the device's step IS the reference's on these rows)
+    th = np.array([0.12, 0.47]); th5 = np.concatenate([th, np.zeros(3)])
+    c, g, H = fgH0(th)
+    assert abs(c - f0(th)) < 1e-12 * max(1.0, c)
+    # Is the chained gradient the derivative of the cost?  At tight solver tolerances, with the consistent IFT (DESIGN.md Q2): to 1e-6.  As
+    # get_contact_gradients evaluates it after step! (data blocks on the post-update state, the default mode): 1e-4 off.  At the reference's
+    # DEFAULT tolerances (what the example runs with) the IFT differentiates the relaxed problem at the central-path parameter the solve ended
+    # on (btol = 1e-4), central differences the terminated iteration as a whole: a few percent apart, both good descent directions.
+    tight = d.SolverOptions(rtol=1e-10, btol=1e-10)
+    h = 1e-5
+    fd_t = np.array([(ex.loss(th5 + h * e, Z, opts=tight) - ex.loss(th5 - h * e, Z, opts=tight)) / (2 * h) for e in np.eye(5)[:2]])
+    g_cons = ex.loss(th5, Z, derivatives=True, grad_mode=1, opts=tight)[1]
+    g_ref = ex.loss(th5, Z, derivatives=True, grad_mode=0, opts=tight)[1]
+    fd = np.array([(f0(th + h * e) - f0(th - h * e)) / (2 * h) for e in np.eye(2)])
+    print("tight tolerances: consistent IFT %s  reference evaluation %s  central differences %s | default tolerances: %s vs %s" % (g_cons, g_ref, fd_t, g, fd))
+    assert np.abs(g_cons - fd_t).max() <= 1e-5 * np.abs(fd_t).max(), (g_cons, fd_t)
+    assert np.abs(g_ref - fd_t).max() <= 1e-3 * np.abs(fd_t).max(), (g_ref, fd_t)
+    assert np.abs(g - fd).max() <= 0.1 * np.abs(fd).max(), (g, fd)
+    sol = ex.quasi_newton_solve(f0, fgH0, np.array([0.0, 1.0]), verbose=False)
+    print("recovered friction_coefficient %.6f, contact_radius %.6f, cost %.3e" % (sol[0], sol[1], f0(sol)))
+    assert abs(sol[0] - 0.2) < 5e-3 and abs(sol[1] - 0.5) < 5e-4 and f0(sol) < 1e-6
