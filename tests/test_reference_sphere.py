@@ -207,3 +207,46 @@ def test_system_identification_on_the_reference_dataset():
     sol = ex.quasi_newton_solve(f0, fgH0, np.array([0.0, 1.0]), verbose=False)
     print("recovered friction_coefficient %.6f, contact_radius %.6f, cost %.3e" % (sol[0], sol[1], f0(sol)))
     assert abs(sol[0] - 0.2) < 5e-3 and abs(sol[1] - 0.5) < 5e-4 and f0(sol) < 1e-6
+
+
+class _OracleBatch:
+    """the slice of api.BatchedMechanism the example uses, served by the CPU oracle (one environment at a time)"""
+
+    def __init__(self, spec, batch, dtype="f64", opts=None):
+        self.o = Oracle(spec, opts=opts); self.B = batch; self.mode = 0
+
+    def set_gradient_mode(self, mode):
+        self.mode = mode
+
+    def step(self, z, with_gradient=False):
+        zn = np.zeros_like(z); st = np.zeros(self.B, np.int32); it = np.zeros(self.B, np.int32)
+        self.dz = np.zeros((self.B, 12, 12)); self.dc = np.zeros((self.B, 12, 5))
+        for b in range(self.B):
+            zn[b], info = self.o.step(z[b]); st[b] = info["status"]; it[b] = info["iters"]
+            if with_gradient:
+                self.dz[b] = self.o.gradients(self.mode)[0]; self.dc[b] = self.o.contact_gradients(self.mode)
+        return zn, st, it
+
+    def gradients(self):
+        return self.dz, None
+
+    def contact_gradients(self):
+        return self.dc
+
+    def close(self):
+        pass
+
+
+def test_system_identification_on_the_reference_dataset_oracle(monkeypatch):
+    """the same example through the ORACLE (CPU tier): its get_contact_gradients restatement recovers the reference's parameters from the
+    reference's data, and the cost vanishes at them"""
+    sys.path.insert(0, os.path.join(HERE, "..", "examples"))
+    import sphere_system_identification_device as ex
+    monkeypatch.setattr(ex.api, "BatchedMechanism", _OracleBatch)
+    Z = ex.dataset()
+    f0 = lambda th: ex.loss(np.concatenate([th, np.zeros(3)]), Z)
+    fgH0 = lambda th: ex.loss(np.concatenate([th, np.zeros(3)]), Z, derivatives=True)
+    assert f0(np.array([0.2, 0.5])) < 1e-20
+    sol = ex.quasi_newton_solve(f0, fgH0, np.array([0.0, 1.0]), verbose=False)
+    print("oracle: recovered friction_coefficient %.6f, contact_radius %.6f" % (sol[0], sol[1]))
+    assert abs(sol[0] - 0.2) < 5e-3 and abs(sol[1] - 0.5) < 5e-4
