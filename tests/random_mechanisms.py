@@ -79,3 +79,34 @@ def random_mechanism(seed, contact_type="nonlinear", nb=None, translational=Fals
     z = coords.minimal_to_maximal(spec, x)
     u = rng.normal(size=spec.nu) * 0.3
     return spec, z, u
+
+
+
+def forest_mechanism():
+    """several trees in one mechanism (bodies hanging on the origin independently): a two-link pendulum, a free sphere with a floor contact,
+    and a single damped link -- three roots, one of them with a branch below it, control batches that span trees"""
+    import numpy as np
+    from dojo_amd.mechanisms import BodySpec, MechanismSpec, Floating, Revolute, box_inertia, sphere_inertia, contact_constraint
+    ll = 0.8
+    bodies = [BodySpec("a1", 1.0, box_inertia(0.1, 0.1, ll, 1.0)), BodySpec("a2", 0.7, box_inertia(0.1, 0.1, ll, 0.7)),
+              BodySpec("ball", 1.3, sphere_inertia(0.25, 1.3)), BodySpec("b1", 0.9, box_inertia(0.1, 0.1, ll, 0.9))]
+    joints = [Revolute("ja1", -1, 0, np.array([1.0, 0, 0]), parent_vertex=np.array([0, 0, 2.0]), child_vertex=np.array([0, 0, ll / 2])),
+              Revolute("ja2", 0, 1, np.array([0, 1.0, 0]), parent_vertex=np.array([0, 0, -ll / 2]), child_vertex=np.array([0, 0, ll / 2])),
+              Floating("jball", -1, 2),
+              Revolute("jb1", -1, 3, np.array([0, 1.0, 0]), parent_vertex=np.array([1.5, 0, 2.0]), child_vertex=np.array([0, 0, ll / 2]))]
+    joints[3].tra.damper = joints[3].rot.damper = 0.3
+    contacts = [contact_constraint("floor", 2, np.array([0, 0, 1.0]), 0.5, contact_radius=0.25)]
+    return MechanismSpec("forest", bodies, joints, contacts, 0.01, None, np.array([0.0, 0.0, -9.81]))
+
+
+def forest_state(spec, oracle, seed=5, pre=3):
+    """a state of forest_mechanism with the ball in contact and everything moving, and a control vector"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    z = oracle.minimal_to_maximal(np.zeros(2 * spec.nu)).reshape(4, 13).copy()
+    z[2, 0:3] = [0.3, -0.2, 0.2505]; z[2, 3:6] = [0.4, 0.1, -0.2]; z[2, 10:13] = [0.5, -1.0, 0.3]          # the ball just above the floor, moving
+    z = z.reshape(-1)
+    u = 0.3 * rng.normal(size=spec.nu)
+    for _ in range(pre):
+        z, info = oracle.step(z, u); assert info["status"] == 0
+    return z, u

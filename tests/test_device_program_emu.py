@@ -688,3 +688,25 @@ def test_body_body_contact_inside_the_ant():
         loaded = loaded or o.get_solution()[-4] > 1e-2
         z = zo
     assert loaded
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gradients_of_a_forest(mode):
+    """Several trees in one mechanism (bodies hanging on the origin independently): a two-link pendulum, a free sphere with a floor contact, and
+    a single damped link.  The IFT sweeps are scheduled by branch with the ROOTS handled apart (their substitutions dealt out over all quads,
+    their body rows' solution posted per root): three roots, one of them with a branch below it, control batches that span trees.  State and
+    control Jacobians and the contact-data Jacobian against the oracle."""
+    from random_mechanisms import forest_mechanism
+    spec = forest_mechanism()
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
+    o = Oracle(spec, opts=opts)
+    from random_mechanisms import forest_state
+    z, u = forest_state(spec, o)
+    zo, info = o.step(z, u)
+    dz, du = o.gradients(mode); dc = o.contact_gradients(mode)
+    r = emu_step(spec, z, u, opts=opts, grad=True, grad_mode=mode, quad=True)
+    assert r["status"][0] == 0 and r["iters"][0] == info["iters"] and np.abs(r["z_next"][0] - zo).max() < 1e-9
+    assert np.abs(r["dz"][0] - dz).max() < 1e-6 * max(1.0, np.abs(dz).max())
+    assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
+    assert np.abs(r["dc"][0] - dc).max() < 1e-6 * max(1.0, np.abs(dc).max())
+    assert np.abs(dz[24:36, 0:24]).max() == 0 and np.abs(dc[0:24]).max() == 0          # (the trees do not talk to each other)

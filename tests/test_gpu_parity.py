@@ -461,6 +461,37 @@ def test_contact_gradient_parity(cfg, batch, pre_steps):
     gm.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_gradients_of_a_forest_on_the_device(dtype):
+    """several trees in one mechanism (tests/random_mechanisms.py: forest_mechanism -- three roots, one with a branch, control batches that span
+    trees): the IFT sweeps handle every root apart (gradient_columns_quad: root phase, per-root x posted for its tree).  State, control and
+    contact-data Jacobians against the oracle, a batch of perturbed states; four environments per wavefront (S = 4)."""
+    from random_mechanisms import forest_mechanism, forest_state
+    spec = forest_mechanism()
+    opts = d.SolverOptions(rtol=1e-8, btol=1e-8)
+    o = Oracle(spec, opts=opts)
+    B = 24
+    Z = []; U = []
+    for b in range(B):
+        z, u = forest_state(spec, o, seed=100 + b, pre=2 + b % 3)
+        Z.append(z); U.append(u)
+    Z = np.array(Z); U = np.array(U)
+    gm = api.BatchedMechanism(spec, B, dtype=dtype, opts=opts)
+    zn, st, it = gm.step(Z.astype(gm.np_dtype), U.astype(gm.np_dtype), with_gradient=True)
+    dz, du = gm.gradients(); dc = gm.contact_gradients()
+    gm.close()
+    tol = 1e-6 if dtype == "f64" else 1e-4
+    for b in range(B):
+        zi = d.fp32_abi_state(Z[b:b + 1])[0] if dtype == "f32" else Z[b]
+        ui = U[b].astype(np.float32).astype(np.float64) if dtype == "f32" else U[b]
+        zo, info = o.step(zi, ui)
+        assert st[b] == 0 and info["status"] == 0
+        gz, gu = o.gradients(0); gc = o.contact_gradients(0)
+        assert np.abs(zn[b] - zo).max() < (1e-9 if dtype == "f64" else 1e-5)
+        for a_, b_ in ((dz[b], gz), (du[b], gu), (dc[b], gc)):
+            assert np.abs(a_ - b_).max() <= tol * max(1.0, np.abs(b_).max()), (b, np.abs(a_ - b_).max())
+
+
 def _fd_coordinate_jacobians(spec, xp, zp, h=1e-6):
     """Finite-difference restatement of minimal_to_maximal_jacobian(x) [12Nb x 2nu] and maximal_to_minimal_jacobian(z)
     [2nu x 12Nb] (the reference tests its analytic ones the same way) with the attitude convention dq = q (x) (0, phi)."""
