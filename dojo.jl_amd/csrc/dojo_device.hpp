@@ -2122,15 +2122,15 @@ struct LaneProgram {
     }
 
     // quad mapping: IFT column solves  X = solmat⁻¹ · datamat  (DESIGN.md §5).
-    // Columns travel through the tree six at a time ("batches") and the two sweeps are software-
-    // pipelined over the batches: in step t of the up-sweep a supernode at level l works on batch
-    // t − (maxlevel − l), in step t of the down-sweep on batch t − l.  Every lane therefore does one
-    // useful block substitution per step instead of idling at the other levels' turns, and the whole
-    // IFT costs (batches + depth) steps per sweep instead of batches × depth.
+    // Columns travel through the tree six at a time ("batches") and the two sweeps are software-pipelined over the batches: supernodes
+    // at different levels work on different batches in the same step, so that every lane does a block substitution per step instead of
+    // idling at the other levels' turns.  Since round 4 the pipelines run per BRANCH (a child of a root with its subtree) over the batches
+    // that are non-zero in that branch, all branches at once, and the roots are handled apart (see the two sweeps below): the Ant's 32
+    // steps per sweep became 10 + 2 root rounds (up) and 10 + a chain-free product phase (down).
     // The sweeps are the forward / backward substitutions of the tree's LU form (factorize_quad_lu):
     //   up    ỹ = L11⁻¹ (r + Σ_children messages);  message to the parent's body rows: u − m ỹ
     //   down  x = U11⁻¹ (ỹ − T x_parent)
-    // Between the sweeps ỹ -- all twelve rows of every supernode -- waits in the output column itself (ABI type = arithmetic
+    // Between the sweeps ỹ -- all twelve rows of every branch supernode; a root's never leaves its registers -- waits in the output column itself (ABI type = arithmetic
     // type: role 0 -> the v rows of the lane's body, role 1 -> the ω rows, roles 2 / 3 -> the x3 / φ3 rows; nobody writes those
     // before the down-sweep has fetched them: the fetch of a batch is issued one step before its output stores, by the same
     // wavefront) or, with a narrower ABI type, in a buffer of its own in the arithmetic type (KernelArgs::ypark,
@@ -2182,9 +2182,10 @@ struct LaneProgram {
         //   phase 1  every branch marches only ITS batches (those that are non-zero somewhere in it, in batch order) through its own
         //            supernodes, all branches at once: a supernode at level l >= 1 works on the i-th batch of its branch in step
         //            i + (maxlevel − l); the level-1 supernodes leave their messages to the root's body rows in KernelArgs::msg;
-        //   phase 2  the roots' forward substitutions -- every batch reaches a root -- are dealt out over ALL quads of the environment
-        //            (idle supernode slots included): quad s takes batches s, s + S, ... on the root's behalf, with the root's factors,
-        //            right-hand sides (its QuadRhs block in LDS) and the messages of phase 1, and parks ỹ where the root would have.
+        //   phase 2  the roots' substitutions -- every batch reaches a root -- are dealt out over ALL quads of the environment (idle
+        //            supernode slots included): quad s takes batches s, s + S, ... on the root's behalf, with the root's factors (staged in
+        //            KernelArgs::lu), right-hand sides (its QuadRhs block in LDS) and the messages of phase 1; the backward substitution
+        //            follows at once in registers (a root has no parent term) and Δv, Δω of the root go to xr (behind msg) for the whole tree.
         // Steps: max over branches of their batch count + maxlevel − 1, plus ceil(NB / S) root rounds (Ant: 8 + 2 + 2 instead of 32).
         // The arithmetic of every (supernode, batch) pair is what it was: the same operations in the same order.
         // -- what every supernode publishes (topology only: identical in every environment of the workgroup)
