@@ -2620,6 +2620,29 @@ struct LaneProgram {
 #pragma unroll
                 for (int j = 0; j < 36; ++j) xc[j] = xn[j];
             }
+            // A mechanism with several trees (bodies hanging on the origin independently): the batches of the OTHER trees never reach this one -- their
+            // blocks of the Jacobians are zero, and every entry of the output has to be written (uniform test: one tree, nothing to do)
+            if (nroots > 1) {
+                unsigned long long z0 = 0ull, z1 = 0ull;
+                if (active) {
+                    const unsigned long long all0 = NB >= 64 ? ~0ull : ((1ull << NB) - 1ull), all1 = NB > 64 ? ((NB >= 128 ? ~0ull : (1ull << (NB - 64)) - 1ull)) : 0ull;
+                    z0 = all0 & ~inf[rootk].bm[0]; z1 = all1 & ~inf[rootk].bm[1];
+                }
+                int cz = 0;
+                while ((z0 | z1) != 0ull) {
+                    int b;
+                    if (z0 != 0ull) { b = __builtin_ctzll(z0); z0 &= z0 - 1ull; } else { b = 64 + __builtin_ctzll(z1); z1 &= z1 - 1ull; }
+                    if (((cz++) & 1) != half) continue;
+                    const bool isS = b < nbs;
+                    TIO* const cb = colbase(b, k, rq);
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) if (col_ok(b, n)) {
+                        TIO* const o = cb + (size_t)((isS && n >= 3) ? n + 3 : n) * nx;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) o[i] = TIO(0);
+                    }
+                }
+            }
         }
 #ifdef DJ_PROF
         pc[4] += wv.clock() - td0; pc[2] = wv.clock() - tpb;

@@ -504,6 +504,16 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         A.blk = (T*)s->d_blk + wave0 * 90 * 64 * NW;
         A.flag = s->d_flag + env0;
     }
+    // Test hook (tests/conftest.py sets it for the GPU tier): the Jacobian buffers are filled with NaN bit patterns before the IFT kernels run, so that
+    // an entry the device fails to write comes back as NaN instead of whatever the allocation held (the kernels must write every entry).
+    static const bool poison_ = getenv("DOJO_POISON_OUTPUTS") != nullptr;
+    if (poison_ && g) {
+        if (dc != nullptr) HIPCHK(hipMemsetAsync(A.dc, 0xFF, (size_t)nenv * nx * 5 * s->M.Nc * sizeof(TIO), st));
+        else {
+            if (A.dz) HIPCHK(hipMemsetAsync(A.dz, 0xFF, (size_t)nenv * nx * nx * sizeof(TIO), st));
+            if (A.du && nu > 0) HIPCHK(hipMemsetAsync(A.du, 0xFF, (size_t)nenv * nx * nu * sizeof(TIO), st));
+        }
+    }
     typedef int (*launcher_t)(const void*, int, void*, int, void*);
     const bool f32 = sizeof(TIO) == 4;
     if (dc != nullptr) {                   // contact-data columns only: the hand-off of the last differentiable step is re-used

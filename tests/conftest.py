@@ -12,6 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     mexpr = config.getoption("-m") or ""
     if "gpu" in mexpr and "not gpu" not in mexpr:
+        os.environ.setdefault("DOJO_POISON_OUTPUTS", "1")     # (dojo_hip.hip, launch(): unwritten Jacobian entries come back as NaN)
         # PyTorch ships its own HIP runtime: in a process that uses both torch tensors and libdojo_hip.so (the
         # BatchedEnvironment tests; bench.py) torch has to bring the GPU up first, or its later initialisation
         # finds no device (INTEGRATION.md "Using the library next to PyTorch").

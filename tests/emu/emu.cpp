@@ -13,6 +13,7 @@
 //  Schur complement may skip, are then the GPU's)
 #include "../../dojo.jl_amd/csrc/dojo_host.hpp"
 #include <thread>
+#include <limits>
 #include <mutex>
 #include <condition_variable>
 #include <cstring>
@@ -109,6 +110,9 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<TIO> zt = castv(z, (size_t)B * nz), ut = castv(u, (size_t)B * M.nu);
     std::vector<TIO> zn((size_t)B * nz), velt(vel ? (size_t)B * 6 * M.Nb : 0), jt(jimp ? (size_t)B * std::max(M.n_joint_imp, 1) : 0),
         ct(csg ? (size_t)B * (2 * dj::NCV) * std::max(M.Nc, 1) : 0), dzt(dz ? (size_t)B * nx * nx : 0), dut(du ? (size_t)B * nx * std::max(M.nu, 1) : 0);
+    // (the device must write EVERY entry of the Jacobians: the product's buffers are not zeroed either -- unwritten entries come back as NaN)
+    for (auto& v : dzt) v = TIO(std::numeric_limits<double>::quiet_NaN());
+    for (auto& v : dut) v = TIO(std::numeric_limits<double>::quiet_NaN());
     dj::KernelArgs<TIO, T> A;
     { const char* rw = std::getenv("EMU_REFINE_W"); A.G = dj::make_globals<T>(M, opts, grad_mode, rw ? std::atof(rw) : INFINITY); }
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
@@ -120,7 +124,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
     A.dz = dz ? dzt.data() : nullptr; A.du = du ? dut.data() : nullptr;
     std::vector<TIO> rest(storage ? (size_t)B * 6 * M.Nb : 0); A.res = storage ? rest.data() : nullptr;
-    std::vector<TIO> dct((dc && QUAD) ? (size_t)B * nx * 5 * std::max(M.Nc, 1) : 0); A.dc = nullptr;
+    std::vector<TIO> dct((dc && QUAD) ? (size_t)B * nx * 5 * std::max(M.Nc, 1) : 0, TIO(std::numeric_limits<double>::quiet_NaN())); A.dc = nullptr;
     std::vector<T> dbgt(dbg ? (size_t)B * M.Nb * 512 : 0); A.dbg = dbg ? dbgt.data() : nullptr;
     std::vector<T> solbuf(dz ? (size_t)B * M.S * dj::sol_record<MAXC>() : 0); A.sol = dz ? solbuf.data() : nullptr;
     int E = W / (M.S * (QUAD ? 4 : 1)), nwaves = (B + E - 1) / E;
