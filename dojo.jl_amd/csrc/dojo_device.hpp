@@ -4159,11 +4159,7 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     // The factors of the final linearization leave this kernel only through A.fac (the refining IFT kernel reads them); the plain IFT
     // kernels linearize once more themselves (lu_prepare / linearize in grad_entry), so a differentiable step without refinement may
     // skip the set_entries! + factorization after the converging iteration exactly like a forward-only one.
-#ifdef DJ_FINAL_LINEARIZE     // (A/B knob: the round-3 behaviour)
-    int status = prog.mehrotra(iters, /*need_factors=*/A.sol != nullptr);
-#else
     int status = prog.mehrotra(iters, /*need_factors=*/QUAD && A.fac != nullptr);
-#endif
 #ifdef DJ_PROF
     prog.pc[7] = wv.clock() - t_all;
 #endif
