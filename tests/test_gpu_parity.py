@@ -493,38 +493,10 @@ def test_gradients_of_a_forest_on_the_device(dtype):
 
 
 def _fd_coordinate_jacobians(spec, xp, zp, h=1e-6):
-    """Finite-difference restatement of minimal_to_maximal_jacobian(x) [12Nb x 2nu] and maximal_to_minimal_jacobian(z)
-    [2nu x 12Nb] (the reference tests its analytic ones the same way) with the attitude convention dq = q (x) (0, phi)."""
-    from dojo_amd import coords
-    from dojo_amd.quat import qmul, qconj
-    Nb, nm = spec.Nb, 2 * spec.nu
-
-    def reduce(zd, z0):                       # maximal difference quotient -> [x v phi w] per body
-        out = np.zeros(12 * Nb)
-        for b in range(Nb):
-            out[12 * b:12 * b + 6] = zd[13 * b:13 * b + 6]
-            out[12 * b + 6:12 * b + 9] = qmul(qconj(z0[13 * b + 6:13 * b + 10]), zd[13 * b + 6:13 * b + 10])[1:]
-            out[12 * b + 9:12 * b + 12] = zd[13 * b + 10:13 * b + 13]
-        return out
-    z0 = ocoords.minimal_to_maximal(spec, xp)
-    Jm = np.zeros((12 * Nb, nm))
-    for j in range(nm):
-        e = np.zeros(nm); e[j] = h
-        Jm[:, j] = reduce((ocoords.minimal_to_maximal(spec, xp + e) - ocoords.minimal_to_maximal(spec, xp - e)) / (2 * h), z0)
-    JM = np.zeros((nm, 12 * Nb))
-    for b in range(Nb):
-        for i in range(12):
-            zs = []
-            for sgn in (1.0, -1.0):
-                z = zp.copy()
-                if i < 6: z[13 * b + i] += sgn * h
-                elif i < 9:
-                    ph = np.zeros(3); ph[i - 6] = sgn * h
-                    z[13 * b + 6:13 * b + 10] = qmul(zp[13 * b + 6:13 * b + 10], np.concatenate([[np.sqrt(1 - h * h)], ph]))
-                else: z[13 * b + 10 + (i - 9)] += sgn * h
-                zs.append(ocoords.maximal_to_minimal(spec, z))
-            JM[:, 12 * b + i] = (zs[0] - zs[1]) / (2 * h)
-    return Jm, JM
+    """minimal_to_maximal_jacobian(x) [12Nb x 2nu] and maximal_to_minimal_jacobian(z) [2nu x 12Nb] by central differences of the
+    oracle's maps (tests/fd_coords.py, shared with tests/test_reference_lqr.py)"""
+    from fd_coords import fd_coordinate_jacobians
+    return fd_coordinate_jacobians(ocoords._o(spec), xp, zp, h)
 
 
 @pytest.mark.parametrize("cfg,pre_steps,mode", [(1, 3, 1), (1, 3, 0), (2, 2, 1), (3, 2, 1), (3, 2, 0), (4, 2, 1)])
