@@ -6,8 +6,8 @@ B = 4096 Ant environments per GPU (BASELINE.json configs[2], the config the metr
 closed loop: z_{k+1} = step(z_k, u_k) with synthetic controls, all buffers resident in HBM.
 N > 1: one process per GPU (torch.distributed / RCCL), the batch is sharded (weak scaling: B per
 GPU is fixed; --batch-total T: strong scaling, T / N per GPU -- the form BASELINE.json quotes
-configs 4 and 5 in) with no data-path collective; the final trajectories are all-gathered once per
-rollout chunk over RCCL inside the timed region.
+configs 4 and 5 in) with no data-path collective; the trajectory chunk [K, B, 13 Nb] of the timed rollout is all-gathered
+once over RCCL inside the timed region (north_star: "RCCL all-gather of trajectories").
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,6 +40,10 @@ def main():
                     "(16 at batch 4096), 1 = one launch per kernel on the caller's stream")
     ap.add_argument("--no-parity", action="store_true", help="skip the grad-inf-err-vs-CPU leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--iter-cap", type=int, default=-1, help="dojo_set_iteration_cap: solves unfinished after this many Newton iterations go on in the continuation "
+                    "kernel (line-search trials side by side; joined steps only: the sync_per_step leg); 0 / -1 = off (the library's default)")
+    ap.add_argument("--timed-only", action="store_true", help="warmup + the timed region only (no joined-per-step leg, no roofline leg, no parity, no CPU baseline): "
+                    "what tools/gpu_pmc.sh profiles, so that its counters cover exactly the timed region's step window")
     ap.add_argument("--refine", type=float, default=None, help="stiffness threshold of the solve refinement (dojo_set_refinement); default: the library's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1: nccl (= RCCL, production) or gloo "
                     "(plumbing check of the N > 1 path on a box with fewer GPUs than ranks: ranks share devices, the gather goes through the host)")
@@ -88,6 +92,7 @@ def main():
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000 + rank]))
     Uall = torch.tensor(0.5 * rng.standard_normal((K + W, B, spec.nu)) * (np.abs(U0) > 0), dtype=tdt, device=dev).contiguous()
     zn = torch.empty_like(z)
+    traj = torch.empty((K,) + tuple(z.shape), dtype=tdt, device=dev)      # the states after each timed step: what the ranks exchange (and what the rollout is for)
     status = torch.empty(B, dtype=torch.int32, device=dev); iters = torch.empty(B, dtype=torch.int32, device=dev)
     grad = not args.no_grad
     dz = torch.empty((B, spec.nx, spec.nx), dtype=tdt, device=dev) if grad else None
@@ -105,6 +110,7 @@ def main():
         gm.set_refinement(args.refine)
     if args.chunks > 0:
         gm.set_groups(args.chunks)
+    gm.set_iteration_cap(args.iter_cap)
     gm.set_async(True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
     lib_gather, lib_stuck = False, False
@@ -139,11 +145,16 @@ def main():
     def ptr(t):
         return C.c_void_p(0 if t is None else t.data_ptr())
 
-    def one_step(k):
+    def one_step(k, out=None):
+        """z <- step(z, u_k); `out`: the buffer the new state is written to (a row of the trajectory), else the ping-pong buffer"""
         nonlocal z, zn
-        api._chk(lib.dojo_step_dev(gm.h, ptr(z), ptr(Uall[k]), ptr(zn), ptr(status), ptr(iters), ptr(dz) if grad else None, ptr(du) if grad else None,
+        dst = zn if out is None else out
+        api._chk(lib.dojo_step_dev(gm.h, ptr(z), ptr(Uall[k]), ptr(dst), ptr(status), ptr(iters), ptr(dz) if grad else None, ptr(du) if grad else None,
                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        z, zn = zn, z
+        if out is None:
+            z, zn = zn, z
+        else:
+            z = out
 
     def barrier():
         if world > 1:
@@ -157,15 +168,26 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
-        one_step(k)
+        one_step(k, traj[k - W])
     gm.join(torch.cuda.current_stream().cuda_stream)       # the environment groups -> torch's stream
-    if args.backend == "nccl" or lib_gather:
-        # the final states over RCCL/xGMI, once per rollout chunk: dojo_allgather_dev (the library's communicator), else torch's
-        z_all = D.all_gather_states_rccl(gm, z, world) if lib_gather else D.all_gather_states(z, world)
-    else:
-        torch.cuda.synchronize(); z_all = D.all_gather_states(z.cpu(), world)
+    gathered_bytes = 0
+    if world > 1:
+        # the trajectory chunk [K, B, 13 Nb] of this rollout over RCCL/xGMI, once: dojo_allgather_dev (the library's communicator), else torch's
+        if args.backend == "nccl" or lib_gather:
+            traj_all = D.all_gather_states_rccl(gm, traj, world) if lib_gather else D.all_gather_states(traj, world)
+        else:
+            torch.cuda.synchronize(); traj_all = D.all_gather_states(traj.cpu(), world)
+        gathered_bytes = traj_all.numel() * traj_all.element_size()
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
+    z = traj[K - 1].clone()
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "differentiable env-steps/sec (fwd+grad) at batch=4096; grad inf-err vs CPU", "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world,
+                              "steps": K, "warmup": W, "ms_per_step": 1e3 * el / K, "note": "--timed-only: warmup + timed region (profiling runs)"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rank_devices = None
     if world > 1:                                 # which device every rank ran on (rank 0 prints it)
         box = [None] * world
@@ -183,16 +205,18 @@ def main():
     ok_frac = float((status == 0).float().mean().item())
     mean_iters = float(iters.float().mean().item())
 
-    # Kernel durations for the roofline, outside the timed region: the same closed loop continued for a few steps as ONE launch
-    # of the whole batch per kernel (groups = 1), so that the hipEvent durations (on the launch stream) are those of a kernel
-    # that has the GPU to itself -- the figure the rocprofv3 --kernel-trace of `bench.py --chunks 1` shows.
-    gm.set_async(False); gm.set_groups(1)
-    z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()                              # from the initial states again: the first steps
-    torch.cuda.synchronize()                                                              # of the rollout, where (almost) nothing stalls
-    one_step(0)
+    # Kernel durations for the roofline, outside the timed region: the SAME closed loop once more from the same initial states with the
+    # same controls -- the warmup steps, then the timed region's K steps -- as ONE launch of the whole batch per kernel (groups = 1), so that
+    # the hipEvent durations (on the launch stream) are those of a kernel that has the GPU to itself: the figure the rocprofv3
+    # --kernel-trace of `bench.py --chunks 1` shows, over the step window the PMC passes of tools/gpu_pmc.sh count (profiles/*_pmc_traffic.json).
+    gm.set_async(False); gm.set_groups(1); gm.set_iteration_cap(0)                        # (whole solves inside dojo_step_kernel, as in the PMC passes)
+    z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()
+    torch.cuda.synchronize()
+    for k in range(W):
+        one_step(k)
     torch.cuda.synchronize()
     per_launch = []
-    for k in range(1, 1 + min(K, 8)):
+    for k in range(W, W + K):
         one_step(k)
         per_launch.append(gm.last_kernel_times())        # (step kernel ms, IFT kernel ms) of this launch; waits for its end event
     step_ms = sum(a for a, _ in per_launch) / len(per_launch); ift_ms = sum(b for _, b in per_launch) / len(per_launch)
@@ -206,6 +230,7 @@ def main():
         # launch: the step kernel reads z,u and writes z_next,status,iters; the IFT kernel writes dz,du.
         traffic = measured_traffic()
         util = measured_valu_utilization()
+        binfo = build_info()
 
         def roof(kernel, ms, nbytes):
             """The bound of these kernels is the fp64 vector ALU (the KKT systems never leave registers / LDS):
@@ -219,6 +244,9 @@ def main():
             r = {"bound": "valu_fp64", "kernel": kernel, "avg_kernel_ms": ms, "achieved": ach_v, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": (ach_v / FP64_VECTOR_PEAK_TFLOPS) if ach_v else None, "executed_fp64_flops_per_launch": fl,
                  "flops_source": t["source"] if t else None,
+                 # the PMC pass belongs to THIS library (content hash of its sources, written by tools/gpu_pmc.sh) and covers the timed region's steps
+                 "flops_source_digest_matches": (t.get("library_digest") == binfo.get("library_digest")) if (t and t.get("library_digest")) else None,
+                 "flops_source_step_window": t.get("step_window") if t else None,
                  "traffic": t["bytes_per_launch"] * scale if t else None,     # HBM bytes per launch, PMC (2 x FETCH_SIZE + WRITE_SIZE), scaled to this launch size
                  "hbm": {"bound": "hbm", "achieved": ach_h, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_h / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}}
             if kernel in util:
@@ -233,9 +261,20 @@ def main():
             if r is not None and r.get("executed_fp64_flops_per_launch") and best > 0:
                 a_ = r["executed_fp64_flops_per_launch"] / (best * 1e-3) / 1e12
                 r["best_launch"] = {"kernel_ms": best, "achieved": a_, "frac": a_ / FP64_VECTOR_PEAK_TFLOPS}
+        for r in (r_step, r_ift):
+            if r is not None and r.get("flops_source_digest_matches") is False:
+                r["warning"] = "STALE COUNTS: %s was taken with another build of the library (digest mismatch); re-run tools/gpu_pmc.sh" % r["flops_source"]
         dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
-        dominant["note"] = ("fp64 vector-ALU-bound lane program; durations from hipEvents on the launch stream with the batch as ONE launch per kernel "
-                            "(measured after the timed region); the HBM roofline asked for by the contract is the `hbm` member")
+        # ... and over the TIMED region itself (the asynchronous rollout, environment groups overlapping): what both kernels execute per
+        # step / ms_per_step -- no kernel has the GPU to itself there, so this is the figure that belongs to `value`
+        fl_step = sum(r_["executed_fp64_flops_per_launch"] for r_ in (r_step, r_ift) if r_ is not None and r_.get("executed_fp64_flops_per_launch"))
+        if fl_step and all(r_ is None or r_.get("executed_fp64_flops_per_launch") for r_ in (r_step, r_ift)):
+            a_ = fl_step / (1e-3 * 1e3 * el / K) / 1e12
+            dominant["timed"] = {"executed_fp64_flops_per_step": fl_step, "ms_per_step": 1e3 * el / K, "achieved": a_, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": a_ / FP64_VECTOR_PEAK_TFLOPS, "note": "step kernel + IFT kernel, executed fp64 flops of one step / ms_per_step of the timed region"}
+        dominant["note"] = ("fp64 vector-ALU-bound lane program; avg_kernel_ms: hipEvents on the launch stream, the batch as ONE launch per kernel, mean over the "
+                            "timed region's K steps replayed after it (same states, same controls); `timed` = both kernels over the timed region itself; "
+                            "the HBM roofline asked for by the contract is the `hbm` member")
         res = {
             "metric": "differentiable env-steps/sec (fwd+grad) at batch=4096; grad inf-err vs CPU" if grad else "env-steps/sec (fwd only)",
             "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -249,6 +288,7 @@ def main():
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
                        "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout)" % (world, NCH),
+                       "iteration_cap": "off (library default; dojo_set_iteration_cap: measured gain only at per-GPU batches <= 2048, DESIGN.md section 6)" if args.iter_cap <= 0 else args.iter_cap,
                        "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters,
                        "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,
                        "sync_per_step_note": "the same %d steps with the environment groups joined into the caller's stream after every step (a barrier per step); `value` is the asynchronous rollout (one join at the end)" % K,
@@ -258,12 +298,28 @@ def main():
         if other is not None:
             res["roofline_second_kernel"] = other
         if grad and not args.no_parity and world == 1:
-            res["grad_inf_err_vs_cpu"] = parity_vs_cpu(spec, B, local)
+            res["grad_inf_err_vs_cpu"] = pv = parity_vs_cpu(spec, B, local)
+            # the norm the metric's second half is claimed in, at the top level: RELATIVE per-environment inf-norm, the absolute one next to it
+            res["grad_err_claim"] = {"norm": "per environment: |J_gpu - J_cpu|_inf / max(1, |J_cpu|_inf) over dz and du (RELATIVE inf-norm); maximum over every environment that converged "
+                                             "on both sides to the same point; the ABSOLUTE inf-norm |J_gpu - J_cpu|_inf is reported next to it",
+                                     "bound_relative": {"f64": 1e-6, "f32": 1e-3},
+                                     "timed_path_f32_abi": {k_: pv.get("f32", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
+                                     "f64_abi": {k_: pv.get("f64", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
+                                     "f64_abi_all_solves_refined": {k_: pv.get("f64_refined", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
+                                     "jacobian_inf_norm_max": pv.get("f64", {}).get("jacobian_inf_norm_max")}
         if not args.no_cpu_baseline and world == 1:
             ex = [r_.get("executed_fp64_flops_per_launch") for r_ in (dominant, other) if r_ is not None]
-            res["cpu_baseline"] = cpu_baseline(spec, grad, mean_iters, (sum(ex) / B) if (ex and all(ex)) else None)
+            res["cpu_baseline"] = cb = cpu_baseline(spec, grad, mean_iters, (sum(ex) / B) if (ex and all(ex)) else None)
+            # the USEFUL share: what a block-sparse direct method needs for this step (cpu_baseline.sparse_lu_flops) / ms_per_step, against the same peak
+            u_ = cb.get("sparse_lu_flops", {}).get("per_env_step")
+            if u_:
+                a_ = u_ * B / (1e-3 * 1e3 * el / K) / 1e12
+                res["roofline"]["useful"] = {"flops_per_step": u_ * B, "achieved": a_, "unit": "TFLOP/s", "frac": a_ / FP64_VECTOR_PEAK_TFLOPS,
+                                             "note": "flops of a block-sparse no-pivot LU (one factorization + two solves per Newton iteration, one + a solve per Jacobian column) / ms_per_step"}
         if world > 1:
-            res["config"]["final_gather"] = "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"
+            res["config"]["trajectory_gather"] = {"what": "the timed rollout's states [K=%d, B=%d, 13 Nb=%d] of every rank, once, inside the timed region" % (K, B, 13 * spec.Nb),
+                                                 "bytes_received_per_rank": gathered_bytes,
+                                                 "through": "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"}
             res["config"]["rank_devices"] = rank_devices
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -358,7 +414,7 @@ def measured_traffic():
         try:
             for k, v in json.load(open(f)).items():
                 out[k] = {"bytes_per_launch": v["bytes_per_launch"], "envs_per_launch": v.get("envs_per_launch", 4096), "source": os.path.relpath(f, ROOT),
-                          "fp64_flops_per_launch": v.get("fp64_flops_per_launch")}
+                          "fp64_flops_per_launch": v.get("fp64_flops_per_launch"), "library_digest": v.get("library_digest"), "step_window": v.get("step_window")}
         except Exception:
             pass
     return out

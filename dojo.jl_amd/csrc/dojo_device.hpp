@@ -71,6 +71,7 @@ constexpr double REG = 1e-10;     // src/Dojo.jl:4
 #define DJ_TRACK_GROWTH 0          // 1: the Gauss-Jordan passes record their largest |multiplier| (dojo_get_diagnostics, tools/hunt_parity.py); ~2 % of the step kernel
 #endif
 #define DJ_STATUS_DEFERRED 3      // internal: the environment's cones became stiff; the refining kernels re-solve it (never reaches the caller)
+#define DJ_STATUS_CONTINUE 4      // internal: the solve reached Globals::iter_cap unfinished; the continuation kernel takes it from there (never reaches the caller)
 
 template <class T>
 struct Globals {
@@ -78,6 +79,8 @@ struct Globals {
     T rtol, btol, undercut, no_progress_undercut;
     T refine_w;                  // refine the linear solves of an environment once max γ/s over its cones exceeds this (inf: never, 0: always)
     int max_iter, max_ls, no_progress_max;
+    int iter_cap;                // > 0: the step kernel hands a solve that is unfinished after this many Newton iterations to the continuation kernel
+                                 // (DJ_STATUS_CONTINUE; KernelArgs::resume / cont_list), which runs the rest with its line-search trials side by side
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
     unsigned char maxch_lev[64]; // largest number of children among the supernodes of each level (bounds the level sweeps' gathers)
@@ -132,6 +135,13 @@ struct Factors {
     T thv_a[3], thv_b[3];        // translational limit: the linear-velocity part of ∂θ/∂(velocities)
 #endif
 };
+
+// what a solve stopped at the iteration cap carries over to its continuation besides the iterate itself (which travels in the
+// step -> IFT hand-off record, KernelArgs::sol): the scalars of mehrotra!'s loop (src/solver/mehrotra.jl:17-21, 51-60)
+template <class T>
+struct SolveCarry { T undercut, rvio, bvio; int n, no_progress, excessive; };
+constexpr int CARRY_PER_ENV = 8;   // doubles per environment of KernelArgs::resume
+constexpr int CARRY_MARK = 7;      // ... of which this one says whether the environment is on the continuation list
 
 template <class T, int MAXC>
 struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][NCV], cg[MAXC][NCV]; };   // solution variables at the start of a line search
@@ -3235,23 +3245,35 @@ struct LaneProgram {
         return cone_line_search(D, tau, tmin(tau, T(0.95)));
     }
 
-    // need_factors: the caller goes on to the IFT (which re-uses the final factors); a forward-only step may skip the
-    // set_entries! + factorization after the iteration that converged.
-    DJ_HD int mehrotra(int& iters_out, bool need_factors = true) {
+    // need_factors: somebody reads the factors of the final linearization (the refining IFT kernel, through KernelArgs::fac); otherwise
+    // a step may skip the set_entries! + factorization after the iteration that converged.
+    // Iteration cap (Globals::iter_cap > 0, only with need_factors = false): a solve that is unfinished after iter_cap iterations leaves
+    // with DJ_STATUS_CONTINUE and its loop scalars in carry_out[] (KernelArgs::resume); RESUME = true is the other end -- the continuation kernel has restored the
+    // iterate (and μ) and *cy, and the loop goes on at iteration cy->n + 1 with the linearization the capped kernel skipped.  The iterates
+    // of the two halves are those of the uncapped loop bit for bit (same functions of the same values in the same order).
+    template <bool RESUME = false>
+    DJ_HD int mehrotra(int& iters_out, bool need_factors = true, const SolveCarry<T>* cy = nullptr, T* carry_out = nullptr) {
         int status = DJ_STATUS_FAILED, excessive = 0;
         T mutarget = T(0), undercut = G.undercut;
         int no_progress = 0;
+        T rvio, bvio;
+        bool done = false;               // per-environment flag (identical on all lanes of an environment)
+        int iters = 0, n0 = 1;
+        if constexpr (RESUME) {
+            undercut = cy->undercut; no_progress = cy->no_progress; excessive = cy->excessive; rvio = cy->rvio; bvio = cy->bvio;
+            iters = cy->n; n0 = cy->n + 1;
+            done = !active;              // (lanes of environments that had finished are inactive here and never change anything)
+            linearize();
+        } else {
         mu = T(0);
         if constexpr (kTrack) refine = T(1) > G.refine_w;        // reset! / initialize! leave every cone at γ/s = 1
         linearize();
 #ifdef DJ_DEBUG
         if (dbg_on) { iters_out = 0; return 0; }   // wave-uniform early exit of the test hook
 #endif
-        T rvio, bvio;
         violations(rvio, bvio);
-        bool done = false;               // per-environment flag (identical on all lanes of an environment)
-        int iters = 0;
-        for (int n = 1; n <= G.max_iter; ++n) {
+        }
+        for (int n = n0; n <= G.max_iter; ++n) {
 #ifdef DJ_DEBUG
             if (trace && wv.lane() == 0) std::printf("%3d  bvio %.3e  rvio %.3e  mu %.3e\n", n, (double)bvio, (double)rvio, (double)mu);
 #endif
@@ -3296,9 +3318,50 @@ struct LaneProgram {
                         if (r2 > rvio && b2 > bvio) { if (ls + 1 < G.max_ls) f *= T(0.5); } else searching = false;
                     }
                 };
+                if constexpr (Wave::kReplicas > 1) {
+                    // Continuation kernel: kReplicas wavefronts hold the same environment(s) with identical state, each in its own LDS block.
+                    // Replica r evaluates trial ls0 + r (step factor alpha / 2^(ls0 + r): halving is exact, so this is the factor the
+                    // sequential search would have reached), the verdicts are exchanged through LDS, and every replica replays the
+                    // sequential accept / halve decisions over them -- the accepted trial is the one line_search! would have stopped
+                    // at (line_search.jl:1-34), the later ones were evaluated for nothing.
+                    constexpr int R = Wave::kReplicas;
+                    const int rep = wv.replica();
+                    const T f0 = f;
+                    T fch = f0, wst = wstiff;
+                    double* const xq = wv.replica_xchg();                       // [R][supernode slots][4]
+                    const int nsn_ = wv.width() >> 2;
+                    for (int ls0 = 0; ls0 < G.max_ls; ls0 += R) {
+                        if (!wv.any(active && searching)) break;
+                        T ft = f0;
+                        for (int i = 0; i < ls0 + rep; ++i) ft *= T(0.5);
+                        int bad = candidate_step(base_sol, D, ft);
+                        { NullBlocks nk; evaluate<false>(nk); }
+                        T r2, b2;
+                        violations(r2, b2);
+                        int anybad;
+                        { T vb[1] = {((active && searching) ? bad : 0) ? T(1) : T(0)}; env_reduce_quad<1>(vb, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); anybad = vb[0] > T(0.5) ? 1 : 0; }
+                        if (q == 0) { double* x_ = xq + (size_t)(rep * nsn_ + (wv.lane() >> 2)) * 4; x_[0] = (double)r2; x_[1] = (double)b2; x_[2] = (double)anybad; x_[3] = (double)wstiff; }
+                        wv.replica_sync();
+                        T fj = f0;
+                        for (int i = 0; i < ls0; ++i) fj *= T(0.5);
+                        for (int j = 0; j < R; ++j) {
+                            if (ls0 + j < G.max_ls && searching) {
+                                const double* y_ = xq + (size_t)(j * nsn_ + (wv.lane() >> 2)) * 4;
+                                excessive |= (int)y_[2];
+                                rc = T(y_[0]); bc = T(y_[1]); wst = T(y_[3]); fch = fj;
+                                if (!(rc > rvio && bc > bvio)) searching = false;
+                            }
+                            fj *= T(0.5);
+                        }
+                        wv.replica_sync();                                      // (the slots are rewritten by the next pass)
+                    }
+                    candidate_step(base_sol, D, fch);                           // every replica moves to the accepted trial's candidate
+                    wstiff = wst;
+                } else {
                 for (int ls = 0; ls < G.max_ls; ++ls) {
                     if (!wv.any(active && searching)) break;
                     trial(ls);
+                }
                 }
                 DJ_PE(3);
                 if (!done) {
@@ -3313,13 +3376,30 @@ struct LaneProgram {
                 // flag success (mehrotra.jl:23-27) -- do that here and skip the linearization nobody will use.
                 if (!need_factors && n < G.max_iter) {
                     const bool conv = done || (rvio < G.rtol && bvio < G.btol);
-                    if (!wv.any(active && !conv)) { if (!done) { status = DJ_STATUS_SUCCESS; done = true; } break; }
+                    if (!wv.any(active && !conv)) {
+                        if (!done) { status = DJ_STATUS_SUCCESS; done = true; }
+                        // (replicas: rb / rj / cres are those of this replica's own trial, not of the accepted one -- evaluate there once more)
+                        if constexpr (Wave::kReplicas > 1) { NullBlocks nk; evaluate<false>(nk); }
+                        break;
+                    }
+                    if constexpr (!RESUME) {
+                        // iteration cap: the unfinished environments of this workgroup go on in the continuation kernel (wave-uniform exit)
+                        if (G.iter_cap > 0 && n >= G.iter_cap && carry_out != nullptr) {
+                            if (!done) {
+                                status = DJ_STATUS_CONTINUE; done = true;
+                                if (active && q == 0 && k == 0) {
+                                    carry_out[0] = undercut; carry_out[1] = rvio; carry_out[2] = bvio; carry_out[3] = T(n); carry_out[4] = T(no_progress); carry_out[5] = T(excessive);
+                                }
+                            }
+                            break;
+                        }
+                    }
                 }
                 // set_entries! + factorization (cone rows now carry the new μ)
                 linearize();
             }
         }
-        if (excessive && status != DJ_STATUS_DEFERRED) status = DJ_STATUS_EXCESSIVE_W;
+        if (excessive && status != DJ_STATUS_DEFERRED && status != DJ_STATUS_CONTINUE) status = DJ_STATUS_EXCESSIVE_W;
         iters_out = iters;
         return status;
     }
@@ -3943,6 +4023,14 @@ struct KernelArgs {
     T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
     T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
+    // iteration cap + continuation (Globals::iter_cap > 0; all three set or all null):
+    T* resume = nullptr;           // [B][CARRY_PER_ENV] solver scalars of the environments the step kernel left unfinished (DJ_STATUS_CONTINUE);
+                                   // entry CARRY_MARK: 1 for the environments of a workgroup on the continuation list, 0 for the others (written by
+                                   // the step kernel for every environment, never by the continuation: the IFT kernel of the others runs next to it)
+    int* cont_list = nullptr;      // [workgroups of this launch] workgroup indices with an unfinished environment, in the order they finished
+    int* cont_count = nullptr;     // [1] entries of cont_list (zeroed before the step kernel, atomically advanced by it)
+    int wave_base = 0;             // index of this launch's first workgroup in the batch: cont_list holds batch-level workgroup indices (the
+                                   // continuation kernels run once over the whole batch, behind the step kernels of all environment groups)
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
 #endif
@@ -4004,7 +4092,11 @@ template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = tru
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
 
 // doubles per supernode in the step -> IFT hand-off record: v ω λ(6), s,γ of the joint limit, s,γ of the contacts, μ,
-// and the pieces of the final linearization the IFT needs besides the factors: t_a, t_b (limit condensation), G134
+// and the pieces of the final linearization the IFT needs besides the factors: t_a, t_b (limit condensation), G134.
+// NOTE: a step that skips the linearization after its converging iteration (need_factors = false: every launch without the refining
+// kernels) leaves t_a / t_b / G134 -- and KernelArgs::diag_out -- at the LAST linearization it did perform, i.e. one iterate back; the plain
+// IFT kernel never reads them (lu_prepare() evaluates the linearization at the restored solution before any use), the refining one
+// re-evaluates them too (grad_entry MODE 2).  They travel for the explicit-inverse consumers only.
 template <int MAXC> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
 template <int MAXC> constexpr int sol_flag_off() { return sol_record<MAXC>() - 1; }
 // quad mapping: the factors themselves travel too (72 values per lane, stored [wave][72][64 lanes]: coalesced)
@@ -4072,8 +4164,19 @@ constexpr int FAC_PER_LANE = 72;
 // MODE 0: state + control columns, pipelined sweeps; 1: contact-data columns; 2: state + control columns of the environments
 // whose solves were being refined, column by column through the refined general solve (LDS layout of the step kernel:
 // NodeP / Lane / Cold stay alive)
-template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, int MODE = 0>
+// CONT (MODE 0, iteration cap): false = the environments the step kernel finished itself (all of them without a cap), true = `wave_index`
+// comes from the continuation list and the environments the continuation kernel finished are served
+template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, int MODE = 0, bool CONT = false>
 DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
+    static_assert(!CONT || MODE == 0, "continuation lists exist for the plain IFT kernel only");
+    if constexpr (QUAD && MODE == 0) {
+        if (A.resume != nullptr) {                              // (uniform) a workgroup without an environment of this launch's kind leaves at once
+            const int stride_ = 4, envl_ = stride_ * A.G.S, E_ = wv.width() / envl_, lane_ = wv.lane();
+            const int env_ = wave_index * E_ + lane_ / envl_, k_ = (lane_ % envl_) / stride_;
+            const bool act_ = (env_ < A.B) && (k_ < A.G.Nb);
+            if (!wv.any(act_ && (A.resume[(size_t)env_ * CARRY_PER_ENV + CARRY_MARK] != T(0)) == CONT)) return;
+        }
+    }
     if constexpr (QUAD && DJ_REFINE && (MODE == 0 || MODE == 2)) {
         // refined environments belong to the MODE 2 kernel; a workgroup without work for this kernel leaves at once (uniform)
         const int stride_ = 4, envl_ = stride_ * A.G.S, E_ = wv.width() / envl_, lane_ = wv.lane();
@@ -4084,7 +4187,8 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     }
     static_assert(MODE != 2 || Wave::kRefine || !(QUAD && DJ_REFINE), "the MODE 2 IFT kernel needs a refining Wave");
     DJ_LANE_SETUP(MODE == 0 ? 1 : MODE == 1 ? 2 : 0,
-                  MODE != 2 || A.sol[(size_t)env * G.S * sol_record<MAXC>() + sol_flag_off<MAXC>()] != T(0))
+                  MODE == 2 ? A.sol[(size_t)env * G.S * sol_record<MAXC>() + sol_flag_off<MAXC>()] != T(0)
+                            : (MODE != 0 || !QUAD || A.resume == nullptr || (A.resume[(size_t)env * CARRY_PER_ENV + CARRY_MARK] != T(0)) == CONT))
     bool flagged = false;
     {   // restore the converged solution (identical on the four lanes of a quad)
         const T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
@@ -4140,14 +4244,18 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #endif
 }
 
-template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave>
+// CONT = true: the continuation kernel's entry (Globals::iter_cap): `wave_index` is a workgroup of the step kernel that left
+// environments unfinished (DJ_STATUS_CONTINUE in KernelArgs::status); their iterate comes back from the hand-off record, the
+// loop scalars from KernelArgs::resume, and the Newton loop goes on.  The other environments of the workgroup stay as they are.
+template <class TIO, class T, class TL, int MAXC, bool QUAD, class Wave, bool CONT = false>
 DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
     constexpr bool RF = QUAD && DJ_REFINE && Wave::kRefine;      // the refining build: re-solves the environments the plain kernel deferred
+    static_assert(!(RF && CONT), "the continuation kernel is a plain build");
     if constexpr (RF) {
         const int envl_ = 4 * A.G.S, E_ = wv.width() / envl_, env_ = wave_index * E_ + wv.lane() / envl_;
         if (A.flag == nullptr || !wv.any(env_ < A.B && A.flag[env_] != 0)) return;          // nothing deferred in this workgroup (uniform)
     }
-    DJ_LANE_SETUP(0, !RF || A.flag[env] != 0)
+    DJ_LANE_SETUP(0, CONT ? A.status[env] == DJ_STATUS_CONTINUE : (!RF || A.flag[env] != 0))
 #ifdef DJ_DEBUG
     prog.dbg_on = A.dbg != nullptr; prog.trace = getenv("DJ_TRACE") != nullptr;
     if (A.dbg && active && q == 0) prog.dbg = A.dbg + ((size_t)env * G.Nb + k) * 512;
@@ -4156,13 +4264,43 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #ifdef DJ_PROF
     unsigned long long t_all = wv.clock();
 #endif
+    int status;
+    if constexpr (CONT) {
+        SolveCarry<T> carry;
+        carry.undercut = G.undercut; carry.rvio = carry.bvio = T(0); carry.n = 0; carry.no_progress = 0; carry.excessive = 0;
+        if (active) {                                          // the iterate the capped solve stopped at (identical on the four lanes of a quad)
+            const T* r = A.sol + ((size_t)env * G.S + (size_t)k) * sol_record<MAXC>();
+            for (int i = 0; i < 3; ++i) { prog.L.v[i] = r[i]; prog.L.w[i] = r[3 + i]; }
+            for (int i = 0; i < 6; ++i) prog.L.lam[i] = r[6 + i];
+            prog.L.ls[0] = r[12]; prog.L.ls[1] = r[13]; prog.L.lg[0] = r[14]; prog.L.lg[1] = r[15];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { prog.L.cs[c][i] = r[16 + 8 * c + i]; prog.L.cg[c][i] = r[20 + 8 * c + i]; }
+            prog.mu = r[16 + 8 * MAXC];
+            const T* cr = A.resume + (size_t)env * CARRY_PER_ENV;
+            carry.undercut = cr[0]; carry.rvio = cr[1]; carry.bvio = cr[2]; carry.n = (int)cr[3]; carry.no_progress = (int)cr[4]; carry.excessive = (int)cr[5];
+        }
+        carry.n = G.iter_cap;                                  // (wave-uniform: the capped loop leaves at exactly this iteration)
+        status = prog.template mehrotra<true>(iters, /*need_factors=*/false, &carry);
+    } else {
     // The factors of the final linearization leave this kernel only through A.fac (the refining IFT kernel reads them); the plain IFT
     // kernels linearize once more themselves (lu_prepare / linearize in grad_entry), so a differentiable step without refinement may
     // skip the set_entries! + factorization after the converging iteration exactly like a forward-only one.
-    int status = prog.mehrotra(iters, /*need_factors=*/QUAD && A.fac != nullptr);
+    status = prog.mehrotra(iters, /*need_factors=*/QUAD && A.fac != nullptr, nullptr,
+                           (!RF && G.iter_cap > 0 && A.resume != nullptr) ? DJ_GLOBAL_PTR(T, A.resume) + (size_t)(env < A.B ? env : 0) * CARRY_PER_ENV : nullptr);
+    }
 #ifdef DJ_PROF
     prog.pc[7] = wv.clock() - t_all;
 #endif
+    if constexpr (!RF && !CONT) {                             // iteration cap: the loop scalars of the unfinished solves, and this workgroup on the continuation list
+        if (A.resume != nullptr) {
+            // (the mark is per WORKGROUP: the IFT of a listed workgroup's finished environments waits for the continuation as well, so that
+            //  no IFT launch ever works on part of a workgroup -- the per-lane staging areas KernelArgs::lu / ypark are indexed by workgroup)
+            const bool listed = wv.any(active && status == DJ_STATUS_CONTINUE);
+            if (active && q == 0 && k == 0) A.resume[(size_t)env * CARRY_PER_ENV + CARRY_MARK] = listed ? T(1) : T(0);
+            if (listed && lane == 0) A.cont_list[wv.atomic_inc(A.cont_count)] = A.wave_base + wave_index;
+        }
+    }
+    if constexpr (CONT) { if (Wave::kReplicas > 1 && wv.replica() != 0) return; }   // every replica holds the same result; the first one writes it
     T gr_env = T(0);
     if constexpr (QUAD && DJ_REFINE) { if (A.diag_out) { T v1[1] = {prog.growth}; prog.template env_reduce_quad_all<1>(v1); gr_env = v1[0]; } }
     if (active && q == 0 && A.sol) {                          // hand-off to the IFT kernel, in the state precision

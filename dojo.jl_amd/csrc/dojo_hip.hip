@@ -94,6 +94,14 @@ struct DojoSim {
     int* d_flag = nullptr;              // [B] environments the plain step kernel deferred to the refining kernels
     double refine_w = -1.0;             // refine once max γ/s of an environment exceeds this (dojo_set_refinement); < 0: chosen from the tolerances
     int *d_status = nullptr, *d_iters = nullptr;
+    // iteration cap + continuation kernel (dojo_set_iteration_cap; dojo_device.hpp Globals::iter_cap)
+    int iter_cap = -1;                  // < 0: automatic (DOJO_DEFAULT_ITERATION_CAP where the continuation kernel exists), 0: off, > 0: as given
+    void* d_resume = nullptr;           // [B][CARRY_PER_ENV] loop scalars of the solves the step kernel left unfinished
+    int *d_cont_list = nullptr, *d_cont_count = nullptr;   // [workgroups of the batch] the continuation list (batch-level workgroup indices), [1] its length
+    int *d_cstat = nullptr;             // [B] status buffer of launches whose caller passed none (the continuation kernel reads it)
+    hipStream_t cstream = nullptr; hipEvent_t cont_event = nullptr, allmain_event = nullptr; std::vector<hipEvent_t> main_events;   // the continuation's stream; "step kernel done" per group
+    int phase_slot = -1;                // timing slot of the phased launch in progress (PH_MAIN -> PH_GRAD of the same group)
+    std::vector<int> group_slot;        // ... per environment group
     bool have_grad = false, have_solution = false, have_u = false;
     std::string err; std::mutex err_m;  // text of the last failure of a call on this handle (dojo_handle_error)
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator of this handle's process group (dojo_comm_init)
@@ -359,6 +367,11 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
 
 int mapping_waves(const dj::HostModel& M);
 bool quad_mapping_of(const DojoSim* s);
+// A step with the iteration cap in force (dojo_set_iteration_cap) is launched in phases: the step kernel of every environment group
+// (PH_MAIN), each followed on its stream by the IFT kernel of the workgroups it finished (PH_GRAD); behind the step kernels of ALL groups,
+// on a stream of its own, the continuation of the listed workgroups and their IFT (PH_CONT, once over the whole batch).  PH_ALL = no cap:
+// step kernel + IFT kernel in one go.
+enum { PH_ALL = 0, PH_MAIN = 1, PH_GRAD = 2, PH_CONT = 3 };
 // wavefronts per workgroup of the quad mapping for this mechanism; 0 = lane mapping
 int mapping_waves(const dj::HostModel& M) {
     if (M.S <= 16) return 1;
@@ -430,11 +443,44 @@ int join_groups(DojoSim* s, hipStream_t st) {
     return DOJO_OK;
 }
 
+// the iteration cap in force for this handle's next step, 0 = none: the continuation kernel exists for the single-wavefront quad mapping
+// (<= 16 bodies) with plain solves (no refinement), NonlinearContact / no contacts (the variants that carry an IFT)
+int effective_cap(const DojoSim* s) {
+    static const char* ecap_ = getenv("DOJO_ITER_CAP");
+    const int cap = s->iter_cap >= 0 ? s->iter_cap : (ecap_ ? atoi(ecap_) : DOJO_DEFAULT_ITERATION_CAP);
+    if (cap <= 0 || cap >= s->opts.max_iter) return 0;
+    if (mapping_waves(s->M) != 1 || std::isfinite(refine_threshold(s))) return 0;
+    if (s->M.contact_model != 0 || s->M.has_ss) return 0;
+    return cap;
+}
+// what a capped step needs besides the groups' streams: the continuation's stream, its end event, a "step kernel done" event per group,
+// the list and its count (zeroed here, on `st`, before the step kernels are forked off it)
+int begin_capped_step(DojoSim* s, size_t NG, hipStream_t st) {
+    if (!s->cstream) {
+        // (DOJO_CONT_PRIORITY=1: a high-priority stream.  Measured: with it the step kernels of the FOLLOWING step take 20..300 ms on some
+        //  queues -- the scheduler's handling of queue priorities, presumably wave save / restore -- so the default is a plain stream, and
+        //  the order of submission below is what puts the continuation in front of the IFT kernels)
+        static const bool prio_ = getenv("DOJO_CONT_PRIORITY") != nullptr && atoi(getenv("DOJO_CONT_PRIORITY")) != 0;
+        int lo_ = 0, hi_ = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
+        if (prio_) HIPCHK(hipStreamCreateWithPriority(&s->cstream, hipStreamNonBlocking, hi_));
+        else HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+    }
+    if (!s->allmain_event) HIPCHK(hipEventCreateWithFlags(&s->allmain_event, hipEventDisableTiming));
+    if (!s->cont_event) HIPCHK(hipEventCreateWithFlags(&s->cont_event, hipEventDisableTiming));
+    while (s->main_events.size() < NG) { hipEvent_t ev_; HIPCHK(hipEventCreateWithFlags(&ev_, hipEventDisableTiming)); s->main_events.push_back(ev_); }
+    if (!s->d_cont_list) {
+        const int NW = mapping_waves(s->M), E = 64 * NW / (s->M.S * 4);
+        HIPCHK(hipMalloc((void**)&s->d_cont_list, (((size_t)s->B + E - 1) / E + 1) * sizeof(int))); HIPCHK(hipMalloc((void**)&s->d_cont_count, sizeof(int)));
+    }
+    HIPCHK(hipMemsetAsync(s->d_cont_count, 0, sizeof(int), st));
+    return DOJO_OK;
+}
+
 // Launches the step (and IFT) kernels for the environments [env0, env0 + nenv) of the batch; all pointers are the
 // batch-level buffers.  env0 must be a multiple of the environments per wavefront.
 template <class TIO, class T, class TL>
 int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr) {
+           void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr, int phase = PH_ALL) {
     if (nenv < 0) nenv = s->B;
     const size_t Nb = s->M.Nb, nu = s->M.nu, nx = 12 * Nb;
     auto off = [&](const void* p, size_t per_env) -> TIO* { return p ? (TIO*)p + env0 * per_env : (TIO*)nullptr; };
@@ -464,15 +510,26 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (g && s->M.contact_model != 0) {   // the reference has no data Jacobians for ImpactContact / LinearContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
         g_err = "gradients are not available for ImpactContact / LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
     }
+    if (g && quad && std::max<size_t>(2 * Nb + (nu + 5) / 6, dc != nullptr ? (size_t)s->M.Nc : 0) > 128) {
+        // (dojo_device.hpp, gradient_columns_quad: the branch schedule keeps batch sets in two 64-bit words; unreachable with <= 32 bodies -- 2 x 32 + 32 --
+        //  but a mapping change must not turn it into silently aliased batches)
+        g_err = "the IFT sweeps support at most 128 column batches per environment"; return DOJO_ERR_UNSUPPORTED;
+    }
     if (dc != nullptr && s->M.Nc > 64) {  // the sweeps' batch masks hold one bit per contact of the environment (dojo_device.hpp, sweep_masks)
         g_err = "contact-data gradients support at most 64 contacts per environment"; return DOJO_ERR_UNSUPPORTED;
     }
     int slot = -1;
-    if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); }
+    if (phase == PH_CONT) timed = false;
+    if (timed && phase == PH_GRAD) slot = s->phase_slot;
+    else if (timed) { int rc_ = acquire_slot(s, &slot); if (rc_ != DOJO_OK) return rc_; HIPCHK(hipEventRecord(s->ring[slot].a, st)); s->phase_slot = slot; }
     A.sol = nullptr;
+    // doubles per supernode of the step -> IFT hand-off record in the kernels that serve this mechanism (the launcher selection below: MAXC by mapping)
+    const int vmaxc = !quad ? (s->M.maxc <= 4 ? 4 : 8) : NW == 2 ? (s->M.maxc <= 1 ? 1 : 4) : (s->M.maxc <= 1 ? 1 : s->M.maxc <= 4 ? 4 : 8);
+    const size_t sol_rec = vmaxc == 1 ? dj::sol_record<1>() : vmaxc == 4 ? dj::sol_record<4>() : dj::sol_record<8>();
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
-        A.sol = (T*)s->d_sol + env0 * s->M.S * dj::sol_record<8>();          // any record size <= sol_record<8> fits this spacing
+        A.sol = (T*)s->d_sol + env0 * s->M.S * sol_rec;                      // (the record size of the kernels of this mechanism: a launch over the whole batch
+                                                                            //  -- the continuation -- must find the records where the groups' launches put them)
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
         if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * dj::LU_PER_LANE * 64 * NW * sizeof(T)));
     }
@@ -497,6 +554,19 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
             A.msg = (T*)s->d_msg + env0 * (size_t)A.msg_stride;
         }
     }
+    // Iteration cap (phased launches only; dojo_step_dev has checked that it applies and has zeroed the list's count): the solves that are
+    // unfinished after `cap` Newton iterations leave the step kernel and go on in the continuation kernel (PH_CONT)
+    A.G.iter_cap = 0;
+    if (phase != PH_ALL) {
+        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));
+        if (!s->d_resume) HIPCHK(hipMalloc(&s->d_resume, (size_t)s->B * dj::CARRY_PER_ENV * sizeof(T)));
+        if (!status && !s->d_cstat) HIPCHK(hipMalloc((void**)&s->d_cstat, (size_t)s->B * sizeof(int)));
+        A.G.iter_cap = effective_cap(s);
+        A.sol = (T*)s->d_sol + env0 * s->M.S * sol_rec;
+        A.resume = (T*)s->d_resume + env0 * dj::CARRY_PER_ENV;
+        A.cont_list = s->d_cont_list; A.cont_count = s->d_cont_count; A.wave_base = (int)wave0;
+        if (!status) A.status = s->d_cstat + env0;
+    }
     A.blk = nullptr; A.flag = nullptr;
     if (quad && A.G.refine_w < INFINITY) {                  // the refining kernels follow the plain ones (dojo_kernels.hip)
         if (!s->d_blk) HIPCHK(hipMalloc(&s->d_blk, waves_total * 90 * 64 * NW * sizeof(T)));
@@ -507,7 +577,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     // Test hook (tests/conftest.py sets it for the GPU tier): the Jacobian buffers are filled with NaN bit patterns before the IFT kernels run, so that
     // an entry the device fails to write comes back as NaN instead of whatever the allocation held (the kernels must write every entry).
     static const bool poison_ = getenv("DOJO_POISON_OUTPUTS") != nullptr;
-    if (poison_ && g) {
+    if (poison_ && g && (phase == PH_ALL || phase == PH_MAIN)) {
         if (dc != nullptr) HIPCHK(hipMemsetAsync(A.dc, 0xFF, (size_t)nenv * nx * 5 * s->M.Nc * sizeof(TIO), st));
         else {
             if (A.dz) HIPCHK(hipMemsetAsync(A.dz, 0xFF, (size_t)nenv * nx * nx * sizeof(TIO), st));
@@ -542,10 +612,14 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
                                   : (f32 ? dojo_launch_float_8_1 : dojo_launch_double_8_1);
     else      fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_float_4_0 : dojo_launch_double_4_0)
                                   : (f32 ? dojo_launch_float_8_0 : dojo_launch_double_8_0);
-    int lrc = fn(&A, (int)grid.x, (void*)st, g, (timed && g) ? (void*)s->ring[slot].m : nullptr);
+    const int phases = phase == PH_ALL ? (1 | (g ? 2 : 0)) : phase == PH_MAIN ? 1 : phase == PH_GRAD ? 2 : (4 | (g ? 8 : 0));
+    const int lgrid = phase == PH_CONT ? (int)std::min<size_t>(waves_total, 128) : (int)grid.x;     // (a continuation workgroup takes a whole CU's LDS and loops over the list)
+    int lrc = fn(&A, lgrid, (void*)st, phases, (timed && g && (phases & 1)) ? (void*)s->ring[slot].m : nullptr);
     if (lrc != 0) { g_err = std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc); return DOJO_ERR_DEVICE; }
     HIPCHK(hipGetLastError());
-    if (timed) { DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = g != 0; e.n = 1; e.used = true; s->last_slot = slot; }
+    if (timed && (phase == PH_ALL || phase == PH_GRAD || (phase == PH_MAIN && !g))) {
+        DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = g != 0; e.n = 1; e.used = true; s->last_slot = slot;
+    }
     if (storage) {                         // record: the Storage rows of the environments of this launch
         const long long n = (long long)nenv * Nb; const int T_ = 128;
         hipLaunchKernelGGL((ckern::storage_kernel<TIO>), dim3((unsigned)((n + T_ - 1) / T_)), dim3(T_), 0, st, (const dj::NodeP<double>*)s->d_nodes,
@@ -557,9 +631,9 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
 }
 
 int launch_any(DojoSim* s, const void* z, const void* u, void* zn, int* status, int* iters, void* vel, void* jimp, void* csg,
-               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr) {
-    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage);
-    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage);
+               void* dz, void* du, hipStream_t st, bool timed, size_t env0 = 0, int nenv = -1, void* dc = nullptr, void* storage = nullptr, int phase = PH_ALL) {
+    if (s->dtype == DOJO_DTYPE_F32) return launch<float, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage, phase);
+    return launch<double, double, double>(s, z, u, zn, status, iters, vel, jimp, csg, dz, du, st, timed, env0, nenv, dc, storage, phase);
 }
 
 // RCCL, opened on first use (dojo_comm_*)
@@ -642,6 +716,12 @@ void dojo_destroy(DojoHandle s) {
     (void)hipSetDevice(s->device);
     void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
+    void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
+    for (void* p : pc) if (p) (void)hipFree(p);
+    if (s->cstream) (void)hipStreamDestroy(s->cstream);
+    if (s->cont_event) (void)hipEventDestroy(s->cont_event);
+    if (s->allmain_event) (void)hipEventDestroy(s->allmain_event);
+    for (auto e_ : s->main_events) (void)hipEventDestroy(e_);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
     if (s->fork_event) (void)hipEventDestroy(s->fork_event);
@@ -764,9 +844,62 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     if ((rc = ensure((void**)&s->d_mu, B * sizeof(double)))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t NG = group_count(s, true);
+    // Iteration cap (dojo_set_iteration_cap): in force for steps that are joined into the caller's stream -- there the step waits for its longest
+    // solve.  An asynchronous handle chains its groups' steps without a barrier and hides that tail behind the other groups' kernels.
+    const bool capped = !s->async && effective_cap(s) > 0;
+    if (capped) {
+        if ((rc = join_groups(s, st))) return rc;                  // (asynchronous steps still in flight)
+        if ((rc = begin_capped_step(s, std::max<size_t>(NG, 1), st))) return rc;
+    }
     if (NG <= 1) {
         if ((rc = join_groups(s, st))) return rc;
+        if (capped) {
+            // (the continuation is enqueued before the IFT of the finished workgroups and on a stream of higher priority: its workgroups need a
+            //  whole CU's LDS each, which they only find before the IFT's wavefronts have spread over the GPU)
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, st, true, 0, -1, nullptr, nullptr, PH_MAIN))) return rc;
+            HIPCHK(hipEventRecord(s->main_events[0], st));
+            HIPCHK(hipStreamWaitEvent(s->cstream, s->main_events[0], 0));
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->cstream, false, 0, -1, nullptr, nullptr, PH_CONT))) return rc;
+            HIPCHK(hipEventRecord(s->cont_event, s->cstream));
+            if (dz && (rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, st, true, 0, -1, nullptr, nullptr, PH_GRAD))) return rc;
+            HIPCHK(hipStreamWaitEvent(st, s->cont_event, 0));
+        } else
         rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, st, true);
+    } else if (capped) {
+        // fork: the step kernel of every group, each followed by the IFT of what it finished; behind ALL step kernels the continuation, once
+        // over the batch, on its own stream; join: the groups and the continuation into the caller's stream
+        if ((rc = ensure_groups(s, NG))) return rc;
+        const size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;
+        s->last_NG = NG; s->last_per = per;
+        HIPCHK(hipEventRecord(s->fork_event, st));
+        for (size_t gi = 0; gi < NG; ++gi) {
+            const size_t env0 = gi * per;
+            if (env0 >= B) break;
+            const int ne = (int)std::min(per, B - env0);
+            HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->fork_event, 0));
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, ne, nullptr, nullptr, PH_MAIN))) return rc;
+            HIPCHK(hipEventRecord(s->main_events[gi], s->gstreams[gi]));
+            HIPCHK(hipStreamWaitEvent(s->cstream, s->main_events[gi], 0));
+            if (s->group_slot.size() <= gi) s->group_slot.resize(gi + 1, -1);
+            s->group_slot[gi] = s->phase_slot;
+        }
+        // The continuation first: its workgroups take a whole CU's LDS each, which they only find while the GPU is empty -- so the groups' IFT
+        // kernels wait until every step kernel is done as well (they would otherwise start behind their own group's step kernel, fill the CUs as
+        // these drain, and keep the continuation out until they are through: measured, +1.2 ms per step), and the continuation's stream has
+        // the higher priority.  The IFT kernels (1.2 ms of work) then run next to the continuation (2-3 ms on a few CUs).
+        HIPCHK(hipEventRecord(s->allmain_event, s->cstream));
+        if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->cstream, false, 0, -1, nullptr, nullptr, PH_CONT))) return rc;
+        HIPCHK(hipEventRecord(s->cont_event, s->cstream));
+        for (size_t gi = 0; gi < NG && dz; ++gi) {
+            const size_t env0 = gi * per;
+            if (env0 >= B) break;
+            HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->allmain_event, 0));
+            s->phase_slot = s->group_slot[gi];
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0), nullptr, nullptr, PH_GRAD))) return rc;
+        }
+        s->pending = true;
+        if ((rc = join_groups(s, st))) return rc;
+        HIPCHK(hipStreamWaitEvent(st, s->cont_event, 0));
     } else {
         // fork: every group waits for what the caller's stream holds (the inputs); group g of this call runs behind group g of
         // the previous call on the same internal stream.  join: the caller's stream waits for all groups -- unless the handle
@@ -800,6 +933,11 @@ int dojo_set_async(DojoHandle s, int32_t on) {
     Enter enter_(s);
     if (!s) { g_err = "dojo_set_async: bad argument"; return DOJO_ERR_INVALID; }
     s->async = on != 0; return DOJO_OK;
+}
+int dojo_set_iteration_cap(DojoHandle s, int32_t cap) {
+    Enter en_(s);
+    if (!s) { g_err = "dojo_set_iteration_cap: bad argument"; return DOJO_ERR_INVALID; }
+    s->iter_cap = cap < 0 ? -1 : cap; return DOJO_OK;
 }
 int dojo_set_groups(DojoHandle s, int32_t n) {
     Enter enter_(s);

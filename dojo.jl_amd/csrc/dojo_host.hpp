@@ -162,6 +162,7 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
     for (int i = 0; i < 3; ++i) G.g[i] = T(M.g[i]);
     G.rtol = T(o.rtol); G.btol = T(o.btol); G.undercut = T(o.undercut); G.no_progress_undercut = T(o.no_progress_undercut);
     G.max_iter = o.max_iter; G.max_ls = o.max_ls; G.no_progress_max = o.no_progress_max;
+    G.iter_cap = 0;              // (the launch decides: dojo_hip.hip launch(), tests/emu)
     G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode; G.contact_model = M.contact_model;
     for (int l = 0; l < 64; ++l) G.maxch_lev[l] = 0;
     for (int b = 0; b < M.Nb; ++b) { int l = M.nodes[b].level; if (l < 64 && M.nodes[b].nchild > G.maxch_lev[l]) G.maxch_lev[l] = (unsigned char)M.nodes[b].nchild; }

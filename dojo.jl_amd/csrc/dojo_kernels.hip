@@ -28,6 +28,8 @@ struct GpuWave {
     static constexpr bool kRefine = RF;
     static constexpr bool kLockstep = true;     // the 64 lanes of a wave (so the 4 lanes of a quad) execute every instruction together
     static constexpr int kWaves = NW;
+    static constexpr int kReplicas = 1;         // (GpuWaveRep: wavefronts that hold the same environment, dojo_stepc_kernel)
+    __device__ __forceinline__ int atomic_inc(int* p) const { return atomicAdd(p, 1); }
     void* lds_;
     double* red_;                               // reduction / vote scratch at the end of the LDS block (NW > 1)
     __device__ __forceinline__ void* lds() const { return lds_; }
@@ -95,6 +97,25 @@ struct GpuWave {
     }
 };
 
+// The continuation kernel's wavefronts (Globals::iter_cap, dojo_stepc_kernel): R wavefronts of one workgroup carry the SAME
+// environment(s), each in an LDS block of its own, and run the same Newton loop on identical values; they only meet in the line
+// search, where replica r evaluates trial ls0 + r and the verdicts cross through `xchg_` between two workgroup barriers.
+template <int R>
+struct GpuWaveRep : GpuWave<1> {
+    static constexpr int kReplicas = R;
+    double* xchg_;                              // [R][16 supernode slots][4]
+    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+    __device__ __forceinline__ int replica() const { return (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ double* replica_xchg() const { return xchg_; }
+    __device__ __forceinline__ void replica_sync() const { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+// replicas per workgroup: what fits the 160 KB of LDS next to the exchange block
+template <class TIO, class TS, int MAXC> constexpr int cont_replicas() {
+    constexpr int per = (dj::StepLds<TIO, TS, MAXC, 0, true, true, 1>::bytes + 15) / 16 * 16;
+    constexpr int r = (160 * 1024 - 4 * 16 * 4 * 8) / per;
+    return r > 4 ? 4 : r;
+}
+
 // TIO = ABI scalar type, TS = state / residual precision, TL = factorization precision.
 // dtype f64: <double,double,double>.  dtype f32: fp32 buffers at the ABI with fp64 internals
 // <float,double,double>: the interior-point iteration drives s·γ to ~1e-9 and the condensed KKT
@@ -119,6 +140,24 @@ dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
+// Globals::iter_cap: the rest of the Newton loops the step kernel left unfinished, one listed workgroup of the step kernel per
+// pass of a workgroup here, the line-search trials side by side on R replicas (quad mapping, one wavefront per environment set)
+template <class TIO, class TS, class TL, int MAXC, int R>
+__global__ void __launch_bounds__(64 * R) __attribute__((amdgpu_waves_per_eu(1, 1)))
+dojo_stepc_kernel(dj::KernelArgs<TIO, TS> A) {
+    typedef dj::StepLds<TIO, TS, MAXC, 0, true, true, 1> LY;
+    constexpr int PER = (LY::bytes + 15) / 16 * 16;
+    __shared__ double lds_buf[(R * PER + R * 16 * 4 * 8) / 8];
+    GpuWaveRep<R> w;
+    const int rep = (int)(threadIdx.x >> 6);
+    w.lds_ = (void*)((char*)lds_buf + rep * PER); w.red_ = (double*)((char*)w.lds_ + LY::red_off);
+    w.xchg_ = (double*)((char*)lds_buf + R * PER);
+    const int n = *(volatile int*)A.cont_count;
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        dj::step_entry<TIO, TS, TL, MAXC, true, GpuWaveRep<R>, true>(w, A, A.cont_list[i]);
+        w.replica_sync();                       // (a replica's LDS block and the exchange slots are reused by the next listed workgroup)
+    }
+}
 // the Newton loop once more, with every linear solve refined once the cones are stiff, for the environments the plain kernel
 // deferred (DJ_STATUS_DEFERRED); workgroups without one leave at once
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
@@ -137,6 +176,18 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
+}
+// Globals::iter_cap: the IFT of the workgroups on the continuation list, behind dojo_stepc_kernel (dojo_grad_kernel skips them)
+template <class TIO, class TS, class TL, int MAXC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DJ_GRAD_WAVES, DJ_GRAD_WAVES)))
+dojo_gradc_kernel(dj::KernelArgs<TIO, TS> A) {
+    typedef dj::StepLds<TIO, TS, MAXC, 1, true, true, 1> LY;
+    __shared__ double lds_buf[(LY::bytes + 7) / 8];
+    GpuWave<1> w;
+    w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    const int n = *(volatile int*)A.cont_count;
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x)
+        dj::grad_entry<TIO, TS, TL, MAXC, true, GpuWave<1>, 0, true>(w, A, A.cont_list[i]);
 }
 // the IFT kernel of the environments whose linear solves were being refined (DJ_REFINE: stiff cones, max γ/s beyond
 // Globals::refine_w): column by column through the refined general solve; workgroups without such an environment leave
@@ -175,22 +226,41 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
 #define DJ_CLAUNCHER DJ_CAT(dojo_launch_cgrad_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #endif
 
-// mid_event (may be null) is recorded between the two kernels so that each can be timed on its own
-extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int grad, void* mid_event) {
+// `phases`: 1 = the step kernel (+ the refining one), 2 = the IFT kernel (+ the refining one), 4 = the continuation of the step kernel
+// (Globals::iter_cap; `grid` = its workgroups, each loops over the list), 8 = the IFT of the continued workgroups.  mid_event (may be null)
+// is recorded behind the step kernels, so that each kernel can be timed on its own.
+extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int phases, void* mid_event) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;
     constexpr int NW = DJ_QUAD == 2 ? 2 : 1;
-    hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
-#if DJ_QUAD != 0 && DJ_REFINE && !DJ_SS
-    if (A.flag != nullptr) hipLaunchKernelGGL((dojo_stepp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+    if (phases & 1) {
+        hipLaunchKernelGGL((dojo_step_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#ifdef DJ_ONLY_STEP      // register-allocation experiments (tools/step_only.sh)
+        return (int)hipGetLastError();
 #endif
-    if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
+#if DJ_QUAD != 0 && DJ_REFINE && !DJ_SS
+        if (A.flag != nullptr) hipLaunchKernelGGL((dojo_stepp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#endif
+        if (mid_event) (void)hipEventRecord((hipEvent_t)mid_event, (hipStream_t)stream);
+    }
+#if DJ_QUAD == 1
+    if ((phases & 4) && A.G.iter_cap > 0 && A.cont_count != nullptr) {      // the unfinished solves go on with their line-search trials side by side
+        constexpr int R = cont_replicas<DJ_TIO, double, DJ_MAXC>();
+        static_assert(R >= 2, "no room for two replicas");
+        hipLaunchKernelGGL((dojo_stepc_kernel<DJ_TIO, double, double, DJ_MAXC, R>), dim3(grid), dim3(64 * R), 0, (hipStream_t)stream, A);
+    }
+#endif
 #if DJ_LINEAR || DJ_SS
-    (void)grad;
     return (int)hipGetLastError();
 #else
-    if (grad) hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+    if (phases & 2) {
+        hipLaunchKernelGGL((dojo_grad_kernel<DJ_TIO, double, double, DJ_MAXC, DJ_QUAD != 0, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
 #if DJ_QUAD != 0 && DJ_REFINE
-    if (grad && A.flag != nullptr) hipLaunchKernelGGL((dojo_gradp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+        if (A.flag != nullptr) hipLaunchKernelGGL((dojo_gradp_kernel<DJ_TIO, double, double, DJ_MAXC, true, NW>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, A);
+#endif
+    }
+#if DJ_QUAD == 1
+    if ((phases & 8) && A.cont_count != nullptr)
+        hipLaunchKernelGGL((dojo_gradc_kernel<DJ_TIO, double, double, DJ_MAXC>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
 #endif
     return (int)hipGetLastError();
 #endif

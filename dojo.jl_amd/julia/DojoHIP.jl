@@ -246,6 +246,8 @@ end
 
 "environment groups of step_dev! (0: the library's choice, 1: one launch on the caller's stream); needs GPU_MAX_HW_QUEUES >= groups + 1"
 set_groups!(bm::BatchedMechanism, n::Integer) = check(@ccall $(fn(:dojo_set_groups))(bm.handle::Ptr{Cvoid}, n::Int32)::Cint)
+"iteration cap of the step kernel: solves unfinished after `cap` Newton iterations go on in the continuation kernel (line-search trials side by side) in joined steps; 0 / < 0: off (the default); include/dojo_hip.h has the measurements"
+set_iteration_cap!(bm::BatchedMechanism, cap::Integer) = check(@ccall $(fn(:dojo_set_iteration_cap))(bm.handle::Ptr{Cvoid}, cap::Int32)::Cint)
 "asynchronous environment groups: consecutive step_dev! calls chain per group; join!(bm; stream) orders `stream` behind everything in flight"
 set_async!(bm::BatchedMechanism, on::Bool) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, on::Int32)::Cint)
 join!(bm::BatchedMechanism; stream::DevPtr=C_NULL) = check(@ccall $(fn(:dojo_join))(bm.handle::Ptr{Cvoid}, stream::Ptr{Cvoid})::Cint)

@@ -228,7 +228,8 @@ int  dojo_get_solution(DojoHandle h, void* vel, void* joint_imp, void* contact_s
  * the last step returned, fp64 [B]: a mehrotra! drop-in writes it back and calls set_entries! so that mechanism.system
  * holds the final un-factored Jacobian and residual like the reference leaves it (src/solver/mehrotra.jl:69). */
 int  dojo_get_mu(DojoHandle h, double* mu);
-/* Diagnostics of the final linearization of every environment's last step (quad mappings), fp64 [B, 2]: [0] max gamma/s over
+/* Diagnostics of the LAST LINEARIZATION PERFORMED in every environment's last step (quad mappings; without the refining kernels a step skips
+ * the set_entries! after its converging iteration, so this is the linearization one iterate before the solution), fp64 [B, 2]: [0] max gamma/s over
  * its cones (what dojo_set_refinement's threshold is compared with), [1] the largest multiplier of the device's un-pivoted
  * Gauss-Jordan eliminations.  The first call switches the recording on (diag may be NULL), later calls read the last step.
  * [0] is 0 while no refinement threshold is in force (reference-default options and no dojo_set_refinement: the kernels then
@@ -262,6 +263,20 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
  * to >= groups + 1 before the HIP runtime starts.  (No counterpart in the reference, which is single-threaded.) */
 int  dojo_set_async(DojoHandle h, int32_t on);
 int  dojo_set_groups(DojoHandle h, int32_t n);
+/* Iteration cap of the step kernel (no counterpart in the reference; the algorithm is unchanged decision for decision).  `mehrotra!` (src/solver/
+ * mehrotra.jl:9-73) is a serial chain of up to max_iter Newton iterations per environment, and an iteration whose line search is exhausted
+ * evaluates the residual up to max_ls times in a row (src/solver/line_search.jl:1-34).  With a cap, a step that is joined into the caller's
+ * stream (dojo_step, dojo_step_dev of a handle that is not asynchronous) runs in phases: the step kernel hands every solve that is unfinished
+ * after `cap` iterations to a continuation kernel, in which several wavefronts hold the same environment and evaluate the line-search trials
+ * alpha, alpha/2, alpha/4, ... side by side before replaying line_search!'s accept / halve decisions over the results; the IFT kernel of the
+ * finished environments runs next to it.  Results: bit for bit those of the uncapped loop under the SIMT emulator; on the GPU the continuation
+ * kernel is a second instantiation of the lane program (other fused multiply-add contractions), so a continued solve differs in its last bits.
+ * Measured on MI355X: a stalled iteration takes 0.087 instead of 0.110 ms; joined Ant steps gain 10 % at B = 512, 4 % at
+ * B = 2048 and lose 3 % at B = 4096 (the IFT can no longer start behind its own group's step kernel) -- hence OFF by default.
+ * cap > 0: in force for joined steps of the single-wavefront quad mapping (<= 16 bodies) without refinement; 0 or < 0: off (the default; the
+ * environment variable DOJO_ITER_CAP=<cap> changes the default, not an explicit setting).  Asynchronous handles and rollouts never cap. */
+#define DOJO_DEFAULT_ITERATION_CAP 0
+int  dojo_set_iteration_cap(DojoHandle h, int32_t cap);
 int  dojo_join(DojoHandle h, void* stream);
 
 /* Multi-GPU (nothing to cite in the reference, which has no multi-device code).  Environments are

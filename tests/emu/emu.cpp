@@ -18,6 +18,8 @@
 #include <condition_variable>
 #include <cstring>
 #include <atomic>
+#include <memory>
+#include <cstdio>
 
 namespace {
 
@@ -51,6 +53,8 @@ struct EmuWaveT {
     static constexpr bool kRefine = RF;         // the refining build of the kernels (DJ_REFINE)
     static constexpr bool kLockstep = false;    // lanes are free-running threads between barriers
     static constexpr int kWaves = NW;           // selects the LDS layout and the workgroup-reduction code paths of the multi-wave kernels
+    static constexpr int kReplicas = 1;
+    int atomic_inc(int* p) { static std::mutex m; std::lock_guard<std::mutex> g(m); return (*p)++; }
     Shared* sh; int l;
     static double rcp(double a) { return 1.0 / a; }
     static float rcp(float a) { return 1.0f / a; }
@@ -93,6 +97,18 @@ struct EmuWaveT {
     double wg_min(double v) { return wg_reduce(v, [](double a, double b) { return a < b ? a : b; }); }
     double wg_sum(double v) { return wg_reduce(v, [](double a, double b) { return a + b; }); }
     int wg_or(int v) { return any(v != 0) ? 1 : 0; }
+};
+
+// the continuation kernel's replicas (Globals::iter_cap): R copies of the workgroup's threads, each copy with "LDS" and barrier of its
+// own, plus one barrier and one exchange block across all of them
+struct RepShared { Barrier bar; std::vector<double> xchg; RepShared(int threads, int n) : bar(threads), xchg(n) {} };
+template <int R>
+struct EmuWaveRep : EmuWaveT<1> {
+    static constexpr int kReplicas = R;
+    RepShared* rs; int rep;
+    int replica() const { return rep; }
+    double* replica_xchg() const { return rs->xchg.data(); }
+    void replica_sync() { rs->bar.wait(); }
 };
 
 template <class TIO, class T, class TL, int MAXC, bool QUAD, int NW = 1>
@@ -145,6 +161,20 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     if (!A.flag) A.blk = nullptr;
     static_assert((size_t)dj::step_lds_bytes<TIO, T, MAXC, 0, QUAD, false, NW>() <= Shared::kLdsBytes && (size_t)dj::step_lds_bytes<TIO, T, MAXC, 1, QUAD, false, NW>() <= Shared::kLdsBytes
                   && (size_t)dj::step_lds_bytes<TIO, T, MAXC, 2, QUAD, false, NW>() <= Shared::kLdsBytes, "the emulated LDS block is too small for this layout");
+    // iteration cap + continuation kernel (EMU_ITER_CAP=<cap>[:<replicas>]; as the product's launch(): single-wavefront quad mapping, no refinement)
+    std::vector<T> resumebuf; std::vector<int> contlist, contcount(1, 0), cstat; int cont_replicas = 4;
+    if constexpr (QUAD && NW == 1) {
+        const char* ec = std::getenv("EMU_ITER_CAP");
+        const int cap = ec ? std::atoi(ec) : 0;
+        if (ec && std::strchr(ec, ':')) cont_replicas = std::atoi(std::strchr(ec, ':') + 1);
+        if (cap > 0 && cap < opts.max_iter && !A.flag && !dbg) {
+            A.G.iter_cap = cap;
+            if (!A.sol) { solbuf.resize((size_t)B * M.S * dj::sol_record<MAXC>()); A.sol = solbuf.data(); }
+            resumebuf.resize((size_t)B * dj::CARRY_PER_ENV); A.resume = resumebuf.data();
+            contlist.resize(nwaves); A.cont_list = contlist.data(); A.cont_count = contcount.data();
+            if (!A.status) { cstat.resize(B); A.status = cstat.data(); }
+        }
+    }
     for (int pass = 0; pass < 4; ++pass) {
         if ((pass == 1 || pass == 3) && !A.flag) continue;
         if (pass >= 2 && !(dz && !dbg)) continue;
@@ -159,6 +189,35 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
                 else { if constexpr (QUAD) dj::grad_entry<TIO, T, TL, MAXC, QUAD, EmuWaveT<NW, true>, 2>(wr, A, wi); }
             });
             for (auto& t : th) t.join();
+        }
+        if constexpr (QUAD && NW == 1) if (pass == 0 && A.G.iter_cap > 0) {
+            // the continuation kernel: every listed workgroup once more, on `cont_replicas` copies of its threads
+            auto cont = [&](auto rtag) {
+                constexpr int R = decltype(rtag)::value;
+                for (int ci = 0; ci < contcount[0]; ++ci) {
+                    const int wi = contlist[ci];
+                    std::vector<std::unique_ptr<Shared>> shs; for (int r = 0; r < R; ++r) shs.emplace_back(new Shared(W));
+                    RepShared rs(W * R, R * (W / 4) * 4);
+                    std::vector<std::thread> th;
+                    for (int r = 0; r < R; ++r) for (int l = 0; l < W; ++l) th.emplace_back([&, r, l]() {
+                        EmuWaveRep<R> w; w.sh = shs[r].get(); w.l = l; w.rs = &rs; w.rep = r;
+                        dj::step_entry<TIO, T, TL, MAXC, QUAD, EmuWaveRep<R>, true>(w, A, wi);
+                    });
+                    for (auto& t : th) t.join();
+                }
+            };
+            if (cont_replicas == 2) cont(std::integral_constant<int, 2>()); else if (cont_replicas == 3) cont(std::integral_constant<int, 3>()); else cont(std::integral_constant<int, 4>());
+            for (int e = 0; e < B; ++e) if (A.status[e] == DJ_STATUS_CONTINUE) { std::fprintf(stderr, "emu: environment %d left unfinished by the continuation kernel\n", e); std::abort(); }
+        }
+        if constexpr (QUAD && NW == 1) if (pass == 2 && A.G.iter_cap > 0) {
+            // ... and the IFT of the listed workgroups (dojo_gradc_kernel; pass 2 above has skipped them)
+            for (int ci = 0; ci < contcount[0]; ++ci) {
+                const int wi = contlist[ci];
+                Shared sh(W);
+                std::vector<std::thread> th;
+                for (int l = 0; l < W; ++l) th.emplace_back([&, l]() { EmuWaveT<NW> w{&sh, l}; dj::grad_entry<TIO, T, TL, MAXC, QUAD, EmuWaveT<NW>, 0, true>(w, A, wi); });
+                for (auto& t : th) t.join();
+            }
         }
     }
     if constexpr (QUAD) if (dz && dc && !dbg && M.Nc > 0) {          // third launch: the contact-data columns (re-uses the hand-off)

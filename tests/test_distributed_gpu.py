@@ -69,7 +69,7 @@ def test_library_rccl_allgather_world_one():
 
 
 def test_bench_two_ranks_plumbing():
-    """bench.py's N > 1 path (torchrun, barrier + max-over-ranks timing, final all-gather, one JSON line from rank 0) on a
+    """bench.py's N > 1 path (torchrun, barrier + max-over-ranks timing, all-gather of the trajectory chunk, one JSON line from rank 0) on a
     one-GPU box: two ranks share device 0 and gloo carries the collectives (--backend gloo); with DOJO_BENCH_GATHER=library-force
     the library's RCCL communicator is tried first and must fall back cleanly (RCCL refuses two ranks on one device)."""
     import json
@@ -82,7 +82,8 @@ def test_bench_two_ranks_plumbing():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
     assert abs(res["value"] - 2 * 512 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]       # whole-job aggregate over both ranks
-    assert "torch.distributed" in res["config"]["final_gather"]
+    tg = res["config"]["trajectory_gather"]                # the trajectory chunk [K, B, 13 Nb] of both ranks, not only the final state
+    assert "torch.distributed" in tg["through"] and tg["bytes_received_per_rank"] == 2 * 3 * 512 * 13 * 13 * 4
 
 
 def test_bench_strong_scaling_line():

@@ -135,7 +135,7 @@ def _split_by_state(es, itg, ito, state_bound, label=""):
     return ~apart, apart
 
 
-APART_CEILING = 1e-2        # measured: 1e-5 .. 2.4e-3 on 36 864 Ant environment-steps (three solves of 34-44 iterations)
+APART_CEILING = 5e-3        # measured: 1e-5 .. 2.4e-3 on 36 864 Ant environment-steps (three solves of 34-44 iterations); twice the worst case seen
 
 
 def _full_batch_bound(label, ok, ez, eu, es, itg, ito, nstat, B, state_bound, grad_bound, min_ok=0.99, max_apart=2e-3, max_stat=2, max_iter_mismatch=2,

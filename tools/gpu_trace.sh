@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(list); res = {}
 for r in rows:
     n = r['Kernel_Name']
-    k = next((x for x in ('dojo_stepp_kernel', 'dojo_gradp_kernel', 'dojo_step_kernel', 'dojo_grad_kernel', 'dojo_sweep_kernel') if x in n), None)
+    k = next((x for x in ('dojo_stepc_kernel', 'dojo_stepp_kernel', 'dojo_gradp_kernel', 'dojo_step_kernel', 'dojo_grad_kernel', 'dojo_sweep_kernel') if x in n), None)
     if k: acc[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6); res[k] = (r.get('LDS_Block_Size', '?'), r.get('Scratch_Size', '?'), r.get('VGPR_Count', '?'), r.get('Accum_VGPR_Count', '?'), r.get('Grid_Size', '?'))
 for k, v in acc.items(): print("   %-18s n=%4d mean %.3f ms min %.3f max %.3f | LDS %s scratch %s VGPR %s AGPR %s grid %s" % ((k, len(v), sum(v) / len(v), min(v), max(v)) + res[k]))
 PY
