@@ -44,7 +44,9 @@ DJ_DECL(dojo_launch_float_4_0) DJ_DECL(dojo_launch_float_8_0) DJ_DECL(dojo_launc
 DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_launch_float_1_2) DJ_DECL(dojo_launch_double_1_2)
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
+DJ_DECL(dojo_launch_tsd_float_4_0) DJ_DECL(dojo_launch_tsd_float_8_0) DJ_DECL(dojo_launch_tsd_double_4_0) DJ_DECL(dojo_launch_tsd_double_8_0)
 DJ_DECL(dojo_launch_lin_float_1_1) DJ_DECL(dojo_launch_lin_float_4_1) DJ_DECL(dojo_launch_lin_double_1_1) DJ_DECL(dojo_launch_lin_double_4_1)     // LinearContact builds
+DJ_DECL(dojo_launch_lin_float_4_0) DJ_DECL(dojo_launch_lin_float_8_0) DJ_DECL(dojo_launch_lin_double_4_0) DJ_DECL(dojo_launch_lin_double_8_0)
 DJ_DECL(dojo_launch_ss_float_1_1) DJ_DECL(dojo_launch_ss_double_1_1)     // body-body contacts (-DDJ_SS=1): single-wavefront quad mapping, <= 1 contact per body, forward only
 #define DJ_CDECL(n) int n(const void*, int, void*);
 DJ_CDECL(dojo_launch_cgrad_float_1_1) DJ_CDECL(dojo_launch_cgrad_float_4_1) DJ_CDECL(dojo_launch_cgrad_float_8_1)
@@ -374,6 +376,10 @@ bool quad_mapping_of(const DojoSim* s);
 enum { PH_ALL = 0, PH_MAIN = 1, PH_GRAD = 2, PH_CONT = 3 };
 // wavefronts per workgroup of the quad mapping for this mechanism; 0 = lane mapping
 int mapping_waves(const dj::HostModel& M) {
+    // translational springs / dampers / limits: the quad builds that carry them are the single-wavefront ones with <= 4 contacts per body;
+    // larger mechanisms take the lane mapping (its DJ_TSD builds: k_*_{4,8}_0_tsd)
+    if (M.has_tsd && (M.S > 16 || M.maxc > 4)) return 0;
+    if (M.contact_model == 2 && (M.S > 16 || M.maxc > 4)) return 0;       // LinearContact likewise (k_*_{4,8}_0_lin)
     if (M.S <= 16) return 1;
     if (M.S <= 32 && M.maxc <= 4 && M.Nc <= 16) return 2;
     return 0;
@@ -603,7 +609,10 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     }
     launcher_t fn;
     if (s->M.has_ss && s->M.contact_model != 2) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
+    else if (s->M.contact_model == 2 && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_lin_float_4_0 : dojo_launch_lin_double_4_0) : (f32 ? dojo_launch_lin_float_8_0 : dojo_launch_lin_double_8_0);
     else if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
+    else if (s->M.has_tsd && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_tsd_float_4_0 : dojo_launch_tsd_double_4_0)
+                                                       : (f32 ? dojo_launch_tsd_float_8_0 : dojo_launch_tsd_double_8_0);
     else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
                                           : (f32 ? dojo_launch_tsd_float_4_1 : dojo_launch_tsd_double_4_1);
     else if (NW == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_float_1_2 : dojo_launch_double_1_2) : (f32 ? dojo_launch_float_4_2 : dojo_launch_double_4_2);
@@ -693,14 +702,11 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     DojoSim* s = new DojoSim();
     int rc = dj::build_host_model(*topo, s->M);
     if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
-    if (s->M.has_tsd && (mapping_waves(s->M) != 1 || s->M.maxc > 4)) {
-        g_err = "translational springs/dampers need the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body)"; delete s; return DOJO_ERR_UNSUPPORTED;
-    }
     if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
         g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
-    if (s->M.contact_model == 2 && (mapping_waves(s->M) != 1 || s->M.maxc > 4 || s->M.has_tsd)) {
-        g_err = "LinearContact needs the single-wavefront quad mapping (<= 16 bodies, <= 4 contacts per body, no translational springs / dampers / limits)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    if (s->M.contact_model == 2 && s->M.has_tsd) {
+        g_err = "LinearContact together with translational springs / dampers / limits is not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
     s->opts = dj::default_options();

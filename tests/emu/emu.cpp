@@ -265,6 +265,8 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || dz != nullptr)) {       // (as dojo_create / launch)
         if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
+    if (two && (M.maxc > 4 || M.Nc > 16 || M.has_tsd || M.contact_model == 2)) {   // (as the product's mapping_waves(): such mechanisms take the lane mapping)
+        if (err) std::strncpy(err, "the two-wavefront quad mapping serves <= 4 contacts per body, <= 16 contacts, no translational springs / dampers, no LinearContact: use the lane mapping", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     int W = M.S * (quad ? 4 : 1) * (envs_per_wave > 0 ? envs_per_wave : 1);
     DojoSolverOptions o = opts ? *opts : dj::default_options();
 #define RUN(TIO, TS, TL, MC) do { if (two) run<TIO, TS, TL, (MC < 4 ? 4 : MC), true, 2>(M, o, grad_mode, B, W, z, u, z_next, status, iters, vel, jimp, csg, dz, du, dbg, dc, storage, fext); \

@@ -712,3 +712,36 @@ def test_gradients_of_a_forest(mode):
     assert np.abs(r["du"][0] - du).max() < 1e-6 * max(1.0, np.abs(du).max())
     assert np.abs(r["dc"][0] - dc).max() < 1e-6 * max(1.0, np.abs(dc).max())
     assert np.abs(dz[24:36, 0:24]).max() == 0 and np.abs(dc[0:24]).max() == 0          # (the trees do not talk to each other)
+
+
+@pytest.mark.parametrize("name,kw", [("nslider", dict(num_bodies=20, springs=1.0, dampers=0.2)), ("snake", dict(num_bodies=18, joint_type="PlanarAxis", springs=1.0, dampers=0.3))])
+def test_translational_springs_dampers_beyond_sixteen_bodies(name, kw):
+    """Translational springs / dampers on mechanisms of more than 16 bodies: the lane mapping (one lane per supernode) evaluates them too
+    (the product routes such mechanisms there, dojo_hip.hip mapping_waves; the two-wavefront quad mapping has no DJ_TSD build and the
+    emulator refuses it like the product) -- states, iteration counts and IFT Jacobians against the oracle."""
+    spec = d.get_mechanism(name, **kw)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    Z, U = d.synthetic_inputs(spec, 2)
+    o = Oracle(spec, opts=opts)
+    r = emu_step(spec, Z, U, opts=opts, quad=False, grad=True, grad_mode=1)
+    for b in range(2):
+        zo, info = o.step(Z[b], U[b]); gz, gu = o.gradients(1)
+        assert r["status"][b] == 0 and info["status"] == 0 and r["iters"][b] == info["iters"]
+        assert np.abs(r["z_next"][b] - zo).max() < 1e-9
+        assert np.abs(r["dz"][b] - gz).max() <= 1e-6 * max(1.0, np.abs(gz).max()) and np.abs(r["du"][b] - gu).max() <= 1e-6 * max(1.0, np.abs(gu).max())
+    with pytest.raises(RuntimeError):
+        emu_step(spec, Z, U, opts=opts, quad=True)
+
+
+def test_linear_contact_beyond_sixteen_bodies():
+    """LinearContact in the lane mapping (an eighteen-link snake with 36 contacts: where the product sends such a mechanism)"""
+    spec = d.get_mechanism("snake", num_bodies=18, joint_type="Revolute", contact_type="linear")
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    Z, U = d.synthetic_inputs(spec, 2)
+    o = Oracle(spec, opts=opts)
+    r = emu_step(spec, Z, U, opts=opts, quad=False)
+    for b in range(2):
+        zo, info = o.step(Z[b], U[b])
+        assert r["status"][b] == 0 and info["status"] == 0 and r["iters"][b] == info["iters"]
+        assert np.abs(r["z_next"][b] - zo).max() < 1e-9
+

@@ -795,6 +795,28 @@ def test_external_force_behaviour_and_parity():
     gm.close()
 
 
+def test_linear_contact_beyond_sixteen_bodies():
+    """LinearContact on a mechanism of more than 16 bodies (an eighteen-link snake on Revolute joints, 36 contacts): the lane mapping's
+    DJ_LINEAR builds (round 5; refused before) -- states, status and iteration counts against the oracle over a ten-step rollout"""
+    spec = d.get_mechanism("snake", num_bodies=18, joint_type="Revolute", contact_type="linear")
+    B = 32
+    Z, U = d.synthetic_inputs(spec, B)
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    z = Z.copy(); nconv = 0
+    for k in range(10):
+        zg, st, it = gm.step(z, U)
+        zo, st_o, it_o, _, _ = o.step_batch(z, U, nthreads=16)
+        reg = (it <= REGULAR_ITERS) & (it_o <= REGULAR_ITERS)
+        assert np.array_equal(st[reg], st_o[reg]) and np.array_equal(it[reg], it_o[reg]) and reg.mean() > 0.7
+        both = (st == 0) & (st_o == 0)
+        same, apart = _split_by_state(np.abs(zg[both] - zo[both]).max(axis=1), it[both], it_o[both], 1e-8, "linear contact, 18 bodies, step %d" % k)
+        assert apart.sum() <= 1
+        nconv += int(both.sum()); z = zo
+    assert nconv > 0.7 * 10 * B
+    gm.close()
+
+
 @pytest.mark.parametrize("name,kw,dtype", [("block", dict(contact_corners=4, friction_coefficient=0.3), "f64"), ("sphere", dict(), "f64"),
                                            ("block", dict(contact_corners=4, friction_coefficient=0.3), "f32")])
 def test_linear_contact_parity_and_properties(name, kw, dtype):
@@ -990,11 +1012,15 @@ def test_two_wavefront_mapping_is_deterministic_with_a_contact_on_node_zero():
 
 
 @pytest.mark.parametrize("name,kw,batch,steps", [("slider", dict(springs=5.0, dampers=0.7), 64, 6), ("nslider", dict(num_bodies=5, springs=4.0, dampers=0.5), 64, 6),
-                                                 ("raiberthopper", dict(), 256, 25), ("raiberthopper", dict(springs=(0.0, 30.0), dampers=(0.0, 2.0)), 64, 25)])
+                                                 ("raiberthopper", dict(), 256, 25), ("raiberthopper", dict(springs=(0.0, 30.0), dampers=(0.0, 2.0)), 64, 25),
+                                                 # more than 16 bodies: the lane mapping's DJ_TSD builds (round 5; refused before)
+                                                 ("nslider", dict(num_bodies=20, springs=4.0, dampers=0.5), 64, 4),
+                                                 ("snake", dict(num_bodies=18, joint_type="PlanarAxis", springs=1.0, dampers=0.3), 32, 6)])
 def test_translational_springs_dampers_gpu(name, kw, batch, steps):
     """Translational springs / dampers (src/joints/translational/springs.jl, dampers.jl) on the reference's slider, nslider
     and raiberthopper (damped Prismatic leg, two contacts): states, iteration counts and IFT Jacobians in both conventions
-    against the oracle, fp64; the fp32-ABI mode within 1e-3."""
+    against the oracle, fp64; the fp32-ABI mode within 1e-3.  Mechanisms of more than 16 bodies (a chain of twenty sliders; an
+    eighteen-link snake on PlanarAxis joints with 36 contacts) take the lane mapping."""
     spec = d.get_mechanism(name, **kw)
     Z, U = d.synthetic_inputs(spec, batch)
     gm = api.BatchedMechanism(spec, batch, dtype="f64", opts=TIGHT)
@@ -1008,7 +1034,8 @@ def test_translational_springs_dampers_gpu(name, kw, batch, steps):
         dzg, dug = gm.gradients()
         zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=mode, nthreads=8)
         ok = np.nonzero((st == 0) & (st_o == 0))[0]
-        assert len(ok) > 0.9 * batch
+        assert len(ok) > (0.7 if name == "snake" else 0.9) * batch       # (the snake's 36 contacts on PlanarAxis joints stall ~15 % of the solves on both sides)
+        assert (st != 0).sum() <= (st_o != 0).sum() + 2
         reg_ = (it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)                   # (stalled solves: see test_forward_parity_fp64)
         assert np.array_equal(it[ok][reg_], it_o[ok][reg_]), (k, int((it[ok] != it_o[ok]).sum()))   # the same Newton iterate path
         es = np.abs(zg[ok] - zo[ok]).max(axis=1)             # parity criterion of DESIGN.md §7: almost-active contacts are defined up to the tolerance
@@ -1020,7 +1047,7 @@ def test_translational_springs_dampers_gpu(name, kw, batch, steps):
         if k == steps - 1:
             z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
             ok32 = np.nonzero((st32 == 0) & (st_o == 0))[0]
-            assert len(ok32) > 0.9 * batch and np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max() < 1e-3
+            assert len(ok32) > (0.7 if name == "snake" else 0.9) * batch and np.abs(z32[ok32].astype(np.float64) - zo[ok32]).max() < 1e-3
         nok += len(ok)
         z = zo
     allz, allu = np.concatenate(allz), np.concatenate(allu)
