@@ -180,6 +180,8 @@ def main():
         gathered_bytes = traj_all.numel() * traj_all.element_size()
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
+    ok_frac = float((status == 0).float().mean().item())          # of the timed region's last step
+    mean_iters = float(iters.float().mean().item())
     z = traj[K - 1].clone()
     if args.timed_only:
         if rank == 0:
@@ -202,8 +204,6 @@ def main():
         one_step(k)
     barrier()
     el_sync = D.max_over_ranks(time.perf_counter() - t1, world, device=dev if args.backend == "nccl" else "cpu")
-    ok_frac = float((status == 0).float().mean().item())
-    mean_iters = float(iters.float().mean().item())
 
     # Kernel durations for the roofline, outside the timed region: the SAME closed loop once more from the same initial states with the
     # same controls -- the warmup steps, then the timed region's K steps -- as ONE launch of the whole batch per kernel (groups = 1), so that
@@ -291,7 +291,7 @@ def main():
                        "iteration_cap": "off (library default; dojo_set_iteration_cap: measured gain only at per-GPU batches <= 2048, DESIGN.md section 6)" if args.iter_cap <= 0 else args.iter_cap,
                        "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters,
                        "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,
-                       "sync_per_step_note": "the same %d steps with the environment groups joined into the caller's stream after every step (a barrier per step); `value` is the asynchronous rollout (one join at the end)" % K,
+                       "sync_per_step_note": "%d more steps of the rollout (the same controls again, from the timed region's end state) with the environment groups joined into the caller's stream after every step (a barrier per step); `value` is the asynchronous rollout (one join at the end)" % K,
                        "build": build_info()},
             "roofline": dominant,
         }
