@@ -56,7 +56,20 @@
                             // sphere_sphere.jl; forward only): ContactCold holds the parent-side rows as well
 #endif
 
+#ifndef DJ_MLIM
+#define DJ_MLIM 0           // 1: builds for mechanisms whose joints carry limits on SEVERAL coordinates (all free coordinates of a half: three
+                            // rotation-vector limits on a Spherical joint, two on a Planar joint's translation ...) or on BOTH halves
+                            // (src/joints/limits.jl:1-61 in general; the other builds know one limited coordinate per joint).  Lane mapping
+                            // only (one lane per supernode); every limit of such a mechanism runs through this path (KernelArgs::mlim).
+#endif
+
 namespace dj {
+
+constexpr int NLM = DJ_MLIM ? 6 : 1;     // limited coordinates per joint in the DJ_MLIM builds: up to 3 translational + 3 rotational
+// per supernode (DJ_MLIM builds): how many coordinates of the parent joint's translational / rotational half are limited (0 or all of the half's
+// free ones) and the bounds, translational coordinates first.  Coordinate m keeps its Δκ row in the padded multiplier slot of its own free
+// coordinate: 6 + nl_t + m for a translational one, 9 + nl_r + (m − nt) for a rotational one.
+template <class T> struct MLimP { int nt, nr; T lo[6], hi[6]; };
 
 constexpr int MAXCH = 4;          // children per body supported by the lane program
 constexpr int LU_PER_LANE = 112;  // values per lane of the IFT kernel's LU-form factors between its phases (KernelArgs::lu; layout: LaneProgram::LU_LM .. LU_DI)
@@ -116,6 +129,9 @@ struct Lane {
     T lam[6];                    // equality multipliers: 3 translational slots, 3 rotational slots
     T ls[2], lg[2];              // rotational joint limit: s = (s_up, s_lo), γ = (γ_up, γ_lo)
     T cs[MAXC][NCV], cg[MAXC][NCV];
+#if DJ_MLIM
+    T mls[NLM][2], mlg[NLM][2];  // limits on several coordinates: (s_up, s_lo), (γ_up, γ_lo) per limited coordinate
+#endif
 };
 
 // factor data of one supernode, kept between the two solves of a Mehrotra iteration and
@@ -144,11 +160,18 @@ constexpr int CARRY_PER_ENV = 8;   // doubles per environment of KernelArgs::res
 constexpr int CARRY_MARK = 7;      // ... of which this one says whether the environment is on the continuation list
 
 template <class T, int MAXC>
-struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][NCV], cg[MAXC][NCV]; };   // solution variables at the start of a line search
+struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][NCV], cg[MAXC][NCV];     // solution variables at the start of a line search
+#if DJ_MLIM
+    T mls[NLM][2], mlg[NLM][2];
+#endif
+};
 
 template <class T, int MAXC>
 struct Step {                    // Newton step of this lane's unknowns
     T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][NCV], dcg[MAXC][NCV];
+#if DJ_MLIM
+    T dmls[NLM][2], dmlg[NLM][2];
+#endif
 };
 
 
@@ -1259,6 +1282,89 @@ struct LaneProgram {
     DJ_HD T lim_lo() const { return P.lim_lo; }
     DJ_HD T lim_hi() const { return P.lim_hi; }
 #endif
+    // ---- joint limits on several coordinates / both halves (DJ_MLIM builds, lane mapping) ----
+    static constexpr bool kMLim = DJ_MLIM != 0 && !QUAD;
+    const MLimP<T>* mlp = nullptr;     // this supernode's entry of KernelArgs::mlim
+    DJ_HD int nlm() const { if constexpr (kMLim) return mlp != nullptr ? mlp->nt + mlp->nr : 0; else return 0; }
+    DJ_HD int mslot(int m) const { return m < mlp->nt ? 6 + P.nl_t + m : 9 + P.nl_r + (m - mlp->nt); }     // the Δκ row of limited coordinate m
+#if DJ_MLIM
+    T mtheta[NLM];                     // the limited minimal coordinates at the last evaluation
+    T mrs[NLM][2];                     // right-hand sides of the slack rows (up, lo) of the solve in progress
+    T mth_a[NLM][6], mth_b[NLM][6];    // ∂θ/∂(v, ω) of parent / child   (Jacobian evaluations)
+    T mt_a[NLM][6], mt_b[NLM][6];      // what a unit of net limit impulse κ = γ_lo − γ_up applies to parent / child
+    // MODE 0: θ and the limit impulses (added to imp_a / imp_b); 1: + ∂θ/∂(velocities), impulse directions; 2: raw ∂θ/∂(x3, φ3) into rx_a / rx_b as well
+    template <int MODE>
+    DJ_HD void mlim_eval(T* imp_a, T* imp_b, const JointCfg<T>& c_, const Kin<T>& ka, const Kin<T>& kb, T dt, T (*rx_a)[6] = nullptr, T (*rx_b)[6] = nullptr) {
+        const int nt = mlp->nt, nr = mlp->nr;
+        // translational coordinates: θ = A_l·e(x3, q3), translational/minimal.jl:56-61 (as tra_limit_eval, one row of the nullspace mask each)
+        if (nt > 0) {
+            T t3[3], wv_[3], u[3];
+            m3vec(t3, kb.R3, P.pb);
+            for (int i = 0; i < 3; ++i) wv_[i] = kb.x3[i] + t3[i] - ka.x3[i];
+            m3tvec(u, ka.R3, wv_);
+            T RaT_Rb[9], Spb[9], Eb[9], Su[9], SuP[9], EbP[9];
+            if (MODE >= 1) {
+                m3tmul(RaT_Rb, ka.R3, kb.R3); m3skew(Spb, P.pb); m3mul(Eb, RaT_Rb, Spb);
+                for (int i = 0; i < 9; ++i) Eb[i] *= T(-2);
+                m3skew(Su, u);
+                for (int i = 0; i < 9; ++i) Su[i] *= T(2);
+                m3mul(SuP, Su, ka.Phi); m3mul(EbP, Eb, kb.Phi);
+            }
+            for (int l = 0; l < 3; ++l) if (l < nt) {
+                const T* a = &P.At[3 * l];
+                mtheta[l] = a[0] * (u[0] - P.pa[0]) + a[1] * (u[1] - P.pa[1]) + a[2] * (u[2] - P.pa[2]);
+                const T kk = L.mlg[l][1] - L.mlg[l][0];              // projector [0; −A; A; C]ᵀ, joint.jl:92
+                T p[3] = {a[0] * kk, a[1] * kk, a[2] * kk}, ia[6], ib[6];
+                tra_impulse(ia, ib, c_, P, p);
+                for (int i = 0; i < 6; ++i) { imp_a[i] += ia[i]; imp_b[i] += ib[i]; }
+                if (MODE >= 1) {
+                    for (int j = 0; j < 3; ++j) {
+                        const T aRaT = a[0] * ka.R3[3 * j] + a[1] * ka.R3[3 * j + 1] + a[2] * ka.R3[3 * j + 2];
+                        mth_a[l][j] = -dt * aRaT; mth_b[l][j] = dt * aRaT;
+                        mth_a[l][3 + j] = a[0] * SuP[j] + a[1] * SuP[3 + j] + a[2] * SuP[6 + j];
+                        mth_b[l][3 + j] = a[0] * EbP[j] + a[1] * EbP[3 + j] + a[2] * EbP[6 + j];
+                        if (MODE == 2) {
+                            rx_a[l][j] = -aRaT; rx_b[l][j] = aRaT;
+                            rx_a[l][3 + j] = a[0] * Su[j] + a[1] * Su[3 + j] + a[2] * Su[6 + j];
+                            rx_b[l][3 + j] = a[0] * Eb[j] + a[1] * Eb[3 + j] + a[2] * Eb[6 + j];
+                        }
+                    }
+                    tra_impulse(mt_a[l], mt_b[l], c_, P, a);
+                }
+            }
+        }
+        // rotational coordinates: θ = A_l·rotation_vector(qoff⁻¹ qa⁻¹ qb), rotational/minimal.jl:4-11, 69-80
+        if (nr > 0) {
+            T qab[4], qr[4], rv[3];
+            qcmul(qab, ka.q3, kb.q3);
+            qcmul(qr, P.qoff, qab);
+            rotvec(rv, qr);
+            for (int l = 0; l < 3; ++l) if (l < nr) {
+                const int m = nt + l;
+                const T* a = &P.Ar[3 * l];
+                mtheta[m] = v3dot(a, rv);
+                const T kk = L.mlg[m][1] - L.mlg[m][0];
+                T p[3] = {a[0] * kk, a[1] * kk, a[2] * kk}, ja[6], jb[6];
+                rot_impulse(ja, jb, c_, p);
+                for (int i = 0; i < 6; ++i) { imp_a[i] += ja[i]; imp_b[i] += jb[i]; }
+                if (MODE >= 1) {
+                    T rho[4], rl[4], rr[4], tb[3], ta0[3], ta[3];
+                    rotvec_jac_row(rho, a, qr);
+                    rowL(rl, rho, qr); rowR(rr, rho, qr);
+                    for (int j = 0; j < 3; ++j) { tb[j] = rl[1 + j]; ta0[j] = -rr[1 + j]; }
+                    m3vec(ta, c_.Roff, ta0);
+                    T thb[3], tha[3];
+                    m3tvec(thb, kb.Phi, tb); m3tvec(tha, ka.Phi, ta);
+                    for (int j = 0; j < 3; ++j) {
+                        mth_a[m][j] = T(0); mth_b[m][j] = T(0); mth_a[m][3 + j] = tha[j]; mth_b[m][3 + j] = thb[j];
+                        if (MODE == 2) { rx_a[m][j] = T(0); rx_b[m][j] = T(0); rx_a[m][3 + j] = ta[j]; rx_b[m][3 + j] = tb[j]; }
+                    }
+                    rot_impulse(mt_a[m], mt_b[m], c_, a);
+                }
+            }
+        }
+    }
+#endif
 #ifdef DJ_DEBUG
     T* dbg = nullptr; bool dbg_on = false; bool trace = false;
 #endif
@@ -1366,6 +1472,9 @@ struct LaneProgram {
 #if DJ_TSD
         if (tsd) tra_damper_eval<JAC>(E, P, *tsd, cfg, va, wa, L.v, L.w, dt, K);
         if (tlim) tra_limit_eval<JAC>(E, P, cfg, ka, kb, L.lg, dt);
+#endif
+#if DJ_MLIM
+        if constexpr (kMLim) { if (nlm() > 0) mlim_eval<JAC ? 1 : 0>(E.imp_a, E.imp_b, cfg, ka, kb, dt); }
 #endif
         for (int i = 0; i < 6; ++i) rj[i] = E.g[i];
         theta = E.theta;
@@ -1520,6 +1629,9 @@ struct LaneProgram {
                     if (G.contact_model == 0) wq = tmax(wq, (g[1] + T(REG)) * trcp(s[1] + T(REG)));
                 }
             }
+#if DJ_MLIM
+            if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) { b = tmax(b, tabs(L.mls[m][0] * L.mlg[m][0])); b = tmax(b, tabs(L.mls[m][1] * L.mlg[m][1])); } }
+#endif
             if (lim_on()) {
                 b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1]));
                 if (kTrack && track_stiffness) { wq = tmax(wq, (L.lg[0] + T(REG)) * trcp(L.ls[0] + T(REG))); wq = tmax(wq, (L.lg[1] + T(REG)) * trcp(L.ls[1] + T(REG))); }
@@ -1536,7 +1648,11 @@ struct LaneProgram {
     // ---------------------------------------------------------------- condensation of cone rows
     // comp-row right-hand sides (r1..r4 per contact, r_cu, r_cl for the limit) -> condensed rhs
     // additions for the parent (ra) and own (rbody) body rows; coefficients for the recovery.
-    struct ConeRhs { T cc[CPL][NCV]; T lim[2]; };      // (cc: this lane's contact slots)
+    struct ConeRhs { T cc[CPL][NCV]; T lim[2];         // (cc: this lane's contact slots)
+#if DJ_MLIM
+        T mlim[NLM][2];
+#endif
+    };
 
     DJ_HD void cone_rhs_from_state(ConeRhs& R, T mu_asm) const {
 #pragma unroll
@@ -1551,6 +1667,9 @@ struct LaneProgram {
         }
         R.lim[0] = -(L.ls[0] * L.lg[0] - mu_asm);
         R.lim[1] = -(L.ls[1] * L.lg[1] - mu_asm);
+#if DJ_MLIM
+        for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) R.mlim[m][i] = -(L.mls[m][i] * L.mlg[m][i] - mu_asm);
+#endif
     }
 
     // contact condensation coefficients: Δγ_{1,3,4} = k0 + coef·(C134 Δw);  also Δs2 etc. for recovery
@@ -1684,6 +1803,20 @@ struct LaneProgram {
     }
     template <class BK>
     DJ_HD void condense_limits(BK& K) {
+#if DJ_MLIM
+        // limits on several coordinates: the same elimination per limited coordinate (below), each Δκ row in the padded multiplier slot of its own
+        // free coordinate; θ of a translational coordinate depends on v and ω
+        if constexpr (kMLim) {
+            for (int m = 0; m < NLM; ++m) if (m < nlm()) {
+                const T wk = (L.mlg[m][1] + T(REG)) * trcp(L.mls[m][1] + T(REG)) + (L.mlg[m][0] + T(REG)) * trcp(L.mls[m][0] + T(REG));
+                const T c_ = trcp(T(1) + wk), sg_ = wk * c_;
+                const int sl_ = mslot(m);
+                K.addS(sl_, sl_, c_ - T(1));
+                for (int j = 0; j < 6; ++j) { K.addS(sl_, j, sg_ * mth_b[m][j]); K.addU(sl_, j, sg_ * mth_a[m][j]); }
+                for (int i = 0; i < 6; ++i) { K.addS(i, sl_, -mt_b[m][i]); K.addL(i, sl_, -mt_a[m][i]); }
+            }
+        }
+#endif
         // joint limit: the pair (s, γ) of both sides is eliminated down to ONE unknown, the net limit impulse Δκ = Δγ_lo − Δγ_up
         // = κ0 − wκ (θ_a Δω_a + θ_b Δω_b), wκ = γ_up/s_up + γ_lo/s_lo, which keeps its own row -- the third rotational multiplier
         // slot, free for the one-dimensional rotational joints that may carry limits -- scaled by 1/(1 + wκ):
@@ -2774,11 +2907,32 @@ struct LaneProgram {
             const T rkap = kap0 * trcp(T(1) + gl * isl + gu * isu);   // the Δκ row (see evaluate)
             if (tlim) rk[8] = rkap; else rk[11] = rkap;
         }
+#if DJ_MLIM
+        if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) {     // the Δκ rows of the limited coordinates (condense_limits)
+            const T su_ = L.mls[m][0] + T(REG), sl_ = L.mls[m][1] + T(REG), gu_ = L.mlg[m][0] + T(REG), gl_ = L.mlg[m][1] + T(REG);
+            const T isu_ = trcp(su_), isl_ = trcp(sl_);
+            const T k0_ = (R.mlim[m][1] - gl_ * mrs[m][1]) * isl_ - (R.mlim[m][0] - gu_ * mrs[m][0]) * isu_;
+            rk[mslot(m)] = k0_ * trcp(T(1) + gl_ * isl_ + gu_ * isu_);
+        } }
+#endif
         T dk[12], dva[6];
         core_solve(rk, up, dk, dva);
         for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
         if (dva_out != nullptr) for (int i = 0; i < 6; ++i) dva_out[i] = dva[i];
+#if DJ_MLIM
+        if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) {
+            if (m < nlm()) {
+                D.dlam[mslot(m) - 6] = T(0);                         // the slot carried Δκ, not a joint multiplier
+                T thd = T(0);
+                for (int j = 0; j < 3; ++j) thd += mth_a[m][j] * dva[j] + mth_a[m][3 + j] * dva[3 + j] + mth_b[m][j] * D.dv[j] + mth_b[m][3 + j] * D.dw[j];
+                const T su_ = L.mls[m][0] + T(REG), sl_ = L.mls[m][1] + T(REG), gu_ = L.mlg[m][0] + T(REG), gl_ = L.mlg[m][1] + T(REG);
+                D.dmls[m][0] = mrs[m][0] - thd; D.dmls[m][1] = mrs[m][1] + thd;
+                D.dmlg[m][0] = (R.mlim[m][0] - gu_ * D.dmls[m][0]) * trcp(su_);
+                D.dmlg[m][1] = (R.mlim[m][1] - gl_ * D.dmls[m][1]) * trcp(sl_);
+            } else { D.dmls[m][0] = D.dmls[m][1] = D.dmlg[m][0] = D.dmlg[m][1] = T(0); }
+        } }
+#endif
         if (lim_on()) { if (tlim) D.dlam[2] = T(0); else D.dlam[5] = T(0); }   // slot 11 (8) carried Δκ, not a joint multiplier
         // recovery of the condensed variables
         if (lim_on()) {
@@ -2884,6 +3038,11 @@ struct LaneProgram {
             rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
             rs[1] = -(L.ls[1] - (theta - lim_lo()));
         }
+#if DJ_MLIM
+        if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) {
+            mrs[m][0] = m < nlm() ? -(L.mls[m][0] - (mlp->hi[m] - mtheta[m])) : T(0);
+            mrs[m][1] = m < nlm() ? -(L.mls[m][1] - (mtheta[m] - mlp->lo[m])) : T(0); } }
+#endif
         if constexpr (kRefine) {
             T dva[6];
             solve_rhs(rk, R, rs, r58, upx, D, dva);
@@ -3036,6 +3195,12 @@ struct LaneProgram {
                 a = tmin(a, ort_step(L.ls[i], D.dls[i], tort));
                 a = tmin(a, ort_step(L.lg[i], D.dlg[i], tort));
             }
+#if DJ_MLIM
+            if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) for (int i = 0; i < 2; ++i) {
+                a = tmin(a, ort_step(L.mls[m][i], D.dmls[m][i], tort));
+                a = tmin(a, ort_step(L.mlg[m][i], D.dmlg[m][i], tort));
+            } }
+#endif
         }
         a = quad_minv(a);
         if constexpr (QUAD) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
@@ -3048,6 +3213,9 @@ struct LaneProgram {
         for (int i = 0; i < 3; ++i) { B.v[i] = L.v[i]; B.w[i] = L.w[i]; }
         for (int i = 0; i < 6; ++i) B.lam[i] = L.lam[i];
         for (int i = 0; i < 2; ++i) { B.ls[i] = L.ls[i]; B.lg[i] = L.lg[i]; }
+#if DJ_MLIM
+        for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { B.mls[m][i] = L.mls[m][i]; B.mlg[m][i] = L.mlg[m][i]; }
+#endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) { const int c = kSplitC ? (cidx(li) < MAXC ? cidx(li) : 0) : li; for (int i = 0; i < NCV; ++i) { B.cs[li][i] = L.cs[c][i]; B.cg[li][i] = L.cg[c][i]; } }
     }
@@ -3060,6 +3228,9 @@ struct LaneProgram {
         if (v3dot(L.w, L.w) > T(3.91) * G.idt2) bad = 1;
         for (int i = 0; i < 6; ++i) L.lam[i] = B.lam[i] + f * D.dlam[i];
         for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
+#if DJ_MLIM
+        for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { L.mls[m][i] = B.mls[m][i] + f * D.dmls[m][i]; L.mlg[m][i] = B.mlg[m][i] + f * D.dmlg[m][i]; }
+#endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) { const int c = cidx(li); if (!kSplitC || c < MAXC) for (int i = 0; i < NCV; ++i) { L.cs[c][i] = B.cs[li][i] + f * D.dcs[li][i]; L.cg[c][i] = B.cg[li][i] + f * D.dcg[li][i]; } }
         share_cone_state();
@@ -3093,6 +3264,9 @@ struct LaneProgram {
         {
             for (int i = 0; i < 6; ++i) L.lam[i] = T(0);
             for (int i = 0; i < 2; ++i) { L.ls[i] = T(1); L.lg[i] = T(1); }            // joints/constraints.jl:440-448
+#if DJ_MLIM
+            for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { L.mls[m][i] = T(1); L.mlg[m][i] = T(1); }
+#endif
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {                                                  // reset! to [1,1,0,0] then initialize! -> 1.5·[1,1,0,0]
                 // (the generic initialize! of an ImpactContact discards its result, initialization.jl:1-5: it starts from reset!'s 1)
@@ -3215,6 +3389,10 @@ struct LaneProgram {
         if constexpr (kSplitC) { T pc_[3] = {p0, p1, p2}; quad_sum(pc_); p0 = pc_[0]; p1 = pc_[1]; p2 = pc_[2]; }   // (the limit terms below are the same on all four lanes)
         if (active) {
             if (lim_on()) for (int i = 0; i < 2; ++i) { p0 += L.ls[i] * L.lg[i]; p1 += (L.ls[i] + aaff * D.dls[i]) * (L.lg[i] + aaff * D.dlg[i]); p2 += T(1); }
+#if DJ_MLIM
+            if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) for (int i = 0; i < 2; ++i) {
+                p0 += L.mls[m][i] * L.mlg[m][i]; p1 += (L.mls[m][i] + aaff * D.dmls[m][i]) * (L.mlg[m][i] + aaff * D.dmlg[m][i]); p2 += T(1); } }
+#endif
         }
         if constexpr (QUAD) { T v3[3] = {p0, p1, p2}; env_reduce_quad<3>(v3, [](T a_, T b_) { return a_ + b_; }); p0 = v3[0]; p1 = v3[1]; p2 = v3[2]; }
         else { p0 = env_sum(wv, p0, envl); p1 = env_sum(wv, p1, envl); p2 = env_sum(wv, p2, envl); }
@@ -3237,6 +3415,9 @@ struct LaneProgram {
         }
         R.lim[0] += -D.dls[0] * D.dlg[0] + mutarget;
         R.lim[1] += -D.dls[1] * D.dlg[1] + mutarget;
+#if DJ_MLIM
+        for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) R.mlim[m][i] += -D.dmls[m][i] * D.dmlg[m][i] + mutarget;
+#endif
         DJ_PB();
         solve(R, D);                                            // corrected direction
         DJ_PE(2);
@@ -3499,6 +3680,26 @@ struct LaneProgram {
 #if DJ_TSD
         if (tlim) tra_limit_eval<true>(E, P, ce, ka, kb, L.lg, dt);
 #endif
+#if DJ_MLIM
+        // limits on several coordinates: raw ∂θ_m/∂(x3, φ3) at the evaluation state -> the slack rows' data columns (up = −∂θ/∂z2, lo = +∂θ/∂z2),
+        // and σ_m = wκ/(1 + wκ) of every limited coordinate
+        T msl_own[NLM][6], msl_par[NLM][6], mwk[NLM], mrs0[NLM];
+        for (int m = 0; m < NLM; ++m) { mwk[m] = mrs0[m] = T(0); for (int j = 0; j < 6; ++j) msl_own[m][j] = msl_par[m][j] = T(0); }
+        if constexpr (kMLim) { if (nlm() > 0) {
+            T rx_a[NLM][6], rx_b[NLM][6], ia_[6] = {0, 0, 0, 0, 0, 0}, ib_[6] = {0, 0, 0, 0, 0, 0};
+            mlim_eval<2>(ia_, ib_, ce, ka, kb, dt, rx_a, rx_b);
+            for (int m = 0; m < NLM; ++m) if (m < nlm()) {
+                for (int j = 0; j < 3; ++j) {
+                    T pb_ = T(0), pa_ = T(0);
+                    for (int m_ = 0; m_ < 3; ++m_) { pb_ += rx_b[m][3 + m_] * kb.Xi[3 * m_ + j]; pa_ += rx_a[m][3 + m_] * ka.Xi[3 * m_ + j]; }
+                    msl_own[m][j] = -rx_b[m][j]; msl_par[m][j] = -rx_a[m][j];            // ∂x3/∂x2 = I
+                    msl_own[m][3 + j] = -pb_; msl_par[m][3 + j] = -pa_;
+                }
+                const T w_ = (L.mlg[m][1] + T(REG)) / (L.mls[m][1] + T(REG)) + (L.mlg[m][0] + T(REG)) / (L.mls[m][0] + T(REG));
+                mwk[m] = w_ / (T(1) + w_);
+            }
+        } }
+#endif
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -3539,6 +3740,14 @@ struct LaneProgram {
             }
             if (P.nlim_r > 0) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pr[q_] += P.Ar[q_] * kk; }
             if (tlim) { T kk = L.lg[1] - L.lg[0]; for (int q_ = 0; q_ < 3; ++q_) pt[q_] += P.At[q_] * kk; }
+#if DJ_MLIM
+            if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) {
+                const T kk = L.mlg[m][1] - L.mlg[m][0];
+                const bool tra_ = m < mlp->nt;
+                const T* a_ = tra_ ? &P.At[3 * m] : &P.Ar[3 * (m - mlp->nt)];
+                for (int q_ = 0; q_ < 3; ++q_) { if (tra_) pt[q_] += a_[q_] * kk; else pr[q_] += a_[q_] * kk; }
+            } }
+#endif
             T Jaa[36], Jab[36], Jba[36], Jbb[36];
 #if DJ_TSD
             T Saa[36], Sab[36], Sba[36], Sbb[36], pf[3] = {0, 0, 0};
@@ -3707,6 +3916,9 @@ struct LaneProgram {
                 for (int i = 0; i < 6; ++i) rk[i] += GK[c][i][0] * r58[c][0] + GK[c][i][1] * r58[c][1] + GK[c][i][2] * r58[c][2] + GK[c][i][3] * r58[c][3];
             }
             if (lim_on()) { if (tlim) rk[8] += wk * rs0; else rk[11] += wk * rs0; }   // the Δκ row
+#if DJ_MLIM
+            if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) rk[mslot(m)] += mwk[m] * mrs0[m]; }
+#endif
             T dk[12], dva[6];
             core_solve(rk, upx, dk, dva);
             for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
@@ -3733,6 +3945,9 @@ struct LaneProgram {
                     for (int i = 0; i < 6; ++i) { rk[i] = T(gb.ParB[i][cc]); rk[6 + i] = T(gb.ParJ[i][cc]); upx[i] = T(gb.UpPar[i][cc]); }
                     rs[0] = T(gb.sl_par[cc]); rs[1] = -rs[0];
                 }
+#if DJ_MLIM
+                for (int m = 0; m < NLM; ++m) mrs0[m] = (is_cfg && mine) ? msl_own[m][cc] : (is_cfg && child_of) ? msl_par[m][cc] : T(0);
+#endif
                 grad_solve(rk, rs[0], r58, upx);
                 if (active && q == 0 && A.dz && write_out) {
                     OutPtr o = A.dz + ((size_t)env * nx + (size_t)(12 * kk + c)) * nx + 12 * k;
@@ -3758,6 +3973,9 @@ struct LaneProgram {
 #pragma unroll
                 for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
                 if (mine) for (int i = 0; i < 6; ++i) { rk[i] = T(gb.UB[i][c]); upx[i] = T(gb.UA[i][c]); }
+#if DJ_MLIM
+                for (int m = 0; m < NLM; ++m) mrs0[m] = T(0);
+#endif
                 grad_solve(rk, rs[0], r58, upx);
                 if (active && q == 0 && A.du && write_out) {
                     OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + c)) * nx + 12 * k;
@@ -4023,6 +4241,7 @@ struct KernelArgs {
     T* mu_out = nullptr;           // [B] or null: mechanism.μ when mehrotra! returned (src/solver/mehrotra.jl:45), fp64
     T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
+    const MLimP<T>* mlim = nullptr;// [Nb + 1] limits on several coordinates per supernode, or null (read by the DJ_MLIM builds only)
     // iteration cap + continuation (Globals::iter_cap > 0; all three set or all null):
     T* resume = nullptr;           // [B][CARRY_PER_ENV] solver scalars of the environments the step kernel left unfinished (DJ_STATUS_CONTINUE);
                                    // entry CARRY_MARK: 1 for the environments of a workgroup on the continuation list, 0 for the others (written by
@@ -4097,8 +4316,10 @@ constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKST
 // kernels) leaves t_a / t_b / G134 -- and KernelArgs::diag_out -- at the LAST linearization it did perform, i.e. one iterate back; the plain
 // IFT kernel never reads them (lu_prepare() evaluates the linearization at the restored solution before any use), the refining one
 // re-evaluates them too (grad_entry MODE 2).  They travel for the explicit-inverse consumers only.
-template <int MAXC> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
+// (MLIM: the DJ_MLIM builds append (s_up, s_lo, γ_up, γ_lo) of up to six limited coordinates; the host sizes the buffer with MLIM = true for such mechanisms)
+template <int MAXC, bool MLIM = (DJ_MLIM != 0)> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + (MLIM ? 24 : 0) + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
 template <int MAXC> constexpr int sol_flag_off() { return sol_record<MAXC>() - 1; }
+template <int MAXC> constexpr int sol_mlim_off() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC; }
 // quad mapping: the factors themselves travel too (72 values per lane, stored [wave][72][64 lanes]: coalesced)
 constexpr int FAC_PER_LANE = 72;
 
@@ -4106,8 +4327,12 @@ constexpr int FAC_PER_LANE = 72;
 // gradient sweeps must not cost the Newton loop its registers).  The IFT kernel rebuilds the lane
 // program from (z, u), restores the converged solution from the hand-off record and re-linearizes
 // there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
-#if DJ_TSD
+#if DJ_TSD && DJ_MLIM
+#define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr; prog.tlim = prog.tsd != nullptr && prog.tsd->nlim > 0; prog.mlp = A.mlim ? A.mlim + (k < G.Nb ? k : G.Nb) : nullptr;
+#elif DJ_TSD
 #define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr; prog.tlim = prog.tsd != nullptr && prog.tsd->nlim > 0;
+#elif DJ_MLIM
+#define DJ_TSD_SETUP prog.mlp = A.mlim ? A.mlim + (k < G.Nb ? k : G.Nb) : nullptr;
 #else
 #define DJ_TSD_SETUP
 #endif
@@ -4200,6 +4425,9 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { prog.L.cs[c][i] = r[16 + 8 * c + i]; prog.L.cg[c][i] = r[20 + 8 * c + i]; }
             prog.mu = r[16 + 8 * MAXC];
+#if DJ_MLIM
+            for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { prog.L.mls[m][i] = r[sol_mlim_off<MAXC>() + 4 * m + i]; prog.L.mlg[m][i] = r[sol_mlim_off<MAXC>() + 4 * m + 2 + i]; }
+#endif
             if (QUAD) {
                 const T* r2 = r + 17 + 8 * MAXC;
                 for (int i = 0; i < 6; ++i) { prog.F.t_a[i] = r2[i]; prog.F.t_b[i] = r2[6 + i]; }
@@ -4311,6 +4539,9 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) for (int i = 0; i < 4; ++i) { r[16 + 8 * c + i] = prog.L.cs[c][i]; r[20 + 8 * c + i] = prog.L.cg[c][i]; }
         r[16 + 8 * MAXC] = prog.mu;
+#if DJ_MLIM
+        for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { r[sol_mlim_off<MAXC>() + 4 * m + i] = prog.L.mls[m][i]; r[sol_mlim_off<MAXC>() + 4 * m + 2 + i] = prog.L.mlg[m][i]; }
+#endif
         if (QUAD) {
             T* r2 = r + 17 + 8 * MAXC;
             for (int i = 0; i < 6; ++i) { r2[i] = prog.F.t_a[i]; r2[6 + i] = prog.F.t_b[i]; }
@@ -4349,8 +4580,19 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
             TIO* jo = A.joint_imp + (size_t)env * G.n_joint_imp + P.imp_off;
             int o2 = 0;
             if (prog.tlim) { jo[o2++] = TIO(prog.L.ls[0]); jo[o2++] = TIO(prog.L.ls[1]); jo[o2++] = TIO(prog.L.lg[0]); jo[o2++] = TIO(prog.L.lg[1]); }   // [tra: s_up s_lo γ_up γ_lo λ_t]
+#if DJ_MLIM
+            // limits on several coordinates: η = [s_up(n); s_lo(n); γ_up(n); γ_lo(n); λ] per half (split_impulses, src/joints/joint.jl)
+            if (prog.kMLim && prog.nlm() > 0) { const int nt_ = prog.mlp->nt;
+                for (int i = 0; i < 2; ++i) for (int m = 0; m < nt_; ++m) jo[o2++] = TIO(prog.L.mls[m][i]);
+                for (int i = 0; i < 2; ++i) for (int m = 0; m < nt_; ++m) jo[o2++] = TIO(prog.L.mlg[m][i]); }
+#endif
             for (int i = 0; i < 3; ++i) if (i < P.nl_t) jo[o2++] = TIO(prog.L.lam[i]);
             if (P.nlim_r > 0) { jo[o2++] = TIO(prog.L.ls[0]); jo[o2++] = TIO(prog.L.ls[1]); jo[o2++] = TIO(prog.L.lg[0]); jo[o2++] = TIO(prog.L.lg[1]); }
+#if DJ_MLIM
+            if (prog.kMLim && prog.nlm() > 0) { const int nt_ = prog.mlp->nt, nr_ = prog.mlp->nr;
+                for (int i = 0; i < 2; ++i) for (int m = 0; m < nr_; ++m) jo[o2++] = TIO(prog.L.mls[nt_ + m][i]);
+                for (int i = 0; i < 2; ++i) for (int m = 0; m < nr_; ++m) jo[o2++] = TIO(prog.L.mlg[nt_ + m][i]); }
+#endif
             for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[3 + i]);
         }
         if (A.contact_sg) {

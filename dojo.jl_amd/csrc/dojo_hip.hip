@@ -45,6 +45,7 @@ DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_laun
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
 DJ_DECL(dojo_launch_tsd_float_4_0) DJ_DECL(dojo_launch_tsd_float_8_0) DJ_DECL(dojo_launch_tsd_double_4_0) DJ_DECL(dojo_launch_tsd_double_8_0)
+DJ_DECL(dojo_launch_mlim_float_4_0) DJ_DECL(dojo_launch_mlim_float_8_0) DJ_DECL(dojo_launch_mlim_double_4_0) DJ_DECL(dojo_launch_mlim_double_8_0)
 DJ_DECL(dojo_launch_lin_float_1_1) DJ_DECL(dojo_launch_lin_float_4_1) DJ_DECL(dojo_launch_lin_double_1_1) DJ_DECL(dojo_launch_lin_double_4_1)     // LinearContact builds
 DJ_DECL(dojo_launch_lin_float_4_0) DJ_DECL(dojo_launch_lin_float_8_0) DJ_DECL(dojo_launch_lin_double_4_0) DJ_DECL(dojo_launch_lin_double_8_0)
 DJ_DECL(dojo_launch_ss_float_1_1) DJ_DECL(dojo_launch_ss_double_1_1)     // body-body contacts (-DDJ_SS=1): single-wavefront quad mapping, <= 1 contact per body, forward only
@@ -73,6 +74,7 @@ struct DojoSim {
     int B = 0, dtype = 0, device = 0, grad_mode = DOJO_GRAD_REFERENCE;
     size_t w = 8;                       // bytes per scalar
     void* d_tsd = nullptr;       // translational springs / dampers per supernode (mechanisms that have them)
+    void* d_mlim = nullptr;      // joint limits on several coordinates per supernode (mechanisms that have them)
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_cz = nullptr;                   // maximal-state scratch of dojo_minimal_to_maximal / dojo_maximal_to_minimal (d_z stays the state of the last step)
@@ -360,6 +362,12 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
         HIPCHK(hipMalloc(&s->d_tsd, tsd.size() * sizeof(dj::TraSD<T>)));
         HIPCHK(hipMemcpy(s->d_tsd, tsd.data(), tsd.size() * sizeof(dj::TraSD<T>), hipMemcpyHostToDevice));
     }
+    if (s->M.has_mlim) {
+        std::vector<dj::MLimP<T>> ml;
+        for (auto& a : s->M.mlim) { dj::MLimP<T> b; b.nt = a.nt; b.nr = a.nr; for (int i = 0; i < 6; ++i) { b.lo[i] = T(a.lo[i]); b.hi[i] = T(a.hi[i]); } ml.push_back(b); }
+        HIPCHK(hipMalloc(&s->d_mlim, ml.size() * sizeof(dj::MLimP<T>)));
+        HIPCHK(hipMemcpy(s->d_mlim, ml.data(), ml.size() * sizeof(dj::MLimP<T>), hipMemcpyHostToDevice));
+    }
     std::vector<int> order;
     for (int lev = 0; lev <= s->M.maxlevel; ++lev) for (int b = 0; b < s->M.Nb; ++b) if (s->M.nodes[b].level == lev) order.push_back(b);
     HIPCHK(hipMalloc((void**)&s->d_order, order.size() * sizeof(int)));
@@ -378,6 +386,7 @@ enum { PH_ALL = 0, PH_MAIN = 1, PH_GRAD = 2, PH_CONT = 3 };
 int mapping_waves(const dj::HostModel& M) {
     // translational springs / dampers / limits: the quad builds that carry them are the single-wavefront ones with <= 4 contacts per body;
     // larger mechanisms take the lane mapping (its DJ_TSD builds: k_*_{4,8}_0_tsd)
+    if (M.has_mlim) return 0;                                             // joint limits on several coordinates / both halves: k_*_{4,8}_0_mlim
     if (M.has_tsd && (M.S > 16 || M.maxc > 4)) return 0;
     if (M.contact_model == 2 && (M.S > 16 || M.maxc > 4)) return 0;       // LinearContact likewise (k_*_{4,8}_0_lin)
     if (M.S <= 16) return 1;
@@ -500,6 +509,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.dz = off(dz, nx * nx); A.du = off(du, nx * nu); A.dc = off(dc, nx * 5 * s->M.Nc);
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
+    A.mlim = s->M.has_mlim ? (const dj::MLimP<T>*)s->d_mlim : nullptr;
     A.mu_out = s->d_mu ? (T*)s->d_mu + env0 : nullptr;
     A.diag_out = (s->d_diag && quad_mapping_of(s)) ? (T*)s->d_diag + 2 * env0 : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
@@ -531,9 +541,10 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.sol = nullptr;
     // doubles per supernode of the step -> IFT hand-off record in the kernels that serve this mechanism (the launcher selection below: MAXC by mapping)
     const int vmaxc = !quad ? (s->M.maxc <= 4 ? 4 : 8) : NW == 2 ? (s->M.maxc <= 1 ? 1 : 4) : (s->M.maxc <= 1 ? 1 : s->M.maxc <= 4 ? 4 : 8);
-    const size_t sol_rec = vmaxc == 1 ? dj::sol_record<1>() : vmaxc == 4 ? dj::sol_record<4>() : dj::sol_record<8>();
+    const size_t sol_rec = s->M.has_mlim ? (vmaxc == 4 ? dj::sol_record<4, true>() : dj::sol_record<8, true>())
+                                         : vmaxc == 1 ? dj::sol_record<1>() : vmaxc == 4 ? dj::sol_record<4>() : dj::sol_record<8>();
     if (g) {
-        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));   // sized for the largest record
+        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(T)));   // sized for the largest record
         A.sol = (T*)s->d_sol + env0 * s->M.S * sol_rec;                      // (the record size of the kernels of this mechanism: a launch over the whole batch
                                                                             //  -- the continuation -- must find the records where the groups' launches put them)
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
@@ -564,7 +575,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     // unfinished after `cap` Newton iterations leave the step kernel and go on in the continuation kernel (PH_CONT)
     A.G.iter_cap = 0;
     if (phase != PH_ALL) {
-        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8>() * sizeof(T)));
+        if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(T)));
         if (!s->d_resume) HIPCHK(hipMalloc(&s->d_resume, (size_t)s->B * dj::CARRY_PER_ENV * sizeof(T)));
         if (!status && !s->d_cstat) HIPCHK(hipMalloc((void**)&s->d_cstat, (size_t)s->B * sizeof(int)));
         A.G.iter_cap = effective_cap(s);
@@ -611,6 +622,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (s->M.has_ss && s->M.contact_model != 2) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
     else if (s->M.contact_model == 2 && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_lin_float_4_0 : dojo_launch_lin_double_4_0) : (f32 ? dojo_launch_lin_float_8_0 : dojo_launch_lin_double_8_0);
     else if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
+    else if (s->M.has_mlim) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_mlim_float_4_0 : dojo_launch_mlim_double_4_0) : (f32 ? dojo_launch_mlim_float_8_0 : dojo_launch_mlim_double_8_0);
     else if (s->M.has_tsd && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_tsd_float_4_0 : dojo_launch_tsd_double_4_0)
                                                        : (f32 ? dojo_launch_tsd_float_8_0 : dojo_launch_tsd_double_8_0);
     else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
@@ -705,6 +717,9 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
         g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
+    if (s->M.has_mlim && (s->M.contact_model == 2 || s->M.has_ss)) {
+        g_err = "joint limits on several coordinates / both halves together with LinearContact or a body-body contact are not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    }
     if (s->M.contact_model == 2 && s->M.has_tsd) {
         g_err = "LinearContact together with translational springs / dampers / limits is not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
@@ -720,7 +735,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_mlim, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
     for (void* p : pc) if (p) (void)hipFree(p);

@@ -18,6 +18,8 @@ struct HostModel {
     std::vector<ContactP<double>> contacts;
     std::vector<TraSD<double>> tsd;   // [Nb + 1] translational springs / dampers per supernode (+ the idle slot's zero entry)
     bool has_tsd = false;
+    std::vector<MLimP<double>> mlim;  // [Nb + 1] joint limits on several coordinates / both halves (has_mlim: every limit of the mechanism lives here)
+    bool has_mlim = false;            // ... the DJ_MLIM kernels (lane mapping)
     bool has_ss = false;          // a body-body contact (SphereSphereCollision): the DJ_SS kernels, forward only
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
     std::string error;
@@ -33,6 +35,15 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     { TraSD<double> z0; z0.spring = z0.damper = 0; z0.off[0] = z0.off[1] = z0.off[2] = 0; z0.lim_lo = z0.lim_hi = 0; z0.nlim = 0; M.tsd.assign(M.Nb + 1, z0); M.has_tsd = false; }
     std::vector<int> pj(M.Nb, -1);
     int uoff = 0, ioff = 0;
+    // limits on several coordinates of a joint half (all of its free ones, src/joints/limits.jl:1-17) or on both halves of a joint: the DJ_MLIM
+    // kernels; then EVERY limit of the mechanism goes through their table instead of NodeP::nlim_r / TraSD::nlim
+    { MLimP<double> z0; z0.nt = z0.nr = 0; for (int i = 0; i < 6; ++i) z0.lo[i] = z0.hi[i] = 0; M.mlim.assign(M.Nb + 1, z0); M.has_mlim = false; }
+    for (int j = 0; j < tp.n_joints; ++j) {
+        const DojoJoint& J = tp.joints[j];
+        for (int h = 0; h < 2; ++h) { const DojoJointHalf& H = h ? J.rot : J.tra;
+            if (H.nlim != 0 && H.nlim != 3 - H.nl) { M.error = "joint limits cover all free coordinates of a joint half or none (nlim = 0 or 3 - nl)"; return DOJO_ERR_INVALID; } }
+        if (J.tra.nlim > 1 || J.rot.nlim > 1 || (J.tra.nlim > 0 && J.rot.nlim > 0)) M.has_mlim = true;
+    }
     for (int j = 0; j < tp.n_joints; ++j) {
         const DojoJoint& J = tp.joints[j];
         if (J.child < 0 || J.child >= M.Nb || J.parent >= M.Nb) { M.error = "joint with invalid body index"; return DOJO_ERR_INVALID; }
@@ -40,13 +51,19 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         pj[J.child] = j;
         NodeP<double>& P = M.nodes[J.child];
         P.parent = J.parent;
-        P.nl_t = J.tra.nl; P.nl_r = J.rot.nl; P.nlim_r = J.rot.nlim;
+        P.nl_t = J.tra.nl; P.nl_r = J.rot.nl; P.nlim_r = M.has_mlim ? 0 : J.rot.nlim;
+        if (M.has_mlim) {
+            MLimP<double>& ml = M.mlim[J.child];
+            ml.nt = J.tra.nlim; ml.nr = J.rot.nlim;
+            for (int i = 0; i < J.tra.nlim; ++i) { ml.lo[i] = J.tra.limit_lo[i]; ml.hi[i] = J.tra.limit_hi[i]; }
+            for (int i = 0; i < J.rot.nlim; ++i) { ml.lo[J.tra.nlim + i] = J.rot.limit_lo[i]; ml.hi[J.tra.nlim + i] = J.rot.limit_hi[i]; }
+        } else
         if (J.tra.nlim != 0) {            // one limited translational coordinate: joints with nl_t = 2, and no rotational limit on the same joint
             if (J.tra.nlim > 1 || J.tra.nl != 2) { M.error = "translational limits need a one-dimensional translational joint (Prismatic type)"; return DOJO_ERR_UNSUPPORTED; }
             if (J.rot.nlim != 0) { M.error = "limits on both halves of one joint are not supported"; return DOJO_ERR_UNSUPPORTED; }
         }
-        if (J.rot.nlim > 1) { M.error = "joint limits on more than one rotational coordinate are not supported"; return DOJO_ERR_UNSUPPORTED; }
-        if (J.rot.nlim == 1 && J.rot.nl != 2) { M.error = "rotational limits need a one-dimensional rotational joint"; return DOJO_ERR_UNSUPPORTED; }
+        if (!M.has_mlim && J.rot.nlim > 1) { M.error = "joint limits on more than one rotational coordinate are not supported"; return DOJO_ERR_UNSUPPORTED; }
+        if (!M.has_mlim && J.rot.nlim == 1 && J.rot.nl != 2) { M.error = "rotational limits need a one-dimensional rotational joint"; return DOJO_ERR_UNSUPPORTED; }
         if (J.tra.nl < 3 && ((J.spring_on && J.tra.spring != 0) || (J.damper_on && J.tra.damper != 0))) {
             // translational spring / damper (joints with free translations): a table of its own next to the nodes, DJ_TSD kernels
             M.has_tsd = true;
@@ -54,7 +71,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
             sd.spring = J.spring_on ? J.tra.spring : 0.0; sd.damper = J.damper_on ? J.tra.damper : 0.0;
             for (int i = 0; i < 3 - J.tra.nl; ++i) sd.off[i] = J.tra.spring_offset[i];
         }
-        if (J.tra.nlim == 1) {
+        if (J.tra.nlim == 1 && !M.has_mlim) {
             M.has_tsd = true;
             TraSD<double>& sd = M.tsd[J.child];
             sd.nlim = 1; sd.lim_lo = J.tra.limit_lo[0]; sd.lim_hi = J.tra.limit_hi[0];

@@ -214,7 +214,9 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
 
 #define DJ_CAT2(a, b, c, d) a##b##_##c##_##d
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
-#if DJ_LINEAR   // LinearContact builds: the step kernel alone (forward only, like the reference; no refinement, no IFT)
+#if DJ_MLIM     // builds for joint limits on several coordinates / both halves (lane mapping; they carry the translational springs / dampers too)
+#define DJ_LAUNCHER DJ_CAT(dojo_launch_mlim_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#elif DJ_LINEAR   // LinearContact builds: the step kernel alone (forward only, like the reference; no refinement, no IFT)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_lin_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #elif DJ_SS     // builds with body-body contacts: the step kernel alone (forward only)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_ss_, DJ_TIO, DJ_MAXC, DJ_QUAD)
@@ -266,7 +268,7 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int phases,
 #endif
 }
 
-#if DJ_QUAD != 0 && !DJ_LINEAR && !DJ_SS
+#if DJ_QUAD != 0 && !DJ_LINEAR && !DJ_SS && !DJ_MLIM
 // the contact-data IFT kernel alone (the step kernel of the same inputs must have run with its hand-off enabled)
 extern "C" int DJ_CLAUNCHER(const void* args, int grid, void* stream) {
     const dj::KernelArgs<DJ_TIO, double>& A = *(const dj::KernelArgs<DJ_TIO, double>*)args;

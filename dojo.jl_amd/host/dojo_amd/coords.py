@@ -169,6 +169,8 @@ def nominal_minimal(spec, **kw):
         leg = kw.get("leg_length", 0.5)
         bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, leg + spec.contacts[0].radius if spec.contacts else leg + 0.05])
         return minimal_state_dict(spec, {"floating_base": [bp[0], bp[1], bp[2], 0, 0, 0], "leg": [-leg]})
+    if n.startswith("limited_"):             # mechanisms.get_limited_chain (tests of multi-coordinate joint limits): zero coordinates
+        return np.zeros(2 * spec.nu)
     raise ValueError(n)
 
 

@@ -127,6 +127,60 @@ def set_limits(spec, joint_limits):
             raise ValueError("joint limits can only be set for one-dimensional joints")
 
 
+def add_limits(spec, joint_name, tra_limits=None, rot_limits=None):
+    """add_limits(mech, joint; tra_limits, rot_limits)  src/joints/limits.jl:31-61: limits (lo[], hi[]) on ALL free coordinates of a joint half
+    (Nb½ = the half's number of minimal coordinates: `constraint` broadcasts them against `minimal_coordinates`, limits.jl:1-17), on either
+    half or both -- e.g. three rotation-vector limits on a Spherical joint, two on a Planar joint's translation, one + one on a Cylindrical."""
+    j = spec.joints[spec.joint_index(joint_name)]
+    for half, lim in ((j.tra, tra_limits), (j.rot, rot_limits)):
+        if lim is None:
+            continue
+        lo, hi = np.atleast_1d(np.array(lim[0], float)), np.atleast_1d(np.array(lim[1], float))
+        if len(lo) != half.nu or len(hi) != half.nu:
+            raise ValueError("limits on %s need %d entries per side (all free coordinates of the half)" % (joint_name, half.nu))
+        half.limits = (lo, hi)
+    return spec
+
+
+def get_limited_chain(kind="spherical", timestep=0.01, input_scaling=None, gravity=-9.81, dampers=0.05):
+    """Test mechanisms for joint limits on several coordinates (src/joints/limits.jl:1-61; the DojoEnvironments builders only limit
+    one-dimensional joints): a link hanging from the origin on
+      "spherical":   a Spherical joint with limits on its three rotation-vector coordinates, a second link below it on a Revolute joint;
+      "planar":      a Planar joint (translation free in two directions) with limits on both, rotation locked;
+      "cylindrical": a Cylindrical joint (one translation + one rotation about the same axis) with a limit on either half;
+      "mixed":       spherical (3 limits) -> cylindrical (1 + 1) -> a foot with a contact."""
+    L = 0.5
+    def link(n): return BodySpec(n, 1.0, box_inertia(0.1, 0.1, L, 1.0))
+    if kind == "spherical":
+        bodies = [link("upper"), link("lower")]
+        joints = [Prototype("Spherical", "shoulder", -1, 0, Z_AXIS, parent_vertex=np.array([0, 0, 1.5]), child_vertex=0.5 * L * Z_AXIS, damper=dampers),
+                  Revolute("elbow", 0, 1, X_AXIS, parent_vertex=-0.5 * L * Z_AXIS, child_vertex=0.5 * L * Z_AXIS, damper=dampers)]
+        spec = MechanismSpec("limited_spherical", bodies, joints, [], timestep, input_scaling, gravity)
+        add_limits(spec, "shoulder", rot_limits=([-0.4, -0.3, -0.5], [0.3, 0.5, 0.4]))
+    elif kind == "planar":
+        bodies = [link("plate")]
+        joints = [Prototype("Planar", "table", -1, 0, X_AXIS, parent_vertex=np.array([0, 0, 1.0]), damper=dampers)]     # free: the two directions normal to x
+        spec = MechanismSpec("limited_planar", bodies, joints, [], timestep, input_scaling, gravity)
+        add_limits(spec, "table", tra_limits=([-0.2, -0.3], [0.25, 0.1]))
+    elif kind == "cylindrical":
+        bodies = [link("rod")]
+        joints = [Prototype("Cylindrical", "sleeve", -1, 0, Z_AXIS, parent_vertex=np.array([0, 0, 1.0]), damper=dampers)]
+        spec = MechanismSpec("limited_cylindrical", bodies, joints, [], timestep, input_scaling, gravity)
+        add_limits(spec, "sleeve", tra_limits=([-0.3], [0.2]), rot_limits=([-0.5], [0.4]))
+    elif kind == "mixed":
+        bodies = [link("upper"), link("rod"), BodySpec("foot", 0.5, sphere_inertia(0.1, 0.5))]
+        joints = [Prototype("Spherical", "shoulder", -1, 0, Z_AXIS, parent_vertex=np.array([0, 0, 1.3]), child_vertex=0.5 * L * Z_AXIS, damper=dampers),
+                  Prototype("Cylindrical", "sleeve", 0, 1, Z_AXIS, parent_vertex=-0.5 * L * Z_AXIS, child_vertex=0.5 * L * Z_AXIS, damper=dampers),
+                  Revolute("ankle", 1, 2, Y_AXIS, parent_vertex=-0.5 * L * Z_AXIS, child_vertex=0.1 * Z_AXIS, damper=dampers)]
+        contacts = [contact_constraint("sole", 2, Z_AXIS, 0.8, contact_radius=0.1)]
+        spec = MechanismSpec("limited_mixed", bodies, joints, contacts, timestep, input_scaling, gravity)
+        add_limits(spec, "shoulder", rot_limits=([-0.6, -0.5, -0.5], [0.5, 0.6, 0.5]))
+        add_limits(spec, "sleeve", tra_limits=([-0.15], [0.15]), rot_limits=([-0.4], [0.4]))
+    else:
+        raise ValueError(kind)
+    return spec
+
+
 def set_springs_dampers(spec, springs=0.0, dampers=0.0):
     """set_springs!/set_dampers!  DojoEnvironments/src/utilities.jl:1-39 (floating base skipped)"""
     for j in spec.joints:
@@ -482,7 +536,7 @@ def get_mechanism(name, **kwargs):
     return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas,
             "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper,
             "npendulum": get_npendulum, "snake": get_snake, "twister": get_twister, "sphere": get_sphere,
-            "cartpole": get_cartpole, "block2d": get_block2d, "dzhanibekov": get_dzhanibekov, "tippetop": get_tippetop}[name](**kwargs)
+            "cartpole": get_cartpole, "block2d": get_block2d, "dzhanibekov": get_dzhanibekov, "tippetop": get_tippetop, "limited_chain": get_limited_chain}[name](**kwargs)
 
 
 # the five BASELINE.json configurations

@@ -13,6 +13,8 @@
 #pragma once
 #include <cmath>
 #include <cassert>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <initializer_list>
@@ -21,15 +23,17 @@ namespace orc {
 
 // ---------------------------------------------------------------------------
 // Small dense matrix with inline storage (no heap), dynamic shape.
-// Largest local object on the path: joint x body-data block 9 x 19 = 171.
+// Largest local object on the path: joint x body-data block, 9 x 19 = 171 for a joint with one limited coordinate, 24 x 19 = 456 for a
+// joint with limits on all six coordinates (src/joints/limits.jl with Nb½ = 3 on both halves).  The capacity is CHECKED (the checker is
+// built with -DNDEBUG: an assert would let a larger block run over the stack).
 // ---------------------------------------------------------------------------
 template <class T>
 struct SM {
-    static constexpr int CAP = 256;
+    static constexpr int CAP = 512;
     int r = 0, c = 0;
     T a[CAP];
     SM() {}
-    SM(int r_, int c_) : r(r_), c(c_) { assert(r * c <= CAP); for (int i = 0; i < r * c; ++i) a[i] = T(0); }
+    SM(int r_, int c_) : r(r_), c(c_) { if (r * c > CAP) { std::fprintf(stderr, "oracle: a %d x %d block exceeds SM::CAP\n", r, c); std::abort(); } for (int i = 0; i < r * c; ++i) a[i] = T(0); }
     SM(const SM& o) : r(o.r), c(o.c) { for (int i = 0; i < r * c; ++i) a[i] = o.a[i]; }
     SM& operator=(const SM& o) { r = o.r; c = o.c; for (int i = 0; i < r * c; ++i) a[i] = o.a[i]; return *this; }
     // row-major literal

@@ -745,3 +745,33 @@ def test_linear_contact_beyond_sixteen_bodies():
         assert r["status"][b] == 0 and info["status"] == 0 and r["iters"][b] == info["iters"]
         assert np.abs(r["z_next"][b] - zo).max() < 1e-9
 
+
+@pytest.mark.parametrize("kind", ["spherical", "planar", "cylindrical", "mixed"])
+def test_joint_limits_on_several_coordinates(kind):
+    """Joint limits on all free coordinates of a half and on both halves of a joint (src/joints/limits.jl:1-61; the -DDJ_MLIM=1 build of the
+    lane program, lane mapping): a rollout into the stops against the oracle -- equal Newton iteration counts, states, the exported limit
+    variables in get_solution order [s_up(n) s_lo(n) gamma_up(n) gamma_lo(n) lambda] per half, and IFT Jacobians in both conventions."""
+    spec = d.get_limited_chain(kind)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    rng = np.random.default_rng(1)
+    z = d.initialize(spec)
+    u = 2.0 * rng.standard_normal(spec.nu)
+    hit = 0
+    for k in range(48):
+        zo, info = o.step(z, u)
+        if k % 8 == 7 or k < 2:
+            mode = (k // 8) % 2
+            r = emu_step(spec, z[None], u[None], opts=opts, quad=False, grad=True, grad_mode=mode)
+            gz, gu = o.gradients(mode)
+            sol = o.get_solution()
+            assert r["status"][0] == 0 and info["status"] == 0 and r["iters"][0] == info["iters"], (k, r["iters"][0], info["iters"])
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+            assert np.abs(r["joint_imp"][0] - sol[:spec.n_joint_impulses]).max() < 1e-8
+            assert np.abs(r["dz"][0] - gz).max() <= 1e-6 * max(1.0, np.abs(gz).max()) and np.abs(r["du"][0] - gu).max() <= 1e-6 * max(1.0, np.abs(gu).max())
+            hit += int(np.abs(sol[:spec.n_joint_impulses]).max() > 1e-2)
+        z = zo
+    assert hit >= 2
+    with pytest.raises(RuntimeError):
+        emu_step(spec, z[None], u[None], opts=opts, quad=True)          # the quad mappings carry one limited coordinate per joint
+

@@ -95,3 +95,42 @@ def test_solmat_translational_limits():
     spec = d.get_raiberthopper(timestep=0.01); set_limits(spec, {"leg": [-0.6, -0.4]})
     err, _ = run_solmat(spec, 0.3)
     assert err < EPS, err
+
+
+@pytest.mark.parametrize("kind", ["spherical", "planar", "cylindrical", "mixed"])
+def test_solmat_limits_on_several_coordinates(kind):
+    """Limits on ALL free coordinates of a joint half and on both halves (src/joints/limits.jl:1-61 in general: three rotation-vector limits
+    on a Spherical joint, two on a Planar joint's translation, one + one on a Cylindrical; dojo_amd.mechanisms.get_limited_chain) -- the
+    identity of test/jacobian.jl on the oracle while the mechanism is driven into its stops, the limited coordinates stay inside their bounds,
+    and with the drive switched off the Planar plate comes to rest ON its lower stop (test/joint_limits.jl's behaviour for a pendulum)."""
+    spec = d.get_limited_chain(kind)
+    o = Oracle(spec, opts=d.SolverOptions(rtol=1e-9, btol=1e-9))
+    rng = np.random.default_rng(1)
+    z = d.initialize(spec)
+    u = 2.0 * rng.standard_normal(spec.nu)
+    worst = 0.0; active = 0
+    lo = np.concatenate([np.concatenate([h.limits[0] for h in (j.tra, j.rot) if h.limits is not None]) for j in spec.joints if j.tra.limits is not None or j.rot.limits is not None])
+    hi = np.concatenate([np.concatenate([h.limits[1] for h in (j.tra, j.rot) if h.limits is not None]) for j in spec.joints if j.tra.limits is not None or j.rot.limits is not None])
+    for k in range(120):
+        z, info = o.step(z, u)
+        assert info["status"] == 0
+        x = o.maximal_to_minimal(z)
+        th = []; off = 0
+        for j in spec.joints:                      # minimal state per joint: [coordinates(nu); velocities(nu)], translational coordinates first
+            if j.tra.limits is not None: th += list(x[off:off + j.tra.nu])
+            if j.rot.limits is not None: th += list(x[off + j.tra.nu:off + j.nu])
+            off += 2 * j.nu
+        th = np.array(th)
+        assert np.all(th >= lo - 1e-6) and np.all(th <= hi + 1e-6), (k, th)
+        active += int(np.any((th < lo + 1e-5) | (th > hi - 1e-5)))
+        if k % 30 == 29:
+            data = o.get_data(); o.set_data(data); sol = o.get_solution()
+            worst = max(worst, np.abs(fd_solution_matrix(o, data, sol) + o.full_matrix()).max())
+    assert active > 20                             # the stops were reached and held
+    assert worst < (1e-4 if kind == "mixed" else EPS), worst      # (mixed: a contact at the edge of its cone, where the central difference straddles the kink)
+    if kind == "planar":
+        for k in range(300):
+            z, info = o.step(z, np.zeros(spec.nu))
+        x = o.maximal_to_minimal(z)
+        assert abs(x[1] - (-0.3)) < 1e-5 and abs(x[3]) < 1e-6, x       # the vertical coordinate rests on its lower stop (the horizontal one still creeps against its damper)
+
