@@ -63,8 +63,15 @@
                             // only (one lane per supernode); every limit of such a mechanism runs through this path (KernelArgs::mlim).
 #endif
 
+#ifndef DJ_CUT
+#define DJ_CUT 0            // 1: builds for mechanisms with KINEMATIC LOOPS (a body with more than one parent joint: src/solver/linear_system.jl:4-5
+                            // `cyclic_children`, the four-bar of test/behaviors.jl:57-81).  The loop-closing ("cut") joints stay out of the tree
+                            // elimination and come back through a low-rank correction of every solve (LaneProgram::cut_*).  Lane mapping only.
+#endif
+
 namespace dj {
 
+constexpr int NCUT = 2;                  // loop-closing joints per mechanism in the DJ_CUT builds
 constexpr int NLM = DJ_MLIM ? 6 : 1;     // limited coordinates per joint in the DJ_MLIM builds: up to 3 translational + 3 rotational
 // per supernode (DJ_MLIM builds): how many coordinates of the parent joint's translational / rotational half are limited (0 or all of the half's
 // free ones) and the bounds, translational coordinates first.  Coordinate m keeps its Δκ row in the padded multiplier slot of its own free
@@ -164,6 +171,9 @@ struct SolSnap { T v[3], w[3], lam[6], ls[2], lg[2], cs[MAXC][NCV], cg[MAXC][NCV
 #if DJ_MLIM
     T mls[NLM][2], mlg[NLM][2];
 #endif
+#if DJ_CUT
+    T clam[NCUT][6];
+#endif
 };
 
 template <class T, int MAXC>
@@ -171,6 +181,9 @@ struct Step {                    // Newton step of this lane's unknowns
     T dv[3], dw[3], dlam[6], dls[2], dlg[2], dcs[MAXC][NCV], dcg[MAXC][NCV];
 #if DJ_MLIM
     T dmls[NLM][2], dmlg[NLM][2];
+#endif
+#if DJ_CUT
+    T dclam[NCUT][6];
 #endif
 };
 
@@ -1282,6 +1295,167 @@ struct LaneProgram {
     DJ_HD T lim_lo() const { return P.lim_lo; }
     DJ_HD T lim_hi() const { return P.lim_hi; }
 #endif
+    // ---- kinematic loops: loop-closing ("cut") joints (DJ_CUT builds, lane mapping) ----
+    // The tree elimination handles the spanning tree K_t.  A cut joint c between bodies a and b (both in the tree) adds, in the unknowns
+    // z_c = [Δw_a(6); Δw_b(6); Δλ_c(6)], the 18 x 18 block M_c = [N_c (rows of the two bodies); Q_c (the joint's rows)]:
+    //     K_t x + Σ_c S_cᵀ N_c z_c = r,     Q_c z_c = r_c,     z_c[0:12] = S_c x   (S_c picks the velocities of a and b)
+    // With W = K_t⁻¹ Sᵀ (12 columns per cut: tree solves with unit right-hand sides, once per linearization) and H = S W:
+    //     x = K_t⁻¹ r − W (N z),      (I + H N) z|bodies + ... = S K_t⁻¹ r,      Q z = r_c        (18·ncut unknowns, dense LU with pivoting)
+    // -- the exact solution of the cyclic system, which the reference reaches through the fill-in of its LDU (src/solver/linear_system.jl:4-5).
+    // Every lane of the environment holds the small system (the values arrive through wave shuffles) and solves it redundantly.
+    static constexpr bool kCut = DJ_CUT != 0 && !QUAD;
+    const NodeP<T>* cutp = nullptr; int ncut = 0;
+#if DJ_CUT
+    T clam[NCUT][6];                  // multipliers of the cut joints (3 translational, 3 rotational slots; identical on all lanes of the environment)
+    T crj[NCUT][6];                   // their residual rows at the last evaluation
+    T cue[NCUT][6];                   // their control inputs of this step
+    T crc[NCUT][6];                   // right-hand sides of their rows in the solve in progress
+    JointCfg<T> ccfg[NCUT];           // joint_cfg at (x2, q2) of the two bodies (the owner lane = body b's lane uses it)
+    T cM[NCUT][18][18];               // M_c of the last linearization
+    T cW[NCUT * 12][12];              // this lane's rows of W
+    T cLU[18 * NCUT][18 * NCUT]; int cpiv[18 * NCUT];
+    DJ_HD int cut_a(int c) const { return cutp[c].parent; }
+    DJ_HD int cut_b(int c) const { return cutp[c].child[0]; }
+    DJ_HD bool cut_owner(int c) const { return active && k == cut_b(c); }
+    // body a's (x2, q2, v, w) on every lane
+    DJ_HD void cut_fetch_a(int c, T* xa, T* qa, T* va, T* wa_) {
+        const int la = base + cut_a(c);
+        T own13[13] = {L.x2[0], L.x2[1], L.x2[2], L.q2[0], L.q2[1], L.q2[2], L.q2[3], L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, o13[13];
+        shfl_vec<13>(wv, o13, own13, la);
+        for (int i = 0; i < 3; ++i) { xa[i] = o13[i]; va[i] = o13[7 + i]; wa_[i] = o13[10 + i]; }
+        for (int i = 0; i < 4; ++i) qa[i] = o13[3 + i];
+    }
+    // set_input! / springs of the cut joints (begin_step's part for the joints that are not a supernode's own)
+    DJ_HD void cut_begin() {
+        for (int c = 0; c < NCUT; ++c) { for (int i = 0; i < 6; ++i) clam[c][i] = crj[c][i] = T(0); }
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            const NodeP<T>& Pc = cutp[c];
+            T xa[3], qa[4], va[3], wa_[3];
+            cut_fetch_a(c, xa, qa, va, wa_);
+            T ina[6] = {0, 0, 0, 0, 0, 0};
+            if (cut_owner(c)) {
+                joint_cfg(ccfg[c], Pc, xa, qa, L.x2, L.q2);
+                T it[3] = {0, 0, 0}, ir[3] = {0, 0, 0};
+                for (int i = 0; i < 3; ++i) {
+                    if (i < Pc.nu_t) for (int kx = 0; kx < 3; ++kx) it[kx] += Pc.At[3 * i + kx] * cue[c][i];
+                    if (i < Pc.nu_r) for (int kx = 0; kx < 3; ++kx) ir[kx] += Pc.Ar[3 * i + kx] * cue[c][Pc.nu_t + i];
+                }
+                for (int kx = 0; kx < 3; ++kx) { it[kx] *= G.input_scaling; ir[kx] *= G.input_scaling; }
+                T ia[6], ib[6];
+                tra_impulse(ia, ib, ccfg[c], Pc, it);
+                for (int i = 0; i < 3; ++i) { ina[i] = ia[i]; ina[3 + i] = T(0.5) * ia[3 + i]; L.dconst[i] -= ib[i]; L.dconst[3 + i] -= T(0.5) * ib[3 + i]; }
+                T ta[3], tb[3];
+                m3vec(ta, ccfg[c].Roff, ir); m3vec(tb, ccfg[c].Rba, ta);
+                for (int i = 0; i < 3; ++i) { ina[3 + i] += -ta[i]; L.dconst[3 + i] -= tb[i]; }
+                T sa[6], sb[6];
+                spring_impulses(sa, sb, Pc, ccfg[c], G.dt);
+                for (int i = 0; i < 6; ++i) { L.dconst[i] -= sb[i]; ina[i] += sa[i]; }
+            }
+            T got[6];
+            shfl_vec<6>(wv, got, ina, base + cut_b(c));
+            if (active && k == cut_a(c)) for (int i = 0; i < 6; ++i) L.dconst[i] -= got[i];
+        }
+    }
+    // residual (and, JAC, M_c) of the cut joints; d = this lane's body residual under construction
+    template <bool JAC>
+    DJ_HD void cut_eval(T* d, const Kin<T>& kb) {
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            const NodeP<T>& Pc = cutp[c];
+            T xa[3], qa[4], va[3], wa_[3];
+            cut_fetch_a(c, xa, qa, va, wa_);
+            T ia6[6] = {0, 0, 0, 0, 0, 0}, g6[6] = {0, 0, 0, 0, 0, 0};
+            FullBlocks<T> Kc;
+            if (JAC) Kc.zero();
+            if (cut_owner(c)) {
+                Kin<T> ka;
+                kin_of(ka, xa, qa, va, wa_, G.dt);
+                JointEval<T> E;
+                const T lg0[2] = {0, 0};
+                NullBlocks nk;
+                if (JAC) joint_eval<1>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, Kc);
+                else joint_eval<0>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, nk);
+                for (int i = 0; i < 6; ++i) { d[i] -= E.imp_b[i]; ia6[i] = E.imp_a[i]; g6[i] = E.g[i]; }
+            }
+            T got[6];
+            shfl_vec<6>(wv, got, ia6, base + cut_b(c));
+            if (active && k == cut_a(c)) for (int i = 0; i < 6; ++i) d[i] -= got[i];
+            shfl_vec<6>(wv, crj[c], g6, base + cut_b(c));
+            if (JAC) {
+                // M_c on the owner: rows [body a; body b; joint] x columns [w_a; w_b; λ] out of the blocks joint_eval fills for a (parent, child) pair
+                T Mo[18][18];
+                for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
+                    Mo[r][j] = Kc.D[6 * r + j]; Mo[r][6 + j] = Kc.L[12 * r + j]; Mo[r][12 + j] = Kc.L[12 * r + 6 + j];
+                    Mo[6 + r][j] = Kc.U[6 * r + j]; Mo[6 + r][6 + j] = Kc.S[12 * r + j]; Mo[6 + r][12 + j] = Kc.S[12 * r + 6 + j];
+                    Mo[12 + r][j] = Kc.U[6 * (6 + r) + j]; Mo[12 + r][6 + j] = Kc.S[12 * (6 + r) + j]; Mo[12 + r][12 + j] = Kc.S[12 * (6 + r) + 6 + j];
+                }
+                for (int i = 0; i < 3; ++i) { Mo[12 + i][12 + i] += (i < Pc.nl_t) ? T(REG) : T(1); Mo[15 + i][15 + i] += (i < Pc.nl_r) ? T(REG) : T(1); }
+                for (int r = 0; r < 18; ++r) shfl_vec<18>(wv, cM[c][r], Mo[r], base + cut_b(c));
+            }
+        }
+    }
+    DJ_HD int cut_body(int c, int row) const { return row < 6 ? cut_a(c) : cut_b(c); }     // the body behind row / column 0..11 of cut c
+    // after the tree factorization: W, H and the LU of the small system
+    DJ_HD void cut_factor() {
+        const int n = 18 * ncut;
+        T H[12 * NCUT][12 * NCUT];
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) for (int col = 0; col < 12; ++col) {
+            T rk[12], up[6] = {0, 0, 0, 0, 0, 0}, dk[12], dva[6];
+            for (int i = 0; i < 12; ++i) rk[i] = T(0);
+            if (active && k == cut_body(c, col)) rk[col % 6] = T(1);
+            core_solve(rk, up, dk, dva);
+            for (int i = 0; i < 12; ++i) cW[12 * c + col][i] = dk[i];
+            for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int row = 0; row < 12; ++row)
+                H[12 * e + row][12 * c + col] = wv.shfl(dk[row % 6], base + cut_body(e, row));
+        }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) cLU[i][j] = T(0);
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            for (int i = 0; i < 12; ++i) {
+                cLU[18 * c + i][18 * c + i] = T(1);
+                for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int j = 0; j < 18; ++j) {
+                    T a_ = T(0);
+                    for (int m = 0; m < 12; ++m) a_ += H[12 * c + i][12 * e + m] * cM[e][m][j];
+                    cLU[18 * c + i][18 * e + j] += a_;
+                }
+            }
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 18; ++j) cLU[18 * c + 12 + i][18 * c + j] = cM[c][12 + i][j];
+        }
+        for (int kk = 0; kk < n; ++kk) {                      // LU with partial pivoting, in place (the same arithmetic on every lane)
+            int p = kk; T best = tabs(cLU[kk][kk]);
+            for (int i = kk + 1; i < n; ++i) { const T v_ = tabs(cLU[i][kk]); if (v_ > best) { best = v_; p = i; } }
+            cpiv[kk] = p;
+            if (p != kk) for (int j = 0; j < n; ++j) { const T t_ = cLU[kk][j]; cLU[kk][j] = cLU[p][j]; cLU[p][j] = t_; }
+            const T ip = T(1) / cLU[kk][kk];
+            for (int i = kk + 1; i < n; ++i) {
+                const T f_ = cLU[i][kk] * ip; cLU[i][kk] = f_;
+                for (int j = kk + 1; j < n; ++j) cLU[i][j] -= f_ * cLU[kk][j];
+            }
+        }
+    }
+    // the tree solve followed by the correction for the cut joints; rc = right-hand sides of their rows, dlc = their multipliers' part of the solution
+    DJ_HD void cut_solve(const T* rk, const T* up, const T (*rc)[6], T* dk, T* dva, T (*dlc)[6]) {
+        core_solve(rk, up, dk, dva);
+        if (ncut == 0) return;
+        const int n = 18 * ncut;
+        T z[18 * NCUT];
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            for (int row = 0; row < 12; ++row) z[18 * c + row] = wv.shfl(dk[row % 6], base + cut_body(c, row));
+            for (int i = 0; i < 6; ++i) z[18 * c + 12 + i] = rc[c][i];
+        }
+        for (int kk = 0; kk < n; ++kk) { const int p = cpiv[kk]; if (p != kk) { const T t_ = z[kk]; z[kk] = z[p]; z[p] = t_; } for (int i = kk + 1; i < n; ++i) z[i] -= cLU[i][kk] * z[kk]; }
+        for (int i = n - 1; i >= 0; --i) { T a_ = z[i]; for (int j = i + 1; j < n; ++j) a_ -= cLU[i][j] * z[j]; z[i] = a_ / cLU[i][i]; }
+        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            for (int m = 0; m < 12; ++m) {
+                T f_ = T(0);
+                for (int j = 0; j < 18; ++j) f_ += cM[c][m][j] * z[18 * c + j];
+                for (int i = 0; i < 12; ++i) dk[i] -= cW[12 * c + m][i] * f_;
+            }
+            for (int i = 0; i < 6; ++i) dlc[c][i] = z[18 * c + 12 + i];
+        }
+        T own6[6] = {dk[0], dk[1], dk[2], dk[3], dk[4], dk[5]}, par6[6];
+        shfl_vec<6>(wv, par6, own6, plane);
+        for (int i = 0; i < 6; ++i) dva[i] = has_parent ? par6[i] : T(0);
+    }
+#endif
     // ---- joint limits on several coordinates / both halves (DJ_MLIM builds, lane mapping) ----
     static constexpr bool kMLim = DJ_MLIM != 0 && !QUAD;
     const MLimP<T>* mlp = nullptr;     // this supernode's entry of KernelArgs::mlim
@@ -1545,6 +1719,9 @@ struct LaneProgram {
 #endif
         if constexpr (QUAD) { mail_post_node<6>(up); mail_add_children_node<6>(d, active, G.maxch); }
         else gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
+#if DJ_CUT
+        if constexpr (kCut) { if (ncut > 0) cut_eval<JAC>(d, kb); }
+#endif
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
         if (JAC) {
             // ---- supernode matrix S = [[D_b, P_b],[G_b, REG]]  (rows/cols: v(3) ω(3) λt(3) λr(3)); joint blocks are already in ----
@@ -1631,6 +1808,9 @@ struct LaneProgram {
             }
 #if DJ_MLIM
             if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) { b = tmax(b, tabs(L.mls[m][0] * L.mlg[m][0])); b = tmax(b, tabs(L.mls[m][1] * L.mlg[m][1])); } }
+#endif
+#if DJ_CUT
+            if constexpr (kCut) { for (int c = 0; c < NCUT; ++c) if (c < ncut) for (int i = 0; i < 6; ++i) r = tmax(r, tabs(crj[c][i])); }
 #endif
             if (lim_on()) {
                 b = tmax(b, tabs(L.ls[0] * L.lg[0])); b = tmax(b, tabs(L.ls[1] * L.lg[1]));
@@ -2916,6 +3096,12 @@ struct LaneProgram {
         } }
 #endif
         T dk[12], dva[6];
+#if DJ_CUT
+        if constexpr (kCut) {
+            for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) D.dclam[c][i] = T(0);
+            if (ncut > 0) cut_solve(rk, up, crc, dk, dva, D.dclam); else core_solve(rk, up, dk, dva);
+        } else
+#endif
         core_solve(rk, up, dk, dva);
         for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         for (int i = 0; i < 6; ++i) D.dlam[i] = dk[6 + i];
@@ -3038,6 +3224,9 @@ struct LaneProgram {
             rs[0] = -(L.ls[0] - (lim_hi() - theta));       // limits.jl:13-14
             rs[1] = -(L.ls[1] - (theta - lim_lo()));
         }
+#if DJ_CUT
+        if constexpr (kCut) { for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) crc[c][i] = c < ncut ? -crj[c][i] : T(0); }
+#endif
 #if DJ_MLIM
         if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) {
             mrs[m][0] = m < nlm() ? -(L.mls[m][0] - (mlp->hi[m] - mtheta[m])) : T(0);
@@ -3216,6 +3405,9 @@ struct LaneProgram {
 #if DJ_MLIM
         for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { B.mls[m][i] = L.mls[m][i]; B.mlg[m][i] = L.mlg[m][i]; }
 #endif
+#if DJ_CUT
+        for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) B.clam[c][i] = clam[c][i];
+#endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) { const int c = kSplitC ? (cidx(li) < MAXC ? cidx(li) : 0) : li; for (int i = 0; i < NCV; ++i) { B.cs[li][i] = L.cs[c][i]; B.cg[li][i] = L.cg[c][i]; } }
     }
@@ -3230,6 +3422,9 @@ struct LaneProgram {
         for (int i = 0; i < 2; ++i) { L.ls[i] = B.ls[i] + f * D.dls[i]; L.lg[i] = B.lg[i] + f * D.dlg[i]; }
 #if DJ_MLIM
         for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { L.mls[m][i] = B.mls[m][i] + f * D.dmls[m][i]; L.mlg[m][i] = B.mlg[m][i] + f * D.dmlg[m][i]; }
+#endif
+#if DJ_CUT
+        for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) clam[c][i] = B.clam[c][i] + f * D.dclam[c][i];
 #endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) { const int c = cidx(li); if (!kSplitC || c < MAXC) for (int i = 0; i < NCV; ++i) { L.cs[c][i] = B.cs[li][i] + f * D.dcs[li][i]; L.cg[c][i] = B.cg[li][i] + f * D.dcg[li][i]; } }
@@ -3361,6 +3556,9 @@ struct LaneProgram {
         }
 #endif
         factorize(K);
+#if DJ_CUT
+        if constexpr (kCut) { if (ncut > 0) cut_factor(); }
+#endif
         }
     }
 
@@ -3680,6 +3878,61 @@ struct LaneProgram {
 #if DJ_TSD
         if (tlim) tra_limit_eval<true>(E, P, ce, ka, kb, L.lg, dt);
 #endif
+#if DJ_CUT
+        // cut joints: their data blocks at the evaluation state, computed by the owner (body b's lane) like a supernode's own joint (below) with
+        // body a in the parent's place, then handed to every lane: joint rows wrt the configuration of b / a (CJb, CJa), rows of body b wrt b / a
+        // (CBbb, CBba), rows of body a wrt b / a (CBab, CBaa), control columns on b / a (CUB, CUA)
+        T CJb[NCUT][6][6], CJa[NCUT][6][6], CBbb[NCUT][6][6], CBba[NCUT][6][6], CBab[NCUT][6][6], CBaa[NCUT][6][6], CUB[NCUT][6][6], CUA[NCUT][6][6], crc0[NCUT][6];
+        for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) { crc0[c][i] = T(0); for (int j = 0; j < 6; ++j) CJb[c][i][j] = CJa[c][i][j] = CBbb[c][i][j] = CBba[c][i][j] = CBab[c][i][j] = CBaa[c][i][j] = CUB[c][i][j] = CUA[c][i][j] = T(0); }
+        if constexpr (kCut) { for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+            const NodeP<T>& Pc = cutp[c];
+            const int lb = base + cut_b(c), la = base + cut_a(c);
+            T own10[13] = {x2e[0], x2e[1], x2e[2], q2e[0], q2e[1], q2e[2], q2e[3], L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, a13[13];
+            shfl_vec<13>(wv, a13, own10, la);
+            T blk[8][36];
+            for (int b_ = 0; b_ < 8; ++b_) for (int i = 0; i < 36; ++i) blk[b_][i] = T(0);
+            if (cut_owner(c)) {
+                const T* xae = a13; const T* qae = a13 + 3; const T* vae = a13 + 7; const T* wae = a13 + 10;
+                JointCfg<T> cc_; joint_cfg(cc_, Pc, xae, qae, x2e, q2e);
+                Kin<T> kac; kin_of(kac, xae, qae, vae, wae, dt);
+                JointEval<T> Ec; const T lg0[2] = {0, 0};
+                { NullBlocks nk; joint_eval<2>(Ec, Pc, cc_, true, kac, kb, wae, L.w, clam[c], lg0, dt, nk); }
+                for (int sl = 0; sl < 6; ++sl) for (int j = 0; j < 3; ++j) {
+                    blk[0][6 * sl + j] = -Ec.GbX[3 * sl + j]; blk[1][6 * sl + j] = -Ec.GaX[3 * sl + j];
+                    T pb_ = T(0), pa_ = T(0);
+                    for (int m_ = 0; m_ < 3; ++m_) { pb_ += Ec.GbP[3 * sl + m_] * kb.Xi[3 * m_ + j]; pa_ += Ec.GaP[3 * sl + m_] * kac.Xi[3 * m_ + j]; }
+                    blk[0][6 * sl + 3 + j] = -pb_; blk[1][6 * sl + 3 + j] = -pa_;
+                }
+                T pt[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+                for (int i = 0; i < 3; ++i) {
+                    if (i < Pc.nl_t) for (int q_ = 0; q_ < 3; ++q_) pt[q_] += Pc.Ct[3 * i + q_] * clam[c][i];
+                    if (i < Pc.nl_r) for (int q_ = 0; q_ < 3; ++q_) pr[q_] += Pc.Cr[3 * i + q_] * clam[c][3 + i];
+                }
+                T Jaa[36], Jab[36], Jba[36], Jbb[36];
+                joint_impulse_cfg_jac(Jaa, Jab, Jba, Jbb, Pc, cc_, pt, pr, wae, L.w, dt);
+                for (int i = 0; i < 36; ++i) { blk[2][i] = Jbb[i]; blk[3][i] = Jba[i]; blk[4][i] = Jab[i]; blk[5][i] = Jaa[i]; }
+                for (int i = 0; i < 3; ++i) {
+                    if (i < Pc.nu_t) {
+                        T ia[6], ib[6];
+                        tra_impulse(ia, ib, cc_, Pc, &Pc.At[3 * i]);
+                        for (int r = 0; r < 3; ++r) { blk[6][6 * r + i] = G.input_scaling * ib[r]; blk[6][6 * (3 + r) + i] = G.input_scaling * T(0.5) * ib[3 + r]; blk[7][6 * r + i] = G.input_scaling * ia[r]; blk[7][6 * (3 + r) + i] = G.input_scaling * T(0.5) * ia[3 + r]; }
+                    }
+                    if (i < Pc.nu_r) {
+                        T ta[3], tb[3];
+                        m3vec(ta, cc_.Roff, &Pc.Ar[3 * i]); m3vec(tb, cc_.Rba, ta);
+                        const int col = Pc.nu_t + i;
+                        for (int r = 0; r < 3; ++r) { blk[6][6 * (3 + r) + col] = G.input_scaling * tb[r]; blk[7][6 * (3 + r) + col] = -G.input_scaling * ta[r]; }
+                    }
+                }
+            }
+            for (int b_ = 0; b_ < 8; ++b_) {
+                T got[36];
+                shfl_vec<36>(wv, got, blk[b_], lb);
+                T (*dst)[6] = b_ == 0 ? CJb[c] : b_ == 1 ? CJa[c] : b_ == 2 ? CBbb[c] : b_ == 3 ? CBba[c] : b_ == 4 ? CBab[c] : b_ == 5 ? CBaa[c] : b_ == 6 ? CUB[c] : CUA[c];
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) dst[i][j] = got[6 * i + j];
+            }
+        } }
+#endif
 #if DJ_MLIM
         // limits on several coordinates: raw ∂θ_m/∂(x3, φ3) at the evaluation state -> the slack rows' data columns (up = −∂θ/∂z2, lo = +∂θ/∂z2),
         // and σ_m = wκ/(1 + wκ) of every limited coordinate
@@ -3920,6 +4173,9 @@ struct LaneProgram {
             if constexpr (kMLim) { for (int m = 0; m < NLM; ++m) if (m < nlm()) rk[mslot(m)] += mwk[m] * mrs0[m]; }
 #endif
             T dk[12], dva[6];
+#if DJ_CUT
+            if constexpr (kCut) { T dlc_[NCUT][6]; if (ncut > 0) cut_solve(rk, upx, crc0, dk, dva, dlc_); else core_solve(rk, upx, dk, dva); } else
+#endif
             core_solve(rk, upx, dk, dva);
             for (int i = 0; i < 3; ++i) { D.dv[i] = dk[i]; D.dw[i] = dk[3 + i]; }
         };
@@ -3947,6 +4203,14 @@ struct LaneProgram {
                 }
 #if DJ_MLIM
                 for (int m = 0; m < NLM; ++m) mrs0[m] = (is_cfg && mine) ? msl_own[m][cc] : (is_cfg && child_of) ? msl_par[m][cc] : T(0);
+#endif
+#if DJ_CUT
+                if constexpr (kCut) { for (int c_ = 0; c_ < NCUT; ++c_) {
+                    const bool isb = c_ < ncut && is_cfg && kk == cut_b(c_), isa = c_ < ncut && is_cfg && kk == cut_a(c_);
+                    for (int i = 0; i < 6; ++i) crc0[c_][i] = isb ? CJb[c_][i][cc] : isa ? CJa[c_][i][cc] : T(0);
+                    if (c_ < ncut && active && k == cut_b(c_)) for (int i = 0; i < 6; ++i) rk[i] += isb ? CBbb[c_][i][cc] : isa ? CBba[c_][i][cc] : T(0);
+                    if (c_ < ncut && active && k == cut_a(c_)) for (int i = 0; i < 6; ++i) rk[i] += isb ? CBab[c_][i][cc] : isa ? CBaa[c_][i][cc] : T(0);
+                } }
 #endif
                 grad_solve(rk, rs[0], r58, upx);
                 if (active && q == 0 && A.dz && write_out) {
@@ -3976,6 +4240,9 @@ struct LaneProgram {
 #if DJ_MLIM
                 for (int m = 0; m < NLM; ++m) mrs0[m] = T(0);
 #endif
+#if DJ_CUT
+                for (int c_ = 0; c_ < NCUT; ++c_) for (int i = 0; i < 6; ++i) crc0[c_][i] = T(0);
+#endif
                 grad_solve(rk, rs[0], r58, upx);
                 if (active && q == 0 && A.du && write_out) {
                     OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pk.u_off + c)) * nx + 12 * k;
@@ -3985,6 +4252,30 @@ struct LaneProgram {
                 }
             }
         }
+#if DJ_CUT
+        // ... and the control columns of the cut joints
+        if constexpr (kCut) { for (int c_ = 0; c_ < NCUT; ++c_) if (c_ < ncut) {
+            const NodeP<T>& Pc = cutp[c_];
+            for (int c = 0; c < Pc.nu_t + Pc.nu_r; ++c) {
+                T rk[12], rs[2] = {0, 0}, r58[MAXC][4], upx[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 12; ++i) rk[i] = T(0);
+                for (int q_ = 0; q_ < MAXC; ++q_) for (int i = 0; i < 4; ++i) r58[q_][i] = T(0);
+                if (active && k == cut_b(c_)) for (int i = 0; i < 6; ++i) rk[i] += CUB[c_][i][c];
+                if (active && k == cut_a(c_)) for (int i = 0; i < 6; ++i) rk[i] += CUA[c_][i][c];
+#if DJ_MLIM
+                for (int m = 0; m < NLM; ++m) mrs0[m] = T(0);
+#endif
+                for (int e_ = 0; e_ < NCUT; ++e_) for (int i = 0; i < 6; ++i) crc0[e_][i] = T(0);
+                grad_solve(rk, rs[0], r58, upx);
+                if (active && q == 0 && A.du && write_out) {
+                    OutPtr o = A.du + ((size_t)env * G.nu + (size_t)(Pc.u_off + c)) * nx + 12 * k;
+                    T pw[3];
+                    m3vec(pw, kb0.Phi, D.dw);
+                    for (int i = 0; i < 3; ++i) { o[i] = dt * D.dv[i]; o[3 + i] = D.dv[i]; o[6 + i] = pw[i]; o[9 + i] = D.dw[i]; }
+                }
+            }
+        } }
+#endif
     }
 
     // ---------------------------------------------------------------- contact-data gradients (quad mapping)
@@ -4242,6 +4533,8 @@ struct KernelArgs {
     T* diag_out = nullptr;         // [B][2] or null: diagnostics of the final linearization: max γ/s of the cones, largest Gauss-Jordan multiplier
     const TraSD<T>* tsd = nullptr; // [Nb + 1] translational springs / dampers per supernode, or null (read by the DJ_TSD builds only)
     const MLimP<T>* mlim = nullptr;// [Nb + 1] limits on several coordinates per supernode, or null (read by the DJ_MLIM builds only)
+    const NodeP<T>* cuts = nullptr;// [ncut] loop-closing joints (read by the DJ_CUT builds only): the joint fields of NodeP, parent = body a, child[0] = body b
+    int ncut = 0;
     // iteration cap + continuation (Globals::iter_cap > 0; all three set or all null):
     T* resume = nullptr;           // [B][CARRY_PER_ENV] solver scalars of the environments the step kernel left unfinished (DJ_STATUS_CONTINUE);
                                    // entry CARRY_MARK: 1 for the environments of a workgroup on the continuation list, 0 for the others (written by
@@ -4316,10 +4609,13 @@ constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKST
 // kernels) leaves t_a / t_b / G134 -- and KernelArgs::diag_out -- at the LAST linearization it did perform, i.e. one iterate back; the plain
 // IFT kernel never reads them (lu_prepare() evaluates the linearization at the restored solution before any use), the refining one
 // re-evaluates them too (grad_entry MODE 2).  They travel for the explicit-inverse consumers only.
-// (MLIM: the DJ_MLIM builds append (s_up, s_lo, γ_up, γ_lo) of up to six limited coordinates; the host sizes the buffer with MLIM = true for such mechanisms)
-template <int MAXC, bool MLIM = (DJ_MLIM != 0)> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + (MLIM ? 24 : 0) + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
+// (GEN: the general lane-mapping builds -- DJ_MLIM and DJ_CUT together -- append (s_up, s_lo, γ_up, γ_lo) of up to six limited coordinates and the multipliers
+//  of the cut joints; the host sizes the buffer with GEN = true for mechanisms that take those builds)
+static_assert((DJ_MLIM != 0) == (DJ_CUT != 0), "the general lane-mapping builds carry DJ_MLIM and DJ_CUT together");
+template <int MAXC, bool GEN = (DJ_MLIM != 0)> constexpr int sol_record() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC + (GEN ? 24 + 6 * NCUT : 0) + 1; }   // last: 1.0 if the environment's solves were being refined (DJ_REFINE)
 template <int MAXC> constexpr int sol_flag_off() { return sol_record<MAXC>() - 1; }
 template <int MAXC> constexpr int sol_mlim_off() { return 6 + 6 + 4 + 8 * MAXC + 1 + 12 + 18 * MAXC; }
+template <int MAXC> constexpr int sol_cut_off() { return sol_mlim_off<MAXC>() + 24; }
 // quad mapping: the factors themselves travel too (72 values per lane, stored [wave][72][64 lanes]: coalesced)
 constexpr int FAC_PER_LANE = 72;
 
@@ -4327,6 +4623,14 @@ constexpr int FAC_PER_LANE = 72;
 // gradient sweeps must not cost the Newton loop its registers).  The IFT kernel rebuilds the lane
 // program from (z, u), restores the converged solution from the hand-off record and re-linearizes
 // there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
+#if DJ_CUT
+#define DJ_CUT_SETUP if constexpr (!QUAD) { prog.cutp = A.cuts; prog.ncut = A.cuts ? A.ncut : 0;                                                         \
+        for (int c_ = 0; c_ < NCUT; ++c_) for (int i = 0; i < 6; ++i)                                                                                \
+            prog.cue[c_][i] = (has_u && c_ < prog.ncut && env < A.B && i < A.cuts[c_].nu_t + A.cuts[c_].nu_r) ? T(A.u[(size_t)env * G.nu + A.cuts[c_].u_off + i]) : T(0); \
+        prog.cut_begin(); }
+#else
+#define DJ_CUT_SETUP
+#endif
 #if DJ_TSD && DJ_MLIM
 #define DJ_TSD_SETUP prog.tsd = A.tsd ? A.tsd + (k < G.Nb ? k : G.Nb) : nullptr; prog.tlim = prog.tsd != nullptr && prog.tsd->nlim > 0; prog.mlp = A.mlim ? A.mlim + (k < G.Nb ? k : G.Nb) : nullptr;
 #elif DJ_TSD
@@ -4383,7 +4687,8 @@ constexpr int FAC_PER_LANE = 72;
     T fe[6] = {0, 0, 0, 0, 0, 0};                                                                                         \
     const bool has_f = A.fext != nullptr;                                                                                 \
     if (active && has_f) for (int i = 0; i < 6; ++i) fe[i] = T(A.fext[(size_t)env * 6 * G.Nb + 6 * k + i]);             \
-    prog.begin_step(zb, has_u ? ue : nullptr, has_f ? fe : nullptr);
+    prog.begin_step(zb, has_u ? ue : nullptr, has_f ? fe : nullptr);                                                        \
+    DJ_CUT_SETUP
 
 // IFT kernel entry: one call per lane
 // MODE 0: state + control columns, pipelined sweeps; 1: contact-data columns; 2: state + control columns of the environments
@@ -4427,6 +4732,9 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
             prog.mu = r[16 + 8 * MAXC];
 #if DJ_MLIM
             for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { prog.L.mls[m][i] = r[sol_mlim_off<MAXC>() + 4 * m + i]; prog.L.mlg[m][i] = r[sol_mlim_off<MAXC>() + 4 * m + 2 + i]; }
+#endif
+#if DJ_CUT
+            for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) prog.clam[c][i] = r[sol_cut_off<MAXC>() + 6 * c + i];
 #endif
             if (QUAD) {
                 const T* r2 = r + 17 + 8 * MAXC;
@@ -4542,6 +4850,9 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #if DJ_MLIM
         for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) { r[sol_mlim_off<MAXC>() + 4 * m + i] = prog.L.mls[m][i]; r[sol_mlim_off<MAXC>() + 4 * m + 2 + i] = prog.L.mlg[m][i]; }
 #endif
+#if DJ_CUT
+        for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) r[sol_cut_off<MAXC>() + 6 * c + i] = prog.clam[c][i];
+#endif
         if (QUAD) {
             T* r2 = r + 17 + 8 * MAXC;
             for (int i = 0; i < 6; ++i) { r2[i] = prog.F.t_a[i]; r2[6 + i] = prog.F.t_b[i]; }
@@ -4595,6 +4906,13 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
 #endif
             for (int i = 0; i < 3; ++i) if (i < P.nl_r) jo[o2++] = TIO(prog.L.lam[3 + i]);
         }
+#if DJ_CUT
+        if constexpr (!QUAD) { if (A.joint_imp && k == 0) for (int c = 0; c < NCUT; ++c) if (c < prog.ncut) {     // the cut joints' multipliers, get_solution order [λ_t; λ_r]
+            TIO* jo = A.joint_imp + (size_t)env * G.n_joint_imp + A.cuts[c].imp_off; int o2 = 0;
+            for (int i = 0; i < 3; ++i) if (i < A.cuts[c].nl_t) jo[o2++] = TIO(prog.clam[c][i]);
+            for (int i = 0; i < 3; ++i) if (i < A.cuts[c].nl_r) jo[o2++] = TIO(prog.clam[c][3 + i]);
+        } }
+#endif
         if (A.contact_sg) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < P.ncontact) {

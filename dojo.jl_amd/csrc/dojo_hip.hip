@@ -45,7 +45,7 @@ DJ_DECL(dojo_launch_float_4_2) DJ_DECL(dojo_launch_double_4_2) DJ_DECL(dojo_laun
 // the builds with translational springs / dampers (-DDJ_TSD=1): single-wavefront quad mapping, <= 4 contacts per body
 DJ_DECL(dojo_launch_tsd_float_1_1) DJ_DECL(dojo_launch_tsd_float_4_1) DJ_DECL(dojo_launch_tsd_double_1_1) DJ_DECL(dojo_launch_tsd_double_4_1)
 DJ_DECL(dojo_launch_tsd_float_4_0) DJ_DECL(dojo_launch_tsd_float_8_0) DJ_DECL(dojo_launch_tsd_double_4_0) DJ_DECL(dojo_launch_tsd_double_8_0)
-DJ_DECL(dojo_launch_mlim_float_4_0) DJ_DECL(dojo_launch_mlim_float_8_0) DJ_DECL(dojo_launch_mlim_double_4_0) DJ_DECL(dojo_launch_mlim_double_8_0)
+DJ_DECL(dojo_launch_gen_float_4_0) DJ_DECL(dojo_launch_gen_float_8_0) DJ_DECL(dojo_launch_gen_double_4_0) DJ_DECL(dojo_launch_gen_double_8_0)
 DJ_DECL(dojo_launch_lin_float_1_1) DJ_DECL(dojo_launch_lin_float_4_1) DJ_DECL(dojo_launch_lin_double_1_1) DJ_DECL(dojo_launch_lin_double_4_1)     // LinearContact builds
 DJ_DECL(dojo_launch_lin_float_4_0) DJ_DECL(dojo_launch_lin_float_8_0) DJ_DECL(dojo_launch_lin_double_4_0) DJ_DECL(dojo_launch_lin_double_8_0)
 DJ_DECL(dojo_launch_ss_float_1_1) DJ_DECL(dojo_launch_ss_double_1_1)     // body-body contacts (-DDJ_SS=1): single-wavefront quad mapping, <= 1 contact per body, forward only
@@ -75,6 +75,7 @@ struct DojoSim {
     size_t w = 8;                       // bytes per scalar
     void* d_tsd = nullptr;       // translational springs / dampers per supernode (mechanisms that have them)
     void* d_mlim = nullptr;      // joint limits on several coordinates per supernode (mechanisms that have them)
+    void* d_cuts = nullptr;      // loop-closing joints (mechanisms with kinematic loops)
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_cz = nullptr;                   // maximal-state scratch of dojo_minimal_to_maximal / dojo_maximal_to_minimal (d_z stays the state of the last step)
@@ -362,6 +363,11 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
         HIPCHK(hipMalloc(&s->d_tsd, tsd.size() * sizeof(dj::TraSD<T>)));
         HIPCHK(hipMemcpy(s->d_tsd, tsd.data(), tsd.size() * sizeof(dj::TraSD<T>), hipMemcpyHostToDevice));
     }
+    if (s->M.has_cut) {
+        std::vector<dj::NodeP<T>> cn; for (auto& n_ : s->M.cuts) cn.push_back(dj::cast_node<T>(n_));
+        HIPCHK(hipMalloc(&s->d_cuts, cn.size() * sizeof(dj::NodeP<T>)));
+        HIPCHK(hipMemcpy(s->d_cuts, cn.data(), cn.size() * sizeof(dj::NodeP<T>), hipMemcpyHostToDevice));
+    }
     if (s->M.has_mlim) {
         std::vector<dj::MLimP<T>> ml;
         for (auto& a : s->M.mlim) { dj::MLimP<T> b; b.nt = a.nt; b.nr = a.nr; for (int i = 0; i < 6; ++i) { b.lo[i] = T(a.lo[i]); b.hi[i] = T(a.hi[i]); } ml.push_back(b); }
@@ -386,7 +392,7 @@ enum { PH_ALL = 0, PH_MAIN = 1, PH_GRAD = 2, PH_CONT = 3 };
 int mapping_waves(const dj::HostModel& M) {
     // translational springs / dampers / limits: the quad builds that carry them are the single-wavefront ones with <= 4 contacts per body;
     // larger mechanisms take the lane mapping (its DJ_TSD builds: k_*_{4,8}_0_tsd)
-    if (M.has_mlim) return 0;                                             // joint limits on several coordinates / both halves: k_*_{4,8}_0_mlim
+    if (M.has_mlim || M.has_cut) return 0;                                // joint limits on several coordinates / both halves, kinematic loops: k_*_{4,8}_0_gen
     if (M.has_tsd && (M.S > 16 || M.maxc > 4)) return 0;
     if (M.contact_model == 2 && (M.S > 16 || M.maxc > 4)) return 0;       // LinearContact likewise (k_*_{4,8}_0_lin)
     if (M.S <= 16) return 1;
@@ -510,6 +516,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.res = storage ? off(s->d_res, 6 * Nb) : (TIO*)nullptr;
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
     A.mlim = s->M.has_mlim ? (const dj::MLimP<T>*)s->d_mlim : nullptr;
+    A.cuts = s->M.has_cut ? (const dj::NodeP<T>*)s->d_cuts : nullptr; A.ncut = (int)s->M.cuts.size();
     A.mu_out = s->d_mu ? (T*)s->d_mu + env0 : nullptr;
     A.diag_out = (s->d_diag && quad_mapping_of(s)) ? (T*)s->d_diag + 2 * env0 : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
@@ -541,7 +548,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.sol = nullptr;
     // doubles per supernode of the step -> IFT hand-off record in the kernels that serve this mechanism (the launcher selection below: MAXC by mapping)
     const int vmaxc = !quad ? (s->M.maxc <= 4 ? 4 : 8) : NW == 2 ? (s->M.maxc <= 1 ? 1 : 4) : (s->M.maxc <= 1 ? 1 : s->M.maxc <= 4 ? 4 : 8);
-    const size_t sol_rec = s->M.has_mlim ? (vmaxc == 4 ? dj::sol_record<4, true>() : dj::sol_record<8, true>())
+    const size_t sol_rec = (s->M.has_mlim || s->M.has_cut) ? (vmaxc == 4 ? dj::sol_record<4, true>() : dj::sol_record<8, true>())
                                          : vmaxc == 1 ? dj::sol_record<1>() : vmaxc == 4 ? dj::sol_record<4>() : dj::sol_record<8>();
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(T)));   // sized for the largest record
@@ -622,7 +629,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     if (s->M.has_ss && s->M.contact_model != 2) fn = f32 ? dojo_launch_ss_float_1_1 : dojo_launch_ss_double_1_1;
     else if (s->M.contact_model == 2 && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_lin_float_4_0 : dojo_launch_lin_double_4_0) : (f32 ? dojo_launch_lin_float_8_0 : dojo_launch_lin_double_8_0);
     else if (s->M.contact_model == 2) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_lin_float_1_1 : dojo_launch_lin_double_1_1) : (f32 ? dojo_launch_lin_float_4_1 : dojo_launch_lin_double_4_1);
-    else if (s->M.has_mlim) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_mlim_float_4_0 : dojo_launch_mlim_double_4_0) : (f32 ? dojo_launch_mlim_float_8_0 : dojo_launch_mlim_double_8_0);
+    else if (s->M.has_mlim || s->M.has_cut) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_gen_float_4_0 : dojo_launch_gen_double_4_0) : (f32 ? dojo_launch_gen_float_8_0 : dojo_launch_gen_double_8_0);
     else if (s->M.has_tsd && !quad) fn = s->M.maxc <= 4 ? (f32 ? dojo_launch_tsd_float_4_0 : dojo_launch_tsd_double_4_0)
                                                        : (f32 ? dojo_launch_tsd_float_8_0 : dojo_launch_tsd_double_8_0);
     else if (s->M.has_tsd) fn = s->M.maxc <= 1 ? (f32 ? dojo_launch_tsd_float_1_1 : dojo_launch_tsd_double_1_1)
@@ -717,8 +724,8 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
         g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
-    if (s->M.has_mlim && (s->M.contact_model == 2 || s->M.has_ss)) {
-        g_err = "joint limits on several coordinates / both halves together with LinearContact or a body-body contact are not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
+    if ((s->M.has_mlim || s->M.has_cut) && (s->M.contact_model == 2 || s->M.has_ss)) {
+        g_err = "joint limits on several coordinates / both halves, or a kinematic loop, together with LinearContact or a body-body contact are not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     if (s->M.contact_model == 2 && s->M.has_tsd) {
         g_err = "LinearContact together with translational springs / dampers / limits is not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
@@ -735,7 +742,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_mlim, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
     for (void* p : pc) if (p) (void)hipFree(p);
@@ -1243,6 +1250,7 @@ int dojo_contact_gradients(DojoHandle s, void* dc) {
 int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stream) {
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (s->M.has_cut) { g_err = "dojo_minimal_to_maximal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const int B = s->B, T_ = 64;
@@ -1254,6 +1262,7 @@ int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stre
 int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stream) {
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (s->M.has_cut) { g_err = "dojo_maximal_to_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
@@ -1268,6 +1277,7 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
 int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_forces, void* stream) {
     Enter enter_(s);
     if (!s || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (s->M.has_cut) { g_err = "dojo_observe_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     if (!z) z = s->d_zn;                   // the state the last host-buffer / minimal-coordinate step left on the handle
     if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
     if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
@@ -1304,6 +1314,7 @@ int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
 int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {
     Enter enter_(s);
     if (!s || !x || !x_next) { g_err = "dojo_step_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (s->M.has_cut) { g_err = "dojo_step_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb;
     int rc;
@@ -1328,6 +1339,7 @@ int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void*
                                void* jx, void* ju, void* stream) {
     Enter enter_(s);
     if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
+    if (s->M.has_cut) { g_err = "dojo_minimal_gradients_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     const size_t B = s->B, w = s->w, Nb = s->M.Nb, nz = 13 * Nb, nx = 12 * Nb, nu = s->M.nu, nm = 2 * nu;
     hipStream_t st = (hipStream_t)stream;

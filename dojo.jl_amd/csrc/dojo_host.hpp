@@ -20,6 +20,8 @@ struct HostModel {
     bool has_tsd = false;
     std::vector<MLimP<double>> mlim;  // [Nb + 1] joint limits on several coordinates / both halves (has_mlim: every limit of the mechanism lives here)
     bool has_mlim = false;            // ... the DJ_MLIM kernels (lane mapping)
+    std::vector<NodeP<double>> cuts;  // loop-closing joints (a body's second, third ... parent joint): the joint fields of NodeP, parent = body a, child[0] = body b
+    bool has_cut = false;             // ... the DJ_CUT kernels (lane mapping)
     bool has_ss = false;          // a body-body contact (SphereSphereCollision): the DJ_SS kernels, forward only
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
     std::string error;
@@ -47,12 +49,22 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     for (int j = 0; j < tp.n_joints; ++j) {
         const DojoJoint& J = tp.joints[j];
         if (J.child < 0 || J.child >= M.Nb || J.parent >= M.Nb) { M.error = "joint with invalid body index"; return DOJO_ERR_INVALID; }
-        if (pj[J.child] >= 0) { M.error = "body with more than one parent joint (kinematic loop) is not supported"; return DOJO_ERR_UNSUPPORTED; }
-        pj[J.child] = j;
-        NodeP<double>& P = M.nodes[J.child];
+        const bool is_cut = pj[J.child] >= 0;       // the body already hangs on an earlier joint: this one closes a loop (src/solver/linear_system.jl:4-5)
+        NodeP<double> cutnode;
+        if (is_cut) {
+            if (J.parent < 0) { M.error = "a loop-closing joint to the origin is not supported (both of its bodies must be bodies of the tree)"; return DOJO_ERR_UNSUPPORTED; }
+            if ((int)M.cuts.size() >= NCUT) { M.error = "more than two loop-closing joints are not supported"; return DOJO_ERR_UNSUPPORTED; }
+            if (J.tra.nlim != 0 || J.rot.nlim != 0) { M.error = "limits on a loop-closing joint are not supported"; return DOJO_ERR_UNSUPPORTED; }
+            if (J.tra.nl < 3 && ((J.spring_on && J.tra.spring != 0) || (J.damper_on && J.tra.damper != 0))) { M.error = "translational springs / dampers on a loop-closing joint are not supported"; return DOJO_ERR_UNSUPPORTED; }
+            cutnode = NodeP<double>(); cutnode.nchild = 1; for (int i = 0; i < MAXCH; ++i) cutnode.child[i] = J.child;
+            cutnode.level = 0; cutnode.ncontact = 0; for (int i = 0; i < 8; ++i) cutnode.contact[i] = 0;
+            cutnode.m = 0; for (int i = 0; i < 9; ++i) cutnode.J[i] = 0;
+            M.has_cut = true;
+        } else pj[J.child] = j;
+        NodeP<double>& P = is_cut ? cutnode : M.nodes[J.child];
         P.parent = J.parent;
         P.nl_t = J.tra.nl; P.nl_r = J.rot.nl; P.nlim_r = M.has_mlim ? 0 : J.rot.nlim;
-        if (M.has_mlim) {
+        if (M.has_mlim && !is_cut) {
             MLimP<double>& ml = M.mlim[J.child];
             ml.nt = J.tra.nlim; ml.nr = J.rot.nlim;
             for (int i = 0; i < J.tra.nlim; ++i) { ml.lo[i] = J.tra.limit_lo[i]; ml.hi[i] = J.tra.limit_hi[i]; }
@@ -90,6 +102,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         for (int i = 0; i < 4; ++i) P.qoff[i] = J.orientation_offset[i];
         P.spring_r = J.rot.spring; P.damper_r = J.rot.damper;
         P.lim_lo = J.rot.limit_lo[0]; P.lim_hi = J.rot.limit_hi[0];
+        if (is_cut) M.cuts.push_back(cutnode);
     }
     M.nu = uoff; M.n_joint_imp = ioff;
     // NB: the u / joint-impulse offsets above follow mechanism.joints order because joints are visited in that order

@@ -214,8 +214,8 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
 
 #define DJ_CAT2(a, b, c, d) a##b##_##c##_##d
 #define DJ_CAT(a, b, c, d) DJ_CAT2(a, b, c, d)
-#if DJ_MLIM     // builds for joint limits on several coordinates / both halves (lane mapping; they carry the translational springs / dampers too)
-#define DJ_LAUNCHER DJ_CAT(dojo_launch_mlim_, DJ_TIO, DJ_MAXC, DJ_QUAD)
+#if DJ_MLIM     // the general lane-mapping builds: joint limits on several coordinates / both halves (DJ_MLIM), kinematic loops (DJ_CUT), translational springs / dampers (DJ_TSD)
+#define DJ_LAUNCHER DJ_CAT(dojo_launch_gen_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #elif DJ_LINEAR   // LinearContact builds: the step kernel alone (forward only, like the reference; no refinement, no IFT)
 #define DJ_LAUNCHER DJ_CAT(dojo_launch_lin_, DJ_TIO, DJ_MAXC, DJ_QUAD)
 #elif DJ_SS     // builds with body-body contacts: the step kernel alone (forward only)

@@ -11,10 +11,12 @@ from .quat import (qmul, qinv, vrot, axis_angle_to_quaternion, rotation_vector, 
 
 
 def _root_to_leaves(spec):
-    order, frontier = [], [k for k, j in enumerate(spec.joints) if j.parent < 0]
+    """joints of the spanning tree, root to leaves; loop-closing joints are left out (set_minimal_coordinates!(...; exclude_ids = [loop_joint_id]),
+    DojoEnvironments/src/mechanisms/fourbar/mechanism.jl:44-50: their coordinates follow from the tree's)"""
+    order, frontier = [], [k for k, j in enumerate(spec.joints) if j.parent < 0 and not getattr(j, "loop", False)]
     while frontier:
         k = frontier.pop(0); order.append(k)
-        frontier += [m for m, j in enumerate(spec.joints) if j.parent == spec.joints[k].child]
+        frontier += [m for m, j in enumerate(spec.joints) if j.parent == spec.joints[k].child and not getattr(j, "loop", False)]
     return order
 
 
@@ -169,6 +171,9 @@ def nominal_minimal(spec, **kw):
         leg = kw.get("leg_length", 0.5)
         bp = np.array(kw.get("body_position", [0, 0, 0]), float) + np.array([0, 0, leg + spec.contacts[0].radius if spec.contacts else leg + 0.05])
         return minimal_state_dict(spec, {"floating_base": [bp[0], bp[1], bp[2], 0, 0, 0], "leg": [-leg]})
+    if n == "fourbar":                       # initialize_fourbar! (fourbar/mechanism.jl:38-52): base_angle = inner_angle = π/4, the loop joint left out
+        ba, ia = kw.get("base_angle", np.pi / 4), kw.get("inner_angle", np.pi / 4)
+        return minimal_state_dict(spec, {"jointb1": [ba + ia], "jointb3": [ba - ia], "joint12": [-2 * ia], "joint34": [2 * ia]})
     if n.startswith("limited_"):             # mechanisms.get_limited_chain (tests of multi-coordinate joint limits): zero coordinates
         return np.zeros(2 * spec.nu)
     raise ValueError(n)

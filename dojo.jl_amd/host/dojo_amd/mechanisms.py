@@ -142,6 +142,27 @@ def add_limits(spec, joint_name, tra_limits=None, rot_limits=None):
     return spec
 
 
+def get_fourbar(timestep=0.01, input_scaling=None, gravity=-9.81, springs=0.0, dampers=0.0, parse_dampers=True):
+    """DojoEnvironments/src/mechanisms/fourbar/mechanism.jl:1-36 + dependencies/fourbar.urdf (floating = false): four unit links (boxes 0.1 x 0.1 x 1,
+    centre of mass half a metre below their joint), link1 and link3 on continuous joints about x to the world at z = 2.1, link2 / link4 below
+    them, and the LOOP joint joint24 between the free ends of link2 and link4 (URDF <loop_joint>): a kinematic loop, the graph is no tree.
+    URDF damping 1.0 on every joint (parse_dampers), joints in document order: jointb1, joint12, jointb3, joint34, joint24."""
+    J = np.diag([0.0841667, 0.0841667, 0.00166667])
+    bodies = [BodySpec("link%d" % i, 1.0, J.copy()) for i in (1, 2, 3, 4)]
+    dmp = 1.0 if parse_dampers else 0.0
+    top, up, dn = np.array([0, 0, 2.1]), 0.5 * Z_AXIS, -0.5 * Z_AXIS
+    joints = [Revolute("jointb1", -1, 0, X_AXIS, parent_vertex=top, child_vertex=up, damper=dmp),
+              Revolute("joint12", 0, 1, X_AXIS, parent_vertex=dn, child_vertex=up, damper=dmp),
+              Revolute("jointb3", -1, 2, X_AXIS, parent_vertex=top, child_vertex=up, damper=dmp),
+              Revolute("joint34", 2, 3, X_AXIS, parent_vertex=dn, child_vertex=up, damper=dmp),
+              Revolute("joint24", 1, 3, X_AXIS, parent_vertex=dn, child_vertex=dn, damper=dmp)]
+    joints[4].loop = True
+    spec = MechanismSpec("fourbar", bodies, joints, [], timestep, input_scaling, gravity)
+    if not parse_dampers:
+        _set_per_joint(spec, springs, dampers)
+    return spec
+
+
 def get_limited_chain(kind="spherical", timestep=0.01, input_scaling=None, gravity=-9.81, dampers=0.05):
     """Test mechanisms for joint limits on several coordinates (src/joints/limits.jl:1-61; the DojoEnvironments builders only limit
     one-dimensional joints): a link hanging from the origin on
@@ -536,7 +557,7 @@ def get_mechanism(name, **kwargs):
     return {"pendulum": get_pendulum, "block": get_block, "ant": get_ant, "quadruped": get_quadruped, "atlas": get_atlas,
             "slider": get_slider, "nslider": get_nslider, "raiberthopper": get_raiberthopper,
             "npendulum": get_npendulum, "snake": get_snake, "twister": get_twister, "sphere": get_sphere,
-            "cartpole": get_cartpole, "block2d": get_block2d, "dzhanibekov": get_dzhanibekov, "tippetop": get_tippetop, "limited_chain": get_limited_chain}[name](**kwargs)
+            "cartpole": get_cartpole, "block2d": get_block2d, "dzhanibekov": get_dzhanibekov, "tippetop": get_tippetop, "limited_chain": get_limited_chain, "fourbar": get_fourbar}[name](**kwargs)
 
 
 # the five BASELINE.json configurations

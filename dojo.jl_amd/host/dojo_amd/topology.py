@@ -120,6 +120,7 @@ class JointSpec:
     vertex_parent: np.ndarray = field(default_factory=lambda: np.zeros(3))
     vertex_child: np.ndarray = field(default_factory=lambda: np.zeros(3))
     orientation_offset: np.ndarray = field(default_factory=lambda: np.array([1.0, 0, 0, 0]))
+    loop: bool = False             # a loop-closing joint (URDF <loop_joint>, src/mechanism/urdf.jl): its child body already hangs on another joint
 
     @property
     def spring_on(self):

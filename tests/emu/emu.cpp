@@ -138,6 +138,8 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     std::vector<dj::MLimP<T>> mlim;          // joint limits on several coordinates (the -DDJ_MLIM=1 build of the emulator reads it)
     for (auto& a : M.mlim) { dj::MLimP<T> b; b.nt = a.nt; b.nr = a.nr; for (int i = 0; i < 6; ++i) { b.lo[i] = T(a.lo[i]); b.hi[i] = T(a.hi[i]); } mlim.push_back(b); }
     A.mlim = M.has_mlim ? mlim.data() : nullptr;
+    std::vector<dj::NodeP<T>> cuts; for (auto& n : M.cuts) cuts.push_back(dj::cast_node<T>(n));      // loop-closing joints (-DDJ_CUT=1 builds)
+    A.cuts = M.has_cut ? cuts.data() : nullptr; A.ncut = (int)cuts.size();
     std::vector<TIO> fet = castv(fext, (size_t)B * 6 * M.Nb); A.fext = fext ? fet.data() : nullptr;
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
@@ -267,8 +269,8 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || dz != nullptr)) {       // (as dojo_create / launch)
         if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
-    if (M.has_mlim && (quad || !DJ_MLIM)) {      // (as the product: the DJ_MLIM builds of the lane mapping)
-        if (err) std::strncpy(err, "joint limits on several coordinates / both halves need the lane mapping of a -DDJ_MLIM=1 build", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if ((M.has_mlim || M.has_cut) && (quad || !DJ_MLIM)) {      // (as the product: the general builds of the lane mapping)
+        if (err) std::strncpy(err, "joint limits on several coordinates / both halves and kinematic loops need the lane mapping of a -DDJ_MLIM=1 -DDJ_CUT=1 build", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths
     if (two && (M.maxc > 4 || M.Nc > 16 || M.has_tsd || M.contact_model == 2)) {   // (as the product's mapping_waves(): such mechanisms take the lane mapping)
         if (err) std::strncpy(err, "the two-wavefront quad mapping serves <= 4 contacts per body, <= 16 contacts, no translational springs / dampers, no LinearContact: use the lane mapping", errlen - 1); return DOJO_ERR_UNSUPPORTED; }

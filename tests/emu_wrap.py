@@ -39,13 +39,14 @@ _lib_mlim = None
 
 
 def lib_mlim():
-    """the emulator compiled with -DDJ_MLIM=1: joint limits on several coordinates / both halves (lane mapping)"""
+    """the emulator compiled with -DDJ_MLIM=1 -DDJ_CUT=1 (the product's general lane-mapping builds): joint limits on several coordinates / both
+    halves, kinematic loops"""
     global _lib_mlim
     if _lib_mlim is None:
         so = os.path.join(_HERE, "emu", "libemu_mlim.so")
         src = [os.path.join(_HERE, "emu", "emu.cpp")] + [os.path.join(_HERE, "..", "dojo.jl_amd", "csrc", f)
                                                          for f in ("dojo_device.hpp", "dojo_host.hpp", "dojo_math.hpp")]
-        _build(so, src, ("-DDJ_MLIM=1",))
+        _build(so, src, ("-DDJ_MLIM=1", "-DDJ_CUT=1"))
         _lib_mlim = C.CDLL(so)
         _lib_mlim.emu_step.restype = C.c_int
     return _lib_mlim
@@ -110,6 +111,7 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     err = C.create_string_buffer(256)
     ss = any(getattr(c, "collision", 0) == 1 for c in spec.contacts)          # body-body contacts: the emulator built with the GPU builds' flags
     mlim = any((j.tra.nlim > 1 or j.rot.nlim > 1 or (j.tra.nlim > 0 and j.rot.nlim > 0)) for j in spec.joints)     # limits on several coordinates / both halves
+    mlim = mlim or len({j.child for j in spec.joints}) < len(spec.joints)                                             # ... or a body with two parent joints (a loop)
     rc = (lib_mlim() if mlim else lib_linear() if linear else lib_ss() if ss else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:

@@ -775,3 +775,32 @@ def test_joint_limits_on_several_coordinates(kind):
     with pytest.raises(RuntimeError):
         emu_step(spec, z[None], u[None], opts=opts, quad=True)          # the quad mappings carry one limited coordinate per joint
 
+
+def test_kinematic_loop_fourbar():
+    """A mechanism whose graph is no tree (DojoEnvironments fourbar, test/behaviors.jl:57-81; the reference's LDU handles it through
+    `cyclic_children`, src/solver/linear_system.jl:4-5): the loop-closing joint stays out of the tree elimination and comes back through a
+    low-rank correction of every solve (LaneProgram::cut_*, the -DDJ_CUT=1 build of the lane program, lane mapping).  Against the oracle (dense
+    LU of the whole cyclic system): equal Newton iteration counts, states, every joint's multipliers -- the loop joint's included -- and IFT
+    Jacobians in both conventions, with inputs on the loop joint as well."""
+    spec = d.get_fourbar(timestep=0.01)
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    o = Oracle(spec, opts=opts)
+    rng = np.random.default_rng(0)
+    z = d.initialize(spec, inner_angle=0.25)
+    for k in range(24):
+        u = np.array([rng.random(), -rng.random(), 0.3 * rng.standard_normal(), 0.0, 0.5 * rng.standard_normal()])
+        zo, info = o.step(z, u)
+        if k % 6 == 0:
+            mode = (k // 6) % 2
+            r = emu_step(spec, z[None], u[None], opts=opts, quad=False, grad=True, grad_mode=mode)
+            gz, gu = o.gradients(mode)
+            sol = o.get_solution()
+            assert r["status"][0] == 0 and info["status"] == 0 and r["iters"][0] == info["iters"]
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+            assert np.abs(r["joint_imp"][0] - sol[:spec.n_joint_impulses]).max() < 1e-8
+            assert np.abs(r["dz"][0] - gz).max() <= 1e-6 * max(1.0, np.abs(gz).max()) and np.abs(r["du"][0] - gu).max() <= 1e-6 * max(1.0, np.abs(gu).max())
+            assert np.abs(gu[:, 4]).max() > 1e-6                        # the loop joint's input does act on the mechanism
+        z = zo
+    with pytest.raises(RuntimeError):
+        emu_step(spec, z[None], u[None], opts=opts, quad=True)
+

@@ -1129,6 +1129,47 @@ def test_joint_prototypes_gpu(joint_type):
         gm.close()
 
 
+def test_kinematic_loop_fourbar_gpu():
+    """A kinematic loop on the GPU (DojoEnvironments fourbar; round 5, refused before): 64 four-bar linkages under random torques on all five
+    joints, 30 steps -- states, iteration counts, every joint's multipliers (the loop joint's included) and IFT Jacobians in both conventions
+    against the oracle; the loop stays closed; the minimal-coordinate entry points refuse the mechanism loudly."""
+    from dojo_amd.quat import vrot
+    spec = d.get_fourbar(timestep=0.01)
+    B = 64
+    rng = np.random.default_rng(2)
+    z = np.stack([d.initialize(spec, inner_angle=0.15 + 0.3 * rng.random(), base_angle=np.pi / 4 + 0.3 * rng.standard_normal()) for _ in range(B)])
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    gm32 = api.BatchedMechanism(spec, B, dtype="f32", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    es = []; ez = []; eu = []; ei = []
+    for k in range(30):
+        U = rng.standard_normal((B, spec.nu)) * np.array([1.0, 0.3, 1.0, 0.3, 0.5])
+        gm.set_gradient_mode(k % 2)
+        zg, st, it = gm.step(z, U, with_gradient=True)
+        dzg, dug = gm.gradients()
+        vel, ji, cs = gm.get_solution()
+        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=k % 2, nthreads=8)
+        assert np.all(st == 0) and np.all(st_o == 0) and np.array_equal(it, it_o)
+        es.append(np.abs(zg - zo).max(axis=1))
+        ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in range(B)])
+        eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in range(B)])
+        if k % 10 == 9:
+            for b in range(4):
+                o.step(z[b], U[b]); ei.append(np.abs(ji[b] - o.get_solution()[:spec.n_joint_impulses]).max())
+            z32, st32, _ = gm32.step(z.astype(np.float32), U.astype(np.float32))
+            assert np.all(st32 == 0) and np.abs(z32.astype(np.float64) - zo).max() < 1e-3
+        z = zo
+    assert np.concatenate(es).max() <= 1e-6 and np.concatenate(ez).max() <= 1e-6 and np.concatenate(eu).max() <= 1e-6, (np.concatenate(es).max(), np.concatenate(ez).max(), np.concatenate(eu).max())
+    assert max(ei) <= 1e-6
+    Z = zg.reshape(B, 4, 13)
+    for b in range(B):
+        e2 = Z[b, 1, :3] + vrot(np.array([0, 0, -0.5]), Z[b, 1, 6:10]); e4 = Z[b, 3, :3] + vrot(np.array([0, 0, -0.5]), Z[b, 3, 6:10])
+        assert np.abs(e2 - e4).max() < 1e-6
+    with pytest.raises(api.DojoError):
+        gm.maximal_to_minimal(zg)
+    gm.close(); gm32.close()
+
+
 @pytest.mark.parametrize("kind", ["spherical", "planar", "cylindrical", "mixed"])
 def test_joint_limits_on_several_coordinates_gpu(kind):
     """Joint limits on all free coordinates of a joint half and on both halves of a joint (src/joints/limits.jl:1-61: three rotation-vector

@@ -233,3 +233,26 @@ def test_block_sparse_timing_variant_matches_the_dense_solver():
         assert np.abs(Zd[ok] - Zs[ok]).max() < 1e-9
         for b in np.nonzero(ok)[0]:
             assert np.abs(dzd[b] - dzs[b]).max() <= 1e-6 * max(1.0, np.abs(dzd[b]).max())
+
+
+@pytest.mark.parametrize("timestep", [0.10, 0.05, 0.01])
+def test_fourbar_linkage_keeps_its_loop_closed(timestep):
+    """test/behaviors.jl:57-81 "Four-bar linkage": the mechanism with a KINEMATIC LOOP (DojoEnvironments fourbar: joint24 closes link2 -- link4)
+    driven by random torques on its two base joints for 5 s; the reference asserts the relations between the joint angles of the rhombus
+    (min_coords[5] = min_coords[4] = -min_coords[3] = min_coords[2] - min_coords[1] to 1e-5) -- here as what they mean in maximal coordinates:
+    the free ends of link2 and link4 coincide, and opposite links stay parallel (link1 || link4, link2 || link3)."""
+    from dojo_amd.quat import vrot
+    spec = d.get_fourbar(timestep=timestep, parse_dampers=False, dampers=0.0)
+    o = Oracle(spec)
+    z = d.initialize(spec, inner_angle=0.25)
+    rng = np.random.default_rng(0)
+    for k in range(int(round(5.0 / timestep))):
+        z, info = o.step(z, np.array([rng.random(), -rng.random(), 0.0, 0.0, 0.0]))
+        assert info["status"] == 0, (k, info)
+    Z = z.reshape(4, 13)
+    e2 = Z[1, :3] + vrot(np.array([0, 0, -0.5]), Z[1, 6:10]); e4 = Z[3, :3] + vrot(np.array([0, 0, -0.5]), Z[3, 6:10])
+    assert np.abs(e2 - e4).max() < 1e-5, np.abs(e2 - e4).max()
+    ax = lambda q: vrot(np.array([0, 0, 1.0]), q)
+    assert np.abs(ax(Z[0, 6:10]) - ax(Z[3, 6:10])).max() < 1e-5 and np.abs(ax(Z[1, 6:10]) - ax(Z[2, 6:10])).max() < 1e-5
+    assert np.abs(Z[:, 0]).max() < 1e-9                                  # the linkage stays in the y-z plane
+
