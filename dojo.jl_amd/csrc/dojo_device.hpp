@@ -119,7 +119,7 @@ struct NodeP {
     T spring_r, damper_r, spring_off_r[3], lim_lo, lim_hi;
 };
 template <class T>
-struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2, o2[3]; int kind; };   // kind 1: SphereSphereCollision: (o, r) = (origin_parent, radius_parent), (o2, r2) = the child's; parent = the owner's tree parent
+struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2, o2[3]; int kind, pbody, cbody; };   // kind 1: SphereSphereCollision: (o, r) = (origin_parent, radius_parent), (o2, r2) = the child's; pbody / cbody: its parent body and its child body (the owner; half-space: -1 / the body)
 
 // ------------------------------------------------------------------------------------------------
 // Lane-local dynamic state
@@ -1317,6 +1317,13 @@ struct LaneProgram {
     DJ_HD int cut_a(int c) const { return cutp[c].parent; }
     DJ_HD int cut_b(int c) const { return cutp[c].child[0]; }
     DJ_HD bool cut_owner(int c) const { return active && k == cut_b(c); }
+    // A body-body contact (SphereSphereCollision) between two bodies that are no tree neighbours is a cut element as well: entry c of
+    // KernelArgs::cuts with ncontact = 1, contact[0] = its index, parent = the contact's parent body a, child[0] = its child body b (the owner:
+    // the contact sits in b's contact list with its cone variables, line searches and centering like any other contact of b).  It has no
+    // multipliers of its own -- the cone rows are condensed as for every contact -- so its M_c carries the identity in the λ block.
+    DJ_HD bool cut_is_contact(int c) const { return cutp[c].ncontact == 1; }
+    DJ_HD int cut_of_contact(int cid) const { for (int c = 0; c < NCUT; ++c) if (c < ncut && cut_is_contact(c) && cutp[c].contact[0] == cid) return c; return -1; }
+    T cPc[NCUT][36];                  // −∂(contact impulse on body a)/∂(v_a, ω_a) of a cut contact at the last Jacobian evaluation (owner lane)
     // body a's (x2, q2, v, w) on every lane
     DJ_HD void cut_fetch_a(int c, T* xa, T* qa, T* va, T* wa_) {
         const int la = base + cut_a(c);
@@ -1328,7 +1335,7 @@ struct LaneProgram {
     // set_input! / springs of the cut joints (begin_step's part for the joints that are not a supernode's own)
     DJ_HD void cut_begin() {
         for (int c = 0; c < NCUT; ++c) { for (int i = 0; i < 6; ++i) clam[c][i] = crj[c][i] = T(0); }
-        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+        for (int c = 0; c < NCUT; ++c) if (c < ncut && !cut_is_contact(c)) {
             const NodeP<T>& Pc = cutp[c];
             T xa[3], qa[4], va[3], wa_[3];
             cut_fetch_a(c, xa, qa, va, wa_);
@@ -1358,9 +1365,16 @@ struct LaneProgram {
     }
     // residual (and, JAC, M_c) of the cut joints; d = this lane's body residual under construction
     template <bool JAC>
-    DJ_HD void cut_eval(T* d, const Kin<T>& kb) {
+    DJ_HD void cut_eval(T* d, const Kin<T>& kb, const T (*cimp_p)[6]) {
         for (int c = 0; c < NCUT; ++c) if (c < ncut) {
             const NodeP<T>& Pc = cutp[c];
+            if (cut_is_contact(c)) {             // a cut contact: what it applies to body a (evaluated by the owner in the contact loop of evaluate())
+                T got[6];
+                shfl_vec<6>(wv, got, cimp_p[c], base + cut_b(c));
+                if (active && k == cut_a(c)) for (int i = 0; i < 6; ++i) d[i] -= got[i];
+                for (int i = 0; i < 6; ++i) crj[c][i] = T(0);
+                continue;
+            }
             T xa[3], qa[4], va[3], wa_[3];
             cut_fetch_a(c, xa, qa, va, wa_);
             T ia6[6] = {0, 0, 0, 0, 0, 0}, g6[6] = {0, 0, 0, 0, 0, 0};
@@ -1393,6 +1407,35 @@ struct LaneProgram {
             }
         }
     }
+#if DJ_SS
+    // M_c of the cut contacts, after evaluate<true> and the condensation (the coefficients of Δγ = k0 + coef (C Δw_b + Cp Δw_a) belong to the
+    // current cone variables): rows of body a: −Gpᵀ coef Cp − ∂(impulse on a)/∂(v_a, ω_a) | −Gpᵀ coef C;  rows of body b: −Gᵀ coef Cp | (own block: in the tree)
+    DJ_HD void cut_contacts_M() {
+        for (int c = 0; c < NCUT; ++c) if (c < ncut && cut_is_contact(c)) {
+            T Mo[18][18];
+            for (int i = 0; i < 18; ++i) for (int j = 0; j < 18; ++j) Mo[i][j] = T(0);
+            for (int i = 0; i < 6; ++i) Mo[12 + i][12 + i] = T(1);
+            if (cut_owner(c)) {
+                int lc = 0;
+                for (int i = 0; i < MAXC; ++i) if (i < P.ncontact && P.contact[i] == cutp[c].contact[0]) lc = i;
+                CCoef Q; T rc0[NCV] = {}, r580[NCV] = {};
+                contact_coef(Q, lc, rc0, r580);
+                const ContactCold<T>& cc_ = ccold(lc);
+                for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
+                    T aa = T(0), ab = T(0), ba = T(0);
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+                        const T cf = Q.coef[3 * a + b];
+                        aa += cc_.Gp134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
+                        ab += cc_.Gp134[6 * a + r] * cf * cc_.C134[6 * b + j];
+                        ba += cc_.G134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
+                    }
+                    Mo[r][j] = -aa - cPc[c][6 * r + j]; Mo[r][6 + j] = -ab; Mo[6 + r][j] = -ba;
+                }
+            }
+            for (int r = 0; r < 18; ++r) shfl_vec<18>(wv, cM[c][r], Mo[r], base + cut_b(c));
+        }
+    }
+#endif
     DJ_HD int cut_body(int c, int row) const { return row < 6 ? cut_a(c) : cut_b(c); }     // the body behind row / column 0..11 of cut c
     // after the tree factorization: W, H and the LU of the small system
     DJ_HD void cut_factor() {
@@ -1423,7 +1466,8 @@ struct LaneProgram {
             int p = kk; T best = tabs(cLU[kk][kk]);
             for (int i = kk + 1; i < n; ++i) { const T v_ = tabs(cLU[i][kk]); if (v_ > best) { best = v_; p = i; } }
             cpiv[kk] = p;
-            if (p != kk) for (int j = 0; j < n; ++j) { const T t_ = cLU[kk][j]; cLU[kk][j] = cLU[p][j]; cLU[p][j] = t_; }
+            // (columns kk.. only: cut_solve applies row exchange kk right before elimination step kk, so the multipliers of the earlier steps stay where they were stored)
+            if (p != kk) for (int j = kk; j < n; ++j) { const T t_ = cLU[kk][j]; cLU[kk][j] = cLU[p][j]; cLU[p][j] = t_; }
             const T ip = T(1) / cLU[kk][kk];
             for (int i = kk + 1; i < n; ++i) {
                 const T f_ = cLU[i][kk] * ip; cLU[i][kk] = f_;
@@ -1671,11 +1715,48 @@ struct LaneProgram {
         T upc[6] = {0, 0, 0, 0, 0, 0};                           // ... and what they apply to it
 #endif
         T dcon[6] = {0, 0, 0, 0, 0, 0}, dww[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // (split contacts: this lane's share of the contact impulses / curvature terms)
+#if DJ_CUT && DJ_SS
+        // cut contacts (a body-body contact between two bodies that are no tree neighbours): the other body's (x2, q2, v, w) on every lane,
+        // what the contact applies to it from the owner's evaluation below
+        T cob[NCUT][13], cimp_p[NCUT][6];
+        for (int e = 0; e < NCUT; ++e) { for (int i = 0; i < 6; ++i) cimp_p[e][i] = T(0); for (int i = 0; i < 13; ++i) cob[e][i] = T(0); }
+        if constexpr (kCut) { for (int e = 0; e < NCUT; ++e) if (e < ncut && cut_is_contact(e)) {
+            T xa_[3], qa_[4], va_[3], wa__[3];
+            cut_fetch_a(e, xa_, qa_, va_, wa__);
+            for (int i = 0; i < 3; ++i) { cob[e][i] = xa_[i]; cob[e][7 + i] = va_[i]; cob[e][10 + i] = wa__[i]; }
+            for (int i = 0; i < 4; ++i) cob[e][3 + i] = qa_[i];
+        } }
+#elif DJ_CUT
+        T cimp_p[NCUT][6];
+        for (int e = 0; e < NCUT; ++e) for (int i = 0; i < 6; ++i) cimp_p[e][i] = T(0);
+#endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) {
             const int c = cidx(li);
             if (c < P.ncontact) {
                 ContactEval<T>& CEc = CE[kEarly ? 0 : li];
+                bool done_ss = false;                            // a cut contact: evaluated here against the other body's state
+#if DJ_CUT && DJ_SS
+                if constexpr (kCut) { if (CP[P.contact[c]].kind == 1) {
+                    const int e = cut_of_contact(P.contact[c]);
+                    if (e >= 0) {
+                        Kin<T> kae; ContactEvalSS<T> CSe;
+                        kin_of(kae, &cob[e][0], &cob[e][3], &cob[e][7], &cob[e][10], dt);
+                        contact_eval_ss<JAC>(CEc, CSe, CP[P.contact[c]], kb, kae, L.v, L.w, &cob[e][7], &cob[e][10], L.cs[c], L.cg[c], dt, G.contact_model == 1);
+                        for (int i = 0; i < 6; ++i) cimp_p[e][i] = CSe.imp_p[i];
+                        if (JAC) {       // the own body's −∂(impulse)/∂(v, ω) beside Dww (contacts/constraints.jl:54-57); the other body's rows and curvature for its cut element
+                            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                                K.addS(i, j, -CSe.Sxx[3 * i + j]); K.addS(i, 3 + j, -CSe.Sxw[3 * i + j]); K.addS(3 + i, j, -CSe.Swx[3 * i + j]);
+                                cPc[e][6 * i + j] = CSe.Sxx[3 * i + j]; cPc[e][6 * i + 3 + j] = CSe.Pxw[3 * i + j]; cPc[e][6 * (3 + i) + j] = CSe.Pwx[3 * i + j]; cPc[e][6 * (3 + i) + 3 + j] = CSe.Pww[3 * i + j];
+                            }
+                            ContactCold<T>& cc_ = ccold(c);
+                            for (int i = 0; i < 18; ++i) { cc_.Cp134[i] = CSe.Cp134[i]; cc_.Gp134[i] = CSe.Gp134[i]; }
+                        }
+                        done_ss = true;
+                    }
+                } }
+#endif
+                if (!done_ss) {
 #if DJ_SS
                 if (kSS && CP[P.contact[c]].kind == 1) {
                     contact_eval_ss<JAC>(CEc, CS[li], CP[P.contact[c]], kb, ka, L.v, L.w, va, wa, L.cs[c], L.cg[c], dt, G.contact_model == 1);
@@ -1683,6 +1764,7 @@ struct LaneProgram {
                 } else
 #endif
                 contact_eval<JAC>(CEc, CP[P.contact[c]], kb, L.v, L.w, L.cs[c], L.cg[c], dt);
+                }
                 if constexpr (kSplitC) { for (int i = 0; i < 6; ++i) dcon[i] += CEc.imp[i]; } else { for (int i = 0; i < 6; ++i) d[i] -= CEc.imp[i]; }
                 for (int i = 0; i < NCV; ++i) cres[li][i] = CEc.c[i];
                 if (!kLinear && G.contact_model == 1) cres[li][1] = T(0);       // ImpactContact: no friction rows (rows 3, 4 are 0 − 0 already)
@@ -1720,7 +1802,7 @@ struct LaneProgram {
         if constexpr (QUAD) { mail_post_node<6>(up); mail_add_children_node<6>(d, active, G.maxch); }
         else gather_children<6>(wv, d, up, P, base, G.maxch, active, stride, q);
 #if DJ_CUT
-        if constexpr (kCut) { if (ncut > 0) cut_eval<JAC>(d, kb); }
+        if constexpr (kCut) { if (ncut > 0) cut_eval<JAC>(d, kb, cimp_p); }
 #endif
         for (int i = 0; i < 6; ++i) rb[i] = d[i];
         if (JAC) {
@@ -3079,6 +3161,15 @@ struct LaneProgram {
             }
         }
         if constexpr (kSplitC) { quad_sum(rkc); for (int i = 0; i < 6; ++i) rk[i] += rkc[i]; }
+#if DJ_CUT && DJ_SS
+        if constexpr (kCut) { for (int e = 0; e < NCUT; ++e) if (e < ncut && cut_is_contact(e)) {     // a cut contact's condensed right-hand side on the rows of its other body
+            T v6[6] = {0, 0, 0, 0, 0, 0}, got[6];
+            if (cut_owner(e)) for (int li = 0; li < CPL; ++li) if (cidx(li) < P.ncontact && P.contact[cidx(li)] == cutp[e].contact[0])
+                for (int i = 0; i < 6; ++i) for (int a = 0; a < 3; ++a) v6[i] += ccold(cidx(li)).Gp134[6 * a + i] * Q[li].k0[a];
+            shfl_vec<6>(wv, got, v6, base + cut_b(e));
+            if (active && k == cut_a(e)) for (int i = 0; i < 6; ++i) rk[i] += got[i];
+        } }
+#endif
         T kap0 = T(0), rsu = rs[0], rsl = rs[1], su = T(0), sl = T(0), gu = T(0), gl = T(0), isu = T(0), isl = T(0);
         if (lim_on()) {
             su = L.ls[0] + T(REG); sl = L.ls[1] + T(REG); gu = L.lg[0] + T(REG); gl = L.lg[1] + T(REG);
@@ -3130,6 +3221,14 @@ struct LaneProgram {
             D.dlg[0] = (R.lim[0] - gu * D.dls[0]) * isu;
             D.dlg[1] = (R.lim[1] - gl * D.dls[1]) * isl;
         } else { D.dls[0] = D.dls[1] = D.dlg[0] = D.dlg[1] = T(0); }
+#if DJ_CUT && DJ_SS
+        T cdwa[NCUT][6];                                       // Δ(v, ω) of a cut contact's other body, for the recovery of its cone variables
+        for (int e = 0; e < NCUT; ++e) for (int i = 0; i < 6; ++i) cdwa[e][i] = T(0);
+        if constexpr (kCut) { for (int e = 0; e < NCUT; ++e) if (e < ncut && cut_is_contact(e)) {
+            T own6[6] = {D.dv[0], D.dv[1], D.dv[2], D.dw[0], D.dw[1], D.dw[2]};
+            shfl_vec<6>(wv, cdwa[e], own6, base + cut_a(e));
+        } }
+#endif
 #pragma unroll
         for (int li = 0; li < CPL; ++li) {
             const int c = cidx(li);
@@ -3137,6 +3236,10 @@ struct LaneProgram {
                 const ContactP<T>& K = CP[P.contact[c]];
                 T cw[3];
                 for (int a = 0; a < 3; ++a) { cw[a] = T(0); for (int j = 0; j < 3; ++j) cw[a] += ccold(c).C134[6 * a + j] * D.dv[j] + ccold(c).C134[6 * a + 3 + j] * D.dw[j]; }
+#if DJ_CUT && DJ_SS
+                if constexpr (kCut) { if (K.kind == 1) { const int e = cut_of_contact(P.contact[c]);
+                    if (e >= 0) for (int a = 0; a < 3; ++a) for (int j = 0; j < 6; ++j) cw[a] += ccold(c).Cp134[6 * a + j] * cdwa[e][j]; } }
+#endif
 #if DJ_SS
                 if constexpr (kSS) { for (int a = 0; a < 3; ++a) for (int j = 0; j < 6; ++j) cw[a] += ccold(c).Cp134[6 * a + j] * dva[j]; }
 #endif
@@ -3557,6 +3660,9 @@ struct LaneProgram {
 #endif
         factorize(K);
 #if DJ_CUT
+#if DJ_SS
+        if constexpr (kCut) { if (ncut > 0) cut_contacts_M(); }
+#endif
         if constexpr (kCut) { if (ncut > 0) cut_factor(); }
 #endif
         }
@@ -4430,13 +4536,14 @@ DJ_HD void contact_impulses(T* imp, T* imp_par, const ContactP<T>& K, int model,
     }
 }
 
-// Body-body contacts (ContactP::kind 1) need the other body: `other(body index, zb[13], v[3], w[3])` loads its state and solution and
-// `nodes` is the node table (null: the mechanism has none).  model / cper: Globals::contact_model and the scalars per contact in csg
-// (8, LinearContact 12).
+// Body-body contacts (ContactP::kind 1) need the other body: `other(body index, zb[13], v[3], w[3])` loads its state and solution; `nodes`
+// non-null says the mechanism may have such contacts, `self` is this body's index and `Nc` the number of contacts of the mechanism (the
+// contacts this body is the PARENT of are found by their ContactP::pbody -- a tree neighbour or any other body).  model / cper:
+// Globals::contact_model and the scalars per contact in csg (8, LinearContact 12).
 struct NoOtherBody { template <class T> DJ_HD void operator()(int, T*, T*, T*) const {} };
 template <class T, class TC, class OTHER = NoOtherBody>
 DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, const T* zb, const T* v, const T* w, const TC* csg, const T* rb, const T* fe = nullptr,
-                       const NodeP<T>* nodes = nullptr, OTHER other = OTHER(), int model = 0, int cper = 8) {
+                       const NodeP<T>* nodes = nullptr, OTHER other = OTHER(), int model = 0, int cper = 8, int self = -1, int Nc = 0) {
     const T x2[3] = {zb[0], zb[1], zb[2]}, v15[3] = {zb[3], zb[4], zb[5]}, q2[4] = {zb[6], zb[7], zb[8], zb[9]}, w15[3] = {zb[10], zb[11], zb[12]};
     Kin<T> kb;
     kin_of(kb, x2, q2, v, w, dt);
@@ -4453,26 +4560,22 @@ DJ_HD void storage_row(T* row, const NodeP<T>& P, const ContactP<T>* CP, T dt, c
         const int id = P.contact[c];
         T cg[6] = {0, 0, 0, 0, 0, 0}, imp[6];
         for (int i = 0; i < nh; ++i) cg[i] = T(csg[cper * id + nh + i]);
-        if (CP[id].kind == 1) {                                  // this body is the child of a body-body contact: its parent's state at the same step
+        if (CP[id].kind == 1) {                                  // this body is the child of a body-body contact: the contact's parent body at the same step
             if (nodes == nullptr) continue;
-            T zo[13], vo[3], wo[3]; other(P.parent, zo, vo, wo);
+            T zo[13], vo[3], wo[3]; other(CP[id].pbody, zo, vo, wo);
             Kin<T> ka; kin_of(ka, zo, zo + 6, vo, wo, dt);
             contact_impulses<T>(imp, nullptr, CP[id], model, kb, &ka, cg);
         } else contact_impulses<T>(imp, nullptr, CP[id], model, kb, nullptr, cg);
         for (int i = 0; i < 6; ++i) p[i] += imp[i];
     }
-    if (nodes != nullptr) for (int ci = 0; ci < P.nchild; ++ci) {      // ... and the parent of its children's body-body contacts
-        const NodeP<T>& Pc = nodes[P.child[ci]];
-        for (int c = 0; c < Pc.ncontact; ++c) {
-            const int id = Pc.contact[c];
-            if (CP[id].kind != 1) continue;
-            T cg[6] = {0, 0, 0, 0, 0, 0}, zo[13], vo[3], wo[3], imp[6], impp[6];
-            for (int i = 0; i < nh; ++i) cg[i] = T(csg[cper * id + nh + i]);
-            other(P.child[ci], zo, vo, wo);
-            Kin<T> kc; kin_of(kc, zo, zo + 6, vo, wo, dt);
-            contact_impulses<T>(imp, impp, CP[id], model, kc, &kb, cg);
-            for (int i = 0; i < 6; ++i) p[i] += impp[i];
-        }
+    if (nodes != nullptr) for (int id = 0; id < Nc; ++id) {            // ... and the parent of others' body-body contacts
+        if (CP[id].kind != 1 || CP[id].pbody != self) continue;
+        T cg[6] = {0, 0, 0, 0, 0, 0}, zo[13], vo[3], wo[3], imp[6], impp[6];
+        for (int i = 0; i < nh; ++i) cg[i] = T(csg[cper * id + nh + i]);
+        other(CP[id].cbody, zo, vo, wo);
+        Kin<T> kc; kin_of(kc, zo, zo + 6, vo, wo, dt);
+        contact_impulses<T>(imp, impp, CP[id], model, kc, &kb, cg);
+        for (int i = 0; i < 6; ++i) p[i] += impp[i];
     }
     for (int i = 0; i < 6; ++i) p[i] *= T(0.5);
     // simulate! clears the external force before it records (simulate.jl:29-31): momentum's D2 is evaluated without it

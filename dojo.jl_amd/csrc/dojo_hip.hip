@@ -214,7 +214,7 @@ __global__ void storage_kernel(const NodeP<double>* nodes, const ContactP<double
         for (int i = 0; i < 13; ++i) zo[i] = (double)z[env * 13 * Nb + 13 * b + i];
         for (int i = 0; i < 3; ++i) { vo[i] = (double)vel[env * 6 * Nb + 6 * b + i]; wo[i] = (double)vel[env * 6 * Nb + 6 * b + 3 + i]; }
     };
-    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * (size_t)cper * Nc, rb, fext ? fe : (const double*)nullptr, nodes, other, model, cper);
+    dj::storage_row(row, nodes[k], contacts, dt, zb, v, w, csg + env * (size_t)cper * Nc, rb, fext ? fe : (const double*)nullptr, nodes, other, model, cper, k, Nc);
     TIO* o = storage + (env * Nb + k) * 25;
     for (int i = 0; i < 25; ++i) o[i] = (TIO)row[i];
 }
@@ -446,6 +446,9 @@ size_t group_count(const DojoSim* s, bool want) {
     // wavefronts (~3 GB): sixteen queues asking for it at once end in HSA_STATUS_ERROR_OUT_OF_RESOURCES (the queue aborts the
     // process).  With refinement in force the batch is stepped as at most three groups (seen green; the default queue count).
     if (std::isfinite(refine_threshold(s))) NG = std::min<size_t>(NG, 3);
+    // The general lane-mapping builds (several limits per joint, cut elements) keep ~40 KB of scratch per lane (the small dense system of the cut
+    // elements, the per-coordinate limit rows): one queue's worth of it at a time
+    if (s->M.has_mlim || s->M.has_cut) NG = 1;
     return NG;
 }
 int ensure_groups(DojoSim* s, size_t NG) {
@@ -529,7 +532,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;        // workgroups, each 64 * NW lanes
     const int g = (dz != nullptr) || (dc != nullptr);
     // (refusals first: a timing slot taken before them would never be marked used)
-    if (g && s->M.has_ss) { g_err = "gradients are not available for mechanisms with a body-body contact"; return DOJO_ERR_UNSUPPORTED; }
+    if (g && (s->M.has_ss || s->M.has_cc)) { g_err = "gradients are not available for mechanisms with a body-body contact"; return DOJO_ERR_UNSUPPORTED; }
     if (g && s->M.contact_model != 0) {   // the reference has no data Jacobians for ImpactContact / LinearContact either (src/gradients/data.jl:152-192 are NonlinearContact methods)
         g_err = "gradients are not available for ImpactContact / LinearContact mechanisms"; return DOJO_ERR_UNSUPPORTED;
     }
@@ -724,7 +727,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
         g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
-    if ((s->M.has_mlim || s->M.has_cut) && (s->M.contact_model == 2 || s->M.has_ss)) {
+    if ((s->M.has_mlim || s->M.has_cut) && (s->M.contact_model == 2 || s->M.has_ss)) {   // (has_ss: a body-body contact along a tree edge -- the quad builds; next to cut elements: not built)
         g_err = "joint limits on several coordinates / both halves, or a kinematic loop, together with LinearContact or a body-body contact are not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     if (s->M.contact_model == 2 && s->M.has_tsd) {

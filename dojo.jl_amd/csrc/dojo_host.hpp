@@ -22,6 +22,7 @@ struct HostModel {
     bool has_mlim = false;            // ... the DJ_MLIM kernels (lane mapping)
     std::vector<NodeP<double>> cuts;  // loop-closing joints (a body's second, third ... parent joint): the joint fields of NodeP, parent = body a, child[0] = body b
     bool has_cut = false;             // ... the DJ_CUT kernels (lane mapping)
+    bool has_cc = false;              // a body-body contact between bodies that are no tree neighbours (a cut element as well; forward only)
     bool has_ss = false;          // a body-body contact (SphereSphereCollision): the DJ_SS kernels, forward only
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
     std::string error;
@@ -139,9 +140,22 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         // a body-body contact (SphereSphereCollision) belongs to the supernode of its CHILD body, next to the joint that ties it to the parent
         int owner = K.body;
         if (K.collision == 1) {
-            if (K.child_body < 0 || K.child_body >= M.Nb || M.nodes[K.child_body].parent != K.body) {
-                M.error = "body-body contact: child_body must be a body whose joint hangs on `body` (the contact has to be an edge of the tree)"; return DOJO_ERR_UNSUPPORTED; }
-            owner = K.child_body; M.has_ss = true;
+            if (K.child_body < 0 || K.child_body >= M.Nb || K.child_body == K.body) { M.error = "body-body contact: invalid child_body"; return DOJO_ERR_INVALID; }
+            owner = K.child_body;
+            if (M.nodes[K.child_body].parent == K.body) M.has_ss = true;              // an edge of the tree: the DJ_SS builds of the quad mapping
+            else {
+                // SphereSphereCollision between ANY two bodies (src/contacts/collisions/sphere_sphere.jl:11-16): not an edge of the tree -- a cut element of
+                // the general lane-mapping builds, like a loop-closing joint (LaneProgram::cut_*)
+                if ((int)M.cuts.size() >= NCUT) { M.error = "more than two cut elements (loop-closing joints + body-body contacts between bodies that are no tree neighbours) are not supported"; return DOJO_ERR_UNSUPPORTED; }
+                NodeP<double> cn = NodeP<double>();
+                cn.parent = K.body; cn.nchild = 1; for (int i = 0; i < MAXCH; ++i) cn.child[i] = K.child_body;
+                cn.level = 0; cn.ncontact = 1; for (int i = 0; i < 8; ++i) cn.contact[i] = c;
+                cn.nl_t = cn.nl_r = 0; cn.nlim_r = 0; cn.spring_on = cn.damper_on = 0; cn.u_off = 0; cn.nu_t = cn.nu_r = 0; cn.imp_off = 0; cn.n_imp = 0;
+                cn.m = 0; for (int i = 0; i < 9; ++i) { cn.J[i] = cn.Ct[i] = cn.Cr[i] = cn.At[i] = cn.Ar[i] = 0; }
+                for (int i = 0; i < 3; ++i) { cn.pa[i] = cn.pb[i] = cn.spring_off_r[i] = 0; }
+                cn.qoff[0] = 1; cn.qoff[1] = cn.qoff[2] = cn.qoff[3] = 0; cn.spring_r = cn.damper_r = cn.lim_lo = cn.lim_hi = 0;
+                M.cuts.push_back(cn); M.has_cut = true; M.has_cc = true;
+            }
         } else if (K.collision != 0) { M.error = "unknown collision (0 = SphereHalfSpaceCollision, 1 = SphereSphereCollision)"; return DOJO_ERR_UNSUPPORTED; }
         NodeP<double>& P = M.nodes[owner];
         if (P.ncontact >= 8) { M.error = "more than 8 contacts on one body is not supported"; return DOJO_ERR_UNSUPPORTED; }
@@ -157,6 +171,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
         for (int i = 0; i < 6; ++i) Q.t[i] = K.model == 1 ? 0.0 : K.tangent[i];
         Q.r = K.radius; Q.mu = K.model == 1 ? 0.0 : K.friction_coefficient;
         Q.kind = K.collision; Q.r2 = K.collision == 1 ? K.child_radius : 0.0;
+        Q.pbody = K.collision == 1 ? K.body : -1; Q.cbody = owner;
         for (int i = 0; i < 3; ++i) Q.o2[i] = K.collision == 1 ? K.child_origin[i] : 0.0;
     }
     return DOJO_OK;
@@ -179,7 +194,7 @@ template <class T> inline ContactP<T> cast_contact(const ContactP<double>& a) {
     ContactP<T> b;
     for (int i = 0; i < 3; ++i) { b.n[i] = T(a.n[i]); b.o[i] = T(a.o[i]); b.off[i] = T(a.off[i]); }
     for (int i = 0; i < 6; ++i) b.t[i] = T(a.t[i]);
-    b.r = T(a.r); b.mu = T(a.mu); b.r2 = T(a.r2); b.kind = a.kind;
+    b.r = T(a.r); b.mu = T(a.mu); b.r2 = T(a.r2); b.kind = a.kind; b.pbody = a.pbody; b.cbody = a.cbody;
     for (int i = 0; i < 3; ++i) b.o2[i] = T(a.o2[i]);
     return b;
 }

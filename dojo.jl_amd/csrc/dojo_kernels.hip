@@ -251,7 +251,7 @@ extern "C" int DJ_LAUNCHER(const void* args, int grid, void* stream, int phases,
         hipLaunchKernelGGL((dojo_stepc_kernel<DJ_TIO, double, double, DJ_MAXC, R>), dim3(grid), dim3(64 * R), 0, (hipStream_t)stream, A);
     }
 #endif
-#if DJ_LINEAR || DJ_SS
+#if DJ_LINEAR || (DJ_SS && !DJ_MLIM)      // forward-only builds (the general builds carry the body-body contact code too, and an IFT kernel: the host refuses gradients per mechanism)
     return (int)hipGetLastError();
 #else
     if (phases & 2) {

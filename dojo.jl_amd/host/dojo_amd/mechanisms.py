@@ -99,18 +99,21 @@ def sphere_sphere_contact(name, parent_body, child_body, radius_parent, radius_c
                           origin_parent=np.zeros(3), origin_child=np.zeros(3)):
     """ContactConstraint((NonlinearContact | LinearContact | ImpactContact with SphereSphereCollision(origin_parent, origin_child, r_parent,
     r_child), parent_id, child_id))  src/contacts/collisions/sphere_sphere.jl:11-16; test/collisions.jl:19-52 builds it with the spheres about
-    the two centres of mass.  Forward only; `child_body`'s joint must hang on `parent_body`."""
+    the two centres of mass.  Forward only.  `child_body`'s joint hanging on `parent_body` makes the contact an edge of the tree (quad mapping);
+    any other pair of bodies is served by the general lane-mapping builds (at most two such contacts / loop joints per mechanism)."""
     return ContactSpec(name, parent_body, float(friction_coefficient), np.zeros(3), np.zeros((2, 3)), np.array(origin_parent, float), float(radius_parent), np.zeros(3),
                        CONTACT_MODELS[contact_type], collision=1, child_body=child_body, child_origin=np.array(origin_child, float), child_radius=float(radius_child))
 
 
 def get_two_spheres(timestep=0.1, input_scaling=None, gravity=-9.81, radius_body1=0.5, radius_body2=0.5, mass_body1=1.0, mass_body2=1.0,
-                    friction_type="nonlinear", friction_coefficient=0.5, joint_world_body1="Fixed"):
+                    friction_type="nonlinear", friction_coefficient=0.5, joint_world_body1="Fixed", free_on="body1"):
     """get_two_body of test/collisions.jl:2-58: a sphere on a Fixed (or Floating) joint to the world and a second, free sphere that
     touches it through a SphereSphereCollision contact.  The reference gives the second sphere no joint at all; here it carries a
     Floating joint (no rows, inputs left at zero) to the first sphere, which makes the contact an edge of the tree next to it."""
     bodies = [BodySpec("sphere1", mass_body1, sphere_inertia(radius_body1, mass_body1)), BodySpec("sphere2", mass_body2, sphere_inertia(radius_body2, mass_body2))]
-    joints = [Fixed("joint", -1, 0) if joint_world_body1 == "Fixed" else Floating("joint", -1, 0), Floating("free", 0, 1)]
+    # free_on="world": the second sphere hangs on the ORIGIN (a free body, as in the reference), so the contact connects two bodies that are no
+    # tree neighbours -- a cut element of the general lane-mapping builds (round 5); "body1": the contact is an edge of the tree (quad builds)
+    joints = [Fixed("joint", -1, 0) if joint_world_body1 == "Fixed" else Floating("joint", -1, 0), Floating("free", 0 if free_on == "body1" else -1, 1)]
     contacts = [sphere_sphere_contact("body_body", 0, 1, radius_body1, radius_body2, friction_coefficient, friction_type)]
     return MechanismSpec("two_spheres", bodies, joints, contacts, timestep, input_scaling, gravity)
 

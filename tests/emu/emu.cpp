@@ -247,7 +247,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
                 for (int i = 0; i < 13; ++i) zo[i] = T(zt[(size_t)e * nz + 13 * b + i]);
                 for (int i = 0; i < 3; ++i) { vo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + i]); wo[i] = T(velt[(size_t)e * 6 * M.Nb + 6 * b + 3 + i]); }
             };
-            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr, nodes.data(), other, M.contact_model, 2 * dj::NCV);
+            dj::storage_row(row, nodes[k], contacts.data(), T(M.dt), zb, v, w, ct.data() + (size_t)e * (2 * dj::NCV) * M.Nc, rb, fext ? fe : (const T*)nullptr, nodes.data(), other, M.contact_model, 2 * dj::NCV, k, M.Nc);
             for (int i = 0; i < 25; ++i) storage[((size_t)e * M.Nb + k) * 25 + i] = (double)TIO(row[i]);
         }
     for (size_t i = 0; i < velt.size(); ++i) vel[i] = velt[i];
@@ -269,6 +269,8 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || dz != nullptr)) {       // (as dojo_create / launch)
         if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if (M.has_cc && dz != nullptr) { if (err) std::strncpy(err, "a body-body contact has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if ((M.has_mlim || M.has_cut) && (M.has_ss || M.contact_model == 2)) { if (err) std::strncpy(err, "cut elements / several limits next to a tree-edge body-body contact or LinearContact: not built", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     if ((M.has_mlim || M.has_cut) && (quad || !DJ_MLIM)) {      // (as the product: the general builds of the lane mapping)
         if (err) std::strncpy(err, "joint limits on several coordinates / both halves and kinematic loops need the lane mapping of a -DDJ_MLIM=1 -DDJ_CUT=1 build", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     const bool two = quad && M.S > 16;          // one environment over two wavefronts: the NW = 2 layout / reduction paths

@@ -109,9 +109,11 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     stor = np.zeros((B, spec.Nb, 25))
     fext = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(B, 6 * spec.Nb))
     err = C.create_string_buffer(256)
-    ss = any(getattr(c, "collision", 0) == 1 for c in spec.contacts)          # body-body contacts: the emulator built with the GPU builds' flags
+    ss = any(getattr(c, "collision", 0) == 1 for c in spec.contacts)          # body-body contacts (tree edges): the emulator built with the GPU builds' flags
     mlim = any((j.tra.nlim > 1 or j.rot.nlim > 1 or (j.tra.nlim > 0 and j.rot.nlim > 0)) for j in spec.joints)     # limits on several coordinates / both halves
     mlim = mlim or len({j.child for j in spec.joints}) < len(spec.joints)                                             # ... or a body with two parent joints (a loop)
+    tree_parent = {j.child: j.parent for j in spec.joints if not getattr(j, "loop", False)}
+    mlim = mlim or any(getattr(c, "collision", 0) == 1 and tree_parent.get(c.child_body) != c.body for c in spec.contacts)   # ... or a body-body contact that is no tree edge
     rc = (lib_mlim() if mlim else lib_linear() if linear else lib_ss() if ss else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:

@@ -692,6 +692,95 @@ def test_body_body_contact_inside_the_ant():
     assert loaded
 
 
+@pytest.mark.parametrize("friction_type", ["nonlinear", "impact"])
+def test_body_body_contact_between_free_bodies(friction_type):
+    """SphereSphereCollision between two bodies that are NO tree neighbours (the reference's get_two_body: the second sphere has no joint at all,
+    test/collisions.jl:2-58; here both spheres hang on the origin): the contact is a cut element of the general lane-mapping builds
+    (LaneProgram::cut_contacts_M: the other body's rows through the low-rank correction of the tree solve).  The same cases as the tree-edge
+    version above: equal status and Newton iteration counts with the oracle on every step, states to 1e-9, cone variables and Storage rows to 1e-8"""
+    nh = {"impact": 1, "nonlinear": 4}[friction_type]
+    for g, joint, x2, v2, w2 in SS_CASES:
+        spec = d.get_two_spheres(friction_type=friction_type, gravity=g, joint_world_body1=joint, free_on="world")
+        o = Oracle(spec)
+        z = _two_sphere_state([0, 0, 0], x2, v2, w2)
+        hit = False
+        for k in range(20):
+            S, st = o.simulate_storage(z, np.zeros((1, spec.nu)))
+            zo, info = o.step(z, np.zeros(spec.nu))
+            r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=False)
+            assert r["status"][0] == info["status"] == 0 and r["iters"][0] == info["iters"], (joint, k)
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-9
+            assert np.abs(r["storage"][0] - S[0]).max() < 1e-8 * max(1.0, np.abs(S[0]).max())       # (momenta: the contact impulse on both spheres, found by ContactP::pbody)
+            sg = o.get_solution()[-2 * nh:]; csg = r["contact_sg"][0]
+            assert np.abs(csg[0:nh] - sg[:nh]).max() < 1e-8 and np.abs(csg[4:4 + nh] - sg[nh:]).max() < 1e-8
+            hit = hit or sg[nh] > 1e-3
+            z = zo
+        assert hit
+
+
+def _ball_on_the_ant(free):
+    """the Ant with a ball above its front left leg link: free = True: the ball is a free body (Floating joint to the origin; its contact with the
+    link is no tree edge), False: it hangs in the tree on the link"""
+    import copy
+    from dojo_amd.mechanisms import BodySpec, Floating, sphere_inertia, sphere_sphere_contact
+    base = d.baseline_config(3)
+    spec = copy.deepcopy(base)
+    link = 1                                                    # front_left_leg
+    spec.bodies.append(BodySpec("ball", 0.3, sphere_inertia(0.1, 0.3)))
+    spec.joints.append(Floating("ball_free", -1 if free else link, spec.Nb - 1))
+    spec.contacts.append(sphere_sphere_contact("ball_on_leg", link, spec.Nb - 1, 0.1, 0.1, 0.6))
+    Z0, U0 = d.synthetic_inputs(base, 1)
+    zb = np.zeros(13); zb[6] = 1.0
+    zb[0:3] = Z0[0][13 * link:13 * link + 3] + np.array([0.02, 0.01, 0.21]); zb[3:6] = Z0[0][13 * link + 3:13 * link + 6]
+    return spec, np.concatenate([Z0[0], zb]), np.concatenate([U0[0], np.zeros(6)])
+
+
+def test_free_ball_on_the_ant():
+    """a cut contact inside a BASELINE mechanism: a FREE ball dropped on the Ant's front left leg link (fourteen bodies, two trees: the Ant and the
+    ball; the four foot contacts stay half-space contacts of the tree).  Status and Newton iteration counts equal to the oracle's on every step,
+    states to 1e-7 where it converges"""
+    spec, z, u = _ball_on_the_ant(True)
+    o = Oracle(spec)
+    loaded = False
+    for k in range(10):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z[None], u[None], quad=False)
+        assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"]
+        if info["status"] == 0:
+            assert np.abs(r["z_next"][0] - zo).max() < 1e-7
+        loaded = loaded or o.get_solution()[-4] > 1e-2
+        z = zo
+    assert loaded
+
+
+def test_a_loop_and_a_free_body_contact_together():
+    """two cut elements of different kinds in one mechanism: the four-bar linkage (a loop-closing Revolute joint) and a free ball that falls on its
+    coupler link (a body-body contact between bodies of different trees): one small system with a joint block and a contact block.  Equal Newton
+    iterates with the oracle through approach, impact and rebound"""
+    import copy
+    from dojo_amd.mechanisms import BodySpec, Floating, sphere_inertia, sphere_sphere_contact
+    base = d.get_fourbar()
+    spec = copy.deepcopy(base)
+    Z0, U0 = d.synthetic_inputs(base, 1)
+    link = 1
+    spec.bodies.append(BodySpec("ball", 0.2, sphere_inertia(0.05, 0.2)))
+    spec.joints.append(Floating("ball_free", -1, spec.Nb - 1))
+    spec.contacts.append(sphere_sphere_contact("ball_on_link", link, spec.Nb - 1, 0.05, 0.05, 0.5))
+    zb = np.zeros(13); zb[6] = 1.0
+    zb[0:3] = Z0[0][13 * link:13 * link + 3] + np.array([0.0, 0.01, 0.13]); zb[3:6] = Z0[0][13 * link + 3:13 * link + 6] + np.array([0, 0, -1.5])     # thrown at the link
+    z = np.concatenate([Z0[0], zb]); u = np.concatenate([U0[0], np.zeros(6)])
+    o = Oracle(spec)
+    loaded = False
+    for k in range(8):
+        zo, info = o.step(z, u)
+        r = emu_step(spec, z[None], u[None], quad=False)
+        assert r["status"][0] == info["status"] == 0 and r["iters"][0] == info["iters"], k
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-8
+        loaded = loaded or o.get_solution()[-4] > 1e-2
+        z = zo
+    assert loaded
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gradients_of_a_forest(mode):
     """Several trees in one mechanism (bodies hanging on the origin independently): a two-link pendulum, a free sphere with a floor contact, and

@@ -127,16 +127,19 @@ def test_friction_between_the_spheres():
 
 # ---- the HIP path (GPU tier): the same mechanism through the C-ABI ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("friction_type,dtype", [("nonlinear", "f64"), ("impact", "f64"), ("linear", "f64"), ("nonlinear", "f32")])
-def test_body_body_contact_on_the_device(friction_type, dtype):
-    """the two-sphere mechanism on the GPU: a batch of 256 environments whose free sphere starts at random places above / beside the other
+@pytest.mark.parametrize("friction_type,dtype,free_on", [("nonlinear", "f64", "body1"), ("impact", "f64", "body1"), ("linear", "f64", "body1"), ("nonlinear", "f32", "body1"),
+                                                         ("nonlinear", "f64", "world"), ("impact", "f64", "world"), ("nonlinear", "f32", "world")])
+def test_body_body_contact_on_the_device(friction_type, dtype, free_on):
+    """(free_on = "world": the second sphere is a free body as in the reference's get_two_body -- the contact is no tree edge but a cut element of the
+    general lane-mapping builds, round 5; "body1": it hangs in the tree on the first sphere, the quad builds)
+    the two-sphere mechanism on the GPU: a batch of 256 environments whose free sphere starts at random places above / beside the other
     one with random velocities and spins, stepped 25 times next to the oracle: every environment-step both sides solve along the same Newton path ends within 1e-6 of the oracle's state (a bound);
     solves that take different paths are counted and bounded (see below) (fp64 ABI; the fp32 ABI, whose states are rounded between the steps); then the reference's resting case through dojo_simulate"""
     from dojo_amd import api
     B = 256
     rng = np.random.default_rng(17)
     for joint in ("Fixed", "Floating"):
-        spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81, joint_world_body1=joint)
+        spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81, joint_world_body1=joint, free_on=free_on)
         Z = np.zeros((B, 2, 13)); Z[:, :, 6] = 1.0
         dirs = rng.normal(size=(B, 3)); dirs[:, 2] = np.abs(dirs[:, 2]) + 0.3; dirs /= np.linalg.norm(dirs, axis=1)[:, None]
         Z[:, 1, 0:3] = dirs * rng.uniform(1.05, 1.6, size=(B, 1))
@@ -175,7 +178,7 @@ def test_body_body_contact_on_the_device(friction_type, dtype):
         with pytest.raises(Exception):
             gm.step(z, np.zeros((B, spec.nu)), with_gradient=True)          # forward only, like the reference's data Jacobians
         gm.close()
-    spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81)
+    spec = d.get_two_spheres(friction_type=friction_type, gravity=-9.81, free_on=free_on)
     gm = api.BatchedMechanism(spec, 4, dtype=dtype)
     z0 = _state(spec, [0, 0, 0], [0, 0, 2.0], [0, 0, 0])
     Zs, S, st = gm.simulate(np.tile(z0, (4, 1)), np.zeros((20, 4, spec.nu)), steps=20)
