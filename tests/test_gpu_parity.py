@@ -1170,6 +1170,43 @@ def test_kinematic_loop_fourbar_gpu():
     gm.close(); gm32.close()
 
 
+def test_general_builds_at_a_large_batch():
+    """the general lane-mapping builds (cut elements, several limits per joint) keep ~40 KB of scratch per lane: a batch of 4096 environments
+    (one launch, one queue -- group_count) steps and differentiates without running out of resources; sampled environments against the oracle"""
+    B = 4096
+    rng = np.random.default_rng(8)
+    spec = d.get_fourbar(timestep=0.01)
+    z = np.stack([d.initialize(spec, inner_angle=0.15 + 0.3 * rng.random(), base_angle=np.pi / 4 + 0.3 * rng.standard_normal()) for _ in range(B)])
+    gm = api.BatchedMechanism(spec, B, dtype="f64", opts=TIGHT)
+    o = Oracle(spec, opts=TIGHT)
+    for k in range(3):
+        U = rng.standard_normal((B, spec.nu)) * np.array([1.0, 0.3, 1.0, 0.3, 0.5])
+        zg, st, it = gm.step(z, U, with_gradient=True)
+        dzg, dug = gm.gradients()
+        assert np.all(st == 0)
+        idx = rng.choice(B, 8, replace=False)
+        zo, st_o, it_o, dz_o, du_o = o.step_batch(z[idx], U[idx], with_grad=True, nthreads=8)
+        assert np.array_equal(it[idx], it_o) and np.abs(zg[idx] - zo).max() < 1e-6
+        assert max(np.abs(dzg[b] - dz_o[i]).max() / max(1.0, np.abs(dz_o[i]).max()) for i, b in enumerate(idx)) < 1e-6
+        z = zg
+    gm.close()
+    spec = d.get_two_spheres(friction_type="nonlinear", gravity=-9.81, joint_world_body1="Floating", free_on="world")
+    Z = np.zeros((B, 2, 13)); Z[:, :, 6] = 1.0
+    dirs = rng.normal(size=(B, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    Z[:, 1, 0:3] = dirs * rng.uniform(1.02, 1.2, size=(B, 1)); Z[:, 1, 3:6] = -dirs * rng.uniform(0.5, 3.0, size=(B, 1)); Z[:, 1, 10:13] = rng.normal(size=(B, 3))
+    z = Z.reshape(B, -1)
+    gm = api.BatchedMechanism(spec, B, dtype="f64"); o = Oracle(spec)
+    for k in range(5):
+        zg, st, it = gm.step(z, np.zeros((B, spec.nu)))
+        idx = rng.choice(B, 16, replace=False)
+        zo, st_o, it_o = o.step_batch(z[idx], np.zeros((16, spec.nu)), nthreads=8)[:3]
+        same = (st[idx] == 0) & (st_o == 0) & (it[idx] == it_o)
+        assert same.sum() >= 14 and np.abs(zg[idx][same] - zo[same]).max() < 1e-6
+        z = zg
+    assert (st == 0).mean() > 0.99
+    gm.close()
+
+
 @pytest.mark.parametrize("kind", ["spherical", "planar", "cylindrical", "mixed"])
 def test_joint_limits_on_several_coordinates_gpu(kind):
     """Joint limits on all free coordinates of a joint half and on both halves of a joint (src/joints/limits.jl:1-61: three rotation-vector
