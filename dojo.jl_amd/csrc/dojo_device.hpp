@@ -72,6 +72,9 @@
 namespace dj {
 
 constexpr int NCUT = 2;                  // loop-closing joints per mechanism in the DJ_CUT builds
+// per-environment workspace of the cut elements in global memory (KernelArgs::cutws): M_c [NCUT][18][18], H [12 NCUT][12 NCUT], the LU of the small
+// system [18 NCUT][18 NCUT] and its row exchanges [18 NCUT] -- written by one lane of the environment, read by all of them
+constexpr int CUTWS_H = NCUT * 324, CUTWS_LU = CUTWS_H + 144 * NCUT * NCUT, CUTWS_PIV = CUTWS_LU + 324 * NCUT * NCUT, CUTWS = CUTWS_PIV + 18 * NCUT;
 constexpr int NLM = DJ_MLIM ? 6 : 1;     // limited coordinates per joint in the DJ_MLIM builds: up to 3 translational + 3 rotational
 // per supernode (DJ_MLIM builds): how many coordinates of the parent joint's translational / rotational half are limited (0 or all of the half's
 // free ones) and the bounds, translational coordinates first.  Coordinate m keeps its Δκ row in the padded multiplier slot of its own free
@@ -1311,9 +1314,14 @@ struct LaneProgram {
     T cue[NCUT][6];                   // their control inputs of this step
     T crc[NCUT][6];                   // right-hand sides of their rows in the solve in progress
     JointCfg<T> ccfg[NCUT];           // joint_cfg at (x2, q2) of the two bodies (the owner lane = body b's lane uses it)
-    T cM[NCUT][18][18];               // M_c of the last linearization
     T cW[NCUT * 12][12];              // this lane's rows of W
-    T cLU[18 * NCUT][18 * NCUT]; int cpiv[18 * NCUT];
+    // M_c of the last linearization, H and the factored small system live in global memory, once per environment (KernelArgs::cutws; as private
+    // arrays they were 23 KB of scratch per lane): the owner lanes write M_c, lane 0 of the environment writes H and factorizes, every lane reads
+    T* cws = nullptr;
+    DJ_HD T& gM(int c, int r, int j) const { return cws[(c * 18 + r) * 18 + j]; }
+    DJ_HD T& gH(int i, int j) const { return cws[CUTWS_H + i * (12 * NCUT) + j]; }
+    DJ_HD T& gLU(int i, int j) const { return cws[CUTWS_LU + i * (18 * NCUT) + j]; }
+    DJ_HD T& gpiv(int i) const { return cws[CUTWS_PIV + i]; }
     DJ_HD int cut_a(int c) const { return cutp[c].parent; }
     DJ_HD int cut_b(int c) const { return cutp[c].child[0]; }
     DJ_HD bool cut_owner(int c) const { return active && k == cut_b(c); }
@@ -1378,61 +1386,53 @@ struct LaneProgram {
             T xa[3], qa[4], va[3], wa_[3];
             cut_fetch_a(c, xa, qa, va, wa_);
             T ia6[6] = {0, 0, 0, 0, 0, 0}, g6[6] = {0, 0, 0, 0, 0, 0};
-            FullBlocks<T> Kc;
-            if (JAC) Kc.zero();
             if (cut_owner(c)) {
                 Kin<T> ka;
                 kin_of(ka, xa, qa, va, wa_, G.dt);
                 JointEval<T> E;
                 const T lg0[2] = {0, 0};
-                NullBlocks nk;
-                if (JAC) joint_eval<1>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, Kc);
-                else joint_eval<0>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, nk);
+                if (JAC) {
+                    FullBlocks<T> Kc;
+                    Kc.zero();
+                    joint_eval<1>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, Kc);
+                    // M_c: rows [body a; body b; joint] x columns [w_a; w_b; λ] out of the blocks joint_eval fills for a (parent, child) pair
+                    for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
+                        gM(c, r, j) = Kc.D[6 * r + j]; gM(c, r, 6 + j) = Kc.L[12 * r + j]; gM(c, r, 12 + j) = Kc.L[12 * r + 6 + j];
+                        gM(c, 6 + r, j) = Kc.U[6 * r + j]; gM(c, 6 + r, 6 + j) = Kc.S[12 * r + j]; gM(c, 6 + r, 12 + j) = Kc.S[12 * r + 6 + j];
+                        gM(c, 12 + r, j) = Kc.U[6 * (6 + r) + j]; gM(c, 12 + r, 6 + j) = Kc.S[12 * (6 + r) + j];
+                        gM(c, 12 + r, 12 + j) = Kc.S[12 * (6 + r) + 6 + j] + ((r == j) ? ((r < 3 ? r < Pc.nl_t : r - 3 < Pc.nl_r) ? T(REG) : T(1)) : T(0));
+                    }
+                } else { NullBlocks nk; joint_eval<0>(E, Pc, ccfg[c], true, ka, kb, wa_, L.w, clam[c], lg0, G.dt, nk); }
                 for (int i = 0; i < 6; ++i) { d[i] -= E.imp_b[i]; ia6[i] = E.imp_a[i]; g6[i] = E.g[i]; }
             }
             T got[6];
             shfl_vec<6>(wv, got, ia6, base + cut_b(c));
             if (active && k == cut_a(c)) for (int i = 0; i < 6; ++i) d[i] -= got[i];
             shfl_vec<6>(wv, crj[c], g6, base + cut_b(c));
-            if (JAC) {
-                // M_c on the owner: rows [body a; body b; joint] x columns [w_a; w_b; λ] out of the blocks joint_eval fills for a (parent, child) pair
-                T Mo[18][18];
-                for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
-                    Mo[r][j] = Kc.D[6 * r + j]; Mo[r][6 + j] = Kc.L[12 * r + j]; Mo[r][12 + j] = Kc.L[12 * r + 6 + j];
-                    Mo[6 + r][j] = Kc.U[6 * r + j]; Mo[6 + r][6 + j] = Kc.S[12 * r + j]; Mo[6 + r][12 + j] = Kc.S[12 * r + 6 + j];
-                    Mo[12 + r][j] = Kc.U[6 * (6 + r) + j]; Mo[12 + r][6 + j] = Kc.S[12 * (6 + r) + j]; Mo[12 + r][12 + j] = Kc.S[12 * (6 + r) + 6 + j];
-                }
-                for (int i = 0; i < 3; ++i) { Mo[12 + i][12 + i] += (i < Pc.nl_t) ? T(REG) : T(1); Mo[15 + i][15 + i] += (i < Pc.nl_r) ? T(REG) : T(1); }
-                for (int r = 0; r < 18; ++r) shfl_vec<18>(wv, cM[c][r], Mo[r], base + cut_b(c));
-            }
         }
     }
 #if DJ_SS
     // M_c of the cut contacts, after evaluate<true> and the condensation (the coefficients of Δγ = k0 + coef (C Δw_b + Cp Δw_a) belong to the
     // current cone variables): rows of body a: −Gpᵀ coef Cp − ∂(impulse on a)/∂(v_a, ω_a) | −Gpᵀ coef C;  rows of body b: −Gᵀ coef Cp | (own block: in the tree)
     DJ_HD void cut_contacts_M() {
-        for (int c = 0; c < NCUT; ++c) if (c < ncut && cut_is_contact(c)) {
-            T Mo[18][18];
-            for (int i = 0; i < 18; ++i) for (int j = 0; j < 18; ++j) Mo[i][j] = T(0);
-            for (int i = 0; i < 6; ++i) Mo[12 + i][12 + i] = T(1);
-            if (cut_owner(c)) {
-                int lc = 0;
-                for (int i = 0; i < MAXC; ++i) if (i < P.ncontact && P.contact[i] == cutp[c].contact[0]) lc = i;
-                CCoef Q; T rc0[NCV] = {}, r580[NCV] = {};
-                contact_coef(Q, lc, rc0, r580);
-                const ContactCold<T>& cc_ = ccold(lc);
-                for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
-                    T aa = T(0), ab = T(0), ba = T(0);
-                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-                        const T cf = Q.coef[3 * a + b];
-                        aa += cc_.Gp134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
-                        ab += cc_.Gp134[6 * a + r] * cf * cc_.C134[6 * b + j];
-                        ba += cc_.G134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
-                    }
-                    Mo[r][j] = -aa - cPc[c][6 * r + j]; Mo[r][6 + j] = -ab; Mo[6 + r][j] = -ba;
+        for (int c = 0; c < NCUT; ++c) if (c < ncut && cut_is_contact(c) && cut_owner(c)) {
+            int lc = 0;
+            for (int i = 0; i < MAXC; ++i) if (i < P.ncontact && P.contact[i] == cutp[c].contact[0]) lc = i;
+            CCoef Q; T rc0[NCV] = {}, r580[NCV] = {};
+            contact_coef(Q, lc, rc0, r580);
+            const ContactCold<T>& cc_ = ccold(lc);
+            for (int r = 0; r < 6; ++r) for (int j = 0; j < 6; ++j) {
+                T aa = T(0), ab = T(0), ba = T(0);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+                    const T cf = Q.coef[3 * a + b];
+                    aa += cc_.Gp134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
+                    ab += cc_.Gp134[6 * a + r] * cf * cc_.C134[6 * b + j];
+                    ba += cc_.G134[6 * a + r] * cf * cc_.Cp134[6 * b + j];
                 }
+                gM(c, r, j) = -aa - cPc[c][6 * r + j]; gM(c, r, 6 + j) = -ab; gM(c, 6 + r, j) = -ba; gM(c, 6 + r, 6 + j) = T(0);
+                gM(c, r, 12 + j) = gM(c, 6 + r, 12 + j) = gM(c, 12 + r, j) = gM(c, 12 + r, 6 + j) = T(0);
+                gM(c, 12 + r, 12 + j) = (r == j) ? T(1) : T(0);
             }
-            for (int r = 0; r < 18; ++r) shfl_vec<18>(wv, cM[c][r], Mo[r], base + cut_b(c));
         }
     }
 #endif
@@ -1440,40 +1440,44 @@ struct LaneProgram {
     // after the tree factorization: W, H and the LU of the small system
     DJ_HD void cut_factor() {
         const int n = 18 * ncut;
-        T H[12 * NCUT][12 * NCUT];
         for (int c = 0; c < NCUT; ++c) if (c < ncut) for (int col = 0; col < 12; ++col) {
             T rk[12], up[6] = {0, 0, 0, 0, 0, 0}, dk[12], dva[6];
             for (int i = 0; i < 12; ++i) rk[i] = T(0);
             if (active && k == cut_body(c, col)) rk[col % 6] = T(1);
             core_solve(rk, up, dk, dva);
             for (int i = 0; i < 12; ++i) cW[12 * c + col][i] = dk[i];
-            for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int row = 0; row < 12; ++row)
-                H[12 * e + row][12 * c + col] = wv.shfl(dk[row % 6], base + cut_body(e, row));
+            for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int row = 0; row < 12; ++row) {
+                const T h_ = wv.shfl(dk[row % 6], base + cut_body(e, row));
+                if (active && k == 0) gH(12 * e + row, 12 * c + col) = h_;
+            }
         }
-        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) cLU[i][j] = T(0);
-        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
-            for (int i = 0; i < 12; ++i) {
-                cLU[18 * c + i][18 * c + i] = T(1);
-                for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int j = 0; j < 18; ++j) {
-                    T a_ = T(0);
-                    for (int m = 0; m < 12; ++m) a_ += H[12 * c + i][12 * e + m] * cM[e][m][j];
-                    cLU[18 * c + i][18 * e + j] += a_;
+        wv.sync_mem();                                            // (M_c from the owner lanes, H from lane 0)
+        if (active && k == 0) {                                   // one lane per environment: I + H M with the elements' own rows below, LU with partial pivoting in place
+            for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) gLU(i, j) = T(0);
+            for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+                for (int i = 0; i < 12; ++i) {
+                    for (int e = 0; e < NCUT; ++e) if (e < ncut) for (int j = 0; j < 18; ++j) {
+                        T a_ = (e == c && j == i) ? T(1) : T(0);
+                        for (int m = 0; m < 12; ++m) a_ += gH(12 * c + i, 12 * e + m) * gM(e, m, j);
+                        gLU(18 * c + i, 18 * e + j) = a_;
+                    }
+                }
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 18; ++j) gLU(18 * c + 12 + i, 18 * c + j) = gM(c, 12 + i, j);
+            }
+            for (int kk = 0; kk < n; ++kk) {
+                int p = kk; T best = tabs(gLU(kk, kk));
+                for (int i = kk + 1; i < n; ++i) { const T v_ = tabs(gLU(i, kk)); if (v_ > best) { best = v_; p = i; } }
+                gpiv(kk) = T(p);
+                // (columns kk.. only: cut_solve applies row exchange kk right before elimination step kk, so the multipliers of the earlier steps stay where they were stored)
+                if (p != kk) for (int j = kk; j < n; ++j) { const T t_ = gLU(kk, j); gLU(kk, j) = gLU(p, j); gLU(p, j) = t_; }
+                const T ip = T(1) / gLU(kk, kk);
+                for (int i = kk + 1; i < n; ++i) {
+                    const T f_ = gLU(i, kk) * ip; gLU(i, kk) = f_;
+                    for (int j = kk + 1; j < n; ++j) gLU(i, j) -= f_ * gLU(kk, j);
                 }
             }
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 18; ++j) cLU[18 * c + 12 + i][18 * c + j] = cM[c][12 + i][j];
         }
-        for (int kk = 0; kk < n; ++kk) {                      // LU with partial pivoting, in place (the same arithmetic on every lane)
-            int p = kk; T best = tabs(cLU[kk][kk]);
-            for (int i = kk + 1; i < n; ++i) { const T v_ = tabs(cLU[i][kk]); if (v_ > best) { best = v_; p = i; } }
-            cpiv[kk] = p;
-            // (columns kk.. only: cut_solve applies row exchange kk right before elimination step kk, so the multipliers of the earlier steps stay where they were stored)
-            if (p != kk) for (int j = kk; j < n; ++j) { const T t_ = cLU[kk][j]; cLU[kk][j] = cLU[p][j]; cLU[p][j] = t_; }
-            const T ip = T(1) / cLU[kk][kk];
-            for (int i = kk + 1; i < n; ++i) {
-                const T f_ = cLU[i][kk] * ip; cLU[i][kk] = f_;
-                for (int j = kk + 1; j < n; ++j) cLU[i][j] -= f_ * cLU[kk][j];
-            }
-        }
+        wv.sync_mem();
     }
     // the tree solve followed by the correction for the cut joints; rc = right-hand sides of their rows, dlc = their multipliers' part of the solution
     DJ_HD void cut_solve(const T* rk, const T* up, const T (*rc)[6], T* dk, T* dva, T (*dlc)[6]) {
@@ -1485,16 +1489,18 @@ struct LaneProgram {
             for (int row = 0; row < 12; ++row) z[18 * c + row] = wv.shfl(dk[row % 6], base + cut_body(c, row));
             for (int i = 0; i < 6; ++i) z[18 * c + 12 + i] = rc[c][i];
         }
-        for (int kk = 0; kk < n; ++kk) { const int p = cpiv[kk]; if (p != kk) { const T t_ = z[kk]; z[kk] = z[p]; z[p] = t_; } for (int i = kk + 1; i < n; ++i) z[i] -= cLU[i][kk] * z[kk]; }
-        for (int i = n - 1; i >= 0; --i) { T a_ = z[i]; for (int j = i + 1; j < n; ++j) a_ -= cLU[i][j] * z[j]; z[i] = a_ / cLU[i][i]; }
-        for (int c = 0; c < NCUT; ++c) if (c < ncut) {
-            for (int m = 0; m < 12; ++m) {
-                T f_ = T(0);
-                for (int j = 0; j < 18; ++j) f_ += cM[c][m][j] * z[18 * c + j];
-                for (int i = 0; i < 12; ++i) dk[i] -= cW[12 * c + m][i] * f_;
+        if (active) {                                             // (every lane of the environment reads the same factors: broadcast loads)
+            for (int kk = 0; kk < n; ++kk) { const int p = (int)gpiv(kk); if (p != kk) { const T t_ = z[kk]; z[kk] = z[p]; z[p] = t_; } for (int i = kk + 1; i < n; ++i) z[i] -= gLU(i, kk) * z[kk]; }
+            for (int i = n - 1; i >= 0; --i) { T a_ = z[i]; for (int j = i + 1; j < n; ++j) a_ -= gLU(i, j) * z[j]; z[i] = a_ / gLU(i, i); }
+            for (int c = 0; c < NCUT; ++c) if (c < ncut) {
+                for (int m = 0; m < 12; ++m) {
+                    T f_ = T(0);
+                    for (int j = 0; j < 18; ++j) f_ += gM(c, m, j) * z[18 * c + j];
+                    for (int i = 0; i < 12; ++i) dk[i] -= cW[12 * c + m][i] * f_;
+                }
+                for (int i = 0; i < 6; ++i) dlc[c][i] = z[18 * c + 12 + i];
             }
-            for (int i = 0; i < 6; ++i) dlc[c][i] = z[18 * c + 12 + i];
-        }
+        } else { for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) dlc[c][i] = T(0); }
         T own6[6] = {dk[0], dk[1], dk[2], dk[3], dk[4], dk[5]}, par6[6];
         shfl_vec<6>(wv, par6, own6, plane);
         for (int i = 0; i < 6; ++i) dva[i] = has_parent ? par6[i] : T(0);
@@ -4638,6 +4644,7 @@ struct KernelArgs {
     const MLimP<T>* mlim = nullptr;// [Nb + 1] limits on several coordinates per supernode, or null (read by the DJ_MLIM builds only)
     const NodeP<T>* cuts = nullptr;// [ncut] loop-closing joints (read by the DJ_CUT builds only): the joint fields of NodeP, parent = body a, child[0] = body b
     int ncut = 0;
+    T* cutws = nullptr;            // [B][CUTWS] workspace of the cut elements (M_c, H, the factored small system), or null
     // iteration cap + continuation (Globals::iter_cap > 0; all three set or all null):
     T* resume = nullptr;           // [B][CARRY_PER_ENV] solver scalars of the environments the step kernel left unfinished (DJ_STATUS_CONTINUE);
                                    // entry CARRY_MARK: 1 for the environments of a workgroup on the continuation list, 0 for the others (written by
@@ -4727,7 +4734,8 @@ constexpr int FAC_PER_LANE = 72;
 // program from (z, u), restores the converged solution from the hand-off record and re-linearizes
 // there -- the same final linearization mehrotra! leaves behind (src/gradients/state.jl:78-84).
 #if DJ_CUT
-#define DJ_CUT_SETUP if constexpr (!QUAD) { prog.cutp = A.cuts; prog.ncut = A.cuts ? A.ncut : 0;                                                         \
+#define DJ_CUT_SETUP if constexpr (!QUAD) { prog.cutp = A.cuts; prog.ncut = (A.cuts && A.cutws) ? A.ncut : 0;                                              \
+        prog.cws = A.cutws ? A.cutws + (size_t)(env < A.B ? env : 0) * CUTWS : nullptr;                                                             \
         for (int c_ = 0; c_ < NCUT; ++c_) for (int i = 0; i < 6; ++i)                                                                                \
             prog.cue[c_][i] = (has_u && c_ < prog.ncut && env < A.B && i < A.cuts[c_].nu_t + A.cuts[c_].nu_r) ? T(A.u[(size_t)env * G.nu + A.cuts[c_].u_off + i]) : T(0); \
         prog.cut_begin(); }

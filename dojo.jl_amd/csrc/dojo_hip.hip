@@ -76,6 +76,7 @@ struct DojoSim {
     void* d_tsd = nullptr;       // translational springs / dampers per supernode (mechanisms that have them)
     void* d_mlim = nullptr;      // joint limits on several coordinates per supernode (mechanisms that have them)
     void* d_cuts = nullptr;      // loop-closing joints (mechanisms with kinematic loops)
+    void* d_cutws = nullptr;     // [B][dj::CUTWS] doubles: per-environment workspace of the cut elements (KernelArgs::cutws)
     void* d_nodes = nullptr; void* d_contacts = nullptr; int* d_order = nullptr;   // tables; bodies in root -> leaves order
     void *d_x = nullptr, *d_xn = nullptr;   // minimal-coordinate buffers of the host-pointer entry points
     void *d_cz = nullptr;                   // maximal-state scratch of dojo_minimal_to_maximal / dojo_maximal_to_minimal (d_z stays the state of the last step)
@@ -367,6 +368,7 @@ int upload_tables(DojoSim* s) {   // tables are stored in the state precision (f
         std::vector<dj::NodeP<T>> cn; for (auto& n_ : s->M.cuts) cn.push_back(dj::cast_node<T>(n_));
         HIPCHK(hipMalloc(&s->d_cuts, cn.size() * sizeof(dj::NodeP<T>)));
         HIPCHK(hipMemcpy(s->d_cuts, cn.data(), cn.size() * sizeof(dj::NodeP<T>), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&s->d_cutws, (size_t)s->B * dj::CUTWS * sizeof(T)));
     }
     if (s->M.has_mlim) {
         std::vector<dj::MLimP<T>> ml;
@@ -520,6 +522,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     A.tsd = s->M.has_tsd ? (const dj::TraSD<T>*)s->d_tsd : nullptr;
     A.mlim = s->M.has_mlim ? (const dj::MLimP<T>*)s->d_mlim : nullptr;
     A.cuts = s->M.has_cut ? (const dj::NodeP<T>*)s->d_cuts : nullptr; A.ncut = (int)s->M.cuts.size();
+    A.cutws = s->M.has_cut ? (T*)s->d_cutws + env0 * (size_t)dj::CUTWS : nullptr;
     A.mu_out = s->d_mu ? (T*)s->d_mu + env0 : nullptr;
     A.diag_out = (s->d_diag && quad_mapping_of(s)) ? (T*)s->d_diag + 2 * env0 : nullptr;
     // mapping: four lanes per supernode when the mechanism has <= 16 bodies (one Ant per wavefront) or <= 32 bodies
@@ -745,7 +748,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_cutws, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
     for (void* p : pc) if (p) (void)hipFree(p);

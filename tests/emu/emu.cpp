@@ -140,6 +140,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     A.mlim = M.has_mlim ? mlim.data() : nullptr;
     std::vector<dj::NodeP<T>> cuts; for (auto& n : M.cuts) cuts.push_back(dj::cast_node<T>(n));      // loop-closing joints (-DDJ_CUT=1 builds)
     A.cuts = M.has_cut ? cuts.data() : nullptr; A.ncut = (int)cuts.size();
+    std::vector<T> cutws(M.has_cut ? (size_t)B * dj::CUTWS : 0); A.cutws = M.has_cut ? cutws.data() : nullptr;
     std::vector<TIO> fet = castv(fext, (size_t)B * 6 * M.Nb); A.fext = fext ? fet.data() : nullptr;
     A.z = zt.data(); A.u = u ? ut.data() : nullptr; A.z_next = zn.data(); A.status = status; A.iters = iters;
     A.vel = vel ? velt.data() : nullptr; A.joint_imp = jimp ? jt.data() : nullptr; A.contact_sg = csg ? ct.data() : nullptr;
