@@ -77,9 +77,11 @@ function export_topology(m::Dojo.Mechanism{T,Nn,Ne,Nb,Ni}) where {T,Nn,Ne,Nb,Ni}
         impact = c.model isa Dojo.ImpactContact
         col = c.model.collision
         if col isa Dojo.SphereSphereCollision
-            # body-body contact (src/contacts/collisions/sphere_sphere.jl): forward only, spheres about the centres of mass, and the child body's
-            # joint must hang on the parent body.  A child body WITHOUT a joint (test/collisions.jl:2-58) gets a Floating joint to the parent here:
-            # no rows; its six inputs come last in the library's u and must stay zero (pad u accordingly).
+            # body-body contact (src/contacts/collisions/sphere_sphere.jl): forward only.  Where the child body's joint hangs on the parent body the
+            # contact is an edge of the tree (the fast quad builds); between any other two bodies the library carries it as a cut element (general
+            # lane-mapping builds, at most two per mechanism, NonlinearContact / ImpactContact).  A child body WITHOUT a joint (test/collisions.jl:2-58)
+            # gets a Floating joint to the parent here -- the tree-edge form: no rows; its six inputs come last in the library's u and must stay zero
+            # (pad u accordingly).
             cb = bidx(c.child_id)
             if !any(j -> j.child == cb, joints)
                 free = CJointHalf(0, 0, ntuple(_ -> 0.0, 9), rowmajor([1.0 0 0; 0 1 0; 0 0 1]), 0.0, 0.0, ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3), ntuple(_ -> 0.0, 3))

@@ -718,6 +718,39 @@ def test_body_body_contact_between_free_bodies(friction_type):
         assert hit
 
 
+def folded_chain(friction_type="nonlinear", r=0.2, spread=None):
+    """a three-link pendulum folded into a triangle, spheres on its first and last link: a body-body contact between two bodies of the SAME tree
+    that are no neighbours (the cut element's H has the coupling of the two bodies through the tree).  spread: a random generator -> perturbed copy"""
+    from dojo_amd.mechanisms import sphere_sphere_contact
+    from dojo_amd.coords import minimal_state_dict, minimal_to_maximal
+    spec = d.get_npendulum(num_bodies=3, timestep=0.01, dampers=0.1)
+    spec.contacts.append(sphere_sphere_contact("first_on_last", 0, 2, r, r, 0.5, friction_type))
+    a = np.array([0.3, 2.15, 2.15]); v = np.array([0.0, 0.5, 1.5])
+    if spread is not None:
+        a = a + 0.05 * spread.standard_normal(3); v = v + 0.3 * spread.standard_normal(3)
+    x = minimal_state_dict(spec, coords={"joint:%d" % (i + 1): [a[i]] for i in range(3)}, vels={"joint:%d" % (i + 1): [v[i]] for i in range(3)})
+    return spec, minimal_to_maximal(spec, x)
+
+
+@pytest.mark.parametrize("friction_type", ["nonlinear", "impact"])
+def test_body_body_contact_between_the_ends_of_a_chain(friction_type):
+    """a cut contact inside ONE tree: the first and the last link of a folded three-link pendulum touch (no tree neighbours: the middle link sits
+    between them).  Approach, impact -- one step on which the reference's algorithm runs into max_iter on both sides --, sliding contact and
+    release: status and Newton iteration counts equal to the oracle's on every step, states to 1e-8"""
+    spec, z = folded_chain(friction_type)
+    o = Oracle(spec)
+    nh = {"impact": 1, "nonlinear": 4}[friction_type]
+    loaded = 0
+    for k in range(25):
+        zo, info = o.step(z, np.zeros(spec.nu))
+        r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=False)
+        assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"], k
+        assert np.abs(r["z_next"][0] - zo).max() < 1e-8
+        loaded += o.get_solution()[-nh] > 1e-2
+        z = zo
+    assert loaded >= 5
+
+
 def _ball_on_the_ant(free):
     """the Ant with a ball above its front left leg link: free = True: the ball is a free body (Floating joint to the origin; its contact with the
     link is no tree edge), False: it hangs in the tree on the link"""

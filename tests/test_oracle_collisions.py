@@ -213,3 +213,28 @@ def test_body_body_contact_off_the_centres_of_mass_on_the_device(friction_type):
             z = zg
         gm.close()
         assert n_apart <= 0.02 * 20 * B, n_apart
+
+
+@pytest.mark.gpu
+def test_body_body_contact_between_the_ends_of_a_chain_on_the_device():
+    """a cut contact inside one tree on the GPU: 64 perturbed copies of tests/test_device_program_emu.py::folded_chain (the first and the last link of
+    a folded three-link pendulum touch), 25 steps next to the oracle: states to 1e-6 wherever both sides take the same Newton path, at most 2 % of
+    the environment-steps apart (the impact step runs into max_iter on both sides for part of the copies)"""
+    from dojo_amd import api
+    from test_device_program_emu import folded_chain
+    B = 64
+    rng = np.random.default_rng(11)
+    spec = folded_chain()[0]
+    z = np.stack([folded_chain(spread=rng)[1] for _ in range(B)])
+    gm = api.BatchedMechanism(spec, B, dtype="f64"); o = Oracle(spec)
+    n_apart = 0; touched = 0
+    for k in range(25):
+        zg, st, it = gm.step(z, np.zeros((B, spec.nu)))
+        Zo, st_o, it_o = o.step_batch(z, np.zeros((B, spec.nu)), nthreads=8)[:3]
+        same = (st == 0) & (st_o == 0) & (it == it_o)
+        n_apart += int(((st != st_o) | ((st == 0) & (st_o == 0) & (it != it_o))).sum())
+        assert np.abs(zg[same] - Zo[same]).max() < 1e-6, (k, np.abs(zg[same] - Zo[same]).max())
+        touched += int((np.linalg.norm(Zo[:, 0:3] - Zo[:, 26:29], axis=1) < 0.4 + 1e-3).sum())
+        z = Zo
+    gm.close()
+    assert touched > B and n_apart <= 0.02 * 25 * B, (touched, n_apart)
