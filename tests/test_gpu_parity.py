@@ -1148,11 +1148,15 @@ def test_kinematic_loop_fourbar_gpu():
         zg, st, it = gm.step(z, U, with_gradient=True)
         dzg, dug = gm.gradients()
         vel, ji, cs = gm.get_solution()
-        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=k % 2, nthreads=8)
+        wg = k % 6 >= 4                                         # (the oracle's IFT: two steps of six, one per convention)
+        res_o = o.step_batch(z, U, with_grad=wg, grad_mode=k % 2, nthreads=8)
+        zo, st_o, it_o = res_o[:3]
         assert np.all(st == 0) and np.all(st_o == 0) and np.array_equal(it, it_o)
         es.append(np.abs(zg - zo).max(axis=1))
-        ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in range(B)])
-        eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in range(B)])
+        if wg:
+            dz_o, du_o = res_o[3], res_o[4]
+            ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in range(B)])
+            eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in range(B)])
         if k % 10 == 9:
             for b in range(4):
                 o.step(z[b], U[b]); ei.append(np.abs(ji[b] - o.get_solution()[:spec.n_joint_impulses]).max())
@@ -1226,14 +1230,18 @@ def test_joint_limits_on_several_coordinates_gpu(kind):
         zg, st, it = gm.step(z, U, with_gradient=True)
         dzg, dug = gm.gradients()
         vel, ji, cs = gm.get_solution()
-        zo, st_o, it_o, dz_o, du_o = o.step_batch(z, U, with_grad=True, grad_mode=k % 2, nthreads=8)
+        wg = k % 8 >= 6                                         # (the oracle's dense IFT solve is the cost of this test: two steps of eight, one per convention)
+        res_o = o.step_batch(z, U, with_grad=wg, grad_mode=k % 2, nthreads=8)
+        zo, st_o, it_o = res_o[:3]
         ok = np.nonzero((st == 0) & (st_o == 0))[0]
         assert len(ok) > 0.9 * B
         reg_ = (it[ok] <= REGULAR_ITERS) & (it_o[ok] <= REGULAR_ITERS)
         assert np.array_equal(it[ok][reg_], it_o[ok][reg_])
         es.append(np.abs(zg[ok] - zo[ok]).max(axis=1))
-        ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
-        eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
+        if wg:
+            dz_o, du_o = res_o[3], res_o[4]
+            ez.append([np.abs(dzg[b] - dz_o[b]).max() / max(1.0, np.abs(dz_o[b]).max()) for b in ok])
+            eu.append([np.abs(dug[b] - du_o[b]).max() / max(1.0, np.abs(du_o[b]).max()) for b in ok])
         if k % 10 == 9:
             for b in ok[:8]:
                 o.step(z[b], U[b])
@@ -1243,7 +1251,7 @@ def test_joint_limits_on_several_coordinates_gpu(kind):
     es, ez, eu = np.concatenate(es), np.concatenate(ez), np.concatenate(eu)
     assert hit > B
     assert es.max() <= 1e-6, (es.max(),)
-    # (mixed: the foot's contact next to two active limits -- one environment-step of 2550 reaches 1.2e-6 at rtol = btol = 1e-8, every other one <= 1e-12;
+    # (mixed: the foot's contact next to two active limits -- one environment-step of 2550 reached 1.2e-6 at rtol = btol = 1e-8 when every step was compared, every other one <= 1e-12;
     #  the tight-tolerance criterion of test_parity_at_the_baseline_batch_distinct_seeds: 1e-4 with at most 0.1 % above 1e-6)
     e_ = np.maximum(ez, eu)
     assert e_.max() <= (1e-4 if kind == "mixed" else 1e-6) and (e_ > 1e-6).mean() <= 1e-3, (ez.max(), eu.max(), int((e_ > 1e-6).sum()))

@@ -18,7 +18,14 @@ for seed in range(s0, s0 + cnt):
     nb = int(rng.choice([1, 2, 3, 5, 8, 12, 15, 16] if TRA else [1, 2, 3, 5, 8, 12, 15, 16, 17, 20, 28, 31, 32, 33, 36, 48]))
     impact = seed % 5 == 4
     try:
-        spec, z0, u0 = random_mechanism(seed, nb=nb, contact_type="impact" if impact else "nonlinear", translational=TRA, tra_limits=TRA)
+        if os.environ.get("SWEEP_CUT", "0") == "1":          # cut elements (tools/random_cut_sweep.py: a loop-closing joint, a free ball on a body, a contact between
+            sys.path.insert(0, os.path.join(ROOT, "tools"))   # two bodies of the tree that are no neighbours); gradients for the loops only (body-body contacts: forward only)
+            from random_cut_sweep import with_cut
+            got = with_cut(seed)
+            if got is None: continue
+            kind, spec, z0, u0 = got; nb = spec.Nb; impact = kind != "loop"
+        else:
+            spec, z0, u0 = random_mechanism(seed, nb=nb, contact_type="impact" if impact else "nonlinear", translational=TRA, tra_limits=TRA)
         B = 3
         Z = np.tile(z0, (B, 1)); U = np.tile(u0, (B, 1)) + rng.normal(size=(B, spec.nu)) * 0.2
         gm = api.BatchedMechanism(spec, B, dtype="f64", opts=opts)
