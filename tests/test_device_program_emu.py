@@ -2,6 +2,7 @@
 thread-based SIMT emulator (tests/emu) against the oracle.  Small cases only (the emulator pays
 two barriers per wave shuffle); the real parity tests are the -m gpu ones."""
 import os
+import sys
 import numpy as np
 import pytest
 import dojo_amd as d
@@ -749,6 +750,17 @@ def test_body_body_contact_between_the_ends_of_a_chain(friction_type):
         loaded += o.get_solution()[-nh] > 1e-2
         z = zo
     assert loaded >= 5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 15, 85, 20])
+def test_random_mechanisms_with_a_cut_element(seed):
+    """tools/random_cut_sweep.py on a handful of its seeds (two per kind: a loop-closing Spherical joint between two random bodies of a random tree,
+    a free ball thrown at a body, a contact between two bodies of the tree that are no neighbours): status, iteration counts and states equal to
+    the oracle's over six steps, the IFT Jacobians of the loops on the last one"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from random_cut_sweep import run
+    msg, worst = run(seed)
+    assert msg.endswith(" ok"), msg
 
 
 def _ball_on_the_ant(free):
