@@ -83,6 +83,21 @@ struct OracleT : IOracle {
             for (int i = 0; i < 3; ++i) out[i] = (double)d[i];
             return 3;
         }
+        if (what >= 19) {
+            // what 19 / 20: impulse_map(:parent / :child, joint half, xa, qa, xb, qb, η) * λ -> 6   (joints/joint.jl:67-86), λ = in[14 : 14 + N]
+            // what 21..24: impulse_map_jacobian(relative, jacobian, joint half, pbody, cbody, λ) -> 6x6, (relative, jacobian) = pp, pc, cp, cc
+            //              (joints/impulses.jl:13-21) -- what test/impulse_map.jl:171-292 ("Impulse map") differentiates
+            const int N = h.N();                          // impulses_length: Nλ + 2 Nb (the projector's columns; <= 15: the p + velocity slots of `in`)
+            M lam(N, 1); for (int i = 0; i < N; ++i) lam[i] = (T)in[14 + i];
+            if (what <= 20) { M r = m.half_impulse_map(what == 19, J, h, xa, qa, xb, qb) * lam; for (int i = 0; i < 6; ++i) out[i] = (double)r[i]; return 6; }
+            if (what > 24) return -1;
+            orc::State<T> pa, ch;
+            pa.x2 = xa; pa.q2 = qa; ch.x2 = xb; ch.q2 = qb;
+            const int k = what - 21;
+            M Jm = m.half_impulse_map_jacobian(k < 2, (k % 2) == 0, J, h, pa, ch, lam);
+            for (int i = 0; i < 36; ++i) out[i] = (double)Jm.a[i];
+            return 36;
+        }
         if (what >= 9) {
             // dampers of the joint half at the states in = [xa qa xb qb | p(3, unused) | va ωa vb ωb] (candidate velocities: vsol[2], ωsol[2]):
             //   what 9 / 10: damper_impulses(:parent / :child, ...) = timestep * damper_force(...; rotate = true, unitary = false) -> 6

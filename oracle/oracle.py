@@ -228,7 +228,10 @@ class Oracle:
     def joint_unit(self, joint, half, what, xa, qa, xb, qb, p=None, vel=None):
         """displacement (what 0) / displacement_jacobian_configuration(:parent 1 | :child 2; attjac) / impulse_transform * p (3 | 4) /
         impulse_transform_jacobian (5..8: pp, pc, cp, cc) / damper impulses (9 | 10) and their configuration (11..14) and velocity
-        (15..18) Jacobians at the velocities vel = [va ωa vb ωb], of one joint half (0 translational, 1 rotational); see oracle/capi.cpp"""
+        (15..18) Jacobians at the velocities vel = [va ωa vb ωb], of one joint half (0 translational, 1 rotational); impulse_map * λ (19 | 20)
+        and impulse_map_jacobian (21..24), λ = p (impulses_length entries); see oracle/capi.cpp"""
+        if what >= 19:
+            p = np.concatenate([np.asarray(p, float), np.zeros(15 - len(p))]); vel = np.zeros(0)
         inp = np.concatenate([xa, qa, xb, qb, np.zeros(3) if p is None else p, np.zeros(12) if vel is None else vel]).astype(np.float64); out = np.zeros(36)
         n = self._L.orc_joint_unit(self.h, int(joint), int(half), int(what), _p(inp), _p(out))
         return out[:n].copy()

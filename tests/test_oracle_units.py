@@ -94,6 +94,38 @@ def test_impulse_transform_jacobians(name, kw, joint, half):
         assert np.abs(J0 - _fd(f, np.concatenate([x, q])) @ att).max() < 1e-6
 
 
+@pytest.mark.parametrize("name,kw,joint,half", [("pendulum", dict(), 0, 1), ("pendulum", dict(), 0, 0), ("twister", dict(num_bodies=3), 2, 1),
+                                                ("slider", dict(), 0, 0), ("pendulum", dict(joint_limits=True), 0, 1)])
+def test_impulse_map_jacobians(name, kw, joint, half):
+    """test/impulse_map.jl:171-292 ("Impulse map"): impulse_map_jacobian(relative, jacobian, joint half, pbody, cbody, λ) against the derivative of
+    impulse_map(relative, joint half, xa, qa, xb, qb, η) * λ w.r.t. the configuration of the `jacobian` body times the attitude Jacobian, all four
+    (relative, jacobian) pairs, at random configurations and a random orientation offset; the reference's two cases (the pendulum's rotational half,
+    λ = rand(2), and its translational one, λ = rand(3)), a joint with non-trivial vertices, a Prismatic joint, and a joint half with limits (the
+    projector's limit columns: η-free, joints/joint.jl:88-94)."""
+    import dojo_amd as d
+    if kw.get("joint_limits"):
+        spec = d.get_mechanism(name); d.set_limits(spec, {spec.joints[0].name: (-0.3, 0.4)})
+    else:
+        spec = d.get_mechanism(name, **kw)
+    rng = np.random.default_rng(6)
+    spec.joints[joint].orientation_offset = _rand_quat(rng)                      # rot0.orientation_offset = rand(QuatRotation).q
+    o = oracle.Oracle(spec)
+    jh = spec.joints[joint].rot if half else spec.joints[joint].tra
+    nlam = jh.N                                                                   # impulses_length of the half: Nλ + 4 x (limited coordinates)
+    xa, xb, qa, qb = rng.normal(size=3), rng.normal(size=3), _rand_quat(rng), _rand_quat(rng)
+    lam = rng.random(nlam)
+    for k, (rel_parent, jac_parent) in enumerate(((True, True), (True, False), (False, True), (False, False))):
+        J0 = o.joint_unit(joint, half, 21 + k, xa, qa, xb, qb, lam).reshape(6, 6)
+        x, q = (xa, qa) if jac_parent else (xb, qb)
+        def f(z):
+            if jac_parent:
+                return o.joint_unit(joint, half, 19 if rel_parent else 20, z[:3], z[3:], xb, qb, lam)
+            return o.joint_unit(joint, half, 19 if rel_parent else 20, xa, qa, z[:3], z[3:], lam)
+        att = np.zeros((7, 6)); att[:3, :3] = np.eye(3); att[3:, 3:] = _lvt(q)
+        assert np.abs(J0).max() > 1e-3
+        assert np.abs(J0 - _fd(f, np.concatenate([x, q])) @ att).max() < 1e-6, (name, half, rel_parent, jac_parent)
+
+
 JOINT_TYPES = ["Fixed", "Prismatic", "Planar", "FixedOrientation", "Revolute", "Cylindrical", "PlanarAxis", "FreeRevolute", "Orbital",
                "PrismaticOrbital", "PlanarOrbital", "FreeOrbital", "Spherical", "CylindricalFree", "PlanarFree"]
 
