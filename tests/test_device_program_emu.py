@@ -938,3 +938,33 @@ def test_kinematic_loop_fourbar():
     with pytest.raises(RuntimeError):
         emu_step(spec, z[None], u[None], opts=opts, quad=True)
 
+
+
+def test_cut_elements_with_several_environments_per_wavefront():
+    """the cut elements' workspace is per ENVIRONMENT (KernelArgs::cutws: lane 0 of every environment gathers H and factorizes, every lane of the
+    environment reads back): a batch of five environments, four per wavefront (the last wavefront holds one and three empty slots) -- the
+    four-bar with gradients and the two free spheres, every environment against the oracle"""
+    rng = np.random.default_rng(21)
+    spec = d.get_fourbar(timestep=0.01)
+    B = 5
+    Z = np.stack([d.initialize(spec, inner_angle=0.15 + 0.3 * rng.random(), base_angle=np.pi / 4 + 0.3 * rng.standard_normal()) for _ in range(B)])
+    U = rng.standard_normal((B, spec.nu)) * np.array([1.0, 0.3, 1.0, 0.3, 0.5])
+    o = Oracle(spec)
+    r = emu_step(spec, Z, U, quad=False, grad=True, envs_per_wave=4)
+    zo, st_o, it_o, dz_o, du_o = o.step_batch(Z, U, with_grad=True)
+    assert np.all(r["status"] == 0) and np.all(st_o == 0) and np.array_equal(r["iters"], it_o)
+    assert np.abs(r["z_next"] - zo).max() < 1e-9
+    for b in range(B):
+        assert np.abs(r["dz"][b] - dz_o[b]).max() <= 1e-6 * max(1.0, np.abs(dz_o[b]).max()) and np.abs(r["du"][b] - du_o[b]).max() <= 1e-6 * max(1.0, np.abs(du_o[b]).max())
+    assert np.abs(r["z_next"][0] - r["z_next"][1]).max() > 1e-3                      # (distinct environments)
+    spec = d.get_two_spheres(friction_type="nonlinear", gravity=-9.81, joint_world_body1="Floating", free_on="world")
+    Z = np.zeros((B, 2, 13)); Z[:, :, 6] = 1.0
+    dirs = rng.normal(size=(B, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    Z[:, 1, 0:3] = dirs * 1.01; Z[:, 1, 3:6] = -dirs * rng.uniform(0.5, 2.0, size=(B, 1)); Z[:, 1, 10:13] = rng.normal(size=(B, 3))
+    Z = Z.reshape(B, -1)
+    o = Oracle(spec)
+    for k in range(3):
+        r = emu_step(spec, Z, np.zeros((B, spec.nu)), quad=False, envs_per_wave=4)
+        zo, st_o, it_o = o.step_batch(Z, np.zeros((B, spec.nu)))[:3]
+        assert np.array_equal(r["status"], st_o) and np.array_equal(r["iters"], it_o) and np.abs(r["z_next"] - zo).max() < 1e-8
+        Z = zo
