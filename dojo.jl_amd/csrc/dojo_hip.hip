@@ -727,8 +727,13 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     DojoSim* s = new DojoSim();
     int rc = dj::build_host_model(*topo, s->M);
     if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
+    if (s->M.has_ss && s->M.contact_model != 2 && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd || s->M.has_mlim || s->M.has_cut)) {
+        // the tree-edge builds (k_*_1_1_ss) do not serve this mechanism: the contact travels as a cut element of the general lane-mapping builds
+        rc = dj::promote_tree_edge_contacts(s->M);
+        if (rc != DOJO_OK) { g_err = s->M.error; delete s; return rc; }
+    }
     if (s->M.has_ss && (mapping_waves(s->M) != 1 || s->M.maxc > 1 || s->M.has_tsd)) {
-        g_err = "a body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
+        g_err = "a LinearContact body-body contact needs the single-wavefront quad mapping (<= 16 bodies), at most one contact per body and no translational springs / dampers / limits"; delete s; return DOJO_ERR_UNSUPPORTED;
     }
     if ((s->M.has_mlim || s->M.has_cut) && (s->M.contact_model == 2 || s->M.has_ss)) {   // (has_ss: a body-body contact along a tree edge -- the quad builds; next to cut elements: not built)
         g_err = "joint limits on several coordinates / both halves, or a kinematic loop, together with LinearContact or a body-body contact are not supported (no kernel build carries both)"; delete s; return DOJO_ERR_UNSUPPORTED;

@@ -28,6 +28,34 @@ struct HostModel {
     std::string error;
 };
 
+// the cut element of a body-body contact (LaneProgram::cut_*): parent = the contact's parent body a, child[0] = its child body b (the owner), contact[0] = its index
+inline NodeP<double> contact_cut_node(int a, int b, int c) {
+    NodeP<double> cn = NodeP<double>();
+    cn.parent = a; cn.nchild = 1; for (int i = 0; i < MAXCH; ++i) cn.child[i] = b;
+    cn.level = 0; cn.ncontact = 1; for (int i = 0; i < 8; ++i) cn.contact[i] = c;
+    cn.nl_t = cn.nl_r = 0; cn.nlim_r = 0; cn.spring_on = cn.damper_on = 0; cn.u_off = 0; cn.nu_t = cn.nu_r = 0; cn.imp_off = 0; cn.n_imp = 0;
+    cn.m = 0; for (int i = 0; i < 9; ++i) { cn.J[i] = cn.Ct[i] = cn.Cr[i] = cn.At[i] = cn.Ar[i] = 0; }
+    for (int i = 0; i < 3; ++i) { cn.pa[i] = cn.pb[i] = cn.spring_off_r[i] = 0; }
+    cn.qoff[0] = 1; cn.qoff[1] = cn.qoff[2] = cn.qoff[3] = 0; cn.spring_r = cn.damper_r = cn.lim_lo = cn.lim_hi = 0;
+    return cn;
+}
+// A body-body contact along a TREE EDGE has builds of its own in the single-wavefront quad mapping (has_ss).  Where those do not serve the mechanism
+// (more than 16 bodies, several contacts per body, translational springs / dampers / limits, several limits per joint, cut elements next to it) the
+// contact is carried as a cut element of the general lane-mapping builds instead -- the cut machinery does not care whether a and b are neighbours.
+inline int promote_tree_edge_contacts(HostModel& M) {
+    for (int c = 0; c < (int)M.contacts.size(); ++c) {
+        const ContactP<double>& Q = M.contacts[c];
+        if (Q.kind != 1 || M.nodes[Q.cbody].parent != Q.pbody) continue;
+        bool have = false;
+        for (auto& cn : M.cuts) if (cn.ncontact == 1 && cn.contact[0] == c) have = true;
+        if (have) continue;
+        if ((int)M.cuts.size() >= NCUT) { M.error = "more than two cut elements (loop-closing joints + body-body contacts outside the single-wavefront quad builds) are not supported"; return DOJO_ERR_UNSUPPORTED; }
+        M.cuts.push_back(contact_cut_node(Q.pbody, Q.cbody, c)); M.has_cut = true; M.has_cc = true;
+    }
+    M.has_ss = false;
+    return DOJO_OK;
+}
+
 inline int build_host_model(const DojoTopology& tp, HostModel& M) {
     M.Nb = tp.n_bodies; M.Nc = tp.n_contacts; M.dt = tp.timestep; M.input_scaling = tp.input_scaling;
     for (int i = 0; i < 3; ++i) M.g[i] = tp.gravity[i];
@@ -147,14 +175,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
                 // SphereSphereCollision between ANY two bodies (src/contacts/collisions/sphere_sphere.jl:11-16): not an edge of the tree -- a cut element of
                 // the general lane-mapping builds, like a loop-closing joint (LaneProgram::cut_*)
                 if ((int)M.cuts.size() >= NCUT) { M.error = "more than two cut elements (loop-closing joints + body-body contacts between bodies that are no tree neighbours) are not supported"; return DOJO_ERR_UNSUPPORTED; }
-                NodeP<double> cn = NodeP<double>();
-                cn.parent = K.body; cn.nchild = 1; for (int i = 0; i < MAXCH; ++i) cn.child[i] = K.child_body;
-                cn.level = 0; cn.ncontact = 1; for (int i = 0; i < 8; ++i) cn.contact[i] = c;
-                cn.nl_t = cn.nl_r = 0; cn.nlim_r = 0; cn.spring_on = cn.damper_on = 0; cn.u_off = 0; cn.nu_t = cn.nu_r = 0; cn.imp_off = 0; cn.n_imp = 0;
-                cn.m = 0; for (int i = 0; i < 9; ++i) { cn.J[i] = cn.Ct[i] = cn.Cr[i] = cn.At[i] = cn.Ar[i] = 0; }
-                for (int i = 0; i < 3; ++i) { cn.pa[i] = cn.pb[i] = cn.spring_off_r[i] = 0; }
-                cn.qoff[0] = 1; cn.qoff[1] = cn.qoff[2] = cn.qoff[3] = 0; cn.spring_r = cn.damper_r = cn.lim_lo = cn.lim_hi = 0;
-                M.cuts.push_back(cn); M.has_cut = true; M.has_cc = true;
+                M.cuts.push_back(contact_cut_node(K.body, K.child_body, c)); M.has_cut = true; M.has_cc = true;
             }
         } else if (K.collision != 0) { M.error = "unknown collision (0 = SphereHalfSpaceCollision, 1 = SphereSphereCollision)"; return DOJO_ERR_UNSUPPORTED; }
         NodeP<double>& P = M.nodes[owner];

@@ -268,6 +268,10 @@ extern "C" int emu_step(const DojoTopology* tp, const DojoSolverOptions* opts, i
     int rc = dj::build_host_model(*tp, M);
     if (rc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return rc; }
     if (quad && M.S > 32) { if (err) std::strncpy(err, "quad mapping needs <= 32 bodies", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
+    if (M.has_ss && M.contact_model != 2 && DJ_MLIM && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || M.has_mlim || M.has_cut)) {      // (as dojo_create: the contact travels as a cut element)
+        int prc = dj::promote_tree_edge_contacts(M);
+        if (prc != DOJO_OK) { if (err) std::strncpy(err, M.error.c_str(), errlen - 1); return prc; }
+    }
     if (M.has_ss && (!quad || M.S > 16 || M.maxc > 1 || M.has_tsd || dz != nullptr)) {       // (as dojo_create / launch)
         if (err) std::strncpy(err, "a body-body contact needs the single-wavefront quad mapping, <= 1 contact per body, and has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }
     if (M.has_cc && dz != nullptr) { if (err) std::strncpy(err, "a body-body contact has no gradients", errlen - 1); return DOJO_ERR_UNSUPPORTED; }

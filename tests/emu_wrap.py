@@ -114,6 +114,9 @@ def emu_step(spec, Z, U=None, opts=None, dtype="f64", grad=False, grad_mode=0, e
     mlim = mlim or len({j.child for j in spec.joints}) < len(spec.joints)                                             # ... or a body with two parent joints (a loop)
     tree_parent = {j.child: j.parent for j in spec.joints if not getattr(j, "loop", False)}
     mlim = mlim or any(getattr(c, "collision", 0) == 1 and tree_parent.get(c.child_body) != c.body for c in spec.contacts)   # ... or a body-body contact that is no tree edge
+    # ... or a tree-edge body-body contact the quad builds do not serve (lane mapping, more than 16 bodies, several contacts per body): promoted to a cut element
+    owners = [getattr(c, "child_body", -1) if getattr(c, "collision", 0) == 1 else c.body for c in spec.contacts]
+    mlim = mlim or (ss and not linear and (not quad or spec.Nb > 16 or (owners and max(owners.count(b) for b in set(owners)) > 1)))
     rc = (lib_mlim() if mlim else lib_linear() if linear else lib_ss() if ss else lib()).emu_step(C.byref(topo), C.byref(o), grad_mode, {"f64": 0, "f32": 1, "f32mixed": 3}[dtype], int(quad), B, envs_per_wave,
                         _p(Z), _p(U), _p(Zn), _p(st), _p(it), _p(vel), _p(jimp), _p(csg), _p(dz), _p(du), _p(dbg), err, 256, _p(dc), _p(stor), _p(fext))
     if rc != 0:

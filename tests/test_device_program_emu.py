@@ -968,3 +968,47 @@ def test_cut_elements_with_several_environments_per_wavefront():
         zo, st_o, it_o = o.step_batch(Z, np.zeros((B, spec.nu)))[:3]
         assert np.array_equal(r["status"], st_o) and np.array_equal(r["iters"], it_o) and np.abs(r["z_next"] - zo).max() < 1e-8
         Z = zo
+
+
+def ball_on_atlas():
+    """Atlas (31 bodies, four contacts per foot) with a ball that hangs in the tree on its upper torso and is thrown at it: a body-body contact
+    ALONG A TREE EDGE in a mechanism the tree-edge builds (single-wavefront quad mapping, one contact per body) do not serve"""
+    import copy
+    from dojo_amd.mechanisms import BodySpec, Floating, sphere_inertia, sphere_sphere_contact
+    base = d.baseline_config(5)
+    spec = copy.deepcopy(base)
+    link = [b.name for b in spec.bodies].index("utorso")
+    spec.bodies.append(BodySpec("ball", 2.0, sphere_inertia(0.15, 2.0)))
+    spec.joints.append(Floating("ball_free", link, spec.Nb - 1))
+    spec.contacts.append(sphere_sphere_contact("ball_on_torso", link, spec.Nb - 1, 0.25, 0.15, 0.6))
+    Z0, U0 = d.synthetic_inputs(base, 1)
+    zb = np.zeros(13); zb[6] = 1.0
+    zb[0:3] = Z0[0][13 * link:13 * link + 3] + np.array([0.03, 0.02, 0.43]); zb[3:6] = Z0[0][13 * link + 3:13 * link + 6] + np.array([0, 0, -1.5])
+    return spec, np.concatenate([Z0[0], zb]), np.concatenate([U0[0], np.zeros(6)])
+
+
+def test_tree_edge_body_body_contacts_outside_the_quad_builds():
+    """where the tree-edge builds do not serve a mechanism -- the lane mapping, more than 16 bodies, several contacts per body -- a body-body contact
+    between a body and its tree child travels as a cut element (dojo_host.hpp promote_tree_edge_contacts; refused until round 5): the two-sphere
+    mechanism through the lane mapping, the ball hanging on the Ant's leg through the lane mapping, and a ball thrown at Atlas's torso (32 bodies,
+    nine contacts).  Status and Newton iteration counts equal to the oracle's on every step -- the steps that run into max_iter on both sides
+    included --, states to 1e-8 where it converges"""
+    for g, joint, x2, v2, w2 in SS_CASES[-2:]:
+        spec = d.get_two_spheres(friction_type="nonlinear", gravity=g, joint_world_body1=joint, free_on="body1")
+        o = Oracle(spec); z = _two_sphere_state([0, 0, 0], x2, v2, w2)
+        for k in range(12):
+            zo, info = o.step(z, np.zeros(spec.nu))
+            r = emu_step(spec, z[None], np.zeros((1, spec.nu)), quad=False)
+            assert r["status"][0] == info["status"] == 0 and r["iters"][0] == info["iters"] and np.abs(r["z_next"][0] - zo).max() < 1e-8, (joint, k)
+            z = zo
+    for (spec, z, u), steps in ((_ball_on_the_ant(False), 8), (ball_on_atlas(), 5)):
+        o = Oracle(spec); loaded = False
+        for k in range(steps):
+            zo, info = o.step(z, u)
+            r = emu_step(spec, z[None], u[None], quad=False)
+            assert r["status"][0] == info["status"] and r["iters"][0] == info["iters"], (spec.Nb, k)
+            if info["status"] == 0:
+                assert np.abs(r["z_next"][0] - zo).max() < 1e-8
+            loaded = loaded or o.get_solution()[-4] > 1e-2
+            z = zo
+        assert loaded

@@ -238,3 +238,30 @@ def test_body_body_contact_between_the_ends_of_a_chain_on_the_device():
         z = Zo
     gm.close()
     assert touched > B and n_apart <= 0.02 * 25 * B, (touched, n_apart)
+
+
+@pytest.mark.gpu
+def test_ball_on_atlas_on_the_device():
+    """a body-body contact in a mechanism of 32 bodies with four contacts per foot (tests/test_device_program_emu.py::ball_on_atlas): the tree-edge
+    builds do not serve it, the contact travels as a cut element of the general lane-mapping builds (refused until round 5).  32 perturbed copies,
+    six steps next to the oracle: states to 1e-6 wherever both sides take the same Newton path, at most 5 % of the environment-steps apart"""
+    from dojo_amd import api
+    from test_device_program_emu import ball_on_atlas
+    spec, z0, u0 = ball_on_atlas()
+    B = 32
+    rng = np.random.default_rng(2)
+    Z = np.tile(z0, (B, 1)); Z[:, -13:-10] += 0.01 * rng.normal(size=(B, 3)); Z[:, -10:-7] += 0.2 * rng.normal(size=(B, 3))
+    U = np.tile(u0, (B, 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f64"); o = Oracle(spec)
+    z = Z.copy(); n_apart = 0; loaded = 0
+    for k in range(6):
+        zg, st, it = gm.step(z, U)
+        vel, ji, cs = gm.get_solution()
+        Zo, st_o, it_o = o.step_batch(z, U, nthreads=8)[:3]
+        same = (st == 0) & (st_o == 0) & (it == it_o)
+        n_apart += int(((st != st_o) | ((st == 0) & (st_o == 0) & (it != it_o))).sum())
+        assert same.any() and np.abs(zg[same] - Zo[same]).max() < 1e-6, (k, np.abs(zg[same] - Zo[same]).max())
+        loaded += int((cs[:, -4] > 1e-2).sum())
+        z = Zo
+    gm.close()
+    assert loaded > B and n_apart <= 0.05 * 6 * B, (loaded, n_apart)
