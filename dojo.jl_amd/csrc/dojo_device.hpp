@@ -63,6 +63,11 @@
                             // only (one lane per supernode); every limit of such a mechanism runs through this path (KernelArgs::mlim).
 #endif
 
+#ifndef DJ_ROWS
+#define DJ_ROWS 2           // the factorization's level passes: 0 = quad layout only (factorize_quad), 1 = row layout only (factorize_rows: the host must
+                            // hand such a build only mechanisms with Globals::rows > 0), 2 = both, Globals::rows decides at run time
+#endif
+
 #ifndef DJ_CUT
 #define DJ_CUT 0            // 1: builds for mechanisms with KINEMATIC LOOPS (a body with more than one parent joint: src/solver/linear_system.jl:4-5
                             // `cyclic_children`, the four-bar of test/behaviors.jl:57-81).  The loop-closing ("cut") joints stay out of the tree
@@ -107,6 +112,13 @@ struct Globals {
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
     unsigned char maxch_lev[64]; // largest number of children among the supernodes of each level (bounds the level sweeps' gathers)
+    // Row layout of the factorization's level passes (LaneProgram::factorize_rows; single-wavefront quad mapping, Wave::kRows): pass t
+    // factorizes up to four supernodes of one tree level, each on a 16-lane row of the wavefront.  rp_slot[t][g] = the supernode slot
+    // (lane >> 2) group g serves in pass t, -1 = none; passes run leaves -> root.  rows = 0: the quad-layout passes (factorize_quad).
+    int rows;
+    signed char rp_slot[16][4];
+    unsigned char rp_lev[16];
+    signed char rp_child[16][4][MAXCH];   // the slots of that supernode's children (-1: none), in NodeP::child order
 };
 
 // per-supernode constants (body k, its parent joint, its contacts)
@@ -2273,6 +2285,171 @@ struct LaneProgram {
         }
     }
 
+    // ---------------------------------------------------------------- quad mapping: the level passes in the ROW layout
+    // factorize_quad runs every level pass on all 16 supernode slots of the wavefront although only the supernodes AT the level change
+    // (an Ant level holds 1 / 4 / 4 / 4 of its 13), and each of its pivot rows costs 24 v_mov_b32_dpp next to 33 multiply-adds.  Here
+    // the supernodes of a level cross to a 16-lane row each (Globals::rp_slot: four per pass; lane r of the row holds matrix row r,
+    // lanes 12..15 idle) through LDS, and the pass runs there: the Gauss-Jordan step  A[r][c] -= f_r A[p][c]  is ONE instruction per
+    // column, v_fmac_f64_dpp row_newbcast:p (Wave::row_fmac) -- the pivot row arrives inside the multiply-add -- and so are the terms of
+    // S^-1 U and L (S^-1 U).  The inverse rows go back to the quad lanes, which keep them for the solves exactly as factorize_quad leaves
+    // them; the Schur complement is posted to the mailbox by the row lanes in the slots the parent's gather reads.  Every number is
+    // produced by the same operations in the same order as in factorize_quad: the two are interchangeable bit for bit
+    // (tests/test_device_program_emu.py::test_row_layout_factorization_is_the_quad_one).
+    static constexpr bool kRowsOk = QUAD && Wave::kRows && MAXC == 1 && !(kTrack && DJ_TRACK_GROWTH);
+    double* stA = nullptr; double* stB = nullptr;      // StepLds::stA_off / stB_off (null: this kernel's LDS layout has no staging areas)
+    int rp_pass = -1, rp_grp = 0;                      // the pass and the group that serve this lane's supernode
+    DJ_HD void rows_init() {
+        if constexpr (kRowsOk) {
+            const int myslot = wv.lane() >> 2;
+            for (int t = 0; t < G.rows; ++t)
+                for (int g = 0; g < 4; ++g) if (G.rp_slot[t][g] == myslot) { rp_pass = t; rp_grp = g; }
+        }
+    }
+    DJ_HD void factorize_rows(QuadBlocks<TL>& K) {
+        constexpr int RS = 13, US = 7;                 // (StepLds::ROW_RS / ROW_US)
+        TL (&A)[3][12] = F.Sq;
+        const int ln = wv.lane(), g = ln >> 4, r = ln & 15;
+        double* const stL = stA; double* const stD = stA + 4 * 6 * RS;
+        const double* const rowS = stA + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;      // this lane's row as a row lane ...
+        const double* const rowU = stB + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
+        const double* const rowL = stL + (size_t)(g * 6 + (r < 6 ? r : 0)) * RS;
+        const double* const rowD = stD + (size_t)(g * 6 + (r < 6 ? r : 0)) * US;
+        double* const qS = stA + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
+        double* const qU = stB + (size_t)(rp_grp * 12 + 3 * q) * US;
+#ifdef DJ_DEBUG
+        if (wv.lane() == 0 && std::getenv("DJ_TRACE_ROWS")) std::fprintf(stderr, "factorize_rows: %d passes\n", G.rows);
+#endif
+        for (int t = 0; t < G.rows; ++t) {
+            const int lev = G.rp_lev[t];
+            const bool mine = rp_pass == t, at = active && mine;
+            wv.sync();
+            // ---- quad lanes -> LDS: the rows of S and of U (a supernode slot beyond the batch stages an identity: cold branch)
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) qS[i * RS + c] = (double)A[i][c];
+                    if (lev > 0) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) qU[i * US + j] = (double)F.Uq[i][j];
+                    }
+                }
+            } else if (mine) {
+                for (int i = 0; i < 3; ++i) { for (int c = 0; c < 12; ++c) qS[i * RS + c] = (3 * q + i == c ? 1.0 : 0.0); for (int j = 0; j < 6; ++j) qU[i * US + j] = 0.0; }
+            }
+            wv.sync();
+            // ---- row lanes <- LDS.  Unconditional loads: lanes 12..15 of a row and rows without a supernode (slot < 0) compute on whatever
+            // the staging area holds -- nobody reads their results (no write-back, no post below), and the loads stay branch-free.
+            const int sl0 = G.rp_slot[t][0], sl1 = G.rp_slot[t][1], sl2 = G.rp_slot[t][2], sl3 = G.rp_slot[t][3];      // (uniform loads, then a select: no per-lane table access)
+            const int sl = g == 0 ? sl0 : g == 1 ? sl1 : g == 2 ? sl2 : sl3;      // this row's supernode slot (< 0: none)
+            const bool rowon = sl >= 0 && r < 12;
+            TL R[12], Ur[6], Lr[12], Dr[6];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) R[c] = TL(rowS[c]);
+            if (lev > 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Ur[j] = TL(rowU[j]);
+            }
+            // children's Schur complements onto rows 0:6 x columns 0:6, summed in NodeP::child order first as in factorize_quad (its row
+            // lanes r < 6 posted them in the children's passes)
+            if (G.maxch_lev[lev] > 0) {
+                TL acc[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
+                for (int ci = 0; ci < G.maxch_lev[lev]; ++ci) {
+                    const int c0 = G.rp_child[t][0][ci], c1 = G.rp_child[t][1][ci], c2 = G.rp_child[t][2][ci], c3 = G.rp_child[t][3][ci];
+                    const int cs = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
+                    if (cs >= 0 && r < 6) {
+                        const double* m_ = mail_slot(4 * cs, r / 3) + 6 * (r % 3);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] += TL(m_[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) R[j] += acc[j];
+            }
+            wv.sync();
+            if (lev > 0) {                                 // (uniform) the parent-side rows: L by rows, Dup -- over the staged S rows, which are in registers now
+                if (at) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stL[(size_t)(rp_grp * 6 + i) * RS + 3 * q + c] = (double)F.Lq[i][c];
+                    if (q < 2) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) stD[(size_t)(rp_grp * 6 + 3 * q + i) * US + j] = (double)K.D[i][j];
+                    }
+                } else if (mine) {
+                    for (int i = 0; i < 6; ++i) for (int c = 0; c < 3; ++c) stL[(size_t)(rp_grp * 6 + i) * RS + 3 * q + c] = 0.0;
+                    if (q < 2) for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) stD[(size_t)(rp_grp * 6 + 3 * q + i) * US + j] = 0.0;
+                }
+                wv.sync();
+#pragma unroll
+                for (int c = 0; c < 12; ++c) Lr[c] = TL(rowL[c]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Dr[j] = TL(rowD[j]);
+                wv.sync();
+            }
+            // ---- Gauss-Jordan in the pivot order of factorize_quad; the pivot row stays unscaled until the end
+            TL ipown = TL(1);
+#pragma unroll
+            for (int pp = 0; pp < 12; ++pp) {
+                const int p = lu_piv(pp), pn = pp + 1 < 12 ? lu_piv(pp + 1) : -1;
+                const TL ip = Wave::rcp(wv.row_bcast(R[p], p));
+                const bool own = (r == p);
+                const TL g_ = R[p] * ip;
+                const TL nfe = own ? TL(0) : -g_;
+                ipown = own ? ip : ipown;
+                // (the column of the NEXT pivot first: its broadcast must not follow the write within two wait states, and the compiler
+                //  does not see the write inside Wave::row_fmac)
+                if (pn >= 0) wv.row_fmac(R[pn], R[pn], nfe, p);
+#pragma unroll
+                for (int c = 0; c < 12; ++c) if (c != p && c != pn) wv.row_fmac(R[c], R[c], nfe, p);
+                R[p] = own ? TL(1) : -g_;
+            }
+#pragma unroll
+            for (int c = 0; c < 12; ++c) R[c] *= ipown;
+            // ---- inverse rows -> LDS -> quad lanes
+            if (rowon) {
+                double* w_ = stA + (size_t)(g * 12 + r) * RS;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) w_[c] = (double)R[c];
+            }
+            wv.sync();
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) A[i][c] = TL(qS[i * RS + c]);
+            }
+            if (lev > 0) {                                 // (uniform) Schur complement onto the parent: Dup - L (S^-1 U), summed as in factorize_quad
+                constexpr int U0 = (DJ_TSD || DJ_SS) ? 0 : 1;
+                TL Tq[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
+#pragma unroll
+                for (int m = 3 * U0; m < 12; ++m)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wv.row_fmac(Tq[j], Ur[j], R[m], m);
+                Wave::dpp_settle();
+                TL upr[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    TL pq[4] = {TL(0), TL(0), TL(0), TL(0)};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+#pragma unroll
+                        for (int m_ = 0; m_ < 3; ++m_) wv.row_fmac(pq[o], Tq[j], Lr[3 * o + m_], 3 * o + m_);
+                    upr[j] = Dr[j] - ((pq[0] + pq[1]) + (pq[2] + pq[3]));
+                }
+                if (sl >= 0 && r < 6) {                    // rows 0:3 -> the slot of role 0, rows 3:6 -> role 1 (mail_add_children reads them there)
+                    double* ms_ = mail_slot(4 * sl, r / 3) + 6 * (r % 3);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ms_[j] = (double)upr[j];
+                }
+            }
+        }
+        wv.sync();
+    }
+
 
     // ---------------------------------------------------------------- quad mapping: LU form of the tree elimination (IFT)
     // The Newton loop inverts every 12x12 supernode matrix explicitly (factorize_quad) and its solves are products with those
@@ -3645,7 +3822,14 @@ struct LaneProgram {
             if constexpr (kRefine) { if (blk != nullptr && wv.any(refine)) store_blocks(K); }   // the rows before the contacts are folded in
             condense_contacts(K);
             DJ_PE(0); DJ_PB();
+#if DJ_ROWS == 1
+            if constexpr (kRowsOk) factorize_rows(K); else factorize_quad(K);
+#elif DJ_ROWS == 2
+            if constexpr (kRowsOk) { if (G.rows > 0 && stA != nullptr) factorize_rows(K); else factorize_quad(K); }
+            else factorize_quad(K);
+#else
             factorize_quad(K);
+#endif
             DJ_PE(1);
             return;
         } else {
@@ -4708,7 +4892,20 @@ struct StepLds {
     static constexpr int red_off = lds_imax(a_end, mail_off + mail_need);
     static constexpr int qred_off = red_off + 64;                    // per-supernode values of the environment reductions (3 at a time)
     static constexpr int info_off = qred_off + (QUAD ? 3 * NSN * 8 : 0);   // SweepInfo per supernode (IFT kernels)
-    static constexpr int bytes = info_off + ((QUAD && GRAD) ? NSN * (int)sizeof(SweepInfo) : 0);
+    static constexpr int info_end = info_off + ((QUAD && GRAD) ? NSN * (int)sizeof(SweepInfo) : 0);
+    // Staging areas of the row-layout level passes (LaneProgram::factorize_rows; step kernels of the single-wavefront quad mapping with one
+    // contact per body): A = 4 supernodes x 12 rows of S (stride ROW_RS doubles: odd, so that the 32 lanes of a ds_read_b64 group hit 32
+    // bank pairs), later their 6 rows of L and of Dup; B = their 12 rows of U (stride ROW_US).  On the GPU A lies over the Newton step /
+    // line-search base, which are dead between the line search and the next solve; B takes what is left of the 40 KB a workgroup may
+    // use with four workgroups per CU.
+    static constexpr int ROW_RS = 13, ROW_US = 7;
+    static constexpr bool rows = QUAD && NW == 1 && MAXC == 1 && GRAD == 0;
+    static constexpr int stA_bytes = 4 * 12 * ROW_RS * 8, stB_bytes = 4 * 12 * ROW_US * 8;
+    static_assert(4 * 6 * (ROW_RS + ROW_US) * 8 <= stA_bytes, "L and Dup rows reuse area A");
+    static constexpr int stA_off = !rows ? 0 : ls_in_lds ? ls_off : info_end;
+    static constexpr int stB_off = !rows ? 0 : ls_in_lds ? info_end : info_end + stA_bytes;
+    static_assert(!rows || !ls_in_lds || ls_slot * NSN >= stA_bytes, "area A must fit the line-search block it overlays");
+    static constexpr int bytes = !rows ? info_end : stB_off + stB_bytes;
 };
 template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
@@ -4781,6 +4978,7 @@ constexpr int FAC_PER_LANE = 72;
         if (GRAD_LAYOUT) prog.sinfo = (SweepInfo*)(lds + LY::info_off);                                                   \
         if (A.msg) prog.msg = DJ_GLOBAL_PTR(T, A.msg) + (size_t)(env < A.B ? env : 0) * (size_t)A.msg_stride;                 \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
+        if (LY::rows) { prog.stA = (double*)(lds + LY::stA_off); prog.stB = (double*)(lds + LY::stB_off); prog.rows_init(); }  \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
         if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * LU_PER_LANE * wv.width() + lane; prog.lu_stride = wv.width(); }                \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \

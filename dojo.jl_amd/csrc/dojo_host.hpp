@@ -8,6 +8,7 @@
 #include <vector>
 #include <string>
 #include <cmath>
+#include <cstdlib>
 
 namespace dj {
 
@@ -232,7 +233,32 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
     G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode; G.contact_model = M.contact_model;
     for (int l = 0; l < 64; ++l) G.maxch_lev[l] = 0;
     for (int b = 0; b < M.Nb; ++b) { int l = M.nodes[b].level; if (l < 64 && M.nodes[b].nchild > G.maxch_lev[l]) G.maxch_lev[l] = (unsigned char)M.nodes[b].nchild; }
+    G.rows = 0;
+    for (int t = 0; t < 16; ++t) { G.rp_lev[t] = 0; for (int g = 0; g < 4; ++g) { G.rp_slot[t][g] = -1; for (int c = 0; c < MAXCH; ++c) G.rp_child[t][g][c] = -1; } }
     return G;
+}
+// The row-layout level passes of the factorization (Globals::rows / rp_slot / rp_lev) for a 64-lane wavefront that holds 16 / S
+// environments of this mechanism in the quad mapping: the supernodes of a level, over all environments of the wavefront, four per pass.
+// mode < 0: where the pass count says it pays (a row pass costs about a third of a quad pass, which serves every supernode of a level at
+// once: DESIGN.md section 6, tools/ubench/gj_rows.hip); 0: never; > 0: always.  DOJO_ROWS in the environment overrides `mode`.
+template <class T> inline void set_row_passes(Globals<T>& G, const HostModel& M, int mode = -1) {
+    G.rows = 0;
+    if (const char* e = std::getenv("DOJO_ROWS")) mode = std::atoi(e);
+    if (mode == 0 || M.S > 16 || M.S < 1 || 16 % M.S != 0) return;
+    const int E = 16 / M.S;
+    int t = 0;
+    for (int lev = M.maxlevel; lev >= 0; --lev) {
+        int g = 0;
+        for (int e = 0; e < E; ++e) for (int b = 0; b < M.Nb; ++b) if (M.nodes[b].level == lev) {
+            if (g == 4) { ++t; g = 0; }
+            if (t >= 16) return;                 // (cannot happen: 16 slots, each in one pass)
+            for (int c = 0; c < MAXCH; ++c) G.rp_child[t][g][c] = c < M.nodes[b].nchild ? (signed char)(e * M.S + M.nodes[b].child[c]) : (signed char)-1;
+            G.rp_slot[t][g++] = (signed char)(e * M.S + b); G.rp_lev[t] = (unsigned char)lev;
+        }
+        if (g > 0) ++t;
+    }
+    if (mode < 0 && 10 * t >= 32 * (M.maxlevel + 1)) return;
+    G.rows = t;
 }
 inline DojoSolverOptions default_options() {
     DojoSolverOptions o; o.rtol = 1e-6; o.btol = 1e-4; o.undercut = INFINITY; o.no_progress_undercut = 10.0;

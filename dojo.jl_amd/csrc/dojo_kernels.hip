@@ -95,6 +95,34 @@ struct GpuWave {
     template <class V> __device__ __forceinline__ V quad_xor(V v, int m) const {        // value of lane (l ^ m) inside my quad, m = 1 or 2
         return m == 1 ? dppx<0xB1>(v) : dppx<0x4E>(v);                                  // quad_perm [1,0,3,2] / [2,3,0,1]
     }
+    // Row layout of the level passes (LaneProgram::factorize_rows): 16 lanes per supernode, one matrix row per lane.  gfx950's DP ALU
+    // knows exactly one DPP control, row_newbcast:P (lane P of every 16-lane row), and takes it INSIDE the fp64 multiply-add: a pivot-row
+    // entry reaches the twelve rows of its supernode in the instruction that uses it -- no separate broadcast, no LDS traffic.
+    static constexpr bool kRows = NW == 1;
+    template <int P> static __device__ __forceinline__ double row_bcast_(double v) {    // v_mov_b64_dpp row_newbcast:P
+        const long long x = __builtin_bit_cast(long long, v);
+        const long long y = __builtin_amdgcn_mov_dpp(x, 0x150 + P, 0xF, 0xF, false);
+        return __builtin_bit_cast(double, y);
+    }
+    __device__ __forceinline__ double row_bcast(double v, int p) const {                // (p folds to a constant after unrolling)
+        switch (p) { case 0: return row_bcast_<0>(v); case 1: return row_bcast_<1>(v); case 2: return row_bcast_<2>(v); case 3: return row_bcast_<3>(v);
+                     case 4: return row_bcast_<4>(v); case 5: return row_bcast_<5>(v); case 6: return row_bcast_<6>(v); case 7: return row_bcast_<7>(v);
+                     case 8: return row_bcast_<8>(v); case 9: return row_bcast_<9>(v); case 10: return row_bcast_<10>(v); default: return row_bcast_<11>(v); }
+    }
+    // acc += (src of lane P of my row) * f.  The compiler's DPP combiner does not fold a 64-bit v_mov_dpp into the multiply-add, hence
+    // the asm statement; its hazard recognizer does not see a VALU write inside one either, so callers keep two instructions between
+    // a row_fmac that writes a register and the next DPP read of that register (CDNA3 ISA 4.5: VALU write -> DPP read, 2 wait states).
+    template <int P> static __device__ __forceinline__ void row_fmac_(double& acc, double src, double f) {
+        __asm__("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(f), "n"(P));
+    }
+    __device__ __forceinline__ void row_fmac(double& acc, double src, double f, int p) const {
+        switch (p) { case 0: row_fmac_<0>(acc, src, f); break; case 1: row_fmac_<1>(acc, src, f); break; case 2: row_fmac_<2>(acc, src, f); break; case 3: row_fmac_<3>(acc, src, f); break;
+                     case 4: row_fmac_<4>(acc, src, f); break; case 5: row_fmac_<5>(acc, src, f); break; case 6: row_fmac_<6>(acc, src, f); break; case 7: row_fmac_<7>(acc, src, f); break;
+                     case 8: row_fmac_<8>(acc, src, f); break; case 9: row_fmac_<9>(acc, src, f); break; case 10: row_fmac_<10>(acc, src, f); break; default: row_fmac_<11>(acc, src, f); break; }
+    }
+    __device__ __forceinline__ void row_fmac(float& acc, float src, float f, int p) const { acc += __shfl(src, (int)((threadIdx.x & 48u) + p), 64) * f; }   // (no fp32 factorization build exists on the GPU)
+    __device__ __forceinline__ float row_bcast(float v, int p) const { return __shfl(v, (int)((threadIdx.x & 48u) + p), 64); }
+    static __device__ __forceinline__ void dpp_settle() { __asm__ volatile("s_nop 1"); }     // the two wait states, where the order of the statements does not give them
 };
 
 // The continuation kernel's wavefronts (Globals::iter_cap, dojo_stepc_kernel): R wavefronts of one workgroup carry the SAME

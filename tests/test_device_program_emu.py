@@ -1012,3 +1012,62 @@ def test_tree_edge_body_body_contacts_outside_the_quad_builds():
             loaded = loaded or o.get_solution()[-4] > 1e-2
             z = zo
         assert loaded
+
+
+def _both_factorizations(spec, Z, U, steps, envs_per_wave, **kw):
+    """the same rollout with the factorization's level passes in the quad layout (DOJO_ROWS=0) and in the row layout (DOJO_ROWS=1)"""
+    outs = {}
+    old = os.environ.get("DOJO_ROWS")
+    try:
+        for rows in ("0", "1"):
+            os.environ["DOJO_ROWS"] = rows
+            z = Z.copy(); seq = []
+            for k in range(steps):
+                seq.append(emu_step(spec, z, U, quad=True, envs_per_wave=envs_per_wave, grad=(k == steps - 1), **kw))
+                z = seq[-1]["z_next"]
+            outs[rows] = seq
+    finally:
+        if old is None: os.environ.pop("DOJO_ROWS", None)
+        else: os.environ["DOJO_ROWS"] = old
+    return outs["0"], outs["1"]
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_row_layout_factorization_is_the_quad_one(cfg):
+    """LaneProgram::factorize_rows (16 lanes per supernode, the pivot row inside v_fmac_f64_dpp on the GPU) performs the operations of
+    factorize_quad in the same order: every output of a rollout -- states, iteration counts, impulses, cone variables, both Jacobians --
+    is equal bit for bit.  Ant and Quadruped: one environment per wavefront, level passes of 1 / 4 / 4 / 4 supernodes."""
+    spec = d.baseline_config(cfg)
+    Z, U = d.synthetic_inputs(spec, 2, seed=11)
+    a, b = _both_factorizations(spec, Z, U, steps=3, envs_per_wave=1)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["status"], rb["status"])
+        for key in ("z_next", "vel", "joint_imp", "contact_sg", "storage"):
+            assert np.array_equal(ra[key], rb[key]), key
+    assert np.array_equal(a[-1]["dz"], b[-1]["dz"]) and np.array_equal(a[-1]["du"], b[-1]["du"])
+    assert min(r["iters"].min() for r in a) >= 3          # (real solves, not early exits)
+
+
+@pytest.mark.parametrize("seed,nb", [(1, None), (3, 4), (5, 2), (8, 7), (9, 3)])
+def test_row_layout_factorization_with_several_environments_per_wavefront(seed, nb):
+    """Random trees of 2 .. 8 bodies, 16 / S environments per 64-lane wavefront (S = supernode slots per environment): a level pass of
+    the row layout serves supernodes of several environments, levels of more than four supernodes take several passes, and the last
+    wavefront of the batch is partly idle (its slots stage identities).  Bit for bit against the quad layout."""
+    from random_mechanisms import random_mechanism
+    spec, z, u = random_mechanism(seed, nb=nb)
+    S = 1
+    while S < spec.Nb: S *= 2
+    E = 16 // S
+    B = E + max(1, E // 2)                                 # one full wavefront and a partly filled one
+    rng = np.random.default_rng(seed)
+    Z = np.stack([z] * B); U = np.stack([u * (1.0 + 0.3 * rng.normal()) for _ in range(B)])
+    opts = d.SolverOptions(rtol=1e-9, btol=1e-9)
+    a, b = _both_factorizations(spec, Z, U, steps=2, envs_per_wave=E, opts=opts)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["status"], rb["status"])
+        for key in ("z_next", "vel", "joint_imp", "contact_sg"):
+            assert np.array_equal(ra[key], rb[key]), key
+    assert np.array_equal(a[-1]["dz"], b[-1]["dz"]) and np.array_equal(a[-1]["du"], b[-1]["du"])
+    o = Oracle(spec, opts=opts)                            # ... and both are the oracle's step
+    zo, info = o.step(Z[0], U[0])
+    assert info["iters"] == a[0]["iters"][0] and np.abs(a[0]["z_next"][0] - zo).max() < 1e-10
