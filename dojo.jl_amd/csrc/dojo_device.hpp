@@ -112,13 +112,19 @@ struct Globals {
     int Nb, Nc, S, nu, n_joint_imp, maxch, maxlevel, grad_mode;
     int contact_model;           // 0: NonlinearContact; 1: ImpactContact = the same rows without the friction block (γ2:4, s2:4 pinned)
     unsigned char maxch_lev[64]; // largest number of children among the supernodes of each level (bounds the level sweeps' gathers)
+    // ... the same, four bits per level: the device reads THIS (a uniform 64-bit scalar load and a shift).  A byte table indexed by the level
+    // becomes a per-lane global load with a full wait in front of every level pass of every sweep (round 6: 12 memory round trips per Newton iteration)
+    unsigned long long maxch_pack[4];
+    DJ_HD int maxch_at(int lev) const { return (int)((maxch_pack[lev >> 4] >> (4 * (lev & 15))) & 15ull); }
     // Row layout of the factorization's level passes (LaneProgram::factorize_rows; single-wavefront quad mapping, Wave::kRows): pass t
     // factorizes up to four supernodes of one tree level, each on a 16-lane row of the wavefront.  rp_slot[t][g] = the supernode slot
     // (lane >> 2) group g serves in pass t, -1 = none; passes run leaves -> root.  rows = 0: the quad-layout passes (factorize_quad).
+    // (one 32-bit word per entry, a signed byte per group: a uniform index then is a scalar load -- byte tables become per-lane global loads)
     int rows;
-    signed char rp_slot[16][4];
-    unsigned char rp_lev[16];
-    signed char rp_child[16][4][MAXCH];   // the slots of that supernode's children (-1: none), in NodeP::child order
+    int rp_slot4[16];                     // byte g: rp_slot[t][g]
+    int rp_lev[16];                       // the level of pass t, and in bits 8.. the largest child count of that level
+    int rp_child4[16][MAXCH];             // byte g of [t][ci]: the slot of child ci of group g's supernode (-1: none), in NodeP::child order
+    DJ_HD static int rp_byte(int w, int g) { return (int)(signed char)((unsigned)w >> (8 * g)); }
 };
 
 // per-supernode constants (body k, its parent joint, its contacts)
@@ -2137,7 +2143,7 @@ struct LaneProgram {
             // receive the children's contributions (they were produced at lev+1)
             TL acc[36];
             for (int i = 0; i < 36; ++i) acc[i] = TL(0);
-            gather_children<36>(wv, acc, up, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
+            gather_children<36>(wv, acc, up, P, base, G.maxch_at(lev), active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Sl[12 * i + j] += acc[6 * i + j];
                 // plain LU of [S U; L Dup] down to the parent's body rows, no pivoting (the host's elimination order makes every pivot
@@ -2191,7 +2197,7 @@ struct LaneProgram {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
             mail_post_roles<18>(upf);
-            mail_add_children<18>(acc, at, G.maxch_lev[lev]);
+            mail_add_children<18>(acc, at, G.maxch_at(lev));
             if (at && q < 2) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -2297,34 +2303,40 @@ struct LaneProgram {
     // (tests/test_device_program_emu.py::test_row_layout_factorization_is_the_quad_one).
     static constexpr bool kRowsOk = QUAD && Wave::kRows && MAXC == 1 && !(kTrack && DJ_TRACK_GROWTH);
     double* stA = nullptr; double* stB = nullptr;      // StepLds::stA_off / stB_off (null: this kernel's LDS layout has no staging areas)
-    int rp_pass = -1, rp_grp = 0;                      // the pass and the group that serve this lane's supernode
+    int rp_pack = -256;                                // (pass << 8) | group: the pass and the group that serve this lane's supernode (pass -1: none)
     DJ_HD void rows_init() {
         if constexpr (kRowsOk) {
             const int myslot = wv.lane() >> 2;
             for (int t = 0; t < G.rows; ++t)
-                for (int g = 0; g < 4; ++g) if (G.rp_slot[t][g] == myslot) { rp_pass = t; rp_grp = g; }
+                for (int g = 0; g < 4; ++g) if (Globals<T>::rp_byte(G.rp_slot4[t], g) == myslot) rp_pack = (t << 8) | g;
         }
     }
     DJ_HD void factorize_rows(QuadBlocks<TL>& K) {
         constexpr int RS = 13, US = 7;                 // (StepLds::ROW_RS / ROW_US)
         TL (&A)[3][12] = F.Sq;
-        const int ln = wv.lane(), g = ln >> 4, r = ln & 15;
-        double* const stL = stA; double* const stD = stA + 4 * 6 * RS;
-        const double* const rowS = stA + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;      // this lane's row as a row lane ...
-        const double* const rowU = stB + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
-        const double* const rowL = stL + (size_t)(g * 6 + (r < 6 ? r : 0)) * RS;
-        const double* const rowD = stD + (size_t)(g * 6 + (r < 6 ? r : 0)) * US;
-        double* const qS = stA + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
-        double* const qU = stB + (size_t)(rp_grp * 12 + 3 * q) * US;
 #ifdef DJ_DEBUG
         if (wv.lane() == 0 && std::getenv("DJ_TRACE_ROWS")) std::fprintf(stderr, "factorize_rows: %d passes\n", G.rows);
 #endif
         for (int t = 0; t < G.rows; ++t) {
-            const int lev = G.rp_lev[t];
+            // (the lane's staging addresses are a handful of integer operations: derived here, from a value the compiler cannot trace,
+            //  instead of living in ten registers through the whole Newton loop -- the loop-invariant form cost the rest of the kernel
+            //  its registers: 43 -> 149 spilled, profiles/r06_*)
+            int ln = wv.lane(), pk = rp_pack;
+            DJ_OPAQUE(ln); DJ_OPAQUE(pk);
+            const int g = ln >> 4, r = ln & 15, rp_pass = pk >> 8, rp_grp = pk & 3;
+            double* const stL = stA; double* const stD = stA + 4 * 6 * RS;
+            const double* const rowS = stA + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;      // this lane's row as a row lane ...
+            const double* const rowU = stB + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
+            const double* const rowL = stL + (size_t)(g * 6 + (r < 6 ? r : 0)) * RS;
+            const double* const rowD = stD + (size_t)(g * 6 + (r < 6 ? r : 0)) * US;
+            double* const qS = stA + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
+            double* const qU = stB + (size_t)(rp_grp * 12 + 3 * q) * US;
+            const int lev = G.rp_lev[t] & 255, maxch = G.rp_lev[t] >> 8;
             const bool mine = rp_pass == t, at = active && mine;
             wv.sync();
-            // ---- quad lanes -> LDS: the rows of S and of U (a supernode slot beyond the batch stages an identity: cold branch)
-            if (at) {
+            // ---- quad lanes -> LDS: the rows of S and of U (a supernode slot beyond the batch stages whatever its registers hold: its
+            // pass runs on that and nobody reads the results -- no read-back below, and its parent is beyond the batch as well)
+            if (mine) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -2334,29 +2346,21 @@ struct LaneProgram {
                         for (int j = 0; j < 6; ++j) qU[i * US + j] = (double)F.Uq[i][j];
                     }
                 }
-            } else if (mine) {
-                for (int i = 0; i < 3; ++i) { for (int c = 0; c < 12; ++c) qS[i * RS + c] = (3 * q + i == c ? 1.0 : 0.0); for (int j = 0; j < 6; ++j) qU[i * US + j] = 0.0; }
             }
             wv.sync();
             // ---- row lanes <- LDS.  Unconditional loads: lanes 12..15 of a row and rows without a supernode (slot < 0) compute on whatever
             // the staging area holds -- nobody reads their results (no write-back, no post below), and the loads stay branch-free.
-            const int sl0 = G.rp_slot[t][0], sl1 = G.rp_slot[t][1], sl2 = G.rp_slot[t][2], sl3 = G.rp_slot[t][3];      // (uniform loads, then a select: no per-lane table access)
-            const int sl = g == 0 ? sl0 : g == 1 ? sl1 : g == 2 ? sl2 : sl3;      // this row's supernode slot (< 0: none)
+            const int sl = Globals<T>::rp_byte(G.rp_slot4[t], g);      // this row's supernode slot (< 0: none): a uniform load and a per-lane shift
             const bool rowon = sl >= 0 && r < 12;
             TL R[12], Ur[6], Lr[12], Dr[6];
 #pragma unroll
             for (int c = 0; c < 12; ++c) R[c] = TL(rowS[c]);
-            if (lev > 0) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) Ur[j] = TL(rowU[j]);
-            }
             // children's Schur complements onto rows 0:6 x columns 0:6, summed in NodeP::child order first as in factorize_quad (its row
             // lanes r < 6 posted them in the children's passes)
-            if (G.maxch_lev[lev] > 0) {
+            if (maxch > 0) {
                 TL acc[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
-                for (int ci = 0; ci < G.maxch_lev[lev]; ++ci) {
-                    const int c0 = G.rp_child[t][0][ci], c1 = G.rp_child[t][1][ci], c2 = G.rp_child[t][2][ci], c3 = G.rp_child[t][3][ci];
-                    const int cs = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
+                for (int ci = 0; ci < maxch; ++ci) {
+                    const int cs = Globals<T>::rp_byte(G.rp_child4[t][ci], g);
                     if (cs >= 0 && r < 6) {
                         const double* m_ = mail_slot(4 * cs, r / 3) + 6 * (r % 3);
 #pragma unroll
@@ -2368,7 +2372,7 @@ struct LaneProgram {
             }
             wv.sync();
             if (lev > 0) {                                 // (uniform) the parent-side rows: L by rows, Dup -- over the staged S rows, which are in registers now
-                if (at) {
+                if (mine) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -2379,15 +2383,7 @@ struct LaneProgram {
 #pragma unroll
                             for (int j = 0; j < 6; ++j) stD[(size_t)(rp_grp * 6 + 3 * q + i) * US + j] = (double)K.D[i][j];
                     }
-                } else if (mine) {
-                    for (int i = 0; i < 6; ++i) for (int c = 0; c < 3; ++c) stL[(size_t)(rp_grp * 6 + i) * RS + 3 * q + c] = 0.0;
-                    if (q < 2) for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) stD[(size_t)(rp_grp * 6 + 3 * q + i) * US + j] = 0.0;
                 }
-                wv.sync();
-#pragma unroll
-                for (int c = 0; c < 12; ++c) Lr[c] = TL(rowL[c]);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) Dr[j] = TL(rowD[j]);
                 wv.sync();
             }
             // ---- Gauss-Jordan in the pivot order of factorize_quad; the pivot row stays unscaled until the end
@@ -2409,6 +2405,15 @@ struct LaneProgram {
             }
 #pragma unroll
             for (int c = 0; c < 12; ++c) R[c] *= ipown;
+            if (lev > 0) {                                 // (their rows of L and Dup: read here, not before the elimination, which needs the registers)
+#pragma unroll
+                for (int c = 0; c < 12; ++c) Lr[c] = TL(rowL[c]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Dr[j] = TL(rowD[j]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Ur[j] = TL(rowU[j]);
+                wv.sync();
+            }
             // ---- inverse rows -> LDS -> quad lanes
             if (rowon) {
                 double* w_ = stA + (size_t)(g * 12 + r) * RS;
@@ -2585,7 +2590,7 @@ struct LaneProgram {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { acc[6 * i + j] = TL(0); upf[6 * i + j] = up[i][j]; }
             mail_post_roles<18>(upf);
-            mail_add_children<18>(acc, at, G.maxch_lev[lev]);
+            mail_add_children<18>(acc, at, G.maxch_at(lev));
             if (at && q < 2) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -3250,7 +3255,7 @@ struct LaneProgram {
             const bool at = active && P.level == lev;
             TL acc[3] = {0, 0, 0};
             mail_post_roles<3>(send3);
-            mail_add_children<3>(acc, at, G.maxch_lev[lev]);
+            mail_add_children<3>(acc, at, G.maxch_at(lev));
             if (at) { r3[0] += acc[0]; r3[1] += acc[1]; r3[2] += acc[2]; }
             TL rf[12];
 #pragma unroll
@@ -3468,7 +3473,7 @@ struct LaneProgram {
         for (int i = 0; i < 12; ++i) rl[i] = TL(rk[i]);
         for (int lev = G.maxlevel; lev >= 0; --lev) {
             TL acc[6] = {0, 0, 0, 0, 0, 0};
-            gather_children<6>(wv, acc, send, P, base, G.maxch_lev[lev], active && P.level == lev, stride, q);
+            gather_children<6>(wv, acc, send, P, base, G.maxch_at(lev), active && P.level == lev, stride, q);
             if (active && P.level == lev) {
                 for (int i = 0; i < 6; ++i) rl[i] += acc[i];
                 for (int k = 0; k < 12; ++k) for (int i = k + 1; i < 12; ++i) rl[i] -= F.Sinv[12 * i + k] * rl[k];      // y = L11⁻¹ r

@@ -233,8 +233,10 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
     G.Nb = M.Nb; G.Nc = M.Nc; G.S = M.S; G.nu = M.nu; G.n_joint_imp = M.n_joint_imp; G.maxch = M.maxch; G.maxlevel = M.maxlevel; G.grad_mode = grad_mode; G.contact_model = M.contact_model;
     for (int l = 0; l < 64; ++l) G.maxch_lev[l] = 0;
     for (int b = 0; b < M.Nb; ++b) { int l = M.nodes[b].level; if (l < 64 && M.nodes[b].nchild > G.maxch_lev[l]) G.maxch_lev[l] = (unsigned char)M.nodes[b].nchild; }
+    for (int w = 0; w < 4; ++w) G.maxch_pack[w] = 0ull;
+    for (int l = 0; l < 64; ++l) G.maxch_pack[l >> 4] |= (unsigned long long)(G.maxch_lev[l] & 15) << (4 * (l & 15));      // (MAXCH = 4 children per body)
     G.rows = 0;
-    for (int t = 0; t < 16; ++t) { G.rp_lev[t] = 0; for (int g = 0; g < 4; ++g) { G.rp_slot[t][g] = -1; for (int c = 0; c < MAXCH; ++c) G.rp_child[t][g][c] = -1; } }
+    for (int t = 0; t < 16; ++t) { G.rp_lev[t] = 0; G.rp_slot4[t] = -1; for (int c = 0; c < MAXCH; ++c) G.rp_child4[t][c] = -1; }
     return G;
 }
 // The row-layout level passes of the factorization (Globals::rows / rp_slot / rp_lev) for a 64-lane wavefront that holds 16 / S
@@ -252,8 +254,9 @@ template <class T> inline void set_row_passes(Globals<T>& G, const HostModel& M,
         for (int e = 0; e < E; ++e) for (int b = 0; b < M.Nb; ++b) if (M.nodes[b].level == lev) {
             if (g == 4) { ++t; g = 0; }
             if (t >= 16) return;                 // (cannot happen: 16 slots, each in one pass)
-            for (int c = 0; c < MAXCH; ++c) G.rp_child[t][g][c] = c < M.nodes[b].nchild ? (signed char)(e * M.S + M.nodes[b].child[c]) : (signed char)-1;
-            G.rp_slot[t][g++] = (signed char)(e * M.S + b); G.rp_lev[t] = (unsigned char)lev;
+            auto put = [](int& w, int g_, int v) { w = (int)(((unsigned)w & ~(0xFFu << (8 * g_))) | ((unsigned)(v & 0xFF) << (8 * g_))); };
+            for (int c = 0; c < MAXCH; ++c) put(G.rp_child4[t][c], g, c < M.nodes[b].nchild ? e * M.S + M.nodes[b].child[c] : -1);
+            put(G.rp_slot4[t], g++, e * M.S + b); G.rp_lev[t] = lev | ((int)G.maxch_lev[lev] << 8);
         }
         if (g > 0) ++t;
     }

@@ -27,8 +27,11 @@ template <class X> __device__ __forceinline__ X* dj_assume_global(X* p) {
     return p;
 }
 #define DJ_GLOBAL_PTR(T, p) dj_assume_global<T>(p)
+// a value the optimizer must take as unknown from here on (keeps cheap address arithmetic next to its use instead of hoisted into long-lived registers)
+#define DJ_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 #else
 #define DJ_GLOBAL_PTR(T, p) (p)
+#define DJ_OPAQUE(x) ((void)0)
 #endif
 
 namespace dj {
