@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = Ant)")
     ap.add_argument("--io-dtype", default="f32")
     ap.add_argument("--no-grad", action="store_true")
+    ap.add_argument("--distribution", default="baseline", choices=["baseline", "standing"],
+                    help="synthetic states: BASELINE.md section 3's perturbation (default, every config) or, for Atlas, states around the reference's standing pose (dojo_amd.coords)")
     ap.add_argument("--chunks", type=int, default=0, help="environment groups the library steps the per-GPU batch as (dojo_set_groups); 0 = the library's choice "
                     "(16 at batch 4096), 1 = one launch per kernel on the caller's stream")
     ap.add_argument("--no-parity", action="store_true", help="skip the grad-inf-err-vs-CPU leg")
@@ -86,7 +88,7 @@ def main():
     w = 4 if args.io_dtype == "f32" else 8
     # synthetic inputs: B DISTINCT seeded environments per rank (perturbed nominal states built in minimal
     # coordinates, so the joints are closed), distinct seeds per rank; controls ~ 0.5 N(0,1) on the actuated inputs, fresh every step
-    Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008 + rank)
+    Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008 + rank, distribution=args.distribution)
     reps = 1
     z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000 + rank]))
@@ -166,6 +168,7 @@ def main():
         one_step(k)
     gm.join(torch.cuda.current_stream().cuda_stream)
     barrier()
+    gm.kernel_time_totals(reset=True)                      # (drains the warmup's event pairs)
     t0 = time.perf_counter()
     for k in range(W, W + K):
         one_step(k, traj[k - W])
@@ -180,6 +183,9 @@ def main():
         gathered_bytes = traj_all.numel() * traj_all.element_size()
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
+    # hipEvent durations of the timed region's launches, summed over the environment groups (every group's kernels on its own stream): against
+    # ms_per_step this is how much the groups overlapped
+    ksum_step, ksum_ift, klaunches = gm.kernel_time_totals(reset=True)
     ok_frac = float((status == 0).float().mean().item())          # of the timed region's last step
     mean_iters = float(iters.float().mean().item())
     z = traj[K - 1].clone()
@@ -264,17 +270,32 @@ def main():
         for r in (r_step, r_ift):
             if r is not None and r.get("flops_source_digest_matches") is False:
                 r["warning"] = "STALE COUNTS: %s was taken with another build of the library (digest mismatch); re-run tools/gpu_pmc.sh" % r["flops_source"]
-        dominant, other = (r_step, r_ift) if (r_ift is None or step_ms >= ift_ms) else (r_ift, r_step)
-        # ... and over the TIMED region itself (the asynchronous rollout, environment groups overlapping): what both kernels execute per
-        # step / ms_per_step -- no kernel has the GPU to itself there, so this is the figure that belongs to `value`
-        fl_step = sum(r_["executed_fp64_flops_per_launch"] for r_ in (r_step, r_ift) if r_ is not None and r_.get("executed_fp64_flops_per_launch"))
-        if fl_step and all(r_ is None or r_.get("executed_fp64_flops_per_launch") for r_ in (r_step, r_ift)):
-            a_ = fl_step / (1e-3 * 1e3 * el / K) / 1e12
-            dominant["timed"] = {"executed_fp64_flops_per_step": fl_step, "ms_per_step": 1e3 * el / K, "achieved": a_, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": a_ / FP64_VECTOR_PEAK_TFLOPS, "note": "step kernel + IFT kernel, executed fp64 flops of one step / ms_per_step of the timed region"}
-        dominant["note"] = ("fp64 vector-ALU-bound lane program; avg_kernel_ms: hipEvents on the launch stream, the batch as ONE launch per kernel, mean over the "
-                            "timed region's K steps replayed after it (same states, same controls); `timed` = both kernels over the timed region itself; "
-                            "the HBM roofline asked for by the contract is the `hbm` member")
+        # The roofline that belongs to `value`: what BOTH kernels execute per step of the timed region (the asynchronous rollout, environment
+        # groups overlapping) / ms_per_step.  The one-launch-per-kernel replay (groups = 1: a kernel that has the GPU to itself, the figure a
+        # rocprofv3 --kernel-trace of `bench.py --chunks 1` shows) rides along as `single_launch`, per kernel.
+        ms_step = 1e3 * el / K
+        parts = [r_ for r_ in (r_step, r_ift) if r_ is not None]
+        have_fl = all(r_.get("executed_fp64_flops_per_launch") for r_ in parts)
+        fl_step = sum(r_["executed_fp64_flops_per_launch"] for r_ in parts) if have_fl else None
+        tr_step = sum(r_["traffic"] for r_ in parts) if all(r_.get("traffic") for r_ in parts) else None
+        alg_bytes = (bytes_fwd + bytes_grad) * B
+        a_ = fl_step / (1e-3 * ms_step) / 1e12 if fl_step else None
+        roofline = {"bound": "valu_fp64", "kernel": "dojo_step_kernel + dojo_grad_kernel: one step of the timed rollout",
+                    "achieved": a_, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (a_ / FP64_VECTOR_PEAK_TFLOPS) if a_ else None,
+                    "executed_fp64_flops_per_step": fl_step, "ms_per_step": ms_step,
+                    "traffic": tr_step,        # HBM bytes per step, PMC (2 x FETCH_SIZE + WRITE_SIZE of both kernels), scaled to this batch
+                    "hbm": {"bound": "hbm", "achieved": alg_bytes / (1e-3 * ms_step) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg_bytes / (1e-3 * ms_step) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_bytes},
+                    "kernel_ms_sum_per_step": {"dojo_step_kernel": ksum_step / K, "dojo_grad_kernel": ksum_ift / K, "launches_per_step": klaunches / K,
+                                               "overlap_factor": (ksum_step + ksum_ift) / K / ms_step if ms_step > 0 else None,
+                                               "note": "hipEvent durations of the timed region's launches summed over the %d environment groups, per step; / ms_per_step = how many kernels were in flight on average" % NCH},
+                    "flops_source": r_step.get("flops_source"), "flops_source_digest_matches": r_step.get("flops_source_digest_matches"),
+                    "single_launch": {r_["kernel"]: r_ for r_ in parts},
+                    "note": ("fp64 vector-ALU-bound lane program. achieved = fp64 flops both kernels EXECUTE per step (PMC pass of this command, x64 lanes, FMA = 2) / ms_per_step "
+                             "of the timed region; single_launch = each kernel as ONE launch of the whole batch (groups = 1), hipEvents on the launch stream, mean over the timed "
+                             "region's K steps replayed after it (same states, same controls); the HBM roofline the contract asks for is the `hbm` member")}
+        if any(r_.get("warning") for r_ in parts):
+            roofline["warning"] = next(r_["warning"] for r_ in parts if r_.get("warning"))
         res = {
             "metric": "differentiable env-steps/sec (fwd+grad) at batch=4096; grad inf-err vs CPU" if grad else "env-steps/sec (fwd only)",
             "value": world * B * K / el, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -285,6 +306,8 @@ def main():
                                     + ("total batch %d sharded over %d GPU(s) = %d per GPU (strong scaling), " % (world * B, world, B) if strong else "batch=%d per GPU, " % B)
                                     + "%s, closed-loop rollout with random controls" % ("fwd + IFT gradients" if grad else "forward only")),
                        "per_rank_batch": B, "total_batch": world * B,
+                       "input_distribution": args.distribution + (" (BASELINE.md section 3: height U(0, 0.3), rotation N(0, 0.1), velocities N(0, 0.5), joints +-0.2)" if args.distribution == "baseline"
+                                                                   else " (Atlas: around the reference's standing pose, dojo_amd.coords._SYNTH_STANDING; other mechanisms as baseline)"),
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
                        "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout)" % (world, NCH),
@@ -293,29 +316,31 @@ def main():
                        "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,
                        "sync_per_step_note": "%d more steps of the rollout (the same controls again, from the timed region's end state) with the environment groups joined into the caller's stream after every step (a barrier per step); `value` is the asynchronous rollout (one join at the end)" % K,
                        "build": build_info()},
-            "roofline": dominant,
+            "roofline": roofline,
         }
-        if other is not None:
-            res["roofline_second_kernel"] = other
         if grad and not args.no_parity and world == 1:
-            res["grad_inf_err_vs_cpu"] = pv = parity_vs_cpu(spec, B, local)
+            res["grad_inf_err_vs_cpu"] = pv = parity_vs_cpu(spec, B, local, args.distribution)
             # the norm the metric's second half is claimed in, at the top level: RELATIVE per-environment inf-norm, the absolute one next to it
-            res["grad_err_claim"] = {"norm": "per environment: |J_gpu - J_cpu|_inf / max(1, |J_cpu|_inf) over dz and du (RELATIVE inf-norm); maximum over every environment that converged "
-                                             "on both sides to the same point; the ABSOLUTE inf-norm |J_gpu - J_cpu|_inf is reported next to it",
-                                     "bound_relative": {"f64": 1e-6, "f32": 1e-3},
-                                     "timed_path_f32_abi": {k_: pv.get("f32", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
-                                     "f64_abi": {k_: pv.get("f64", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
-                                     "f64_abi_all_solves_refined": {k_: pv.get("f64_refined", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds")},
+            res["grad_err_claim"] = {"norm": "per environment, over dz and du, maximum over every environment that converged on both sides to the same point: ABSOLUTE inf-norm |J_gpu - J_cpu|_inf "
+                                             "(the contract's norm: `within_bounds`) and RELATIVE inf-norm |J_gpu - J_cpu|_inf / max(1, |J_cpu|_inf) (`within_relative_bound`)",
+                                     "bound": {"f64": 1e-6, "f32": 1e-3},
+                                     "statement": "the timed path (fp32 ABI) meets 1e-3 in both norms; the fp64 ABI meets 1e-6 in the relative norm on every such environment and in the "
+                                                  "absolute norm on all but `n_grad_abs_err_above_bound` of them (Jacobians with entries ~1e3: 1e-6 absolute = 1e-9 relative); with every "
+                                                  "linear solve refined (dojo_set_refinement(h, 0)) it meets it in the absolute norm as well",
+                                     "timed_path_f32_abi": {k_: pv.get("f32", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds", "within_relative_bound", "n_grad_abs_err_above_bound")},
+                                     "f64_abi": {k_: pv.get("f64", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds", "within_relative_bound", "n_grad_abs_err_above_bound", "jacobian_inf_norm_of_worst_abs")},
+                                     "f64_abi_all_solves_refined": {k_: pv.get("f64_refined", {}).get(k_) for k_ in ("grad_inf_err_max", "grad_abs_inf_err_max", "state_inf_err_max", "within_bounds", "within_relative_bound", "n_grad_abs_err_above_bound")},
                                      "jacobian_inf_norm_max": pv.get("f64", {}).get("jacobian_inf_norm_max")}
         if not args.no_cpu_baseline and world == 1:
-            ex = [r_.get("executed_fp64_flops_per_launch") for r_ in (dominant, other) if r_ is not None]
-            res["cpu_baseline"] = cb = cpu_baseline(spec, grad, mean_iters, (sum(ex) / B) if (ex and all(ex)) else None)
+            res["cpu_baseline"] = cb = cpu_baseline(spec, grad, mean_iters, (fl_step / B) if fl_step else None, args.distribution)
             # the USEFUL share: what a block-sparse direct method needs for this step (cpu_baseline.sparse_lu_flops) / ms_per_step, against the same peak
             u_ = cb.get("sparse_lu_flops", {}).get("per_env_step")
             if u_:
                 a_ = u_ * B / (1e-3 * 1e3 * el / K) / 1e12
                 res["roofline"]["useful"] = {"flops_per_step": u_ * B, "achieved": a_, "unit": "TFLOP/s", "frac": a_ / FP64_VECTOR_PEAK_TFLOPS,
-                                             "note": "flops of a block-sparse no-pivot LU (one factorization + two solves per Newton iteration, one + a solve per Jacobian column) / ms_per_step"}
+                                             "lane_efficiency": (u_ * B / fl_step) if fl_step else None,
+                                             "note": "flops of a block-sparse no-pivot LU (one factorization + two solves per Newton iteration, one + a solve per Jacobian column) / ms_per_step; "
+                                                     "lane_efficiency = these / the executed fp64 flops (assembly and line-search residuals are NOT in the numerator: a lower bound of the useful share)"}
         if world > 1:
             res["config"]["trajectory_gather"] = {"what": "the timed rollout's states [K=%d, B=%d, 13 Nb=%d] of every rank, once, inside the timed region" % (K, B, 13 * spec.Nb),
                                                  "bytes_received_per_rank": gathered_bytes,
@@ -347,7 +372,7 @@ def spawn_ranks(n, backend):
     return subprocess.call(cmd, env=env)
 
 
-def parity_vs_cpu(spec, B, device):
+def parity_vs_cpu(spec, B, device, distribution="baseline"):
     """The metric's second half: state and gradient inf-norm error of the device against the CPU oracle at the BASELINE batch
     with B DISTINCT seeded environments, reference-default solver options, after 8 closed-loop steps (so that feet are on the
     ground).  fp64 ABI against the north-star bound 1e-6, fp32 ABI (what the timed loop uses) against 1e-3.  Gradient error is
@@ -358,7 +383,7 @@ def parity_vs_cpu(spec, B, device):
     from dojo_amd import api
     from oracle import Oracle
     cores = os.cpu_count() or 1
-    Z, U = d.synthetic_inputs(spec, B)
+    Z, U = d.synthetic_inputs(spec, B, distribution=distribution)
     out = {"envs": B, "pre_steps": 8, "solver_options": "reference defaults", "oracle": "C++ restatement, dense pivoted LU + 2 rounds of long-double refinement"}
     o = Oracle(spec)
     g64 = api.BatchedMechanism(spec, B, dtype="f64", device=device)
@@ -388,11 +413,16 @@ def parity_vs_cpu(spec, B, device):
         if not same.any():
             out[name] = {"converged_both": int(ok.sum()), "error": "no environment converged on both sides to the same point"}
             continue
-        gb, ab = (1e-6, 1e-5) if dt == np.float64 else (1e-3, 1e-3)           # north-star bounds (relative norm; the absolute norm asserted next to it for fp64: |J|_inf <= 2e3 here)
+        # north_star: "state/gradient inf-norm <= 1e-6 fp64, <= 1e-3 fp32" -- the ABSOLUTE inf-norm decides `within_bounds`; the relative one
+        # (|dJ|_inf / max(1, |J|_inf): what fp64 arithmetic on Jacobians with entries up to 2e3 can promise) rides along as `within_relative_bound`
+        gb, ab = (1e-6, 1e-6) if dt == np.float64 else (1e-3, 1e-3)
         out[name] = {"converged_both": int(ok.sum()), "status_mismatch": int((st != st_o).sum()), "iters_mismatch": int((it[ok] != it_o[ok]).sum()),
                      "state_inf_err_max": float(ez[same].max()), "state_inf_err_max_unfiltered": float(ez.max()), "n_state_err_above_bound": int(apart.sum()), "state_bound": tol_s,
                      "grad_inf_err_max": float(eg[same].max()), "grad_abs_inf_err_max": float(ea[same].max()), "grad_inf_err_max_unfiltered": float(eg.max()),
-                     "grad_bound_relative": gb, "grad_bound_absolute": ab, "within_bounds": bool(eg[same].max() <= gb and ea[same].max() <= ab and ez[same].max() <= tol_s),
+                     "grad_bound_relative": gb, "grad_bound_absolute": ab, "within_bounds": bool(ea[same].max() <= ab and ez[same].max() <= tol_s),
+                     "within_relative_bound": bool(eg[same].max() <= gb and ez[same].max() <= tol_s),
+                     "n_grad_abs_err_above_bound": int((ea[same] > ab).sum()),
+                     "jacobian_inf_norm_of_worst_abs": float(max(np.abs(dz_o[idx[i]]).max(), np.abs(du_o[idx[i]]).max()) if (i := int(np.argmax(np.where(same, ea, -1.0)))) >= 0 else 0.0),
                      "grad_inf_err_q99": float(np.quantile(eg, 0.99)),
                      "grad_inf_err_q50": float(np.quantile(eg, 0.5)), "n_grad_err_above_1e-6": int((eg[same] > 1e-6).sum()),
                      "jacobian_inf_norm_max": float(max(np.abs(dz_o[b]).max() for b in idx)),
@@ -450,7 +480,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
+def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None, distribution="baseline"):
     """The C++ oracle ("port": the reference itself needs Julia, which is not installed) timed on the host's PHYSICAL cores: one
     persistent thread pinned to each core, every thread owns a copy of the mechanism (its workspaces and symbolic factorization
     are set up by one untimed step) and walks 128 environments of the same synthetic batch, once per solver variant; the clock
@@ -471,7 +501,7 @@ def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None):
     o.set_refine_steps(0)
     per_thread = 128
     nsample = per_thread * cores
-    Z, U = d.synthetic_inputs(spec, nsample)
+    Z, U = d.synthetic_inputs(spec, nsample, distribution=distribution)
     out = {}
     for name, sparse in (("sparse", True), ("dense", False)):
         o.set_sparse_solver(sparse)

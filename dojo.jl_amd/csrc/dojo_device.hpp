@@ -64,8 +64,8 @@
 #endif
 
 #ifndef DJ_ROWS
-#define DJ_ROWS 2           // the factorization's level passes: 0 = quad layout only (factorize_quad), 1 = row layout only (factorize_rows: the host must
-                            // hand such a build only mechanisms with Globals::rows > 0), 2 = both, Globals::rows decides at run time
+#define DJ_ROWS 2           // the factorization's level passes: 0 = quad layout only (factorize_quad), 1 = row layout wherever the kernel has the staging
+                            // areas (experiments: run such a build with DOJO_ROWS=1, it ignores Globals::rows = 0), 2 = both, Globals::rows decides at run time
 #endif
 
 #ifndef DJ_CUT
@@ -2302,7 +2302,8 @@ struct LaneProgram {
     // produced by the same operations in the same order as in factorize_quad: the two are interchangeable bit for bit
     // (tests/test_device_program_emu.py::test_row_layout_factorization_is_the_quad_one).
     static constexpr bool kRowsOk = QUAD && Wave::kRows && MAXC == 1 && !(kTrack && DJ_TRACK_GROWTH);
-    double* stA = nullptr; double* stB = nullptr;      // StepLds::stA_off / stB_off (null: this kernel's LDS layout has no staging areas)
+    double* stA = nullptr; double* stB = nullptr;      // StepLds::stA_off / stB_off (luA_off / luB_off in the IFT kernel)
+    bool rows_here = false;                            // this kernel's LDS layout has the staging areas (a constant of the kernel: StepLds::rows / rows_lu)
     int rp_pack = -256;                                // (pass << 8) | group: the pass and the group that serve this lane's supernode (pass -1: none)
     DJ_HD void rows_init() {
         if constexpr (kRowsOk) {
@@ -2388,21 +2389,21 @@ struct LaneProgram {
             }
             // ---- Gauss-Jordan in the pivot order of factorize_quad; the pivot row stays unscaled until the end
             TL ipown = TL(1);
-#pragma unroll
-            for (int pp = 0; pp < 12; ++pp) {
-                const int p = lu_piv(pp), pn = pp + 1 < 12 ? lu_piv(pp + 1) : -1;
-                const TL ip = Wave::rcp(wv.row_bcast(R[p], p));
+            // (compile-time pivot index: the lane of the DPP control is part of the instruction; static_for, not `#pragma unroll` -- past its size
+            //  threshold the unroller leaves a run-time loop with a 12-way switch in front of every multiply-add)
+            static_for<0, 12>([&](auto pp_) {
+                constexpr int pp = decltype(pp_)::value, p = lu_piv(pp), pn = pp + 1 < 12 ? lu_piv(pp + 1) : -1;
+                const TL ip = Wave::rcp(wv.template row_bcast_c<p>(R[p]));
                 const bool own = (r == p);
                 const TL g_ = R[p] * ip;
                 const TL nfe = own ? TL(0) : -g_;
                 ipown = own ? ip : ipown;
                 // (the column of the NEXT pivot first: its broadcast must not follow the write within two wait states, and the compiler
                 //  does not see the write inside Wave::row_fmac)
-                if (pn >= 0) wv.row_fmac(R[pn], R[pn], nfe, p);
-#pragma unroll
-                for (int c = 0; c < 12; ++c) if (c != p && c != pn) wv.row_fmac(R[c], R[c], nfe, p);
+                if constexpr (pn >= 0) wv.template row_fmac_c<p>(R[pn], R[pn], nfe);
+                static_for<0, 12>([&](auto c_) { constexpr int c = decltype(c_)::value; if constexpr (c != p && c != pn) wv.template row_fmac_c<p>(R[c], R[c], nfe); });
                 R[p] = own ? TL(1) : -g_;
-            }
+            });
 #pragma unroll
             for (int c = 0; c < 12; ++c) R[c] *= ipown;
             if (lev > 0) {                                 // (their rows of L and Dup: read here, not before the elimination, which needs the registers)
@@ -2430,19 +2431,15 @@ struct LaneProgram {
             if (lev > 0) {                                 // (uniform) Schur complement onto the parent: Dup - L (S^-1 U), summed as in factorize_quad
                 constexpr int U0 = (DJ_TSD || DJ_SS) ? 0 : 1;
                 TL Tq[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
+                static_for<3 * U0, 12>([&](auto m_) { constexpr int m = decltype(m_)::value;
 #pragma unroll
-                for (int m = 3 * U0; m < 12; ++m)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) wv.row_fmac(Tq[j], Ur[j], R[m], m);
+                    for (int j = 0; j < 6; ++j) wv.template row_fmac_c<m>(Tq[j], Ur[j], R[m]); });
                 Wave::dpp_settle();
                 TL upr[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     TL pq[4] = {TL(0), TL(0), TL(0), TL(0)};
-#pragma unroll
-                    for (int o = 0; o < 4; ++o)
-#pragma unroll
-                        for (int m_ = 0; m_ < 3; ++m_) wv.row_fmac(pq[o], Tq[j], Lr[3 * o + m_], 3 * o + m_);
+                    static_for<0, 12>([&](auto m_) { constexpr int m = decltype(m_)::value; wv.template row_fmac_c<m>(pq[m / 3], Tq[j], Lr[m]); });
                     upr[j] = Dr[j] - ((pq[0] + pq[1]) + (pq[2] + pq[3]));
                 }
                 if (sl >= 0 && r < 6) {                    // rows 0:3 -> the slot of role 0, rows 3:6 -> role 1 (mail_add_children reads them there)
@@ -2652,6 +2649,150 @@ struct LaneProgram {
                     for (int j = 0; j < 6; ++j) up[i][j] = q < 2 ? TL(K.D[i][j]) : TL(0);
             }
         }
+    }
+
+    // The same LU-form pass in the ROW layout (see factorize_rows): the supernodes of a level on a 16-lane row each, lane r with row r of
+    // [S | U], lanes 0..5 also with row i of the parent's [L | Dup]; a pivot step is one v_fmac_f64_dpp per entry that changes.  Factor rows,
+    // T and m go back to the quad lanes in the places factorize_quad_lu leaves them (store_lu reads them there); the Schur complement is
+    // posted by the row lanes.  Same operations in the same order: bit for bit the quad passes.
+    DJ_HD void factorize_rows_lu(QuadBlocks<TL>& K) {
+        constexpr int RS = 12, US = 7, DS = 6;         // (StepLds::LU_RS / ROW_US / LU_DS)
+        TL (&A)[3][12] = F.Sq;
+#ifdef DJ_DEBUG
+        if (wv.lane() == 0 && std::getenv("DJ_TRACE_ROWS")) std::fprintf(stderr, "factorize_rows_lu: %d passes\n", G.rows);
+#endif
+        for (int t = 0; t < G.rows; ++t) {
+            int ln = wv.lane(), pk = rp_pack;
+            DJ_OPAQUE(ln); DJ_OPAQUE(pk);
+            const int g = ln >> 4, r = ln & 15, rp_pass = pk >> 8, rp_grp = pk & 3;
+            double* const stU = stB; double* const stD = stB + 4 * 12 * US; double* const stL = stA;
+            double* const rowS = stA + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;            // this lane's rows as a row lane ...
+            double* const rowU = stU + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
+            double* const rowL = stL + (size_t)(g * 6 + (r < 6 ? r : 0)) * RS;
+            const double* const rowD = stD + (size_t)(g * 6 + (r < 6 ? r : 0)) * DS;
+            double* const qS = stA + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
+            double* const qU = stU + (size_t)(rp_grp * 12 + 3 * q) * US;
+            const int lev = G.rp_lev[t] & 255, maxch = G.rp_lev[t] >> 8;
+            const bool mine = rp_pass == t, at = active && mine;
+            wv.sync();
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) qS[i * RS + c] = (double)A[i][c];
+                    if (lev > 0) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) qU[i * US + j] = (double)F.Uq[i][j];
+                    }
+                }
+                if (lev > 0 && q < 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) stD[(size_t)(rp_grp * 6 + 3 * q + i) * DS + j] = (double)K.D[i][j];
+                }
+            }
+            wv.sync();
+            const int sl = Globals<T>::rp_byte(G.rp_slot4[t], g);
+            const bool rowon = sl >= 0 && r < 12;
+            TL R[12], Ur[6], Lr[12], Dr[6];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) R[c] = TL(rowS[c]);
+            if (lev > 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { Ur[j] = TL(rowU[j]); Dr[j] = TL(rowD[j]); }
+            }
+            if (maxch > 0) {                               // children's Schur complements, summed first in NodeP::child order (factorize_quad_lu)
+                TL acc[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
+                for (int ci = 0; ci < maxch; ++ci) {
+                    const int cs = Globals<T>::rp_byte(G.rp_child4[t][ci], g);
+                    if (cs >= 0 && r < 6) {
+                        const double* m_ = mail_slot(4 * cs, r / 3) + 6 * (r % 3);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] += TL(m_[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) R[j] += acc[j];
+            }
+            wv.sync();
+            if (lev > 0) {                                 // (uniform) the parent's rows of L, over the staged S rows
+                if (mine) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stL[(size_t)(rp_grp * 6 + i) * RS + 3 * q + c] = (double)F.Lq[i][c];
+                }
+                wv.sync();
+#pragma unroll
+                for (int c = 0; c < 12; ++c) Lr[c] = TL(rowL[c]);
+                wv.sync();
+            }
+            // ---- elimination in the pivot order: rows (and the parent's rows) that come later take the update
+            static_for<0, 12>([&](auto pp_) {
+                constexpr int pp = decltype(pp_)::value, p = lu_piv(pp), pn = pp + 1 < 12 ? lu_piv(pp + 1) : -1;
+                const TL ip = Wave::rcp(wv.template row_bcast_c<p>(R[p]));
+                const int pos = r < 3 ? r : r < 6 ? r + 3 : r < 9 ? r - 3 : r;            // lu_piv(r): this row's place in the order
+                const bool later = pos > pp;
+                const TL f = R[p] * ip;
+                const TL nfe = later ? -f : TL(0);
+                if constexpr (pn >= 0) wv.template row_fmac_c<p>(R[pn], R[pn], nfe);
+                static_for<0, 12>([&](auto c_) { constexpr int c = decltype(c_)::value; if constexpr (lu_piv(c) > pp && c != pn) wv.template row_fmac_c<p>(R[c], R[c], nfe); });
+                if (lev > 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wv.template row_fmac_c<p>(Ur[j], Ur[j], nfe);
+                }
+                R[p] = later ? f : R[p];
+                if (lev > 0) {                             // the six body rows of the parent: m = (row i, column p) / pivot
+                    const TL m = Lr[p] * ip, nm = -m;
+                    static_for<0, 12>([&](auto c_) { constexpr int c = decltype(c_)::value; if constexpr (lu_piv(c) > pp) wv.template row_fmac_c<p>(Lr[c], R[c], nm); });
+                    Lr[p] = m;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wv.template row_fmac_c<p>(Dr[j], Ur[j], nm);
+                }
+            });
+            // ---- factor rows and T -> LDS -> quad lanes; the Schur complement to the mailbox
+            if (rowon) {
+#pragma unroll
+                for (int c = 0; c < 12; ++c) rowS[c] = (double)R[c];
+                if (lev > 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) rowU[j] = (double)Ur[j];
+                }
+            }
+            if (lev > 0 && sl >= 0 && r < 6) {
+                double* ms_ = mail_slot(4 * sl, r / 3) + 6 * (r % 3);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) ms_[j] = (double)Dr[j];
+            }
+            wv.sync();
+            if (at) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) A[i][c] = TL(qS[i * RS + c]);
+                    if (lev > 0) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) F.Uq[i][j] = TL(qU[i * US + j]);
+                    }
+                }
+            }
+            if (lev > 0) {                                 // ... and the rows of m, over the factor rows the quad lanes have read
+                wv.sync();
+                if (sl >= 0 && r < 6) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) rowL[c] = (double)Lr[c];
+                }
+                wv.sync();
+                if (at) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) F.Lq[i][c] = TL(stL[(size_t)(rp_grp * 6 + i) * RS + 3 * q + c]);
+                }
+            }
+        }
+        wv.sync();
     }
 
     // The right-hand sides of one batch (NC columns, this lane's role: three rows each) of the supernode `idk` -- the executing lane's own
@@ -3828,9 +3969,9 @@ struct LaneProgram {
             condense_contacts(K);
             DJ_PE(0); DJ_PB();
 #if DJ_ROWS == 1
-            if constexpr (kRowsOk) factorize_rows(K); else factorize_quad(K);
+            if constexpr (kRowsOk) { if (rows_here) factorize_rows(K); else factorize_quad(K); } else factorize_quad(K);
 #elif DJ_ROWS == 2
-            if constexpr (kRowsOk) { if (G.rows > 0 && stA != nullptr) factorize_rows(K); else factorize_quad(K); }
+            if constexpr (kRowsOk) { if (rows_here && G.rows > 0) factorize_rows(K); else factorize_quad(K); }
             else factorize_quad(K);
 #else
             factorize_quad(K);
@@ -4124,7 +4265,14 @@ struct LaneProgram {
 #endif
         // (a root's joint hangs on the origin, whose "velocity" is no unknown: its U block was assembled like any other, but the
         //  down-sweep must not apply it -- store_lu writes T = 0 for the roots)
+#if DJ_ROWS == 1
+        if constexpr (kRowsOk) { if (rows_here) factorize_rows_lu(K); else factorize_quad_lu(K); } else factorize_quad_lu(K);
+#elif DJ_ROWS == 2
+        if constexpr (kRowsOk) { if (rows_here && G.rows > 0) factorize_rows_lu(K); else factorize_quad_lu(K); }
+        else factorize_quad_lu(K);
+#else
         factorize_quad_lu(K);
+#endif
         store_lu();
         DJ_PE(1); DJ_PB();
         }
@@ -4910,7 +5058,17 @@ struct StepLds {
     static constexpr int stA_off = !rows ? 0 : ls_in_lds ? ls_off : info_end;
     static constexpr int stB_off = !rows ? 0 : ls_in_lds ? info_end : info_end + stA_bytes;
     static_assert(!rows || !ls_in_lds || ls_slot * NSN >= stA_bytes, "area A must fit the line-search block it overlays");
-    static constexpr int bytes = !rows ? info_end : stB_off + stB_bytes;
+    // ... and of the IFT kernel's LU-form passes (LaneProgram::factorize_rows_lu; GRAD == 1): A = the S rows in and the factor rows out (stride
+    // LU_RS), the rows of L in and of m out over its first half; B = the rows of U in / T out (stride ROW_US) and of Dup in (stride LU_DS).  B
+    // lies where the right-hand-side blocks reach beyond the phase-A data -- nothing of them is alive while the linearization is factored --
+    // when that stretch is long enough (fp32 ABI: exactly), A behind everything else: 40 768 of the 40 960 bytes of four workgroups per CU.
+    static constexpr int LU_RS = 12, LU_DS = 6;
+    static constexpr bool rows_lu = QUAD && NW == 1 && MAXC == 1 && GRAD == 1;
+    static constexpr int luA_bytes = 4 * 12 * LU_RS * 8, luB_bytes = 4 * 12 * ROW_US * 8 + 4 * 6 * LU_DS * 8;
+    static constexpr bool luB_in_rhs = rows_lu && (rhs_off + rhs_bytes - a_end >= luB_bytes) && (mail_off >= a_end + luB_bytes);
+    static constexpr int luA_off = info_end;
+    static constexpr int luB_off = luB_in_rhs ? a_end : info_end + luA_bytes;
+    static constexpr int bytes = rows ? stB_off + stB_bytes : rows_lu ? (luB_in_rhs ? info_end + luA_bytes : info_end + luA_bytes + luB_bytes) : info_end;
 };
 template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP = true, int NW = 1>
 constexpr int step_lds_bytes() { return StepLds<TIO, T, MAXC, GRAD, QUAD, LOCKSTEP, NW>::bytes; }
@@ -4983,7 +5141,9 @@ constexpr int FAC_PER_LANE = 72;
         if (GRAD_LAYOUT) prog.sinfo = (SweepInfo*)(lds + LY::info_off);                                                   \
         if (A.msg) prog.msg = DJ_GLOBAL_PTR(T, A.msg) + (size_t)(env < A.B ? env : 0) * (size_t)A.msg_stride;                 \
         if (LY::ls_in_lds) prog.ls_lds = lds + LY::ls_off + (size_t)(lane / 4) * LY::ls_slot;                              \
+        prog.rows_here = LY::rows || LY::rows_lu;                                                                         \
         if (LY::rows) { prog.stA = (double*)(lds + LY::stA_off); prog.stB = (double*)(lds + LY::stB_off); prog.rows_init(); }  \
+        if (LY::rows_lu) { prog.stA = (double*)(lds + LY::luA_off); prog.stB = (double*)(lds + LY::luB_off); prog.rows_init(); } \
         if (SHARE) { prog.lane_slots = lds + LY::lane_off; prog.lane_slot_stride = (int)sizeof(LaneSlot<T, MAXC>); }              \
         if (A.lu) { prog.lu = DJ_GLOBAL_PTR(T, A.lu) + (size_t)wave_index * LU_PER_LANE * wv.width() + lane; prog.lu_stride = wv.width(); }                \
         if (A.blk) { prog.blk = DJ_GLOBAL_PTR(T, A.blk) + (size_t)wave_index * 90 * wv.width() + lane; prog.blk_stride = wv.width(); }     \

@@ -911,13 +911,16 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
         if ((rc = ensure_groups(s, NG))) return rc;
         const size_t per = ((B + NG - 1) / NG + 63) / 64 * 64;
         s->last_NG = NG; s->last_per = per;
+        bool cont_recorded = false;
+        // a failure after the fork: what is already running on the internal streams must be ordered before the caller's stream all the same
+        auto unwind = [&](int rc_) { s->pending = true; (void)join_groups(s, st); if (cont_recorded) (void)hipStreamWaitEvent(st, s->cont_event, 0); return rc_; };
         HIPCHK(hipEventRecord(s->fork_event, st));
         for (size_t gi = 0; gi < NG; ++gi) {
             const size_t env0 = gi * per;
             if (env0 >= B) break;
             const int ne = (int)std::min(per, B - env0);
             HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->fork_event, 0));
-            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, ne, nullptr, nullptr, PH_MAIN))) return rc;
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, ne, nullptr, nullptr, PH_MAIN))) return unwind(rc);
             HIPCHK(hipEventRecord(s->main_events[gi], s->gstreams[gi]));
             HIPCHK(hipStreamWaitEvent(s->cstream, s->main_events[gi], 0));
             if (s->group_slot.size() <= gi) s->group_slot.resize(gi + 1, -1);
@@ -928,14 +931,14 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
         // these drain, and keep the continuation out until they are through: measured, +1.2 ms per step), and the continuation's stream has
         // the higher priority.  The IFT kernels (1.2 ms of work) then run next to the continuation (2-3 ms on a few CUs).
         HIPCHK(hipEventRecord(s->allmain_event, s->cstream));
-        if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->cstream, false, 0, -1, nullptr, nullptr, PH_CONT))) return rc;
-        HIPCHK(hipEventRecord(s->cont_event, s->cstream));
+        if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->cstream, false, 0, -1, nullptr, nullptr, PH_CONT))) return unwind(rc);
+        HIPCHK(hipEventRecord(s->cont_event, s->cstream)); cont_recorded = true;
         for (size_t gi = 0; gi < NG && dz; ++gi) {
             const size_t env0 = gi * per;
             if (env0 >= B) break;
             HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->allmain_event, 0));
             s->phase_slot = s->group_slot[gi];
-            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0), nullptr, nullptr, PH_GRAD))) return rc;
+            if ((rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0), nullptr, nullptr, PH_GRAD))) return unwind(rc);
         }
         s->pending = true;
         if ((rc = join_groups(s, st))) return rc;
@@ -956,7 +959,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
             if (env0 >= B) break;
             HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->fork_event, 0));
             rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0));
-            if (rc != DOJO_OK) return rc;
+            if (rc != DOJO_OK) { s->pending = true; (void)join_groups(s, st); return rc; }      // (the groups already launched stay ordered before the caller's stream)
         }
         s->pending = true;
         if (!s->async && (rc = join_groups(s, st))) return rc;
@@ -977,7 +980,7 @@ int dojo_set_async(DojoHandle s, int32_t on) {
 int dojo_set_iteration_cap(DojoHandle s, int32_t cap) {
     Enter en_(s);
     if (!s) { g_err = "dojo_set_iteration_cap: bad argument"; return DOJO_ERR_INVALID; }
-    s->iter_cap = cap < 0 ? -1 : cap; return DOJO_OK;
+    s->iter_cap = cap <= 0 ? 0 : cap; return DOJO_OK;      // (0 or < 0: an EXPLICIT off -- DOJO_ITER_CAP in the environment only decides for handles that never called this)
 }
 int dojo_set_groups(DojoHandle s, int32_t n) {
     Enter enter_(s);
@@ -1262,7 +1265,7 @@ int dojo_contact_gradients(DojoHandle s, void* dc) {
 int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stream) {
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_minimal_to_maximal_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (s->M.has_cut) { g_err = "dojo_minimal_to_maximal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
+    if (s->M.has_loop) { g_err = "dojo_minimal_to_maximal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const int B = s->B, T_ = 64;
@@ -1274,7 +1277,7 @@ int dojo_minimal_to_maximal_dev(DojoHandle s, const void* x, void* z, void* stre
 int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stream) {
     Enter enter_(s);
     if (!s || !x || !z) { g_err = "dojo_maximal_to_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (s->M.has_cut) { g_err = "dojo_maximal_to_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
+    if (s->M.has_loop) { g_err = "dojo_maximal_to_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     { int rcj = join_groups(s, (hipStream_t)stream); if (rcj != DOJO_OK) return rcj; }   // (asynchronous steps still in flight may write / read these buffers)
     const long long n = (long long)s->B * s->M.Nb; const int T_ = 256;
@@ -1289,7 +1292,7 @@ int dojo_maximal_to_minimal_dev(DojoHandle s, const void* z, void* x, void* stre
 int dojo_observe_dev(DojoHandle s, const void* z, void* obs, int32_t contact_forces, void* stream) {
     Enter enter_(s);
     if (!s || !obs) { g_err = "dojo_observe_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (s->M.has_cut) { g_err = "dojo_observe_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
+    if (s->M.has_loop) { g_err = "dojo_observe_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     if (!z) z = s->d_zn;                   // the state the last host-buffer / minimal-coordinate step left on the handle
     if (!z) { g_err = "dojo_observe_dev: z is NULL and the handle holds no state yet"; return DOJO_ERR_INVALID; }
     if (contact_forces && !s->have_solution) { g_err = "dojo_observe_dev: contact forces need a step on this handle"; return DOJO_ERR_INVALID; }
@@ -1326,7 +1329,7 @@ int dojo_observe(DojoHandle s, void* obs, int32_t contact_forces) {
 int dojo_step_minimal_dev(DojoHandle s, const void* x, const void* u, void* x_next, int32_t* status, int32_t* iters, void* stream) {
     Enter enter_(s);
     if (!s || !x || !x_next) { g_err = "dojo_step_minimal_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (s->M.has_cut) { g_err = "dojo_step_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
+    if (s->M.has_loop) { g_err = "dojo_step_minimal_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     size_t B = s->B, w = s->w, nz = 13 * s->M.Nb;
     int rc;
@@ -1351,7 +1354,7 @@ int dojo_minimal_gradients_dev(DojoHandle s, const void* x, const void* u, void*
                                void* jx, void* ju, void* stream) {
     Enter enter_(s);
     if (!s || !x || !x_next || !jx) { g_err = "dojo_minimal_gradients_dev: bad argument"; return DOJO_ERR_INVALID; }
-    if (s->M.has_cut) { g_err = "dojo_minimal_gradients_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
+    if (s->M.has_loop) { g_err = "dojo_minimal_gradients_dev: the minimal coordinates of a mechanism with a kinematic loop are not those of a tree traversal (the reference sets them with exclude_ids): not supported"; return DOJO_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
     const size_t B = s->B, w = s->w, Nb = s->M.Nb, nz = 13 * Nb, nx = 12 * Nb, nu = s->M.nu, nm = 2 * nu;
     hipStream_t st = (hipStream_t)stream;

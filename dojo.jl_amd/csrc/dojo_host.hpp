@@ -23,6 +23,7 @@ struct HostModel {
     bool has_mlim = false;            // ... the DJ_MLIM kernels (lane mapping)
     std::vector<NodeP<double>> cuts;  // loop-closing joints (a body's second, third ... parent joint): the joint fields of NodeP, parent = body a, child[0] = body b
     bool has_cut = false;             // ... the DJ_CUT kernels (lane mapping)
+    bool has_loop = false;            // ... of which at least one is a loop-closing JOINT (has_cut alone may be a body-body contact carried as a cut element: still a tree)
     bool has_cc = false;              // a body-body contact between bodies that are no tree neighbours (a cut element as well; forward only)
     bool has_ss = false;          // a body-body contact (SphereSphereCollision): the DJ_SS kernels, forward only
     double dt = 0.01, input_scaling = 0.01, g[3] = {0, 0, -9.81};
@@ -89,7 +90,7 @@ inline int build_host_model(const DojoTopology& tp, HostModel& M) {
             cutnode = NodeP<double>(); cutnode.nchild = 1; for (int i = 0; i < MAXCH; ++i) cutnode.child[i] = J.child;
             cutnode.level = 0; cutnode.ncontact = 0; for (int i = 0; i < 8; ++i) cutnode.contact[i] = 0;
             cutnode.m = 0; for (int i = 0; i < 9; ++i) cutnode.J[i] = 0;
-            M.has_cut = true;
+            M.has_cut = true; M.has_loop = true;
         } else pj[J.child] = j;
         NodeP<double>& P = is_cut ? cutnode : M.nodes[J.child];
         P.parent = J.parent;

@@ -120,6 +120,10 @@ struct GpuWave {
                      case 4: row_fmac_<4>(acc, src, f); break; case 5: row_fmac_<5>(acc, src, f); break; case 6: row_fmac_<6>(acc, src, f); break; case 7: row_fmac_<7>(acc, src, f); break;
                      case 8: row_fmac_<8>(acc, src, f); break; case 9: row_fmac_<9>(acc, src, f); break; case 10: row_fmac_<10>(acc, src, f); break; default: row_fmac_<11>(acc, src, f); break; }
     }
+    template <int P> __device__ __forceinline__ void row_fmac_c(double& acc, double src, double f) const { row_fmac_<P>(acc, src, f); }
+    template <int P> __device__ __forceinline__ double row_bcast_c(double v) const { return row_bcast_<P>(v); }
+    template <int P> __device__ __forceinline__ void row_fmac_c(float& acc, float src, float f) const { row_fmac(acc, src, f, P); }
+    template <int P> __device__ __forceinline__ float row_bcast_c(float v) const { return row_bcast(v, P); }
     __device__ __forceinline__ void row_fmac(float& acc, float src, float f, int p) const { acc += __shfl(src, (int)((threadIdx.x & 48u) + p), 64) * f; }   // (no fp32 factorization build exists on the GPU)
     __device__ __forceinline__ float row_bcast(float v, int p) const { return __shfl(v, (int)((threadIdx.x & 48u) + p), 64); }
     static __device__ __forceinline__ void dpp_settle() { __asm__ volatile("s_nop 1"); }     // the two wait states, where the order of the statements does not give them

@@ -5,6 +5,8 @@
 // (src/orientation/quaternion.jl `LVᵀmat`, so the rotation angle is 2|φ|).
 #pragma once
 #include <math.h>
+#include <type_traits>
+#include <utility>
 #ifndef DJ_FAST_SQRT
 #define DJ_FAST_SQRT 1
 #endif
@@ -35,6 +37,12 @@ template <class X> __device__ __forceinline__ X* dj_assume_global(X* p) {
 #endif
 
 namespace dj {
+
+// compile-time loop: f(std::integral_constant<int, I>()) for I = I0 .. I1-1.  Where a loop index must be a constant of the instruction
+// (the lane of a DPP control), `#pragma unroll` is not enough: past its size threshold the unroller leaves a run-time loop behind.
+template <int I0, int I1, class F> DJ_HD void static_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>()); static_for<I0 + 1, I1>(f); }
+}
 
 template <class T> DJ_HD T tmax(T a, T b) { return a > b ? a : b; }
 template <class T> DJ_HD T tmin(T a, T b) { return a < b ? a : b; }

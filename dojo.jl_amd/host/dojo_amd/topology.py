@@ -221,6 +221,14 @@ class MechanismSpec:
                 lo[:s.nlim] = s.limits[0]; hi[:s.nlim] = s.limits[1]
             h.limit_lo, h.limit_hi = d3(*lo), d3(*hi)
 
+        # The C side takes the FIRST joint that names a body as its tree joint and every later one as loop-closing (dojo_host.hpp, build_host_model);
+        # the host-side traversals (coords._root_to_leaves) go by JointSpec.loop.  The two must describe the same spanning tree.
+        seen = set()
+        for j in self.joints:
+            if getattr(j, "loop", False) != (j.child in seen):
+                raise ValueError("joint %r: %s" % (j.name, "flagged loop=True but no earlier joint has body %d as its child: list its tree joint first" % j.child
+                                                   if getattr(j, "loop", False) else "body %d already hangs on an earlier joint: flag this one loop=True" % j.child))
+            seen.add(j.child)
         for i, j in enumerate(self.joints):
             J[i].parent, J[i].child = j.parent, j.child
             J[i].spring_on, J[i].damper_on = int(j.spring_on), int(j.damper_on)

@@ -83,6 +83,8 @@ struct EmuWaveT {
     static constexpr bool kRows = NW == 1;
     template <class V> V row_bcast(V v, int p) { return shfl(v, (l & ~15) + p); }
     template <class V> void row_fmac(V& acc, V src, V f, int p) { acc += shfl(src, (l & ~15) + p) * f; }
+    template <int P, class V> V row_bcast_c(V v) { return row_bcast(v, P); }
+    template <int P, class V> void row_fmac_c(V& acc, V src, V f) { row_fmac(acc, src, f, P); }
     static void dpp_settle() {}
     bool any(bool p) {
         sh->islot[l] = p ? 1 : 0;

@@ -164,8 +164,9 @@ def _full_batch_bound(label, ok, ez, eu, es, itg, ito, nstat, B, state_bound, gr
     return eg[same].max()
 
 
-@pytest.mark.parametrize("cfg,B,pre,dtype", [(2, 1024, 30, "f64"), (4, 8192, 8, "f64"), (5, 2048, 12, "f64"), (4, 8192, 8, "f32"), (5, 2048, 12, "f32")])
-def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
+@pytest.mark.parametrize("cfg,B,pre,dtype,dist", [(2, 1024, 30, "f64", "standing"), (4, 8192, 8, "f64", "standing"), (5, 2048, 12, "f64", "standing"), (4, 8192, 8, "f32", "standing"),
+                                                  (5, 2048, 12, "f32", "standing"), (5, 2048, 8, "f64", "baseline"), (5, 2048, 8, "f32", "baseline")])
+def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype, dist):
     """BASELINE configs[1], [3], [4] at their full batches with DISTINCT seeded environments (Block-on-plane 1024, Quadruped
     8192 -- the batch its line shards over 8 GPUs -- and Atlas 2048), reference-default options, after `pre` closed-loop
     steps: one differentiable step against the oracle on all host cores, the kernels bench.py times.  fp64 ABI: state and gradient
@@ -174,9 +175,13 @@ def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
     reference's solver itself stalls on 2-8 % of the steps, is over and every solve converges: the same gates as the other configurations
     (round 4 allowed Atlas 40 status mismatches and 10 % unconverged on a thrown-about distribution).  fp32 ABI (what BASELINE
     quotes configs 3-5 in; the oracle steps the state the fp32 buffer stands for): state <= 1e-5 (output rounding of |z| <= ~1e2),
-    gradient max <= 1e-4 (the north-star bound for fp32: 1e-3)."""
+    gradient max <= 1e-4 (the north-star bound for fp32: 1e-3).
+    dist = "baseline": Atlas on BASELINE.md section 3's perturbation (what bench.py --config 5 measures by default), eight steps in: the robot
+    has been thrown onto its foot edges, the reference's solver (the oracle) stalls on 5-9 % of such steps and a stalled solve ends where its
+    iterate happens to be -- looser gates, stated here: >= 85 % converged on both sides, <= 60 status mismatches, <= 30 iteration mismatches,
+    long solves up to 1e-2 apart; every environment that converged on both sides to the same point still meets the state and gradient bounds."""
     spec = d.baseline_config(cfg)
-    Z, U = d.synthetic_inputs(spec, B)
+    Z, U = d.synthetic_inputs(spec, B, distribution=dist)
     gm = api.BatchedMechanism(spec, B, dtype="f64")
     for _ in range(pre):
         Z, st, it = gm.step(Z, U)
@@ -187,8 +192,8 @@ def test_parity_at_the_other_baseline_batches(cfg, B, pre, dtype):
     ok, ez, eu, es, itg, ito, nstat = _grad_errors(spec, Z, U, d.SolverOptions(), dtype=dtype)
     # (fp32 ABI gradient bound 1e-4 -- the contract's is 1e-3: a 39/40-iteration Quadruped solve ends 9e-6 from the oracle's point, inside the fp32 state
     #  bound, with a Jacobian 1.3e-5 off; every other environment of the three batches: <= 9e-8)
-    _full_batch_bound("BASELINE cfg %d B %d %s ABI" % (cfg, B, dtype), ok, ez, eu, es, itg, ito, nstat, B, 1e-5 if f32 else 1e-6, 1e-4 if f32 else 1e-6,
-                      min_ok=0.99, max_apart=2e-3, max_stat=4, max_iter_mismatch=4)
+    gates = dict(min_ok=0.99, max_apart=2e-3, max_stat=4, max_iter_mismatch=4) if dist == "standing" else dict(min_ok=0.85, max_apart=1e-2, max_stat=60, max_iter_mismatch=30)
+    _full_batch_bound("BASELINE cfg %d B %d %s ABI (%s)" % (cfg, B, dtype, dist), ok, ez, eu, es, itg, ito, nstat, B, 1e-5 if f32 else 1e-6, 1e-4 if f32 else 1e-6, **gates)
 
 
 def test_solution_export_matches_oracle():

@@ -10,7 +10,7 @@ for cap in ${CAPS:-0 -1 20 24 0 -1}; do
 import json
 try:
     r = json.load(open("gpurun_out/cap_$cap.json"))
-    print("cap $cap: value %.0f  ms/step %.3f  sync %.0f (%.3f ms)  step_kernel %.3f ms (best %.3f)  ift %.3f" % (r["value"], r["ms_per_step"], r["config"]["sync_per_step_value"], r["config"]["sync_per_step_ms"], r["roofline"]["avg_kernel_ms"], r["roofline"]["best_launch"]["kernel_ms"], r["roofline_second_kernel"]["avg_kernel_ms"]))
+    print("cap $cap: value %.0f  ms/step %.3f  sync %.0f (%.3f ms)  step_kernel %.3f ms (best %.3f)  ift %.3f" % (r["value"], r["ms_per_step"], r["config"]["sync_per_step_value"], r["config"]["sync_per_step_ms"], r['roofline']['single_launch']['dojo_step_kernel']['avg_kernel_ms'], r['roofline']['single_launch']['dojo_step_kernel']['best_launch']['kernel_ms'], r['roofline']['single_launch']['dojo_grad_kernel']["avg_kernel_ms"]))
 except Exception as e:
     print("cap $cap: no line", e); print(open("gpurun_out/cap_$cap.json").read()[-600:])
 PY

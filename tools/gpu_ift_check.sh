@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 make -C oracle > /dev/null 2>&1
 for dt in f32 f64; do
   echo "=== bench $dt"; timeout 600 python bench.py --steps 20 --warmup 3 --no-parity --no-cpu-baseline --io-dtype $dt 2>&1 | tail -1 | python -c "
-import sys, json; r = json.loads(sys.stdin.readline()); print('value %.0f sync %.0f ms/step %.3f step_kernel %.3f ift_kernel %.3f (best %.3f / %.3f)' % (r['value'], r['config']['sync_per_step_value'], r['ms_per_step'], r['roofline']['avg_kernel_ms'], r['roofline_second_kernel']['avg_kernel_ms'], r['roofline']['best_launch']['kernel_ms'], r['roofline_second_kernel']['best_launch']['kernel_ms']))"
+import sys, json; r = json.loads(sys.stdin.readline()); print('value %.0f sync %.0f ms/step %.3f step_kernel %.3f ift_kernel %.3f (best %.3f / %.3f)' % (r['value'], r['config']['sync_per_step_value'], r['ms_per_step'], r['roofline']['single_launch']['dojo_step_kernel']['avg_kernel_ms'], r['roofline']['single_launch']['dojo_grad_kernel']['avg_kernel_ms'], r['roofline']['single_launch']['dojo_step_kernel']['best_launch']['kernel_ms'], r['roofline']['single_launch']['dojo_grad_kernel']['best_launch']['kernel_ms']))"
 done
 cd /tmp
 for set in FETCH_SIZE WRITE_SIZE; do

@@ -48,7 +48,7 @@ constexpr int RS = 13;                    // row stride of the staged S rows (do
 constexpr int US = 7;                     // ... of the staged U / Tq rows
 // MODE 0: quad layout; 1: row layout; 2: row layout, Gauss-Jordan alone on resident rows (the review's kill criterion: <= 2.6 k cycles)
 template <int MODE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k(double* out, unsigned long long* cyc, double seed, int lev_slot0) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k(double* out, unsigned long long* cyc, double seed, int lev_slot0, unsigned long long* ph) {
     __shared__ double lds[4 * 16 * RS + 4 * 16 * US + 4 * 6 * RS + 4 * 6 * US + 16 * 40];
     const int lane = threadIdx.x, wave = blockIdx.x;
     const int s = lane >> 2, q = lane & 3;                  // quad layout: supernode slot, role
@@ -66,6 +66,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     double* stS = lds; double* stU = stS + 4 * 16 * RS; double* stL = stU + 4 * 16 * US; double* stD = stL + 4 * 6 * RS; double* mail = stD + 4 * 6 * US;
     double Rres[12];
     for (int c = 0; c < 12; ++c) Rres[c] = r < 12 ? elemS(wave * 4 + g, r, c, seed) : (r == c ? 1.0 : 0.0);
+    unsigned long long pa[5] = {0, 0, 0, 0, 0}, tp = 0;
+#define PH_B() do { if (ph) { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp = __builtin_readcyclecounter(); } } while (0)
+#define PH_E(i) do { if (ph) { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_readcyclecounter(); pa[i] += t_ - tp; tp = t_; } } while (0)
     unsigned long long t0 = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int it = 0; it < N_IT; ++it) {
@@ -151,6 +154,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
         } else {
             double R[12], Ur[6], Lr[12], Dr[6];
+            PH_B();
             if (MODE == 1) {
                 // ---- quad lanes at the level -> LDS
                 if (at) {
@@ -197,6 +201,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { Ur[j] = 0.0; Dr[j] = 0.0; }
             }
+            PH_E(0);
             // ---- Gauss-Jordan, the pivot row inside the multiply-add
             double ipown = 1.0;
 #pragma unroll
@@ -218,12 +223,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
 #pragma unroll
             for (int c = 0; c < 12; ++c) R[c] *= ipown;
+            PH_E(1);
             if (MODE == 1) {
                 // ---- inverse rows back to the quad lanes
                 if (r < 12) {
 #pragma unroll
                     for (int c = 0; c < 12; ++c) stS[(g * 16 + r) * RS + c] = R[c];
                 }
+                PH_E(2);
                 // ---- Tq = S^-1 U (rows 0:3 of U are structurally zero), up = Dup - L Tq in the quad layout's summation order
                 double Tq[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -247,14 +254,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
                     for (int j = 0; j < 6; ++j) mail[(2 * sl + r / 3) * 20 + 6 * (r % 3) + j] = upr[j];
                 }
-                __asm__ volatile("" ::: "memory");
+                PH_E(3);
                 if (at) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int c = 0; c < 12; ++c) A0[i][c] = stS[(gq * 16 + 3 * q + i) * RS + c];
                 }
-                __asm__ volatile("" ::: "memory");
+                PH_E(4);
             } else {
 #pragma unroll
                 for (int c = 0; c < 12; ++c) A0[0][c] = R[c];
@@ -280,18 +287,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (int c = 0; c < 12; ++c) o[g * 180 + r * 12 + c] = A[0][c];
     }
     if (lane == 0) cyc[wave] = t1 - t0;
+    if (ph && lane == 0) for (int i = 0; i < 5; ++i) ph[wave * 5 + i] = pa[i];
 }
-template <int MODE> std::vector<double> run(const char* name, int waves) {
+template <int MODE> std::vector<double> run(const char* name, int waves, bool phases = false) {
     double* out; unsigned long long* cyc;
     const size_t n = (size_t)waves * 4 * 180;
     hipMalloc(&out, n * 8); hipMalloc(&cyc, waves * 8); hipMemset(out, 0, n * 8);
-    k<MODE><<<waves, 64>>>(out, cyc, 1.0, 2); hipDeviceSynchronize();
+    unsigned long long* ph = nullptr; if (phases) hipMalloc(&ph, waves * 5 * 8);
+    k<MODE><<<waves, 64>>>(out, cyc, 1.0, 2, ph); hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0); k<MODE><<<waves, 64>>>(out, cyc, 1.0, 2); hipEventRecord(e1); hipDeviceSynchronize();
+    hipEventRecord(e0); k<MODE><<<waves, 64>>>(out, cyc, 1.0, 2, ph); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(waves); hipMemcpy(h.data(), cyc, waves * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (auto v : h) avg += v; avg /= waves;
     printf("%-78s waves %5d  %.3f ms   cycles per level pass %.0f\n", name, waves, ms, avg / N_IT);
+    if (phases) { std::vector<unsigned long long> hp(waves * 5); hipMemcpy(hp.data(), ph, waves * 5 * 8, hipMemcpyDeviceToHost); double a5[5] = {0, 0, 0, 0, 0}; for (int w = 0; w < waves; ++w) for (int i = 0; i < 5; ++i) a5[i] += hp[w * 5 + i]; printf("    phases (cycles per pass, a full LDS wait at every boundary): stage in + row loads %.0f | Gauss-Jordan %.0f | inverse rows out %.0f | S^-1 U, Schur, post %.0f | read-back %.0f\n", a5[0] / waves / N_IT, a5[1] / waves / N_IT, a5[2] / waves / N_IT, a5[3] / waves / N_IT, a5[4] / waves / N_IT); }
     std::vector<double> r(n); hipMemcpy(r.data(), out, n * 8, hipMemcpyDeviceToHost);
     hipFree(out); hipFree(cyc);
     return r;
@@ -299,6 +309,7 @@ template <int MODE> std::vector<double> run(const char* name, int waves) {
 int main() {
     auto a = run<0>("A quad layout: GJ 12x12 + S^-1 U + Schur, quad_perm broadcasts (16 slots, 4 at the level)", 1024);
     auto b = run<1>("R row layout: LDS transposition + fused row_newbcast GJ + S^-1 U + Schur + back", 1024);
+    run<1>("R row layout once more, with a timer and a full LDS wait at every phase boundary", 1024, true);
     auto c = run<2>("R' row layout: the 12-pivot Gauss-Jordan alone on resident rows (kill criterion 2.6 k)", 1024);
     size_t nd = 0, ndc = 0; double worst = 0, sum = 0;
     for (size_t i = 0; i < a.size(); ++i) { if (std::memcmp(&a[i], &b[i], 8) != 0) { ++nd; double d = a[i] - b[i]; if (d < 0) d = -d; if (d > worst) worst = d; } sum += a[i]; }
