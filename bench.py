@@ -88,7 +88,11 @@ def main():
     w = 4 if args.io_dtype == "f32" else 8
     # synthetic inputs: B DISTINCT seeded environments per rank (perturbed nominal states built in minimal
     # coordinates, so the joints are closed), distinct seeds per rank; controls ~ 0.5 N(0,1) on the actuated inputs, fresh every step
-    Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008 + rank, distribution=args.distribution)
+    # (strong scaling: ONE batch of batch_total environments all ranks agree on, rank r steps its contiguous slice [r B, (r + 1) B); weak: B fresh ones per rank)
+    if strong:
+        Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008, distribution=args.distribution, offset=rank * B)
+    else:
+        Z0, U0 = d.synthetic_inputs(spec, B, seed=20241008 + rank, distribution=args.distribution)
     reps = 1
     z = torch.tensor(Z0, dtype=tdt, device=dev).contiguous()
     rng = np.random.Generator(np.random.Philox(key=[20241008, 1000 + rank]))
@@ -181,6 +185,8 @@ def main():
         else:
             torch.cuda.synchronize(); traj_all = D.all_gather_states(traj.cpu(), world)
         gathered_bytes = traj_all.numel() * traj_all.element_size()
+        # rank r's block of the gathered trajectory is what rank r computed (rank order = the order of the contiguous batch shards): every rank checks its own
+        gather_ok = bool(torch.equal(traj_all.reshape((world,) + tuple(traj.shape))[rank].to(traj.device), traj))
     barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, world, device=dev if args.backend == "nccl" else "cpu")
     # hipEvent durations of the timed region's launches, summed over the environment groups (every group's kernels on its own stream): against
@@ -201,6 +207,10 @@ def main():
         box = [None] * world
         dist.all_gather_object(box, "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(local)))
         rank_devices = box
+        box2 = [None] * world
+        dist.all_gather_object(box2, {"rank": rank, "env_range": [rank * B, (rank + 1) * B] if strong else [0, B], "own_block_of_the_gather_matches": gather_ok,
+                                      "first_state_checksum": float(Z0[0].sum())})
+        rank_slices = box2
     # the same closed loop with a join of the environment groups into the caller's stream after EVERY step (what a policy over the
     # whole batch needs: a barrier per step; the max_iter tail of a step is then not hidden behind the next step), outside the timed region
     gm.set_async(False)
@@ -346,6 +356,7 @@ def main():
                                                  "bytes_received_per_rank": gathered_bytes,
                                                  "through": "dojo_allgather_dev (the library's RCCL communicator)" if lib_gather else "torch.distributed all_gather (RCCL)"}
             res["config"]["rank_devices"] = rank_devices
+            res["config"]["rank_slices"] = rank_slices        # (strong scaling: rank r = environments [r B, (r + 1) B) of the one batch_total-environment batch)
         print(json.dumps(res), flush=True)
     if world > 1:
         if lib_stuck:                            # a thread is still inside the library's communicator set-up: leave without the teardown that would wait for it

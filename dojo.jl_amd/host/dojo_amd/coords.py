@@ -219,10 +219,19 @@ def synthetic_distribution(distribution=None):
     return dist
 
 
-def synthetic_inputs(spec, batch, seed=20241008, height=None, rot_sigma=None, vel_sigma=None, u_sigma=0.5, joint_range=None, distribution=None):
+def synthetic_inputs(spec, batch, seed=20241008, height=None, rot_sigma=None, vel_sigma=None, u_sigma=0.5, joint_range=None, distribution=None, offset=0):
     """Perturb the nominal state in minimal coordinates and map to maximal with the host FK so
     joints stay closed.  Counter-based RNG (Philox) keyed by (seed, config, field); row b of every
-    field depends only on b, so a smaller batch is a prefix of a larger one."""
+    field depends only on b, so a smaller batch is a prefix of a larger one -- and `offset` gives rows offset .. offset + batch - 1
+    of that one sequence (a rank's contiguous shard of a batch all ranks agree on: bench.py --batch-total)."""
+    if offset:
+        return _synthetic_rows(spec, (int(offset), int(offset) + int(batch)), seed, height, rot_sigma, vel_sigma, u_sigma, joint_range, distribution)
+    return _synthetic_rows(spec, (0, int(batch)), seed, height, rot_sigma, vel_sigma, u_sigma, joint_range, distribution)
+
+
+def _synthetic_rows(spec, rows, seed, height, rot_sigma, vel_sigma, u_sigma, joint_range, distribution):
+    lo_, hi_ = rows
+    batch = hi_
     dflt = dict(_SYNTH_GENERAL, **(_SYNTH_STANDING.get(spec.name, {}) if synthetic_distribution(distribution) == "standing" else {}))
     cid = _CONFIG_ID.get(spec.name, 9)
     height = dflt["height"] if height is None else height; rot_sigma = dflt["rot_sigma"] if rot_sigma is None else rot_sigma
@@ -238,7 +247,7 @@ def synthetic_inputs(spec, batch, seed=20241008, height=None, rot_sigma=None, ve
     N_v = rng(3).normal(0.0, vel_sigma, size=(batch, max(nu, 1)))
     N_u = rng(4).normal(0.0, u_sigma, size=(batch, max(nu, 1)))
     Z = np.zeros((batch, 13 * spec.Nb)); U = np.zeros((batch, nu))
-    for b in range(batch):
+    for b in range(lo_, batch):
         x = x0.copy(); o = 0; iu = 0
         for j in spec.joints:
             n = j.nu
@@ -257,7 +266,7 @@ def synthetic_inputs(spec, batch, seed=20241008, height=None, rot_sigma=None, ve
                 U[b, iu:iu + n] = N_u[b, iu:iu + n]
             o += 2 * n; iu += n
         Z[b] = minimal_to_maximal(spec, x)
-    return Z, U
+    return Z[lo_:], U[lo_:]
 
 
 def fp32_abi_state(Z):

@@ -104,6 +104,54 @@ def test_bench_strong_scaling_line():
     assert r.returncode != 0 and "not a multiple" in (r.stderr + r.stdout)
 
 
+def test_bench_eight_ranks_strong_scaling_plumbing():
+    """The 8-GPU line of BASELINE configs[3] as the driver will launch it -- `bench.py --config 4 --batch-total 8192 --gpus 8` -- with its eight ranks on the ONE
+    GPU of this box and gloo carrying the collectives: rendezvous, every rank's contiguous slice of the one 8192-environment batch ([r 1024, (r + 1) 1024)),
+    the all-gather of the trajectory chunk [K, 1024, 13 Nb] of every rank (each rank finds its own block at its own place), "scaling": "strong", the
+    whole-job value.  No scaling curve can be measured here; this is so that the first run on eight GPUs is not spent on plumbing."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    K = 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", "1", "--config", "4", "--batch-total", "8192",
+                        "--backend", "gloo", "--no-parity", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and cfg["per_rank_batch"] == 1024 and cfg["total_batch"] == 8192
+    assert abs(res["value"] - 8192 * K / (res["ms_per_step"] * K * 1e-3)) < 1e-6 * res["value"]
+    nb = 13                                                  # Quadruped: trunk + 12 links
+    assert cfg["trajectory_gather"]["bytes_received_per_rank"] == 8 * K * 1024 * 13 * nb * 4
+    assert len(cfg["rank_devices"]) == 8
+    sl = sorted(cfg["rank_slices"], key=lambda x: x["rank"])
+    assert [x["env_range"] for x in sl] == [[1024 * i, 1024 * (i + 1)] for i in range(8)]
+    assert all(x["own_block_of_the_gather_matches"] for x in sl)
+    assert len({x["first_state_checksum"] for x in sl}) == 8                 # eight different shards, not eight copies of one
+
+
+def test_library_communicator_failure_modes():
+    """dojo_comm_init / dojo_allgather_dev refuse what cannot work with a return code and a message instead of hanging or crashing: a rank outside the world,
+    an empty world, no id, a gather without a communicator; a communicator of one rank reports itself through dojo_comm_info."""
+    import ctypes as C
+    import dojo_amd as d
+    from dojo_amd import api
+    lib = api.lib()
+    gm = api.BatchedMechanism(d.baseline_config(1), 8, dtype="f64")
+    uid = gm.comm_unique_id()
+    INVALID = -1                                             # DOJO_ERR_INVALID (include/dojo_hip.h)
+    for rank, world, idp in ((1, 1, uid), (0, 0, uid), (-1, 2, uid), (2, 2, uid), (0, 1, None)):
+        rc = lib.dojo_comm_init(gm.h, rank, world, C.c_char_p(idp) if idp is not None else None)
+        assert rc == INVALID and b"dojo_comm_init" in lib.dojo_last_error(), (rank, world, rc, lib.dojo_last_error())
+    buf = (C.c_double * 8)()
+    rc = lib.dojo_allgather_dev(gm.h, C.cast(buf, C.c_void_p), C.cast(buf, C.c_void_p), C.c_int64(8), 0, C.c_void_p(0))
+    assert rc == INVALID and b"no communicator" in lib.dojo_last_error()
+    rk, wd = C.c_int32(-7), C.c_int32(-7)
+    assert lib.dojo_comm_info(gm.h, C.byref(rk), C.byref(wd)) == 0 and wd.value == 1          # no communicator: a world of one
+    gm.comm_init(0, 1, uid)
+    assert lib.dojo_comm_info(gm.h, C.byref(rk), C.byref(wd)) == 0 and (rk.value, wd.value) == (0, 1)
+    gm.close()
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT a launcher: bench.py re-executes itself as two ranks (torch.distributed.run on 127.0.0.1)
     and rank 0 prints the one JSON line with n_gpus = 2 and the device of every rank (gloo: the two ranks share the one GPU)."""
