@@ -56,3 +56,25 @@ def test_headline_objects_compile_from_clean(tmp_path):
     defined = {m.group(1) for m in re.finditer(r"FUNC\s+GLOBAL\s+\w+\s+(?!UND)\d+\s+(dojo_[a-z0-9_]+)\b", syms)}
     missing = {d_ for d_ in declared if d_ not in defined and not d_.startswith("dojo_launch_")}
     assert not missing, sorted(missing)
+
+
+# one object of every other FAMILY of kernel builds (__graft_entry__.build_hip's variant table): the feature code behind -DDJ_TSD / the general
+# lane-mapping builds / LinearContact / body-body contacts compiles from this tree as well, and exports its launcher
+FAMILIES = [("tsd", ["-DDJ_TIO=float", "-DDJ_MAXC=1", "-DDJ_QUAD=1", "-DDJ_TSD=1", "-DDJ_LINEAR=0", "-DDJ_SS=0", "-DDJ_MLIM=0", "-DDJ_CUT=0"], "dojo_launch_tsd_float_1_1"),
+            ("gen", ["-DDJ_TIO=float", "-DDJ_MAXC=4", "-DDJ_QUAD=0", "-DDJ_TSD=1", "-DDJ_LINEAR=0", "-DDJ_SS=1", "-DDJ_MLIM=1", "-DDJ_CUT=1"], "dojo_launch_gen_float_4_0"),
+            ("two_wavefronts", ["-DDJ_TIO=float", "-DDJ_MAXC=4", "-DDJ_QUAD=2", "-DDJ_TSD=0", "-DDJ_LINEAR=0", "-DDJ_SS=0", "-DDJ_MLIM=0", "-DDJ_CUT=0"], "dojo_launch_float_4_2")]
+
+
+@pytest.mark.skipif(HIPCC is None or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="no hipcc / llvm tools")
+def test_one_object_of_every_build_family_compiles_from_clean(tmp_path):
+    jobs = []
+    for name, flags, _ in FAMILIES:
+        obj = str(tmp_path / ("k_%s.o" % name))
+        jobs.append((obj, subprocess.Popen([HIPCC] + COMMON + flags + ["-c", os.path.join(CSRC, "dojo_kernels.hip"), "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for (obj, j), (name, _, launcher) in zip(jobs, FAMILIES):
+        out, _ = j.communicate(timeout=1500)
+        assert j.returncode == 0, name + ": " + out[-2000:]
+        syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--symbols", "--wide", obj], capture_output=True, text=True).stdout
+        assert re.search(r"FUNC\s+GLOBAL\s+\w+\s+(?!UND)\d+\s+" + launcher + r"\b", syms), (name, launcher)
+        res = _resources(obj)
+        assert "dojo_step_kernel" in res and res["dojo_step_kernel"][0] <= 65536, (name, res)          # (LDS of a workgroup)

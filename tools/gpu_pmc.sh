@@ -11,8 +11,10 @@ PMC_STEPS=${PMC_STEPS:-20}; export PMC_STEPS
 ARGS="${BENCH_ARGS:---steps $PMC_STEPS --warmup 5 --timed-only --chunks 1}"; export BENCH_ARGS_USED="$ARGS"
 cd /tmp
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc/pmc_summary.txt
+IFS=';' read -ra EXTRA <<< "${PMC_EXTRA_SETS:-}"      # further passes, ';'-separated sets of counters
 # PMC_EXTRA_SETS: further passes (e.g. the memory-stall counters of the IFT kernel, review item 4 of round 5): a pass whose counters this GPU does not have fails alone
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" "FETCH_SIZE" "WRITE_SIZE" $PMC_EXTRA_SETS; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" "FETCH_SIZE" "WRITE_SIZE" "${EXTRA[@]}"; do
+  [ -z "$set" ] && continue
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 600 rocprofv3 --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc/$name.log 2>&1
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/pmc/$name -name "*counter_collection.csv" | head -1)
