@@ -1236,6 +1236,13 @@ struct LaneProgram {
     // identically (quad mapping): one LDS write per supernode, then every lane folds the S values of its environment --
     // instead of log2(4S) butterfly steps of two ds_bpermute each.
     template <int NV, class OP> DJ_HD void env_reduce_quad(T (&v)[NV], OP op) {
+        if constexpr (Wave::kWaveReduce) {
+            if (G.S == 16) {                                   // (uniform) the environment is the wavefront: no LDS, Wave::reduce_quads16
+#pragma unroll
+                for (int n = 0; n < NV; ++n) v[n] = Wave::reduce_quads16(v[n], op);
+                return;
+            }
+        }
         const int nsn = wv.width() >> 2;
         wv.sync();
         if (q == 0) {

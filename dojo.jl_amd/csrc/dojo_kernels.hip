@@ -95,6 +95,19 @@ struct GpuWave {
     template <class V> __device__ __forceinline__ V quad_xor(V v, int m) const {        // value of lane (l ^ m) inside my quad, m = 1 or 2
         return m == 1 ? dppx<0xB1>(v) : dppx<0x4E>(v);                                  // quad_perm [1,0,3,2] / [2,3,0,1]
     }
+    // Reduction over the 16 supernode slots of a wavefront that is ONE environment (LaneProgram::env_reduce_quad; the four lanes of a quad hold
+    // the same value): two rotations inside every 16-lane row on the DPP path, then the four rows through v_readlane -- about twenty
+    // instructions and no LDS round trip (the LDS form: a write, then eight dependent ds_read2_b64, each behind a full wait, per value).
+    // Every lane ends with the same bits: the result is formed from the four row values in SGPRs, in row order.
+    static constexpr bool kWaveReduce = NW == 1;
+    static __device__ __forceinline__ double rdlane(double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); }
+    static __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+    template <class V, class OP> static __device__ __forceinline__ V reduce_quads16(V v, OP op) {
+        v = op(v, dppx<0x124>(v));          // row_ror:4
+        v = op(v, dppx<0x128>(v));          // row_ror:8: every lane holds its row's four supernodes
+        const V r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
+        return op(op(op(r0, r1), r2), r3);
+    }
     // Row layout of the level passes (LaneProgram::factorize_rows): 16 lanes per supernode, one matrix row per lane.  gfx950's DP ALU
     // knows exactly one DPP control, row_newbcast:P (lane P of every 16-lane row), and takes it INSIDE the fp64 multiply-add: a pivot-row
     // entry reaches the twelve rows of its supernode in the instruction that uses it -- no separate broadcast, no LDS traffic.

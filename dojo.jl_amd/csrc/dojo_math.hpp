@@ -73,7 +73,45 @@ DJ_HD double tsqrt(double a) {
 #endif
 }
 DJ_HD float  tatan(float a)  { return atanf(a); }
+// atan(a).  Device, fp64: the device library's algorithm (argument reduction to [0, 1] by a division, a degree-19 polynomial in v^2, pi/2 as a
+// product of two doubles) operation for operation -- the results are its results bit for bit (tools/ubench/atan_table.hip) -- but the twenty
+// coefficients come from a table in constant memory (scalar loads) and every multiply-add reads its coefficient as an SGPR operand.  The
+// library form builds each coefficient in the VGPR pair a two-address v_fmac_f64 accumulates into (two v_mov_b32 with literals); inlined
+// three times per evaluation of a joint with limits or a damper (rotvec, rotvec_jac_row), the compiler kept those forty moves out of the
+// Newton loop and then SPILLED them: sixty dependent scratch loads per evaluation, each behind a full wait (round 6: 103 -> 8 spilled
+// registers in the step kernel, 58 -> 12 scratch instructions in its Newton loop).  Measured next to it: the coefficients as s_mov_b32
+// literal pairs at the point of use (no table) -- no gain over the library form (profiles/r06_b_ab.txt).
+#ifndef DJ_ATAN_TABLE
+#define DJ_ATAN_TABLE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && DJ_ATAN_TABLE
+static __constant__ unsigned long long dj_atan_bits[20] = {
+    0x3EEBA404B5E68A13ull, 0xBF23E260BD3237F4ull, 0x3F4B2BB069EFB384ull, 0xBF67952DAF56DE9Bull, 0x3F7D6D43A595C56Full,
+    0xBF8C6EA4A57D9582ull, 0x3F967E295F08B19Full, 0xBF9E9AE6FC27006Aull, 0x3FA2C15B5711927Aull, 0xBFA59976E82D3FF0ull,
+    0x3FA82D5D6EF28734ull, 0xBFAAE5CE6A214619ull, 0x3FAE1BB48427B883ull, 0xBFB110E48B207F05ull, 0x3FB3B13657B87036ull,
+    0xBFB745D119378E4Full, 0x3FBC71C717E1913Cull, 0xBFC2492492376B7Dull, 0x3FC99999999952CCull, 0xBFD5555555555523ull};
+DJ_HD double tatan(double a) {
+    const double v0 = fabs(a);
+    const bool g = v0 > 1.0;
+    const double v = g ? 1.0 / v0 : v0;
+    const double t = v * v;
+    // p = fma(t, p, c_i), c_i read from its SGPR pair by the instruction itself (left to the compiler, every coefficient is first copied
+    // into the VGPR pair of a v_fmac_f64 -- the forty moves again)
+    double p = __longlong_as_double((long long)dj_atan_bits[0]);
+#pragma unroll
+    for (int i = 1; i < 20; ++i) {
+        const double c = __longlong_as_double((long long)dj_atan_bits[i]);
+        double pn;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(pn) : "v"(t), "v"(p), "s"(c));
+        p = pn;
+    }
+    const double r = fma(v, t * p, v);
+    const double hi = fma(__longlong_as_double(0x3FEDD9AD336A0500ll), __longlong_as_double(0x3FFAF154EEB562D6ll), -r);
+    return copysign(g ? hi : r, a);
+}
+#else
 DJ_HD double tatan(double a) { return atan(a); }
+#endif
 
 // ---- 3-vectors -------------------------------------------------------------------------------
 template <class T> DJ_HD void v3set(T* a, T x, T y, T z) { a[0] = x; a[1] = y; a[2] = z; }
