@@ -1237,9 +1237,9 @@ struct LaneProgram {
     // instead of log2(4S) butterfly steps of two ds_bpermute each.
     template <int NV, class OP> DJ_HD void env_reduce_quad(T (&v)[NV], OP op) {
         if constexpr (Wave::kWaveReduce) {
-            if (G.S == 16) {                                   // (uniform) the environment is the wavefront: no LDS, Wave::reduce_quads16
-#pragma unroll
-                for (int n = 0; n < NV; ++n) v[n] = Wave::reduce_quads16(v[n], op);
+            if (G.S == 16 * Wave::kWaves) {                    // (uniform) the environment is the workgroup: Wave::reduce_quads16 per wavefront, no LDS loop
+                static_assert(NV * Wave::kWaves <= 8, "Wave::red_ holds eight doubles");
+                wv.template reduce_slots<NV>(v, op);
                 return;
             }
         }
@@ -1272,14 +1272,49 @@ struct LaneProgram {
             for (int i = 0; i < N; ++i) ms_[i] = (double)v[i]; }
         wv.sync();
     }
-    // ... and a parent adds up what the same role of each of its children posted
+    // ... and a parent adds up what the same role of each of its children posted.
+    // Two LDS round trips for all children (round 6): the children's mailbox slots come from ONE word (a byte per child: the supernode slot
+    // inside the workgroup; 0xFF: none) kept behind the supernode's NodeP in LDS (NodeSlot::pad_), and the posts of all MAXCH children are
+    // read before the first is used -- a missing child reads the quad's own post and is not added.  The plain loop (`ci < maxch` and
+    // `ci < P.nchild` in front of every child, the child's index read from LDS, then its post) is three dependent round trips per child
+    // with the one wave of the SIMD waiting through each.  The order of the additions is the order of the children, as before.  Only the
+    // three-value exchange of the solves' forward sweeps takes this path: with six or eighteen values per child in flight, or with the word
+    // in a register, the step kernel's register allocation tips over (6 -> 77 spilled registers) and the gain is gone (profiles/r06_b_ab.txt).
+    DJ_HD int& chpack_ref() const { return *(int*)((char*)&P + sizeof(NodeP<T>)); }
+    DJ_HD void chpack_init() {
+        if constexpr (QUAD && Wave::kLockstep) {
+            unsigned pk = 0xFFFFFFFFu;
+            if (active) for (int ci = 0; ci < MAXCH; ++ci) if (ci < P.nchild) pk = (pk & ~(0xFFu << (8 * ci))) | ((unsigned)(((base + stride * P.child[ci]) >> 2) & 0xFF) << (8 * ci));
+            wv.sync();
+            if (q == 0) chpack_ref() = (int)pk;
+            wv.sync();
+        }
+    }
     template <int N, class TV> DJ_HD void mail_add_children(TV* acc, bool act, int maxch) {
+        if constexpr (N == 3 && Wave::kLockstep) {
+            (void)maxch;
+            double got[MAXCH][N]; bool use[MAXCH];
+            const int chpack = chpack_ref();
+#pragma unroll
+            for (int ci = 0; ci < MAXCH; ++ci) {
+                const int cs = (chpack >> (8 * ci)) & 0xFF;
+                use[ci] = act && q < 2 && cs != 0xFF;
+                const double* cs_ = mail + (size_t)((use[ci] ? cs : (qb >> 2)) * 2 + (q & 1)) * MAIL_STRIDE;
+#pragma unroll
+                for (int i = 0; i < N; ++i) got[ci][i] = cs_[i];
+            }
+#pragma unroll
+            for (int ci = 0; ci < MAXCH; ++ci)
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[i] = use[ci] ? acc[i] + TV(got[ci][i]) : acc[i];
+        } else {
         for (int ci = 0; ci < maxch; ++ci) {
             if (act && q < 2 && ci < P.nchild) {
                 const double* cs_ = mail_slot(base + stride * P.child[ci], q);
 #pragma unroll
                 for (int i = 0; i < N; ++i) acc[i] += TV(cs_[i]);
             }
+        }
         }
     }
     template <int N, class TV> DJ_HD void mail_add_children_node(TV* acc, bool act, int maxch) {   // all four lanes read the children's node posts
@@ -1625,6 +1660,17 @@ struct LaneProgram {
 #define DJ_PB() ((void)0)
 #define DJ_PE(i) ((void)0)
 #endif
+    // DJ_PROF2: finer cycle counters of the Newton loop (tools/gpu_probe.py phases2).  The counters live in LDS (StepLds has no room: a block of
+    // the kernel's own), lane 0 adds the uniform differences: no register stays live for them.  Every probe is a full LDS wait (s_memtime
+    // returns through lgkmcnt), so the sum of the parts is somewhat longer than the uninstrumented loop.
+#ifdef DJ_PROF2
+    unsigned long long* p2c = nullptr; unsigned long long pt1 = 0;
+#define DJ_P2B() (pt1 = wv.clock())
+#define DJ_P2E(i) do { const unsigned long long t_ = wv.clock(); if (wv.lane() == 0) p2c[i] += t_ - pt1; pt1 = t_; } while (0)
+#else
+#define DJ_P2B() ((void)0)
+#define DJ_P2E(i) ((void)0)
+#endif
     // Bodies with four or more contacts (Block, Atlas' feet; MAXC >= 4 builds of the quad mapping): the contacts are split over the four
     // lanes of the quad -- lane q handles contacts q, q + 4, ... -- instead of every lane doing all of them.  What a contact contributes
     // to the whole supernode (impulse on the body, its curvature term, the condensed right-hand side, its share of the centering sums) is
@@ -1715,9 +1761,11 @@ struct LaneProgram {
         Kin<T> kb, ka;
         kin_of(kb, L.x2, L.q2, L.v, L.w, dt);
         kin_of(ka, L.xa2, L.qa2, va, wa, dt);
+        DJ_P2E(JAC ? 15 : 9);
         JointEval<T> E;
         if (JAC) K.zero();
         joint_eval<JAC ? 1 : 0>(E, P, cfg, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, K);
+        DJ_P2E(JAC ? 16 : 10);
 #if DJ_TSD
         if (tsd) tra_damper_eval<JAC>(E, P, *tsd, cfg, va, wa, L.v, L.w, dt, K);
         if (tlim) tra_limit_eval<JAC>(E, P, cfg, ka, kb, L.lg, dt);
@@ -1824,6 +1872,7 @@ struct LaneProgram {
                 share_contact_rows();
             }
         }
+        DJ_P2E(JAC ? 17 : 11);
         // what this lane's joint applies to the parent body travels up the tree
         T up[6];
         for (int i = 0; i < 6; ++i) up[i] = has_parent ? -E.imp_a[i] : T(0);
@@ -1892,6 +1941,7 @@ struct LaneProgram {
 #endif
             for (int j = 0; j < 6; ++j) { F.t_a[j] = E.t_a[j]; F.t_b[j] = E.t_b[j]; }
         }
+        DJ_P2E(JAC ? 18 : 12);
     }
 
     // ---------------------------------------------------------------- violations (src/solver/violations.jl)
@@ -1936,6 +1986,7 @@ struct LaneProgram {
             else { T v2[2] = {r, b}; env_reduce_quad<2>(v2, [](T a_, T b_) { return a_ > b_ ? a_ : b_; }); rvio = v2[0]; bvio = v2[1]; }
         }
         else { rvio = env_max(wv, r, envl); bvio = env_max(wv, b, envl); if constexpr (kTrack) wstiff = env_max(wv, wq, envl); }
+        DJ_P2E(13);
     }
 
     // ---------------------------------------------------------------- condensation of cone rows
@@ -2985,6 +3036,7 @@ struct LaneProgram {
 #pragma unroll
             for (int i = 0; i < 3 * NC; ++i) ms_[i] = 0.0; }
         const int nsteps1 = G.maxlevel >= 1 ? maxn + G.maxlevel - 1 : 0;
+        DJ_P2B();
         for (int t = 0; t < nsteps1; ++t) {
             const int ib = t - (G.maxlevel - lvl);                // position of this step's batch in the branch's list
             const bool have = k < G.Nb && lvl >= 1 && ib >= 0 && (rem0 | rem1) != 0ull;
@@ -3007,6 +3059,7 @@ struct LaneProgram {
                     for (int i = 0; i < 3 * NC; ++i) acc[i] += uf * TG(cs_[i]);
                 }
             }
+            DJ_P2E(0);
             const bool isS = b < nbs;
             const int kk = b >> 1, typ = b & 1;
             const bool mine = valid && isS && (k == kk), par = valid && isS && typ == 0 && has_parent && (sp.parent == kk);
@@ -3020,7 +3073,9 @@ struct LaneProgram {
             // the six columns of the batch together: right-hand sides, one forward substitution of all six, then the messages
             TG r3a[NC][3];
             sweep_rhs<MODE, NC>(r3a, R, k, sp.parent, has_parent, sp.u_off, myu, sp.nlim_r, TG(wk), sp.ncontact, sp.contact, b, nbs, valid, acc);
+            DJ_P2E(1);
             lu_forward_quad<NC>(Lm, r3a);                         // ỹ = L11⁻¹ r
+            DJ_P2E(2);
             T* const mg = msg_top + (size_t)(ib > 0 ? ib : 0) * 36;
             const bool to_root = valid && lvl == 1 && q < 2;      // the parent is a root: it reads the message in phase 2
 #pragma unroll
@@ -3059,6 +3114,7 @@ struct LaneProgram {
                     }
                 }
             }
+            DJ_P2E(3);
         }
         }
 #ifdef DJ_PROF
@@ -3236,6 +3292,7 @@ struct LaneProgram {
         };
         advance(0);
         const int nstepsA = G.maxlevel >= 1 ? maxn + G.maxlevel - 1 : 0;
+        DJ_P2B();
         for (int t = 0; t < nstepsA; ++t) {
             const int b = bnxt < 0 ? 0 : bnxt;
             const bool valid = active && bnxt >= 0;
@@ -3246,6 +3303,7 @@ struct LaneProgram {
 #pragma unroll
             for (int j = 0; j < 9; ++j) xcur[j] = xnext[j];
             advance(t + 1);
+            DJ_P2E(4);
             const bool isS = b < nbs;
             const bool mine = valid && isS && (k == (b >> 1)) && ((b & 1) == 0);
             TIO* const cb = colbase(b, k, q);                     // never a null select: the pointer must stay a GLOBAL pointer (flat stores tie up lgkmcnt)
@@ -3273,7 +3331,9 @@ struct LaneProgram {
                         x3[n][i] = a_; }
                 }
             }
+            DJ_P2E(5);
             lu_backward_quad<NC>(Um, di, x3);
+            DJ_P2E(6);
             wv.sync();                                            // (every supernode has read its parent's Δv, Δω of the previous step)
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
@@ -3298,6 +3358,7 @@ struct LaneProgram {
                     }
                 }
             }
+            DJ_P2E(7);
         }
         }
         // ---- phase B: everybody's rows of the batches of the OTHER branches (a root: of all its batches) ----
@@ -3434,6 +3495,7 @@ struct LaneProgram {
                 }
             }
         }
+        DJ_P2E(2);
         // backward: root -> leaves
         TL d3[3] = {y3[0], y3[1], y3[2]};
         TL dva[6] = {0, 0, 0, 0, 0, 0};
@@ -3472,6 +3534,7 @@ struct LaneProgram {
             for (int i = 0; i < 3; ++i) dk_out[3 * o + i] = T(wv.quad_bcast(d3[i], o));
 #pragma unroll
         for (int i = 0; i < 6; ++i) dva_out[i] = T(dva[i]);
+        DJ_P2E(3);
     }
 
     // ---------------------------------------------------------------- solve with the current factors
@@ -3523,6 +3586,7 @@ struct LaneProgram {
         } }
 #endif
         T dk[12], dva[6];
+        DJ_P2E(1);
 #if DJ_CUT
         if constexpr (kCut) {
             for (int c = 0; c < NCUT; ++c) for (int i = 0; i < 6; ++i) D.dclam[c][i] = T(0);
@@ -3607,6 +3671,7 @@ struct LaneProgram {
                 D.dcg[li][0] = dg1; D.dcg[li][1] = fz * dg2; D.dcg[li][2] = fz * dg3; D.dcg[li][3] = fz * dg4;
             } else { for (int i = 0; i < NCV; ++i) D.dcs[li][i] = D.dcg[li][i] = T(0); }
         }
+        DJ_P2E(4);
     }
 
     // forward / backward substitution through the tree with the current factors:
@@ -3831,7 +3896,7 @@ struct LaneProgram {
 #endif
         }
         a = quad_minv(a);
-        if constexpr (QUAD) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); return v1[0]; }
+        if constexpr (QUAD) { T v1[1] = {a}; env_reduce_quad<1>(v1, [](T a_, T b_) { return a_ < b_ ? a_ : b_; }); DJ_P2E(5); return v1[0]; }
         else return env_min(wv, a, envl);
     }
 
@@ -3974,6 +4039,7 @@ struct LaneProgram {
             condense_limits(K);
             if constexpr (kRefine) { if (blk != nullptr && wv.any(refine)) store_blocks(K); }   // the rows before the contacts are folded in
             condense_contacts(K);
+            DJ_P2E(19);
             DJ_PE(0); DJ_PB();
 #if DJ_ROWS == 1
             if constexpr (kRowsOk) { if (rows_here) factorize_rows(K); else factorize_quad(K); } else factorize_quad(K);
@@ -3983,6 +4049,7 @@ struct LaneProgram {
 #else
             factorize_quad(K);
 #endif
+            DJ_P2E(20);
             DJ_PE(1);
             return;
         } else {
@@ -4016,6 +4083,7 @@ struct LaneProgram {
     DJ_HD T newton_direction(StepT& D, T rvio, T bvio, T undercut, T& mutarget) {
         ConeRhs R;
         cone_rhs_from_state(R, mu);                             // pull_residual!: cone rows carry μ of the last set_entries!
+        DJ_P2E(0);
         DJ_PB();
         solve(R, D);                                            // affine direction
         DJ_PE(4);
@@ -4065,6 +4133,7 @@ struct LaneProgram {
 #if DJ_MLIM
         for (int m = 0; m < NLM; ++m) for (int i = 0; i < 2; ++i) R.mlim[m][i] += -D.dmls[m][i] * D.dmlg[m][i] + mutarget;
 #endif
+        DJ_P2E(6);
         DJ_PB();
         solve(R, D);                                            // corrected direction
         DJ_PE(2);
@@ -4101,6 +4170,7 @@ struct LaneProgram {
 #endif
         violations(rvio, bvio);
         }
+        DJ_P2B();
         for (int n = n0; n <= G.max_iter; ++n) {
 #ifdef DJ_DEBUG
             if (trace && wv.lane() == 0) std::printf("%3d  bvio %.3e  rvio %.3e  mu %.3e\n", n, (double)bvio, (double)rvio, (double)mu);
@@ -4111,6 +4181,7 @@ struct LaneProgram {
             // Lanes of finished environments keep executing (wave-uniform control flow, all lanes must
             // take part in the shuffles) but never change their state: their step factor is 0.
             if (!done) iters = n;
+            DJ_P2E(21);
             StepT D_local;
             StepT& D = kLsInLds ? *(StepT*)ls_lds : D_local;
             T alpha = newton_direction(D, rvio, bvio, undercut, mutarget);
@@ -4122,10 +4193,12 @@ struct LaneProgram {
                 SnapT base_local;
                 SnapT& base_sol = kLsInLds ? *(SnapT*)(ls_lds + sizeof(StepT)) : base_local;
                 snapshot(base_sol);
+                DJ_P2E(7);
                 DJ_PB();
                 // one trial: candidate, residual, violations, accept / halve
                 auto trial = [&](int ls) {
                     int bad = candidate_step(base_sol, D, f);       // finished searches recompute the same candidate
+                    DJ_P2E(8);
                     { NullBlocks nk; evaluate<false>(nk); }
                     T r2, b2;
                     violations(r2, b2);
@@ -4224,6 +4297,7 @@ struct LaneProgram {
                     }
                 }
                 // set_entries! + factorization (cone rows now carry the new μ)
+                DJ_P2E(14);
                 linearize();
             }
         }
@@ -5118,6 +5192,11 @@ constexpr int FAC_PER_LANE = 72;
 #else
 #define DJ_TSD_SETUP
 #endif
+#ifdef DJ_PROF2
+#define DJ_P2_SETUP { prog.p2c = (unsigned long long*)wv.p2_; wv.sync(); if (lane < 24) prog.p2c[lane] = 0ull; wv.sync(); }
+#else
+#define DJ_P2_SETUP
+#endif
 #define DJ_LANE_SETUP(GRAD_LAYOUT, ENV_OK)                                                                                \
     const Globals<T>& G = A.G;                                                                                            \
     const int stride = QUAD ? 4 : 1;                                                                                      \
@@ -5143,7 +5222,8 @@ constexpr int FAC_PER_LANE = 72;
         prog.cpool = (ContactCold<T>*)(lds + LY::pool_off); prog.pool_by_id = LY::pool_by_id;                             \
         prog.pool_base = LY::pool_by_id ? 0 : (SHARE ? lane / 4 : lane) * MAXC;                                           \
         prog.gb_lds = ((GRAD_LAYOUT) == 2) ? (void*)(((ConRhs<MAXC>*)(lds + LY::rhs_off)) + lane / 4) : (void*)(((QuadRhs<TIO>*)lds) + lane / 4); \
-        prog.mail = (double*)(lds + LY::mail_off);                                                                        \
+        prog.mail = (double*)(lds + LY::mail_off); prog.chpack_init();                                                    \
+        DJ_P2_SETUP                                                                                                       \
         prog.qred = (double*)(lds + LY::qred_off);                                                                        \
         if (GRAD_LAYOUT) prog.sinfo = (SweepInfo*)(lds + LY::info_off);                                                   \
         if (A.msg) prog.msg = DJ_GLOBAL_PTR(T, A.msg) + (size_t)(env < A.B ? env : 0) * (size_t)A.msg_stride;                 \
@@ -5256,6 +5336,9 @@ DJ_HD void grad_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         }
     }
     else if constexpr (QUAD) prog.gradients_contact(A, env);
+#ifdef DJ_PROF2
+    if (active && q == 0 && A.vel && k == 8) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 48; for (int i = 0; i < 16; ++i) vo[i] = TIO((double)prog.p2c[i]); }
+#endif
 #ifdef DJ_PROF
     if (active && q == 0 && A.vel && k == 2) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 12; vo[0] = TIO((double)prog.pc[0]); vo[1] = TIO((double)prog.pc[1]); vo[2] = TIO((double)prog.pc[5]); vo[3] = TIO((double)prog.pc[6]); vo[4] = TIO((double)(wv.clock() - t_all)); vo[5] = TIO((double)prog.pc[4]); vo[6] = TIO((double)prog.pc[2]); vo[7] = TIO((double)prog.pc[3]); vo[8] = TIO((double)prog.pc[7]); }
 #endif
@@ -5363,6 +5446,9 @@ DJ_HD void step_entry(Wave& wv, const KernelArgs<TIO, T>& A, int wave_index) {
         if constexpr (QUAD && DJ_REFINE) { if (k == 0 && A.diag_out) { A.diag_out[2 * env] = prog.wstiff; A.diag_out[2 * env + 1] = gr_env; } }
         if (A.vel) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 3; ++i) { vo[i] = TIO(prog.L.v[i]); vo[3 + i] = TIO(prog.L.w[i]); } }
         if (A.res) { TIO* ro = A.res + (size_t)env * 6 * G.Nb + 6 * k; for (int i = 0; i < 6; ++i) ro[i] = TIO(prog.rb[i]); }
+#ifdef DJ_PROF2
+        if (A.vel && k == 4 && G.Nb >= 9) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 24; for (int i = 0; i < 24; ++i) vo[i] = TIO((double)prog.p2c[i]); }
+#endif
 #ifdef DJ_PROF
         if (A.vel && k == 0) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb; for (int i = 0; i < 6; ++i) vo[i] = TIO((double)prog.pc[i]); }   // phases 0-5 (cycles)
         if (A.vel && k == 1) { TIO* vo = A.vel + (size_t)env * 6 * G.Nb + 6; vo[0] = TIO((double)prog.pc[7]); vo[1] = TIO((double)iters); vo[2] = TIO((double)prog.pc[6]); }

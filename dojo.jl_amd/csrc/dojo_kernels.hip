@@ -32,6 +32,9 @@ struct GpuWave {
     __device__ __forceinline__ int atomic_inc(int* p) const { return atomicAdd(p, 1); }
     void* lds_;
     double* red_;                               // reduction / vote scratch at the end of the LDS block (NW > 1)
+#ifdef DJ_PROF2
+    void* p2_;                                  // 24 cycle counters (LaneProgram::p2)
+#endif
     __device__ __forceinline__ void* lds() const { return lds_; }
     // NW = 1: LDS instructions of a wave execute in issue order, so lanes only need the compiler to keep LDS accesses in
     // program order.  (__syncthreads() would also drain the outstanding global stores -- vmcnt(0) -- which costs the IFT
@@ -99,7 +102,7 @@ struct GpuWave {
     // the same value): two rotations inside every 16-lane row on the DPP path, then the four rows through v_readlane -- about twenty
     // instructions and no LDS round trip (the LDS form: a write, then eight dependent ds_read2_b64, each behind a full wait, per value).
     // Every lane ends with the same bits: the result is formed from the four row values in SGPRs, in row order.
-    static constexpr bool kWaveReduce = NW == 1;
+    static constexpr bool kWaveReduce = true;   // (NW = 2: every wavefront reduces its 16 slots, the two results cross through red_)
     static __device__ __forceinline__ double rdlane(double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); }
     static __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
     template <class V, class OP> static __device__ __forceinline__ V reduce_quads16(V v, OP op) {
@@ -107,6 +110,24 @@ struct GpuWave {
         v = op(v, dppx<0x128>(v));          // row_ror:8: every lane holds its row's four supernodes
         const V r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
         return op(op(op(r0, r1), r2), r3);
+    }
+    template <int NV, class V, class OP> __device__ __forceinline__ void reduce_slots(V (&v)[NV], OP op) const {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n] = reduce_quads16(v[n], op);
+        if (NW == 1) return;
+        sync();                                     // (whoever used red_ before has read it)
+        if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) red_[(threadIdx.x >> 6) * NV + n] = (double)v[n];
+        }
+        sync();
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            V r = V(red_[n]);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) r = op(r, V(red_[w * NV + n]));
+            v[n] = r;
+        }
     }
     // Row layout of the level passes (LaneProgram::factorize_rows): 16 lanes per supernode, one matrix row per lane.  gfx950's DP ALU
     // knows exactly one DPP control, row_newbcast:P (lane P of every 16-lane row), and takes it INSIDE the fp64 multiply-add: a pivot-row
@@ -176,6 +197,11 @@ template <class TIO, class TS, int MAXC> constexpr int cont_replicas() {
 #ifndef DJ_GRAD_WAVES
 #define DJ_GRAD_WAVES 1
 #endif
+#ifdef DJ_PROF2
+#define DJ_P2_DECL(w) __shared__ unsigned long long p2_buf[24]; (w).p2_ = (void*)p2_buf;
+#else
+#define DJ_P2_DECL(w)
+#endif
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DJ_FWD_WAVES, DJ_FWD_WAVES)))
 dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
@@ -183,6 +209,7 @@ dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
 // Globals::iter_cap: the rest of the Newton loops the step kernel left unfinished, one listed workgroup of the step kernel per
@@ -196,6 +223,7 @@ dojo_stepc_kernel(dj::KernelArgs<TIO, TS> A) {
     GpuWaveRep<R> w;
     const int rep = (int)(threadIdx.x >> 6);
     w.lds_ = (void*)((char*)lds_buf + rep * PER); w.red_ = (double*)((char*)w.lds_ + LY::red_off);
+    DJ_P2_DECL(w)
     w.xchg_ = (double*)((char*)lds_buf + R * PER);
     const int n = *(volatile int*)A.cont_count;
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
@@ -211,6 +239,7 @@ __global__ void __launch_bounds__(64 * NW) dojo_stepp_kernel(dj::KernelArgs<TIO,
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW, true> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW, true>>(w, A, (int)blockIdx.x);
 }
 template <class TIO, class TS, class TL, int MAXC, bool QUAD, int NW>
@@ -220,6 +249,7 @@ dojo_grad_kernel(dj::KernelArgs<TIO, TS> A) {
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
 }
 // Globals::iter_cap: the IFT of the workgroups on the continuation list, behind dojo_stepc_kernel (dojo_grad_kernel skips them)
@@ -230,6 +260,7 @@ dojo_gradc_kernel(dj::KernelArgs<TIO, TS> A) {
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<1> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     const int n = *(volatile int*)A.cont_count;
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x)
         dj::grad_entry<TIO, TS, TL, MAXC, true, GpuWave<1>, 0, true>(w, A, A.cont_list[i]);
@@ -243,6 +274,7 @@ __global__ void __launch_bounds__(64 * NW) dojo_gradp_kernel(dj::KernelArgs<TIO,
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW, true> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW, true>, 2>(w, A, (int)blockIdx.x);
 }
 // the IFT kernel for the contact-data columns (get_contact_gradients); quad mappings only
@@ -252,6 +284,7 @@ __global__ void __launch_bounds__(64 * NW) dojo_cgrad_kernel(dj::KernelArgs<TIO,
     __shared__ double lds_buf[(LY::bytes + 7) / 8];
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
+    DJ_P2_DECL(w)
     dj::grad_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>, 1>(w, A, (int)blockIdx.x);
 }
 

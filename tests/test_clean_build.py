@@ -43,9 +43,9 @@ def test_headline_objects_compile_from_clean(tmp_path):
     res = _resources(kobj)
     assert {"dojo_step_kernel", "dojo_grad_kernel", "dojo_cgrad_kernel"} <= set(res), res
     lds, scratch, spills = res["dojo_step_kernel"]
-    assert lds <= 40960 and scratch <= 384 and spills <= 110, res["dojo_step_kernel"]        # (tests/test_kernel_resources.py: round 6, both layouts of the level passes)
+    assert lds <= 40960 and scratch <= 256 and spills <= 40, res["dojo_step_kernel"]        # (tests/test_kernel_resources.py: round 6, both layouts of the level passes)
     lds, scratch, spills = res["dojo_grad_kernel"]
-    assert lds <= 40960 and scratch <= 1536, res["dojo_grad_kernel"]
+    assert lds <= 40960 and scratch <= 1664, res["dojo_grad_kernel"]
     shipped = os.path.join(CSRC, "build", "k_float_1_1.o")
     if os.path.exists(shipped) and os.path.getmtime(shipped) >= max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))):
         assert _resources(shipped) == res                       # the object the library was linked from is this compilation

@@ -26,10 +26,11 @@ def test_headline_kernels_keep_their_register_footprint():
     # (round 6: the kernel carries both layouts of the factorization's level passes -- factorize_quad and factorize_rows, chosen per mechanism at run
     #  time -- 352 B / 103 spilled; the quad-only build (-DDJ_ROWS=0) has 256 / 43, the rows-only one (-DDJ_ROWS=1) 288 / 76 and runs no faster than this
     #  one on the same box, profiles/README.md r06)
-    assert scratch <= 384 and spills <= 110, ("step kernel: scratch %d B/lane, %d spilled VGPRs (was 352 / 103)" % (scratch, spills))
+    # (later in round 6: the device atan with its coefficients in SGPRs -- dojo_math.hpp tatan -- took the spilled coefficient moves away: 176 B / 6 spilled)
+    assert scratch <= 256 and spills <= 40, ("step kernel: scratch %d B/lane, %d spilled VGPRs (was 176 / 6)" % (scratch, spills))
     assert lds <= 40960, lds                                  # four workgroups (one wave per SIMD) per CU
     scratch, spills, lds = res["dojo_grad_kernel"]
-    assert scratch <= 1536 and lds <= 40960, (scratch, lds)   # (its spills sit in the once-per-step prologue -- linearization, LU-form factorization, data blocks)
+    assert scratch <= 1664 and lds <= 40960, (scratch, lds)   # (its spills sit in the once-per-step prologue -- linearization, LU-form factorization, data blocks)
     # ... and not in the pipelined sweeps: with one wave per SIMD nothing hides a scratch round trip (30 of them per pipeline step ran
     # the sweeps at half speed).  tools/isa_loops.py lists the loops of the kernel with their instruction mix.
     import ast

@@ -92,6 +92,36 @@ if what == "phases":
         json.dump(dict(total=tot.tolist(), iters=iters.tolist()), open(os.path.join(out, "phase_hist_grad%d.json" % grad), "w"))
     gm.close()
 
+if what == "phases2":
+    # needs a -DDJ_PROF2 build (DOJO_HIP_LIB): 24 cycle counters of the Newton loop per wave, through the `vel` export (slots 24..47)
+    spec = d.baseline_config(3)
+    Z0, U0 = d.synthetic_inputs(spec, 64)
+    B = 4096
+    Z = np.tile(Z0, (B // 64, 1)); U = np.tile(U0, (B // 64, 1))
+    gm = api.BatchedMechanism(spec, B, dtype="f32")
+    gm.set_groups(1)
+    z = Z.astype(np.float32)
+    for k in range(3):
+        zn, st, it = gm.step(z, U, with_gradient=False); z = zn
+    vel, ji, cs = gm.get_solution()
+    c = vel[:, 24:48].astype(np.float64).mean(axis=0)
+    names = ["cone rhs", "solve: prologue", "solve: forward sweep", "solve: backward sweep", "solve: recovery", "cone line search", "centering + correction", "snapshot",
+             "candidate_step", "evalF: parent + kinematics", "evalF: joint", "evalF: contacts", "evalF: gather + rest", "violations", "trial logic + bookkeeping",
+             "evalT: parent + kinematics", "evalT: joint", "evalT: contacts", "evalT: gather + blocks", "condense", "factorize", "loop top", "-", "-"]
+    print("phases2 kernel %.2f ms; iters %.2f; sum of counters %.0f cycles/wave" % (gm.last_kernel_ms(), it.mean(), c.sum()))
+    for n, v in zip(names, c):
+        if n != "-": print("   %-28s %9.0f cycles %5.1f%%  (%.0f per iteration)" % (n, v, 100 * v / c.sum(), v / it.mean()))
+    # ... and the IFT kernel's sweeps (slots 48..63, written by dojo_grad_kernel)
+    for k in range(2):
+        zn, st, it = gm.step(z, U, with_gradient=True); z = zn
+    vel, ji, cs = gm.get_solution()
+    g = vel[:, 48:64].astype(np.float64).mean(axis=0)
+    gn = ["up-sweep: children's messages", "up-sweep: right-hand sides", "up-sweep: forward substitution", "up-sweep: messages + park stores",
+          "down-sweep: pop + prefetch", "down-sweep: parent's x, T x", "down-sweep: backward substitution", "down-sweep: posts + output stores"]
+    print("IFT sweeps (cycles per wave; the branch phases only)")
+    for n, v in zip(gn, g): print("   %-36s %9.0f" % (n, v))
+    gm.close()
+
 if what == "stragglers":
     # closed-loop rollout like bench.py (fp64 ABI so the inputs are exact): dump the (z, u) of every environment-step that
     # did not converge, with the iteration histogram, for a CPU-side comparison with the oracle
