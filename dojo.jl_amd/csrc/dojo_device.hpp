@@ -2572,6 +2572,10 @@ struct LaneProgram {
     // wave per SIMD cannot hide: the sweeps ran at half speed).
     enum { LU_LM = 0, LU_M = 36, LU_UM = 54, LU_T = 90, LU_DI = 108, LU_END = 111 };            // (dj::LU_PER_LANE values per lane, static_assert in store_lu)
     T* lu = nullptr; int lu_stride = 0;
+    // (the stride is the workgroup's width: a compile-time constant on the GPU, so that the 54 / 57 elements a sweep loads sit at immediate offsets
+    //  from a few bases.  As a run-time member the compiler formed all their 64-bit addresses early and spilled them: every factor load of the
+    //  sweeps' prologues was `scratch_load (the address); s_waitcnt vmcnt(0); global_load` -- 160 serialized round trips per environment-step)
+    DJ_HD size_t lu_S() const { if constexpr (Wave::kWidth > 0) return (size_t)Wave::kWidth; else return (size_t)lu_stride; }
     // A supernode's rows of the in-place factors (F.Sq) stay as its own level left them -- on every other level its updates have a zero
     // multiplier -- so the split into the zero-filled triangles the substitutions read happens here, once, after the last level (kept
     // inside the level loop, the 75 values were loop-carried state next to the 90 of the factorization itself: past the 256 architectural
@@ -2595,7 +2599,7 @@ struct LaneProgram {
                 W.Um[r][c] = (active && lu_piv(c) > pos) ? a_ * di_ : TL(0);
             }
         }
-        T* o = lu; const size_t S_ = (size_t)lu_stride;
+        T* o = lu; const size_t S_ = lu_S();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -2605,8 +2609,17 @@ struct LaneProgram {
             o[(size_t)(LU_DI + i) * S_] = T(W.di[i]);
         }
     }
+    // (the loads start from a base the optimizer cannot connect with store_lu's addresses: it kept those 111 addresses alive from the stores to
+    //  the loads, i.e. spilled them, and every factor load of a sweep's prologue became `scratch_load (its address); s_waitcnt vmcnt(0); global_load`)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const T __attribute__((address_space(1)))* LuPtr;     // (behind the opaque statement the pointer is generic again: the loads would be FLAT ones)
+    DJ_HD LuPtr lu_base(int dl = 0) const { const T* o = lu + dl; DJ_OPAQUE(o); return (LuPtr)o; }
+#else
+    typedef const T* LuPtr;
+    DJ_HD LuPtr lu_base(int dl = 0) const { return lu + dl; }
+#endif
     DJ_HD void load_lu_up(TL (&Lm)[3][12], TL (&m)[6][3]) const {
-        const T* o = lu; const size_t S_ = (size_t)lu_stride;
+        LuPtr o = lu_base(); const size_t S_ = lu_S();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -2616,7 +2629,7 @@ struct LaneProgram {
         }
     }
     DJ_HD void load_lu_down(TL (&Um)[3][12], TL (&Tq)[3][6], TL (&di)[3]) const {
-        const T* o = lu; const size_t S_ = (size_t)lu_stride;
+        LuPtr o = lu_base(); const size_t S_ = lu_S();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -3130,13 +3143,13 @@ struct LaneProgram {
             if (inf[a].level != 0) continue;                      // (uniform: the tables are the same in every environment)
             const int dl = base + 4 * a + q - wv.lane();          // from this lane to the root's lane of the same role
             TG Lm[3][12];
-            { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+            { LuPtr o = lu_base(dl); const size_t S_ = lu_S();
 #pragma unroll
               for (int i = 0; i < 3; ++i)
 #pragma unroll
                   for (int j = 0; j < 12; ++j) Lm[i][j] = TL(o[(size_t)(LU_LM + 12 * i + j) * S_]); }
             TG Um[3][12], di[3];
-            { const T* o = lu + dl; const size_t S_ = (size_t)lu_stride;
+            { LuPtr o = lu_base(dl); const size_t S_ = lu_S();
 #pragma unroll
               for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -3759,7 +3772,7 @@ struct LaneProgram {
     template <class BK>
     DJ_HD void store_blocks(const BK& K) {
         T* o = blk;
-        const size_t W = (size_t)blk_stride;
+        const size_t W = Wave::kWidth > 0 ? (size_t)Wave::kWidth : (size_t)blk_stride;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -3769,8 +3782,14 @@ struct LaneProgram {
         }
     }
     DJ_HD void refine_solution(const T* rk0, const ConeRhs& R, const T* rs, const T (*r58)[NCV], const T* upx, StepT& D, T* dva) {
+        // (an opaque base and a compile-time stride, as for the IFT's staged factors -- lu_base: otherwise the 90 addresses live from store_blocks to here, spilled)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const T* blo = blk; DJ_OPAQUE(blo);
+        const T __attribute__((address_space(1)))* const bl = (const T __attribute__((address_space(1)))*)blo;
+#else
         const T* bl = blk;
-        const size_t W = (size_t)blk_stride;
+#endif
+        const size_t W = Wave::kWidth > 0 ? (size_t)Wave::kWidth : (size_t)blk_stride;
         T xk[12];
         for (int i = 0; i < 3; ++i) { xk[i] = D.dv[i]; xk[3 + i] = D.dw[i]; }
         for (int i = 0; i < 6; ++i) xk[6 + i] = D.dlam[i];

@@ -28,6 +28,7 @@ struct GpuWave {
     static constexpr bool kRefine = RF;
     static constexpr bool kLockstep = true;     // the 64 lanes of a wave (so the 4 lanes of a quad) execute every instruction together
     static constexpr int kWaves = NW;
+    static constexpr int kWidth = 64 * NW;      // lanes of the workgroup, for strides that must be compile-time constants (0: ask width())
     static constexpr int kReplicas = 1;         // (GpuWaveRep: wavefronts that hold the same environment, dojo_stepc_kernel)
     __device__ __forceinline__ int atomic_inc(int* p) const { return atomicAdd(p, 1); }
     void* lds_;

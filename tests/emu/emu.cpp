@@ -81,6 +81,7 @@ struct EmuWaveT {
     template <class V> V quad_xor(V v, int m) { return shfl(v, l ^ m); }
     // the row layout of the level passes (LaneProgram::factorize_rows): lane p of my 16-lane row, alone and inside a multiply-add
     static constexpr bool kRows = NW == 1;
+    static constexpr int kWidth = 0;            // (the emulator's workgroup width is a run-time value: width())
     static constexpr bool kWaveReduce = false;  // (GPU: the 16-slot reductions on the DPP path, Wave::reduce_quads16)
     template <class V> V row_bcast(V v, int p) { return shfl(v, (l & ~15) + p); }
     template <class V> void row_fmac(V& acc, V src, V f, int p) { acc += shfl(src, (l & ~15) + p) * f; }

@@ -45,7 +45,7 @@ def test_headline_objects_compile_from_clean(tmp_path):
     lds, scratch, spills = res["dojo_step_kernel"]
     assert lds <= 40960 and scratch <= 256 and spills <= 40, res["dojo_step_kernel"]        # (tests/test_kernel_resources.py: round 6, both layouts of the level passes)
     lds, scratch, spills = res["dojo_grad_kernel"]
-    assert lds <= 40960 and scratch <= 1664, res["dojo_grad_kernel"]
+    assert lds <= 40960 and scratch <= 1024, res["dojo_grad_kernel"]
     shipped = os.path.join(CSRC, "build", "k_float_1_1.o")
     if os.path.exists(shipped) and os.path.getmtime(shipped) >= max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))):
         assert _resources(shipped) == res                       # the object the library was linked from is this compilation
