@@ -124,6 +124,10 @@ struct Globals {
     int rp_slot4[16];                     // byte g: rp_slot[t][g]
     int rp_lev[16];                       // the level of pass t, and in bits 8.. the largest child count of that level
     int rp_child4[16][MAXCH];             // byte g of [t][ci]: the slot of child ci of group g's supernode (-1: none), in NodeP::child order
+    // Two-wavefront workgroups (17..32 bodies): every wavefront runs the passes of ITS OWN sixteen supernode slots, four per pass, both in step (pass t
+    // = the same tree level on both; a wavefront without a supernode in a pass idles through it).  The tables above are wavefront 0's, these wavefront 1's.
+    int rp_slot4_w1[16];
+    int rp_child4_w1[16][MAXCH];
     DJ_HD static int rp_byte(int w, int g) { return (int)(signed char)((unsigned)w >> (8 * g)); }
 };
 
@@ -2359,15 +2363,18 @@ struct LaneProgram {
     // them; the Schur complement is posted to the mailbox by the row lanes in the slots the parent's gather reads.  Every number is
     // produced by the same operations in the same order as in factorize_quad: the two are interchangeable bit for bit
     // (tests/test_device_program_emu.py::test_row_layout_factorization_is_the_quad_one).
-    static constexpr bool kRowsOk = QUAD && Wave::kRows && MAXC == 1 && !(kTrack && DJ_TRACK_GROWTH);
+    static constexpr bool kRowsOk = QUAD && Wave::kRows && (Wave::kWaves == 1 ? MAXC == 1 : Wave::kWaves == 2) && !(kTrack && DJ_TRACK_GROWTH);
+    static constexpr bool kRowsLuOk = kRowsOk && Wave::kWaves == 1;      // (the IFT's LU-form passes: single-wavefront layouts only)
+    DJ_HD int rp_slots_of(int t, int w) const { if constexpr (Wave::kWaves > 1) return w ? G.rp_slot4_w1[t] : G.rp_slot4[t]; else return G.rp_slot4[t]; }
+    DJ_HD int rp_children_of(int t, int ci, int w) const { if constexpr (Wave::kWaves > 1) return w ? G.rp_child4_w1[t][ci] : G.rp_child4[t][ci]; else return G.rp_child4[t][ci]; }
     double* stA = nullptr; double* stB = nullptr;      // StepLds::stA_off / stB_off (luA_off / luB_off in the IFT kernel)
     bool rows_here = false;                            // this kernel's LDS layout has the staging areas (a constant of the kernel: StepLds::rows / rows_lu)
     int rp_pack = -256;                                // (pass << 8) | group: the pass and the group that serve this lane's supernode (pass -1: none)
     DJ_HD void rows_init() {
         if constexpr (kRowsOk) {
-            const int myslot = wv.lane() >> 2;
+            const int myslot = wv.lane() >> 2, myw = Wave::kWaves > 1 ? (wv.lane() >> 6) : 0;
             for (int t = 0; t < G.rows; ++t)
-                for (int g = 0; g < 4; ++g) if (Globals<T>::rp_byte(G.rp_slot4[t], g) == myslot) rp_pack = (t << 8) | g;
+                for (int g = 0; g < 4; ++g) if (Globals<T>::rp_byte(rp_slots_of(t, myw), g) == myslot) rp_pack = (t << 8) | g;
         }
     }
     DJ_HD void factorize_rows(QuadBlocks<TL>& K) {
@@ -2382,14 +2389,17 @@ struct LaneProgram {
             //  its registers: 43 -> 149 spilled, profiles/r06_*)
             int ln = wv.lane(), pk = rp_pack;
             DJ_OPAQUE(ln); DJ_OPAQUE(pk);
-            const int g = ln >> 4, r = ln & 15, rp_pass = pk >> 8, rp_grp = pk & 3;
-            double* const stL = stA; double* const stD = stA + 4 * 6 * RS;
-            const double* const rowS = stA + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;      // this lane's row as a row lane ...
-            const double* const rowU = stB + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
+            // (two-wavefront workgroups: wavefront wq serves its own sixteen slots from staging areas of its own; g = the row group inside the wavefront)
+            const int wq = Wave::kWaves > 1 ? (ln >> 6) : 0;
+            const int g = (Wave::kWaves > 1 ? (ln & 63) : ln) >> 4, r = ln & 15, rp_pass = pk >> 8, rp_grp = pk & 3;
+            double* const stAw = stA + (size_t)wq * (4 * 12 * RS); double* const stBw = stB + (size_t)wq * (4 * 12 * US);
+            double* const stL = stAw; double* const stD = stAw + 4 * 6 * RS;
+            const double* const rowS = stAw + (size_t)(g * 12 + (r < 12 ? r : 0)) * RS;      // this lane's row as a row lane ...
+            const double* const rowU = stBw + (size_t)(g * 12 + (r < 12 ? r : 0)) * US;
             const double* const rowL = stL + (size_t)(g * 6 + (r < 6 ? r : 0)) * RS;
             const double* const rowD = stD + (size_t)(g * 6 + (r < 6 ? r : 0)) * US;
-            double* const qS = stA + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
-            double* const qU = stB + (size_t)(rp_grp * 12 + 3 * q) * US;
+            double* const qS = stAw + (size_t)(rp_grp * 12 + 3 * q) * RS;                    // ... and its three rows as a quad lane
+            double* const qU = stBw + (size_t)(rp_grp * 12 + 3 * q) * US;
             const int lev = G.rp_lev[t] & 255, maxch = G.rp_lev[t] >> 8;
             const bool mine = rp_pass == t, at = active && mine;
             wv.sync();
@@ -2409,7 +2419,7 @@ struct LaneProgram {
             wv.sync();
             // ---- row lanes <- LDS.  Unconditional loads: lanes 12..15 of a row and rows without a supernode (slot < 0) compute on whatever
             // the staging area holds -- nobody reads their results (no write-back, no post below), and the loads stay branch-free.
-            const int sl = Globals<T>::rp_byte(G.rp_slot4[t], g);      // this row's supernode slot (< 0: none): a uniform load and a per-lane shift
+            const int sl = Globals<T>::rp_byte(rp_slots_of(t, wq), g);      // this row's supernode slot (< 0: none): a uniform load and a per-lane shift
             const bool rowon = sl >= 0 && r < 12;
             TL R[12], Ur[6], Lr[12], Dr[6];
 #pragma unroll
@@ -2419,7 +2429,7 @@ struct LaneProgram {
             if (maxch > 0) {
                 TL acc[6] = {TL(0), TL(0), TL(0), TL(0), TL(0), TL(0)};
                 for (int ci = 0; ci < maxch; ++ci) {
-                    const int cs = Globals<T>::rp_byte(G.rp_child4[t][ci], g);
+                    const int cs = Globals<T>::rp_byte(rp_children_of(t, ci, wq), g);
                     if (cs >= 0 && r < 6) {
                         const double* m_ = mail_slot(4 * cs, r / 3) + 6 * (r % 3);
 #pragma unroll
@@ -2475,7 +2485,7 @@ struct LaneProgram {
             }
             // ---- inverse rows -> LDS -> quad lanes
             if (rowon) {
-                double* w_ = stA + (size_t)(g * 12 + r) * RS;
+                double* w_ = stAw + (size_t)(g * 12 + r) * RS;
 #pragma unroll
                 for (int c = 0; c < 12; ++c) w_[c] = (double)R[c];
             }
@@ -4366,9 +4376,9 @@ struct LaneProgram {
         // (a root's joint hangs on the origin, whose "velocity" is no unknown: its U block was assembled like any other, but the
         //  down-sweep must not apply it -- store_lu writes T = 0 for the roots)
 #if DJ_ROWS == 1
-        if constexpr (kRowsOk) { if (rows_here) factorize_rows_lu(K); else factorize_quad_lu(K); } else factorize_quad_lu(K);
+        if constexpr (kRowsLuOk) { if (rows_here) factorize_rows_lu(K); else factorize_quad_lu(K); } else factorize_quad_lu(K);
 #elif DJ_ROWS == 2
-        if constexpr (kRowsOk) { if (rows_here && G.rows > 0) factorize_rows_lu(K); else factorize_quad_lu(K); }
+        if constexpr (kRowsLuOk) { if (rows_here && G.rows > 0) factorize_rows_lu(K); else factorize_quad_lu(K); }
         else factorize_quad_lu(K);
 #else
         factorize_quad_lu(K);
@@ -5152,9 +5162,9 @@ struct StepLds {
     // line-search base, which are dead between the line search and the next solve; B takes what is left of the 40 KB a workgroup may
     // use with four workgroups per CU.
     static constexpr int ROW_RS = 13, ROW_US = 7;
-    static constexpr bool rows = QUAD && NW == 1 && MAXC == 1 && GRAD == 0;
-    static constexpr int stA_bytes = 4 * 12 * ROW_RS * 8, stB_bytes = 4 * 12 * ROW_US * 8;
-    static_assert(4 * 6 * (ROW_RS + ROW_US) * 8 <= stA_bytes, "L and Dup rows reuse area A");
+    static constexpr bool rows = QUAD && GRAD == 0 && ((NW == 1 && MAXC == 1) || NW == 2);    // (two wavefronts: staging areas per wavefront, behind the layout)
+    static constexpr int stA_bytes = NW * 4 * 12 * ROW_RS * 8, stB_bytes = NW * 4 * 12 * ROW_US * 8;
+    static_assert(4 * 6 * (ROW_RS + ROW_US) * 8 <= stA_bytes / NW, "L and Dup rows reuse area A");
     static constexpr int stA_off = !rows ? 0 : ls_in_lds ? ls_off : info_end;
     static constexpr int stB_off = !rows ? 0 : ls_in_lds ? info_end : info_end + stA_bytes;
     static_assert(!rows || !ls_in_lds || ls_slot * NSN >= stA_bytes, "area A must fit the line-search block it overlays");

@@ -530,7 +530,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     // else one lane per supernode
     const int NW = mapping_waves(s->M);
     const bool quad = NW > 0;
-    if (NW == 1) dj::set_row_passes(A.G, s->M);             // the factorization's level passes in the row layout (dojo_device.hpp, factorize_rows), where they pay
+    if (NW == 1 || NW == 2) dj::set_row_passes(A.G, s->M);             // the factorization's level passes in the row layout (dojo_device.hpp, factorize_rows), where they pay
     int E = 64 * (quad ? NW : 1) / (s->M.S * (quad ? 4 : 1));
     dim3 grid((nenv + E - 1) / E);
     const size_t waves_total = (s->B + E - 1) / E, wave0 = env0 / E;        // workgroups, each 64 * NW lanes

@@ -237,7 +237,7 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
     for (int w = 0; w < 4; ++w) G.maxch_pack[w] = 0ull;
     for (int l = 0; l < 64; ++l) G.maxch_pack[l >> 4] |= (unsigned long long)(G.maxch_lev[l] & 15) << (4 * (l & 15));      // (MAXCH = 4 children per body)
     G.rows = 0;
-    for (int t = 0; t < 16; ++t) { G.rp_lev[t] = 0; G.rp_slot4[t] = -1; for (int c = 0; c < MAXCH; ++c) G.rp_child4[t][c] = -1; }
+    for (int t = 0; t < 16; ++t) { G.rp_lev[t] = 0; G.rp_slot4[t] = -1; G.rp_slot4_w1[t] = -1; for (int c = 0; c < MAXCH; ++c) { G.rp_child4[t][c] = -1; G.rp_child4_w1[t][c] = -1; } }
     return G;
 }
 // The row-layout level passes of the factorization (Globals::rows / rp_slot / rp_lev) for a 64-lane wavefront that holds 16 / S
@@ -246,7 +246,31 @@ template <class T> inline Globals<T> make_globals(const HostModel& M, const Dojo
 // once: DESIGN.md section 6, tools/ubench/gj_rows.hip); 0: never; > 0: always.  DOJO_ROWS in the environment overrides `mode`.
 template <class T> inline void set_row_passes(Globals<T>& G, const HostModel& M, int mode = -1) {
     G.rows = 0;
+    for (int t = 0; t < 16; ++t) { G.rp_slot4_w1[t] = -1; for (int c = 0; c < MAXCH; ++c) G.rp_child4_w1[t][c] = -1; }
     if (const char* e = std::getenv("DOJO_ROWS")) mode = std::atoi(e);
+    auto put = [](int& w, int g_, int v) { w = (int)(((unsigned)w & ~(0xFFu << (8 * g_))) | ((unsigned)(v & 0xFF) << (8 * g_))); };
+    if (M.S == 32) {
+        // two-wavefront workgroups (one environment of 17..32 bodies): slot = body; wavefront w runs the passes of the slots 16 w .. 16 w + 15, both
+        // in step -- a level takes as many passes as the fuller of its two halves needs (Atlas: one per level, 11 passes of at most 3 + 3 supernodes)
+        if (mode == 0) return;
+        int t = 0;
+        for (int lev = M.maxlevel; lev >= 0; --lev) {
+            int n[2] = {0, 0}, t0 = t;
+            for (int b = 0; b < M.Nb; ++b) if (M.nodes[b].level == lev) {
+                const int w = b >> 4, pass = t0 + n[w] / 4, g = n[w] % 4;
+                if (pass >= 16) return;
+                int* slots = w ? G.rp_slot4_w1 : G.rp_slot4;
+                for (int c = 0; c < MAXCH; ++c) put(w ? G.rp_child4_w1[pass][c] : G.rp_child4[pass][c], g, c < M.nodes[b].nchild ? M.nodes[b].child[c] : -1);
+                put(slots[pass], g, b); ++n[w];
+            }
+            const int np = std::max((n[0] + 3) / 4, (n[1] + 3) / 4);
+            for (int p_ = 0; p_ < np; ++p_) { if (t0 + p_ >= 16) return; G.rp_lev[t0 + p_] = lev | ((int)G.maxch_lev[lev] << 8); }
+            t = t0 + np;
+        }
+        if (mode < 0 && 10 * t >= 16 * (M.maxlevel + 1)) return;      // (a quad pass of two wavefronts costs what it costs one: rows pay while passes < 1.6 x levels)
+        G.rows = t;
+        return;
+    }
     if (mode == 0 || M.S > 16 || M.S < 1 || 16 % M.S != 0) return;
     const int E = 16 / M.S;
     int t = 0;
@@ -255,7 +279,6 @@ template <class T> inline void set_row_passes(Globals<T>& G, const HostModel& M,
         for (int e = 0; e < E; ++e) for (int b = 0; b < M.Nb; ++b) if (M.nodes[b].level == lev) {
             if (g == 4) { ++t; g = 0; }
             if (t >= 16) return;                 // (cannot happen: 16 slots, each in one pass)
-            auto put = [](int& w, int g_, int v) { w = (int)(((unsigned)w & ~(0xFFu << (8 * g_))) | ((unsigned)(v & 0xFF) << (8 * g_))); };
             for (int c = 0; c < MAXCH; ++c) put(G.rp_child4[t][c], g, c < M.nodes[b].nchild ? e * M.S + M.nodes[b].child[c] : -1);
             put(G.rp_slot4[t], g++, e * M.S + b); G.rp_lev[t] = lev | ((int)G.maxch_lev[lev] << 8);
         }

@@ -133,7 +133,7 @@ struct GpuWave {
     // Row layout of the level passes (LaneProgram::factorize_rows): 16 lanes per supernode, one matrix row per lane.  gfx950's DP ALU
     // knows exactly one DPP control, row_newbcast:P (lane P of every 16-lane row), and takes it INSIDE the fp64 multiply-add: a pivot-row
     // entry reaches the twelve rows of its supernode in the instruction that uses it -- no separate broadcast, no LDS traffic.
-    static constexpr bool kRows = NW == 1;
+    static constexpr bool kRows = NW <= 2;      // (two wavefronts: each runs the row passes of its own sixteen slots)
     template <int P> static __device__ __forceinline__ double row_bcast_(double v) {    // v_mov_b64_dpp row_newbcast:P
         const long long x = __builtin_bit_cast(long long, v);
         const long long y = __builtin_amdgcn_mov_dpp(x, 0x150 + P, 0xF, 0xF, false);

@@ -80,7 +80,7 @@ struct EmuWaveT {
     template <class V> V quad_bcast(V v, int o) { return shfl(v, (l & ~3) + o); }
     template <class V> V quad_xor(V v, int m) { return shfl(v, l ^ m); }
     // the row layout of the level passes (LaneProgram::factorize_rows): lane p of my 16-lane row, alone and inside a multiply-add
-    static constexpr bool kRows = NW == 1;
+    static constexpr bool kRows = NW <= 2;
     static constexpr int kWidth = 0;            // (the emulator's workgroup width is a run-time value: width())
     static constexpr bool kWaveReduce = false;  // (GPU: the 16-slot reductions on the DPP path, Wave::reduce_quads16)
     template <class V> V row_bcast(V v, int p) { return shfl(v, (l & ~15) + p); }
@@ -140,7 +140,7 @@ void run(const dj::HostModel& M, const DojoSolverOptions& opts, int grad_mode, i
     for (auto& v : dut) v = TIO(std::numeric_limits<double>::quiet_NaN());
     dj::KernelArgs<TIO, T> A;
     { const char* rw = std::getenv("EMU_REFINE_W"); A.G = dj::make_globals<T>(M, opts, grad_mode, rw ? std::atof(rw) : INFINITY); }
-    if constexpr (QUAD && NW == 1) { if (W == 64) dj::set_row_passes(A.G, M); }     // (as the product's launch(): the factorization's level passes in the row layout)
+    if constexpr (QUAD && (NW == 1 || NW == 2)) { if (W == 64 * NW) dj::set_row_passes(A.G, M); }     // (as the product's launch(): the factorization's level passes in the row layout)
     A.nodes = nodes.data(); A.contacts = contacts.data(); A.B = B;
     std::vector<dj::TraSD<T>> tsd;
     for (auto& a : M.tsd) { dj::TraSD<T> b; b.spring = T(a.spring); b.damper = T(a.damper); for (int i = 0; i < 3; ++i) b.off[i] = T(a.off[i]); b.lim_lo = T(a.lim_lo); b.lim_hi = T(a.lim_hi); b.nlim = a.nlim; tsd.push_back(b); }

@@ -1048,6 +1048,21 @@ def test_row_layout_factorization_is_the_quad_one(cfg):
     assert min(r["iters"].min() for r in a) >= 3          # (real solves, not early exits)
 
 
+def test_row_layout_factorization_over_two_wavefronts():
+    """Atlas (31 bodies, two wavefronts per environment, bodies with four contacts): every wavefront runs the row passes of its own sixteen
+    supernode slots, both in step, one pass per tree level (11 passes of at most 3 + 3 supernodes); children's Schur complements cross between
+    the wavefronts through the mailbox.  Bit for bit against the quad layout."""
+    spec = d.baseline_config(5)
+    Z, U = d.synthetic_inputs(spec, 1, seed=5, distribution="standing")
+    a, b = _both_factorizations(spec, Z, U, steps=2, envs_per_wave=1)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["status"], rb["status"])
+        for key in ("z_next", "vel", "joint_imp", "contact_sg"):
+            assert np.array_equal(ra[key], rb[key]), key
+    assert np.array_equal(a[-1]["dz"], b[-1]["dz"]) and np.array_equal(a[-1]["du"], b[-1]["du"])
+    assert min(r["iters"].min() for r in a) >= 3
+
+
 @pytest.mark.parametrize("seed,nb", [(1, None), (3, 4), (5, 2), (8, 7), (9, 3)])
 def test_row_layout_factorization_with_several_environments_per_wavefront(seed, nb):
     """Random trees of 2 .. 8 bodies, 16 / S environments per 64-lane wavefront (S = supernode slots per environment): a level pass of
