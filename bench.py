@@ -350,10 +350,17 @@ def main():
             u_ = cb.get("sparse_lu_flops", {}).get("per_env_step")
             if u_:
                 a_ = u_ * B / (1e-3 * 1e3 * el / K) / 1e12
+                rf_ = cb.get("sparse_lu_flops", {}).get("reference_formula_flops", {}).get("per_env_step")
                 res["roofline"]["useful"] = {"flops_per_step": u_ * B, "achieved": a_, "unit": "TFLOP/s", "frac": a_ / FP64_VECTOR_PEAK_TFLOPS,
                                              "lane_efficiency": (u_ * B / fl_step) if fl_step else None,
+                                             "reference_formula_flops_per_step": (rf_ * B) if rf_ else None,
+                                             "algorithm_flops_over_executed": ((u_ + rf_) * B / fl_step) if (fl_step and rf_) else None,
                                              "note": "flops of a block-sparse no-pivot LU (one factorization + two solves per Newton iteration, one + a solve per Jacobian column) / ms_per_step; "
-                                                     "lane_efficiency = these / the executed fp64 flops (assembly and line-search residuals are NOT in the numerator: a lower bound of the useful share)"}
+                                                     "lane_efficiency = these / the executed fp64 flops (the linear algebra alone: a lower bound of the useful share).  reference_formula_flops_per_step = "
+                                                     "what the reference's own formulas execute OUTSIDE the solves (assembly, line-search residuals, violations, IFT data matrix), counted by running "
+                                                     "the oracle on an operation-counting scalar (cpu_baseline.sparse_lu_flops.reference_formula_flops); algorithm_flops_over_executed = (LU + those) / "
+                                                     "executed: the reference's generic small-matrix products cost several times the flops of the device's closed forms, so this ratio is an UPPER "
+                                                     "estimate of the useful share (the device's redundancy -- four lanes evaluate every joint -- is in the denominator, its cheaper formulas are not in the numerator)"}
         if world > 1:
             res["config"]["trajectory_gather"] = {"what": "the timed rollout's states [K=%d, B=%d, 13 Nb=%d] of every rank, once, inside the timed region" % (K, B, 13 * spec.Nb),
                                                  "bytes_received_per_rank": gathered_bytes,
@@ -548,6 +555,25 @@ def cpu_baseline(spec, grad, mean_iters=None, executed_flops_per_env=None, distr
         la["per_env_step"] = mean_iters * la["per_newton_iteration"] + la["ift"]
         if executed_flops_per_env:
             la["frac_of_executed_fp64"] = la["per_env_step"] / executed_flops_per_env
+    # ... and what the reference's FORMULAS need outside the linear solves: set_entries!, every residual evaluation of the line searches, the
+    # violations, the data matrix of the IFT -- the oracle on an operation-counting scalar (oracle/counted.hpp; + - * / sqrt sin cos atan = 1 each,
+    # so a multiply-add = 2 as in the PMC figures), 16 environments of the same batch.  The oracle restates the reference's generic small-matrix
+    # algebra (products with structurally zero blocks included), not the device's closed forms: an upper estimate of the useful assembly work.
+    try:
+        import numpy as np
+        oc = Oracle(spec, dtype="count")
+        oc.op_count()
+        ops_step, ops_grad, its_ = [], [], []
+        for i in range(min(16, len(Z))):
+            _, info = oc.step(Z[i], U[i]); ops_step.append(oc.op_count())
+            if grad:
+                oc.gradients(0); ops_grad.append(oc.op_count())
+            its_.append(info["iters"])
+        sc_ = (mean_iters / float(np.mean(its_))) if (mean_iters and np.mean(its_) > 0) else 1.0      # (the sample's solves against the timed rollout's mean iteration count)
+        la["reference_formula_flops"] = {"per_env_step": float(sc_ * np.mean(ops_step) + (np.mean(ops_grad) if ops_grad else 0.0)), "newton_loop_of_the_sample": float(np.mean(ops_step)),
+                                         "ift_data_matrix": float(np.mean(ops_grad)) if ops_grad else 0.0, "mean_iters_of_the_sample": float(np.mean(its_)), "scaled_to_iters": mean_iters, "envs": len(its_)}
+    except Exception as e:      # (an oracle library older than the counting scalar)
+        la["reference_formula_flops"] = {"error": str(e)}
     return {"value": out["sparse"]["value"], "unit": "env-steps/s", "cores": cores, "threads": cores, "kind": "port",
             "single_thread": out["sparse"]["single_thread"], "parallel_efficiency": out["sparse"]["parallel_efficiency"],
             "cpu_seconds": out["sparse"]["cpu_seconds"] + out["dense"]["cpu_seconds"],

@@ -193,12 +193,12 @@ struct OracleT : IOracle {
         pre.clear(); for (auto& B : m.bodies) pre.push_back(B.st);
         m.update_state();
         std::vector<T> o(nz);
-        if (z_state) { m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z_state[i] = o[i]; }
-        if (z_return) { m.get_next_state(o.data()); for (int i = 0; i < nz; ++i) z_return[i] = o[i]; }
+        if (z_state) { m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z_state[i] = (double)o[i]; }
+        if (z_return) { m.get_next_state(o.data()); for (int i = 0; i < nz; ++i) z_return[i] = (double)o[i]; }
         if (iters) *iters = m.last_iters;
         return status;
     }
-    void get_solution(double* sol) override { std::vector<T> s(m.n); m.get_solution(s.data()); for (int i = 0; i < m.n; ++i) sol[i] = s[i]; }
+    void get_solution(double* sol) override { std::vector<T> s(m.n); m.get_solution(s.data()); for (int i = 0; i < m.n; ++i) sol[i] = (double)s[i]; }
     void set_solution(const double* sol) override { auto s = cast(sol, m.n); m.set_solution(s.data()); }
     void gradients(int mode, double* dz, double* du) override {
         int nx = 12 * (int)m.bodies.size(), nu = m.nu();
@@ -217,8 +217,8 @@ struct OracleT : IOracle {
         } else {
             m.get_maximal_gradients(solmat, a.data(), b.data());
         }
-        for (size_t i = 0; i < (size_t)nx * nx; ++i) dz[i] = a[i];
-        for (size_t i = 0; i < (size_t)nx * nu; ++i) du[i] = b[i];
+        for (size_t i = 0; i < (size_t)nx * nx; ++i) dz[i] = (double)a[i];
+        for (size_t i = 0; i < (size_t)nx * nu; ++i) du[i] = (double)b[i];
     }
     void contact_gradients(int mode, double* dc) override {
         int nx = 12 * (int)m.bodies.size(), nc = 5 * (int)m.contacts.size();
@@ -230,18 +230,18 @@ struct OracleT : IOracle {
             m.get_contact_gradients(solmat, a.data());
             for (size_t i = 0; i < post.size(); ++i) m.bodies[i].st = post[i];
         } else m.get_contact_gradients(solmat, a.data());
-        for (size_t i = 0; i < (size_t)nx * nc; ++i) dc[i] = a[i];
+        for (size_t i = 0; i < (size_t)nx * nc; ++i) dc[i] = (double)a[i];
     }
-    void get_data(double* d) override { int nd = m.data_dim(false); std::vector<T> v(nd); m.get_data(v.data()); for (int i = 0; i < nd; ++i) d[i] = v[i]; }
+    void get_data(double* d) override { int nd = m.data_dim(false); std::vector<T> v(nd); m.get_data(v.data()); for (int i = 0; i < nd; ++i) d[i] = (double)v[i]; }
     void set_data(const double* d) override { auto v = cast(d, m.data_dim(false)); m.set_data(v.data()); }
     void evaluate_residual(const double* data, const double* sol, double* out) override {
         auto d = cast(data, m.data_dim(false)); auto s = cast(sol, m.n); std::vector<T> o(m.n);
         m.evaluate_residual(d.data(), s.data(), o.data());
-        for (int i = 0; i < m.n; ++i) out[i] = o[i];
+        for (int i = 0; i < m.n; ++i) out[i] = (double)o[i];
     }
-    void full_matrix(double* out) override { for (size_t i = 0; i < (size_t)m.n * m.n; ++i) out[i] = m.A[i]; }
-    void data_matrix(double* out) override { std::vector<T> D; int nd; m.jacobian_data(D, nd); for (size_t i = 0; i < D.size(); ++i) out[i] = D[i]; }
-    void data_attjac(double* out) override { std::vector<T> G; int nr, nc; m.data_attitude_jacobian(G, nr, nc); for (size_t i = 0; i < G.size(); ++i) out[i] = G[i]; }
+    void full_matrix(double* out) override { for (size_t i = 0; i < (size_t)m.n * m.n; ++i) out[i] = (double)m.A[i]; }
+    void data_matrix(double* out) override { std::vector<T> D; int nd; m.jacobian_data(D, nd); for (size_t i = 0; i < D.size(); ++i) out[i] = (double)D[i]; }
+    void data_attjac(double* out) override { std::vector<T> G; int nr, nc; m.data_attitude_jacobian(G, nr, nc); for (size_t i = 0; i < G.size(); ++i) out[i] = (double)G[i]; }
     void set_state(const double* z) override {   // state without touching inputs (for simulate!)
         int Nb = (int)m.bodies.size();
         for (int i = 0; i < Nb; ++i) {
@@ -251,7 +251,7 @@ struct OracleT : IOracle {
         }
         m.initialize_simulation();
     }
-    void get_state(double* z) override { int nz = 13 * (int)m.bodies.size(); std::vector<T> o(nz); m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z[i] = o[i]; }
+    void get_state(double* z) override { int nz = 13 * (int)m.bodies.size(); std::vector<T> o(nz); m.get_maximal_state(o.data()); for (int i = 0; i < nz; ++i) z[i] = (double)o[i]; }
     void set_external_force(int body, const double* force, const double* torque, const double* vertex) override {
         // set_external_force!(body; force, torque, vertex)  bodies/set.jl:96-101
         State<T>& s = m.bodies[body].st;
@@ -271,7 +271,7 @@ struct OracleT : IOracle {
         return st;
     }
     void body_velocity_solution(double* v) override {
-        for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { v[6 * i + k] = m.bodies[i].st.vsol[1][k]; v[6 * i + 3 + k] = m.bodies[i].st.wsol[1][k]; }
+        for (size_t i = 0; i < m.bodies.size(); ++i) for (int k = 0; k < 3; ++k) { v[6 * i + k] = (double)m.bodies[i].st.vsol[1][k]; v[6 * i + 3 + k] = (double)m.bodies[i].st.wsol[1][k]; }
     }
     void save_to_storage(double* out) override {
         std::vector<T> o(25 * m.bodies.size()); m.save_to_storage(o.data());
@@ -291,8 +291,8 @@ struct OracleT : IOracle {
         m.mu = 0;
         for (auto& c : m.contacts) m.initialize_contact(c);
         m.set_entries();
-        for (size_t i = 0; i < (size_t)m.n * m.n; ++i) A[i] = m.A[i];
-        for (int i = 0; i < m.n; ++i) b[i] = m.b[i];
+        for (size_t i = 0; i < (size_t)m.n * m.n; ++i) A[i] = (double)m.A[i];
+        for (int i = 0; i < m.n; ++i) b[i] = (double)m.b[i];
     }
     void check_solution(const double* z, const double* u, const double* sol, double* viol) override {
         // residual_violation / bilinear_violation (src/solver/violations.jl) of a candidate solution of step!(z, u)
@@ -310,7 +310,11 @@ struct OracleT : IOracle {
 
 extern "C" {
 
+// dtype 99: the counting scalar (oracle/counted.hpp): orc_op_count(reset) = floating-point operations of this THREAD's counted instances outside the
+// linear solves since the last reset
+long long orc_op_count(int reset) { const long long n = Counted::ops(); if (reset) Counted::ops() = 0; return n; }
 void* orc_create(const DojoTopology* tp, int dtype) {
+    if (dtype == 99) return new OracleT<Counted>(*tp);
     if (dtype == DOJO_DTYPE_F32) return new OracleT<float>(*tp);
     return new OracleT<double>(*tp);
 }

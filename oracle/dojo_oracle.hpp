@@ -31,6 +31,7 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
 #pragma once
 #include <functional>
+#include "counted.hpp"
 #include "oracle_math.hpp"
 #include "../include/dojo_hip.h"
 #include <limits>
@@ -1311,10 +1312,13 @@ struct Mechanism {
             if (verbose) std::printf("%3d  bvio %.3e  rvio %.3e  alpha %.3e  mu %.3e\n", it, (double)bvio, (double)rvio, (double)last_alpha, (double)mutarget);
             if (rvio < T(opts.rtol) && bvio < T(opts.btol)) { status = DOJO_STATUS_SUCCESS; break; }
             rcache = b;                                   // pull_residual!
+            {
+            OpPause<T> pause_;                            // (oracle/counted.hpp: the linear solves are not counted with the assembly)
             if (sparse_solver) { if (splu.n != n) build_sparse_order(); splu.factor(A); splu.solve(b.data(), 1); }
             else {
             lu.factor(A, n);                              // ldu_factorization!
             lu.solve_refined(b.data(), 1, refine_steps);  // ldu_backsubstitution!  -> Δaff in b
+            }
             }
             T aaff = cone_line_search(T(0.95), T(0.95));
             T nu_, nuaff; centering(aaff, nu_, nuaff);
@@ -1326,7 +1330,7 @@ struct Mechanism {
             mu = mutarget;
             correction();
             b = rcache;                                   // push_residual!
-            if (sparse_solver) splu.solve(b.data(), 1); else lu.solve_refined(b.data(), 1, refine_steps);
+            { OpPause<T> pause_; if (sparse_solver) splu.solve(b.data(), 1); else lu.solve_refined(b.data(), 1, refine_steps); }
             T tau = std::fmax(T(0.95), T(1) - std::fmax(rvio, bvio) * std::fmax(rvio, bvio));
             T alpha = cone_line_search(tau, std::fmin(tau, T(0.95)));
             last_alpha = alpha;
@@ -1776,8 +1780,9 @@ struct Mechanism {
         int nc = (int)cols.size();
         std::vector<T>& R = w_R; R.resize((size_t)n * nc);
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + cols[c]];
+        { OpPause<T> pause_;
         if (sparse_solver) { if (splu.n != n) build_sparse_order(); splu.factor(solmat); splu.solve(R.data(), nc); }
-        else { DenseLU<T>& lu = w_lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps); }   // data_jacobian = solmat \ datamat
+        else { DenseLU<T>& lu = w_lu; lu.factor(solmat, n); lu.solve_refined(R.data(), nc, refine_steps); } }   // data_jacobian = solmat \ datamat
         std::fill(jac_state, jac_state + (size_t)nx * nx, T(0));
         std::fill(jac_control, jac_control + (size_t)nx * nu_, T(0));
         auto out = [&](int row, int c) -> T& { return c < nx ? jac_state[(size_t)row * nx + c] : jac_control[(size_t)row * nu_ + (c - nx)]; };
@@ -1810,7 +1815,7 @@ struct Mechanism {
         int nc = 5 * (int)contacts.size();
         std::vector<T> R((size_t)n * std::max(nc, 1));
         for (int r = 0; r < n; ++r) for (int c = 0; c < nc; ++c) R[(size_t)r * nc + c] = Dm[(size_t)r * nd + o + c];
-        DenseLU<T> lu; lu.factor(solmat, n); if (nc > 0) lu.solve_refined(R.data(), nc, refine_steps);
+        { OpPause<T> pause_; DenseLU<T> lu; lu.factor(solmat, n); if (nc > 0) lu.solve_refined(R.data(), nc, refine_steps); }
         std::fill(jac_contact, jac_contact + (size_t)nx * nc, T(0));
         for (int i = 0; i < Nb; ++i) {
             const State<T>& s = bodies[i].st;

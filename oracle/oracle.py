@@ -42,6 +42,7 @@ def lib(fast=False):
         _lib.orc_physical_cores.restype = C.c_int
         _lib.orc_set_refine_steps.restype = None
         _lib.orc_set_sparse_solver.restype = None; _lib.orc_sparse_flops.restype = C.c_longlong; _lib.orc_sparse_solve_flops.restype = C.c_longlong
+        _lib.orc_op_count.restype = C.c_longlong; _lib.orc_op_count.argtypes = [C.c_int]
         _lib.orc_ls_stats.restype = None
         _lib.orc_unit.restype = C.c_int; _lib.orc_joint_unit.restype = C.c_int; _lib.orc_contact_unit.restype = C.c_int
         _lib.orc_input_impulses.restype = None
@@ -65,7 +66,8 @@ class Oracle:
         self.spec = spec
         self._L = lib(fast)
         self._topo, self._keep = spec.to_ctypes()
-        self.h = C.c_void_p(self._L.orc_create(C.byref(self._topo), 0 if dtype == "f64" else 1))
+        # dtype "count": the operation-counting scalar (oracle/counted.hpp; op_count() reads the thread's counter)
+        self.h = C.c_void_p(self._L.orc_create(C.byref(self._topo), 0 if dtype == "f64" else 99 if dtype == "count" else 1))
         d = (C.c_int * 7)()
         self._L.orc_dims(self.h, d)
         self.n, self.nu, self.nd_full, self.nd, self.Nb, self.Ne, self.Nc = list(d)
@@ -218,6 +220,11 @@ class Oracle:
     def set_sparse_solver(self, on=True):
         """timing variant (bench.py cpu_baseline): sparse LU without pivoting in the elimination order of the mechanism graph"""
         self._L.orc_set_sparse_solver(self.h, int(bool(on)))
+
+    def op_count(self, reset=True):
+        """floating-point operations (+ - * / sqrt sin cos atan pow, one each: a multiply-add = 2) the counting instances (dtype="count") of the calling
+        thread have executed OUTSIDE their linear solves since the last reset"""
+        return int(self._L.orc_op_count(1 if reset else 0))
 
     def ls_stats(self):
         """(line searches, residual evaluations) of this instance since creation (single-environment calls only)"""

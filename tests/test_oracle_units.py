@@ -160,3 +160,22 @@ def test_damper_jacobians(joint_type):
             ec = np.abs(Jc - _fd(force_cfg, np.concatenate([x, q])) @ att).max()
             ev = np.abs(Jv - _fd(force_vel, vel[0 if jac_parent else 6:6 if jac_parent else 12])).max()
             assert ec < 1e-8 and ev < 1e-8, (joint_type, half, rel_parent, jac_parent, ec, ev)
+
+
+def test_operation_counting_scalar_runs_the_same_algorithm():
+    """oracle/counted.hpp (bench.py's `roofline.useful.reference_formula_flops_per_step`): the oracle on the operation-counting scalar takes the
+    same Newton path to the same state as on double (it IS double arithmetic), counts nothing inside its linear solves, and its count of a step
+    grows with the iterations of that step."""
+    import dojo_amd as d
+    from oracle import Oracle
+    spec = d.baseline_config(1)                     # pendulum
+    z, u = d.synthetic_inputs(spec, 2, seed=3)
+    o, oc = Oracle(spec), Oracle(spec, dtype="count")
+    oc.op_count()
+    zs, info = o.step(z[0], u[0]); zc, infoc = oc.step(z[0], u[0])
+    n1 = oc.op_count()
+    assert info["iters"] == infoc["iters"] and np.array_equal(zs, zc)
+    assert 1000 * info["iters"] < n1 < 1000000 * max(1, info["iters"])      # assembly + residuals of a two-body mechanism: thousands of flops per iteration, no 13^3 of a dense solve
+    assert oc.op_count() == 0                        # (reset by the read above)
+    dz, du = o.gradients(0); dzc, duc = oc.gradients(0)
+    assert np.array_equal(dz, dzc) and np.array_equal(du, duc) and oc.op_count() > 0
