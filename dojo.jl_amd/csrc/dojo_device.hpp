@@ -146,6 +146,10 @@ struct NodeP {
 template <class T>
 struct ContactP { T n[3], t[6], o[3], off[3], r, mu; T r2, o2[3]; int kind, pbody, cbody; };   // kind 1: SphereSphereCollision: (o, r) = (origin_parent, radius_parent), (o2, r2) = the child's; pbody / cbody: its parent body and its child body (the owner; half-space: -1 / the body)
 
+// the node constants of a workgroup's supernode slots in LDS (lock-step quad mappings: StepLds, DJ_LANE_SETUP)
+template <class T>
+struct NodeSlot { NodeP<T> P; char pad_[(sizeof(NodeP<T>) / 8) % 2 == 0 ? 8 : 16]; };                    // odd stride in 8-byte words
+
 // ------------------------------------------------------------------------------------------------
 // Lane-local dynamic state
 // ------------------------------------------------------------------------------------------------
@@ -4341,13 +4345,18 @@ struct LaneProgram {
     // traffic for a tree like the Ant's).  MODE 0: second-kind batches = control batches (six input columns each); 1: contacts.
     template <int MODE, class KA>
     DJ_HD void sweep_masks(const KA& A, SweepP& sp) const {
+        // (the walk reads the environment's node constants where the workgroup keeps them -- its LDS node slots: from KernelArgs::nodes every step
+        //  up the tree was a dependent GLOBAL load, ~40 of them per lane and launch: 25 k cycles of the IFT kernel's prologue)
+        auto node_at = [&](int a) -> const NodeP<T>& {
+            if constexpr (QUAD && Wave::kLockstep) return ((const NodeSlot<T>*)&P)[a - k].P; else return A.nodes[a];
+        };
         unsigned long long sub = 0, ub = 0;
         for (int j = 0; j < G.Nb; ++j) {
             int a = j, guard = 0; bool in = false;
-            while (a >= 0 && guard++ < 64) { if (a == k) { in = true; break; } a = A.nodes[a].parent; }
+            while (a >= 0 && guard++ < 64) { if (a == k) { in = true; break; } a = node_at(a).parent; }
             if (!in) continue;
             sub |= 1ull << j;
-            const NodeP<T>& Pj = A.nodes[j];
+            const NodeP<T>& Pj = node_at(j);
             if (MODE == 0) { const int n = Pj.nu_t + Pj.nu_r; for (int c = 0; c < n; ++c) ub |= 1ull << ((Pj.u_off + c) / 6); }
             else for (int c = 0; c < Pj.ncontact; ++c) ub |= 1ull << Pj.contact[c];
         }
@@ -4407,6 +4416,7 @@ struct LaneProgram {
         DJ_PB();
         // ---- quad mapping: the final linearization once more at the restored solution, factored in LU form (factorize_quad_lu) ----
         if constexpr (QUAD && !PRECISE) lu_prepare();
+        DJ_P2B();
         // ---- kinematics of the solution (chain) ----
         T own6[6] = {L.v[0], L.v[1], L.v[2], L.w[0], L.w[1], L.w[2]}, par6[6], va[3], wa[3];
         if (lane_slots) {
@@ -4434,6 +4444,7 @@ struct LaneProgram {
         kin_of(ka, xa2e, qa2e, va, wa, dt);
         JointEval<T> E;
         { NullBlocks nk; joint_eval<2>(E, P, ce, has_parent, ka, kb, wa, L.w, L.lam, L.lg, dt, nk); }
+        DJ_P2E(8);
 #if DJ_TSD
         if (tlim) tra_limit_eval<true>(E, P, ce, ka, kb, L.lg, dt);
 #endif
@@ -4512,6 +4523,7 @@ struct LaneProgram {
             }
         } }
 #endif
+        DJ_P2E(9);
         // ---- data blocks (datamat = −∂residual/∂θ) ----
         T OwnB[6][12], OwnJ[6][6], ParB[6][6], ParJ[6][6], UpOwn[6][6], UpPar[6][6], sl_own[6], sl_par[6], Cc[MAXC][4][6], UB[6][6], UA[6][6];
         for (int i = 0; i < 6; ++i) { for (int j = 0; j < 12; ++j) OwnB[i][j] = T(0); for (int j = 0; j < 6; ++j) { OwnJ[i][j] = ParB[i][j] = ParJ[i][j] = UpOwn[i][j] = UpPar[i][j] = UB[i][j] = UA[i][j] = T(0); } sl_own[i] = sl_par[i] = T(0); }
@@ -4581,6 +4593,7 @@ struct LaneProgram {
                 UpPar[i][j] = Jaa[6 * i + j];
             }
         }
+        DJ_P2E(10);
         // contacts: body rows <- own φ2 (data.jl:126-135), contact rows <- own configuration (data.jl:194-205)
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -4598,6 +4611,7 @@ struct LaneProgram {
                 }
             }
         }
+        DJ_P2E(11);
         // control columns: input_jacobian_control (translational/input.jl:33-44, rotational/input.jl:23-40)
         for (int i = 0; i < 3; ++i) {
             if (i < P.nu_t) {
@@ -4617,6 +4631,7 @@ struct LaneProgram {
                 }
             }
         }
+        DJ_P2E(12);
         // ---- condensation maps for a right-hand side without cone terms (computed once) ----
         // contact rows r58 -> body rhs:  rk[0:6] += GK r58 ;  limit slack rows (rs, −rs) -> rk += t_b wk rs, up += t_a wk rs
         T GK[MAXC][6][4], wk = T(0);
@@ -4637,6 +4652,7 @@ struct LaneProgram {
         // the body-row blocks of the IFT right-hand sides are kept in the ABI type (QuadRhs)
         typedef typename KA::io_type TIO; typedef TIO TB;
         if constexpr (QUAD && !PRECISE) {
+            DJ_P2E(13);
             // ---- stash the right-hand sides once per supernode in LDS, cone condensation folded in ----
             // everything read from NodeP / Lane / Cold below this point is cached first: the right-hand sides overlay them
             SweepP sp;
@@ -5117,8 +5133,6 @@ struct KernelArgs {
 //   [reduction scratch, 64 B] at the end
 template <class T, int MAXC>
 struct LaneSlot { Lane<T, MAXC> L; T pad_[(sizeof(Lane<T, MAXC>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };   // odd stride in 8-byte words
-template <class T>
-struct NodeSlot { NodeP<T> P; char pad_[(sizeof(NodeP<T>) / 8) % 2 == 0 ? 8 : 16]; };                    // odd stride in 8-byte words
 constexpr int lds_imax(int a, int b) { return a > b ? a : b; }
 // GRAD: 0 = step kernel, 1 = IFT kernel (state + control columns), 2 = IFT kernel for the contact-data columns
 template <class TIO, class T, int MAXC, int GRAD, bool QUAD, bool LOCKSTEP, int NW = 1>

@@ -120,6 +120,9 @@ if what == "phases2":
           "down-sweep: pop + prefetch", "down-sweep: parent's x, T x", "down-sweep: backward substitution", "down-sweep: posts + output stores"]
     print("IFT sweeps (cycles per wave; the branch phases only)")
     for n, v in zip(gn, g): print("   %-36s %9.0f" % (n, v))
+    pn = ["prologue: kinematics + joint_eval<2>", "prologue: slack rows, mlim", "prologue: body / joint rows, joint_impulse_cfg_jac", "prologue: contacts", "prologue: control columns", "prologue: condensation maps (GK)"]
+    print("IFT prologue behind lu_prepare (cycles per wave)")
+    for n, v in zip(pn, g[8:14]): print("   %-48s %9.0f" % (n, v))
     gm.close()
 
 if what == "stragglers":
