@@ -1459,3 +1459,39 @@ def test_ragged_batches_with_refinement(cfg, batch):
         if info["status"] == 0 and st[b] == 0 and it[b] <= REGULAR_ITERS:
             assert info["iters"] == it[b] and np.abs(zn[b] - zo).max() < 1e-6
     g1.close()
+
+
+@pytest.mark.parametrize("cfg,batch,steps,dist", [(3, 256, 6, "baseline"), (5, 64, 14, "standing")])
+def test_row_and_quad_level_passes_agree_on_the_device(cfg, batch, steps, dist):
+    """The factorization's level passes in the row layout (the default where the host's tables say so: Ant one wavefront per environment, Atlas two)
+    against the quad layout (DOJO_ROWS=0, read at every launch) in one process: ONE differentiable step from the same states (reached by a rollout
+    with the default).  The same operations in the same order -- bit for bit under the emulator (tests/test_device_program_emu.py); on the device
+    the two builds of a pass may contract differently, so: equal status and iteration counts on every environment but a few, states within 1e-9
+    where both converged along the same path, Jacobians within 1e-6 relative."""
+    spec = d.baseline_config(cfg)
+    Z, U = d.synthetic_inputs(spec, batch, distribution=dist)
+    gm = api.BatchedMechanism(spec, batch, dtype="f64")
+    for k in range(steps - 1):
+        Z, st, it = gm.step(Z, U)
+    gm.close()
+    outs = {}
+    old = os.environ.get("DOJO_ROWS")
+    try:
+        for rows in ("0", None):
+            if rows is None: os.environ.pop("DOJO_ROWS", None)
+            else: os.environ["DOJO_ROWS"] = rows
+            gm = api.BatchedMechanism(spec, batch, dtype="f64")
+            Zn, st, it = gm.step(Z, U, with_gradient=True)
+            dz, du = gm.gradients()
+            outs[rows] = (Zn.copy(), st.copy(), it.copy(), dz.copy(), du.copy())
+            gm.close()
+    finally:
+        if old is None: os.environ.pop("DOJO_ROWS", None)
+        else: os.environ["DOJO_ROWS"] = old
+    (Zq, sq, iq, dzq, duq), (Zr, sr, ir, dzr, dur) = outs["0"], outs[None]
+    both = (sq == 0) & (sr == 0)
+    assert both.mean() > 0.9 and (sq != sr).sum() <= 2 and (iq[both] != ir[both]).sum() <= 2, (both.mean(), int((sq != sr).sum()), int((iq[both] != ir[both]).sum()))
+    same = both & (iq == ir) & (iq <= REGULAR_ITERS)
+    assert np.abs(Zq[same] - Zr[same]).max() <= 1e-9, np.abs(Zq[same] - Zr[same]).max()
+    e = max(np.abs(dzq[b] - dzr[b]).max() / max(1.0, np.abs(dzq[b]).max()) for b in np.nonzero(same)[0])
+    assert e <= 1e-6, e
