@@ -8,6 +8,26 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU tier (`-m "not gpu"`) is dominated by the SIMT emulator's tests (every lane a thread: ~45 CPU-minutes): with pytest-xdist installed and
+    no `-n` on the command line it runs on six workers (~12 min on the 8 cores of the build container).  The GPU tier stays one process: its tests
+    share one device and some of them time things.  DOJO_TEST_WORKERS=0 switches it off, another number sets the count."""
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None                           # (a worker of such a run: it must not start workers of its own)
+    mexpr = getattr(config.option, "markexpr", "") or ""
+    if "not gpu" not in mexpr or not hasattr(config.option, "numprocesses") or config.option.numprocesses is not None:
+        return None
+    want = os.environ.get("DOJO_TEST_WORKERS", "6")
+    try:
+        n = max(0, min(int(want), os.cpu_count() or 1))
+    except ValueError:
+        n = 0
+    if n > 1:
+        config.option.numprocesses = n      # (pytest-xdist's own pytest_cmdline_main, which runs after this one, turns it into `--tx popen` x n, --dist load)
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # Atlas in the tests: states around the reference's standing pose (dojo_amd.coords, distribution "standing") -- the gates of the Atlas
