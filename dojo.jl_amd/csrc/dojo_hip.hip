@@ -440,6 +440,18 @@ size_t csg_per(const DojoSim* s) { return s->M.contact_model == 2 ? 12 : 8; }
 size_t group_count(const DojoSim* s, bool want) {
     const size_t B = (size_t)s->B;
     size_t NG = (want && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
+    // An asynchronous handle (dojo_set_async) chains its groups' steps: a group that holds a long solve delays only itself, so below 4096 environments
+    // smaller groups hide more of that tail than 256-environment ones -- down to 64 WORKGROUPS per group, for the single-wavefront quad mapping
+    // (Ant, Quadruped: one environment per wavefront; the Block's sixteen per wavefront leave its B = 1024 at four groups: sixteen launches of
+    // four wavefronts halved its rate).  profiles/r06_f_small_batches.txt: Ant B = 1024 0.47 -> 0.60 M, B = 2048 0.94 -> 1.02-1.09 M, B = 512
+    // 0.30 -> 0.37 M; Quadruped B = 1024 0.48 -> 0.66 M.  The two-wavefront mapping keeps the 256-environment groups (Atlas B = 2048 with 16 groups:
+    // +4 % on BASELINE's perturbation, -1 % standing, -19 % over the landing steps), and so does a handle that joins after every step: the groups'
+    // launches are on its critical path.
+    if (s->async && want && mapping_waves(s->M) == 1) {
+        const size_t per_wg = std::max<size_t>(1, 16 / (size_t)std::max(1, s->M.S));      // environments per 64-lane workgroup (16 supernode slots)
+        const size_t min_envs = 64 * per_wg;
+        if (B >= 2 * min_envs) NG = std::max<size_t>(NG, std::min<size_t>(16, B / min_envs));
+    }
     if (s->groups > 0) NG = std::min<size_t>(std::min<size_t>((size_t)s->groups, 16), std::max<size_t>(1, B / 64));   // (more than 16 queues in flight collapse: 0.68 M against 1.00 M at 24, same session)
     const char* hq = getenv("GPU_MAX_HW_QUEUES");
     const int nq = hq ? atoi(hq) : 4;

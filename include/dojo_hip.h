@@ -253,7 +253,8 @@ int  dojo_get_state(DojoHandle h, void* z);
 int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
                    int32_t* status, int32_t* iters, void* dz, void* du, void* stream);
 /* Environment groups.  Environments are independent, so dojo_step_dev steps a batch of >= 512 environments as up to 16
- * groups on internal HIP streams: a group that holds an environment running into max_iter (~5x the mean step time for
+ * groups on internal HIP streams (of >= 256 environments each; an asynchronous handle, below, of a mechanism with one
+ * wavefront per workgroup: of >= 64 workgroups, so that batches of 128 .. 2048 Ants are split further): a group that holds an environment running into max_iter (~5x the mean step time for
  * its wavefront) delays only itself.  By default the call forks from and joins into `stream`, i.e. it behaves like one
  * launch on `stream`.  dojo_set_async(h, 1) drops the join: consecutive dojo_step_dev calls then chain per group (group g
  * of call k+1 runs behind group g of call k and behind what `stream` held at call time), and dojo_join(h, stream)
