@@ -42,6 +42,8 @@ def main():
                     "(16 at batch 4096), 1 = one launch per kernel on the caller's stream")
     ap.add_argument("--no-parity", action="store_true", help="skip the grad-inf-err-vs-CPU leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=0, help="1: dojo_set_async(h, 2) -- the IFT kernel of a group's step runs next to the group's next step kernel "
+                    "(two hand-off records in turn; the rollout's states and controls sit in per-step buffers, as the asynchronous contract wants); 0: plain asynchronous groups")
     ap.add_argument("--iter-cap", type=int, default=-1, help="dojo_set_iteration_cap: solves unfinished after this many Newton iterations go on in the continuation "
                     "kernel (line-search trials side by side; joined steps only: the sync_per_step leg); 0 / -1 = off (the library's default)")
     ap.add_argument("--timed-only", action="store_true", help="warmup + the timed region only (no joined-per-step leg, no roofline leg, no parity, no CPU baseline): "
@@ -117,7 +119,7 @@ def main():
     if args.chunks > 0:
         gm.set_groups(args.chunks)
     gm.set_iteration_cap(args.iter_cap)
-    gm.set_async(True)
+    gm.set_async(2 if args.pipeline else True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
     lib_gather, lib_stuck = False, False
     gather_pref = os.environ.get("DOJO_BENCH_GATHER", "library")       # "torch": never try the library's communicator; "library-force": try it under gloo too (plumbing check of the fall-back)
@@ -168,8 +170,9 @@ def main():
         torch.cuda.synchronize()
 
     torch.cuda.synchronize()                     # inputs were produced on the default stream
+    wtraj = torch.empty((max(W, 1),) + tuple(traj.shape[1:]), device=traj.device, dtype=traj.dtype)      # (per-step buffers for the warmup too: the inputs of un-joined steps stay untouched)
     for k in range(W):
-        one_step(k)
+        one_step(k, wtraj[k])
     gm.join(torch.cuda.current_stream().cuda_stream)
     barrier()
     gm.kernel_time_totals(reset=True)                      # (drains the warmup's event pairs)
@@ -320,7 +323,7 @@ def main():
                                                                    else " (Atlas: around the reference's standing pose, dojo_amd.coords._SYNTH_STANDING; other mechanisms as baseline)"),
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
-                       "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout)" % (world, NCH),
+                       "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout%s)" % (world, NCH, "; pipelined: a group's IFT kernel of step k next to its step kernel of step k + 1" if args.pipeline else ""),
                        "iteration_cap": "off (library default; dojo_set_iteration_cap: measured gain only at per-GPU batches <= 2048, DESIGN.md section 6)" if args.iter_cap <= 0 else args.iter_cap,
                        "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters,
                        "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,

@@ -89,7 +89,10 @@ struct DojoSim {
     void *d_fext = nullptr, *d_res = nullptr, *d_z = nullptr, *d_u = nullptr, *d_zn = nullptr, *d_vel = nullptr, *d_jimp = nullptr, *d_csg = nullptr, *d_dz = nullptr, *d_du = nullptr;
     std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gevents; hipEvent_t fork_event = nullptr;   // environment groups (rollouts, dojo_step_dev)
     int groups = -1;                    // environment groups of dojo_step_dev: -1 = chosen from the batch size, 1 = one launch on the caller's stream
-    bool async = false, pending = false;   // dojo_set_async: dojo_step_dev returns without joining the groups into the caller's stream
+    int async = 0; bool pending = false;   // dojo_set_async: 1 = dojo_step_dev returns without joining the groups into the caller's stream; 2 = ... and the IFT of a
+                                        // group's step runs on a second stream of the group, next to its NEXT step kernel (two hand-off records in turn)
+    std::vector<hipStream_t> gstreams2; std::vector<hipEvent_t> gevents2, grad_done[2];   // pipelined groups: the IFT streams, their join events, "IFT that read record p is through"
+    void* d_sol2 = nullptr; int sol_cur = 0; bool plain_phases = false;                   // the second hand-off record; the one in use; phased launches without the iteration cap's lists
     size_t last_NG = 0, last_per = 0;      // environment-group partition of the last grouped dojo_step_dev (per-group chaining assumes it repeats)
     void* d_sol = nullptr;              // step kernel -> IFT kernel hand-off (converged solution, fp64)
     void* d_fac = nullptr;              // ... and the final supernode factors (quad mapping; explicit-inverse consumers only)
@@ -473,10 +476,26 @@ int ensure_groups(DojoSim* s, size_t NG) {
     if (!s->fork_event) HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
     return DOJO_OK;
 }
+// pipelined groups (dojo_set_async(h, 2)): a second stream per group for its IFT kernels, events, the second hand-off record
+// (the IFT streams are shared: ROCm runs ~20 streams side by side before the hardware queues are time-sliced -- 24 collapse --, so the 16 groups get
+//  pipe_streams() of them, group g on stream g % n; the IFT kernels of the groups that share one run one after the other, off the critical path)
+size_t pipe_streams() { static const char* e_ = getenv("DOJO_PIPE_STREAMS"); const int n = e_ ? atoi(e_) : 4; return (size_t)std::max(1, std::min(n, 16)); }
+int ensure_pipe(DojoSim* s, size_t NG) {
+    while (s->gstreams2.size() < std::min(NG, pipe_streams())) {
+        hipStream_t g_; HIPCHK(hipStreamCreateWithFlags(&g_, hipStreamNonBlocking)); s->gstreams2.push_back(g_);
+        hipEvent_t jev_; HIPCHK(hipEventCreateWithFlags(&jev_, hipEventDisableTiming)); s->gevents2.push_back(jev_);
+    }
+    while (s->grad_done[0].size() < NG)
+        for (int p = 0; p < 2; ++p) { hipEvent_t dev_; HIPCHK(hipEventCreateWithFlags(&dev_, hipEventDisableTiming)); s->grad_done[p].push_back(dev_); }
+    while (s->main_events.size() < NG) { hipEvent_t ev_; HIPCHK(hipEventCreateWithFlags(&ev_, hipEventDisableTiming)); s->main_events.push_back(ev_); }
+    if (!s->d_sol2) HIPCHK(hipMalloc(&s->d_sol2, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(double)));
+    return DOJO_OK;
+}
 // the caller's stream waits for everything the environment groups have in flight
 int join_groups(DojoSim* s, hipStream_t st) {
     if (!s->pending) return DOJO_OK;
     for (size_t gi = 0; gi < s->gstreams.size(); ++gi) { HIPCHK(hipEventRecord(s->gevents[gi], s->gstreams[gi])); HIPCHK(hipStreamWaitEvent(st, s->gevents[gi], 0)); }
+    for (size_t gi = 0; gi < s->gstreams2.size(); ++gi) { HIPCHK(hipEventRecord(s->gevents2[gi], s->gstreams2[gi])); HIPCHK(hipStreamWaitEvent(st, s->gevents2[gi], 0)); }
     s->pending = false;
     return DOJO_OK;
 }
@@ -571,7 +590,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
                                          : vmaxc == 1 ? dj::sol_record<1>() : vmaxc == 4 ? dj::sol_record<4>() : dj::sol_record<8>();
     if (g) {
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(T)));   // sized for the largest record
-        A.sol = (T*)s->d_sol + env0 * s->M.S * sol_rec;                      // (the record size of the kernels of this mechanism: a launch over the whole batch
+        A.sol = (T*)((s->sol_cur && s->d_sol2) ? s->d_sol2 : s->d_sol) + env0 * s->M.S * sol_rec;   // (the record size of the kernels of this mechanism: a launch over the whole batch
                                                                             //  -- the continuation -- must find the records where the groups' launches put them)
         if (quad && !s->d_fac) HIPCHK(hipMalloc(&s->d_fac, waves_total * dj::FAC_PER_LANE * 64 * NW * sizeof(T)));
         if (quad && !s->d_lu) HIPCHK(hipMalloc(&s->d_lu, waves_total * dj::LU_PER_LANE * 64 * NW * sizeof(T)));
@@ -604,10 +623,12 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         if (!s->d_sol) HIPCHK(hipMalloc(&s->d_sol, (size_t)s->B * s->M.S * dj::sol_record<8, true>() * sizeof(T)));
         if (!s->d_resume) HIPCHK(hipMalloc(&s->d_resume, (size_t)s->B * dj::CARRY_PER_ENV * sizeof(T)));
         if (!status && !s->d_cstat) HIPCHK(hipMalloc((void**)&s->d_cstat, (size_t)s->B * sizeof(int)));
-        A.G.iter_cap = effective_cap(s);
-        A.sol = (T*)s->d_sol + env0 * s->M.S * sol_rec;
-        A.resume = (T*)s->d_resume + env0 * dj::CARRY_PER_ENV;
-        A.cont_list = s->d_cont_list; A.cont_count = s->d_cont_count; A.wave_base = (int)wave0;
+        A.sol = (T*)((s->sol_cur && s->d_sol2) ? s->d_sol2 : s->d_sol) + env0 * s->M.S * sol_rec;
+        if (!s->plain_phases) {                               // (pipelined groups launch the two kernels apart without the cap's lists)
+            A.G.iter_cap = effective_cap(s);
+            A.resume = (T*)s->d_resume + env0 * dj::CARRY_PER_ENV;
+            A.cont_list = s->d_cont_list; A.cont_count = s->d_cont_count; A.wave_base = (int)wave0;
+        }
         if (!status) A.status = s->d_cstat + env0;
     }
     A.blk = nullptr; A.flag = nullptr;
@@ -620,7 +641,7 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     // Test hook (tests/conftest.py sets it for the GPU tier): the Jacobian buffers are filled with NaN bit patterns before the IFT kernels run, so that
     // an entry the device fails to write comes back as NaN instead of whatever the allocation held (the kernels must write every entry).
     static const bool poison_ = getenv("DOJO_POISON_OUTPUTS") != nullptr;
-    if (poison_ && g && (phase == PH_ALL || phase == PH_MAIN)) {
+    if (poison_ && g && (phase == PH_ALL || phase == (s->plain_phases ? PH_GRAD : PH_MAIN))) {    // (pipelined: on the IFT's stream, behind the previous step's IFT)
         if (dc != nullptr) HIPCHK(hipMemsetAsync(A.dc, 0xFF, (size_t)nenv * nx * 5 * s->M.Nc * sizeof(TIO), st));
         else {
             if (A.dz) HIPCHK(hipMemsetAsync(A.dz, 0xFF, (size_t)nenv * nx * nx * sizeof(TIO), st));
@@ -766,7 +787,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
 void dojo_destroy(DojoHandle s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_cutws, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
+    void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_cutws, s->d_sol2, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
     void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
     for (void* p : pc) if (p) (void)hipFree(p);
@@ -775,6 +796,9 @@ void dojo_destroy(DojoHandle s) {
     if (s->allmain_event) (void)hipEventDestroy(s->allmain_event);
     for (auto e_ : s->main_events) (void)hipEventDestroy(e_);
     for (auto g_ : s->gstreams) (void)hipStreamDestroy(g_);
+    for (auto g_ : s->gstreams2) (void)hipStreamDestroy(g_);
+    for (auto e_ : s->gevents2) (void)hipEventDestroy(e_);
+    for (int p_ = 0; p_ < 2; ++p_) for (auto e_ : s->grad_done[p_]) (void)hipEventDestroy(e_);
     for (auto gev_ : s->gevents) (void)hipEventDestroy(gev_);
     if (s->fork_event) (void)hipEventDestroy(s->fork_event);
     if (s->comm && rccl::comm_destroy) (void)rccl::comm_destroy(s->comm);
@@ -966,13 +990,39 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
         if (s->pending && (s->last_NG != NG || s->last_per != per) && (rc = join_groups(s, st))) return rc;
         s->last_NG = NG; s->last_per = per;
         HIPCHK(hipEventRecord(s->fork_event, st));
+        // Pipelined groups (dojo_set_async(h, 2), plain solves): the IFT kernel of a group's step k goes onto the group's SECOND stream, behind its
+        // step kernel and next to the step kernel of step k + 1 -- both depend on step k alone.  Step k + 1 writes the other hand-off record; step
+        // k + 2 re-uses record k's and waits for IFT k.  What this buys: while a group's step kernel drains (its launch lasts as long as its slowest
+        // wavefront) the group has another kernel ready for the SIMDs that fall idle -- with 16 groups x 64 wavefronts = 1024 SIMDs there is no other
+        // work to fill them.  The caller's inputs of un-joined calls stay untouched (the asynchronous contract): the IFT of step k reads z, u of step k.
+        const bool piped = s->async == 2 && dz != nullptr && !std::isfinite(refine_threshold(s));
+        if (piped) {
+            if ((rc = ensure_pipe(s, NG))) return rc;
+            s->sol_cur ^= 1; s->plain_phases = true;
+            if (s->group_slot.size() < NG) s->group_slot.resize(NG, -1);
+        }
         for (size_t gi = 0; gi < NG; ++gi) {
             const size_t env0 = gi * per;
             if (env0 >= B) break;
+            const int ne = (int)std::min(per, B - env0);
             HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->fork_event, 0));
-            rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, (int)std::min(per, B - env0));
-            if (rc != DOJO_OK) { s->pending = true; (void)join_groups(s, st); return rc; }      // (the groups already launched stay ordered before the caller's stream)
+            if (piped) {
+                HIPCHK(hipStreamWaitEvent(s->gstreams[gi], s->grad_done[s->sol_cur][gi], 0));      // (the IFT that read this record two calls ago)
+                rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, ne, nullptr, nullptr, PH_MAIN);
+                if (rc == DOJO_OK) {
+                    s->group_slot[gi] = s->phase_slot;
+                    HIPCHK(hipEventRecord(s->main_events[gi], s->gstreams[gi]));
+                    hipStream_t st2 = s->gstreams2[gi % s->gstreams2.size()];
+                    HIPCHK(hipStreamWaitEvent(st2, s->main_events[gi], 0));
+                    s->phase_slot = s->group_slot[gi];
+                    rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, st2, true, env0, ne, nullptr, nullptr, PH_GRAD);
+                    if (rc == DOJO_OK) HIPCHK(hipEventRecord(s->grad_done[s->sol_cur][gi], st2));
+                }
+            } else
+            rc = launch_any(s, z, u, z_next, status, iters, s->d_vel, s->d_jimp, s->d_csg, dz, du, s->gstreams[gi], true, env0, ne);
+            if (rc != DOJO_OK) { s->plain_phases = false; s->pending = true; (void)join_groups(s, st); return rc; }      // (the groups already launched stay ordered before the caller's stream)
         }
+        s->plain_phases = false;
         s->pending = true;
         if (!s->async && (rc = join_groups(s, st))) return rc;
     }
@@ -987,7 +1037,7 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
 int dojo_set_async(DojoHandle s, int32_t on) {
     Enter enter_(s);
     if (!s) { g_err = "dojo_set_async: bad argument"; return DOJO_ERR_INVALID; }
-    s->async = on != 0; return DOJO_OK;
+    s->async = on == 2 ? 2 : (on != 0 ? 1 : 0); return DOJO_OK;
 }
 int dojo_set_iteration_cap(DojoHandle s, int32_t cap) {
     Enter en_(s);

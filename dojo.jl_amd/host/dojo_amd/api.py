@@ -113,8 +113,9 @@ class BatchedMechanism:
         _chk(lib().dojo_set_gradient_mode(self.h, int(mode)))
 
     def set_async(self, on=True):
-        """dojo_step_dev no longer joins its environment groups into the caller's stream; join() does it once."""
-        _chk(lib().dojo_set_async(self.h, int(bool(on))))
+        """dojo_step_dev no longer joins its environment groups into the caller's stream; join() does it once.  on = 2: pipelined groups as well
+        (the IFT kernel of a group's step runs next to the group's next step kernel, include/dojo_hip.h)"""
+        _chk(lib().dojo_set_async(self.h, 2 if on == 2 else int(bool(on))))
 
     def set_groups(self, n):
         _chk(lib().dojo_set_groups(self.h, int(n)))

@@ -252,6 +252,7 @@ set_groups!(bm::BatchedMechanism, n::Integer) = check(@ccall $(fn(:dojo_set_grou
 set_iteration_cap!(bm::BatchedMechanism, cap::Integer) = check(@ccall $(fn(:dojo_set_iteration_cap))(bm.handle::Ptr{Cvoid}, cap::Int32)::Cint)
 "asynchronous environment groups: consecutive step_dev! calls chain per group; join!(bm; stream) orders `stream` behind everything in flight"
 set_async!(bm::BatchedMechanism, on::Bool) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, on::Int32)::Cint)
+set_async!(bm::BatchedMechanism, mode::Integer) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, Int32(mode)::Int32)::Cint)      # 2: pipelined groups (dojo_hip.h)
 join!(bm::BatchedMechanism; stream::DevPtr=C_NULL) = check(@ccall $(fn(:dojo_join))(bm.handle::Ptr{Cvoid}, stream::Ptr{Cvoid})::Cint)
 
 """

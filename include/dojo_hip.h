@@ -261,7 +261,14 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
  * -- or any host-pointer entry point -- orders `stream` behind everything in flight.  The caller must not touch the
  * outputs, nor overwrite the inputs, of un-joined calls.  dojo_set_groups(h, n): n groups, at most 16 (n <= 0: automatic; 1: a
  * single launch on the caller's stream).  ROCm runs at most GPU_MAX_HW_QUEUES (default 4) streams concurrently: set it
- * to >= groups + 1 before the HIP runtime starts.  (No counterpart in the reference, which is single-threaded.) */
+ * to >= groups + 1 before the HIP runtime starts.  (No counterpart in the reference, which is single-threaded.)
+ * dojo_set_async(h, 2): asynchronous AND pipelined -- the IFT kernel of a group's step k runs on a second internal stream of the group, behind
+ * its step kernel and NEXT TO the step kernel of step k + 1 (both depend on step k alone; two step -> IFT hand-off records in turn), so that the
+ * SIMDs a draining step kernel leaves idle find work.  Same contract (inputs and outputs of un-joined calls stay untouched -- here the IFT of
+ * step k still reads z, u of step k while step k + 1 runs: do not hand step k's z in as z_next of step k + 1); dz / du of consecutive calls
+ * are written in call order.  Plain solves only (with refinement in force the groups run as under 1); 2 x groups + 1 hardware queues.
+ * Where it pays: batches that leave SIMDs idle (Atlas at B = 256 in two groups: 155 k -> 240 k env-steps/s, B = 512: 260 k -> 300 k,
+ * profiles/r06_g_pipeline.txt); at batches that fill the GPU the plain groups are as fast or faster (Ant B = 1024 .. 4096: -3 .. -5 %). */
 int  dojo_set_async(DojoHandle h, int32_t on);
 int  dojo_set_groups(DojoHandle h, int32_t n);
 /* Iteration cap of the step kernel (no counterpart in the reference; the algorithm is unchanged decision for decision).  `mehrotra!` (src/solver/

@@ -30,7 +30,13 @@ if rank == 0:
     zf, sf, itf = step(Z, U)
     assert np.array_equal(zg.numpy(), zf) and np.array_equal(sg.numpy(), sf) and np.array_equal(ig.numpy(), itf), "sharded != unsharded"
     lo, hi = D.shard_slice(B, rank, world)
-    print("GLOO_OK", lo, hi, int(ig.sum()))
+    print("GLOO_OK", lo, hi, int(ig.sum()), flush=True)
+# (every rank stays until rank 0 has finished its unsharded check, and the process group is torn down in order: a rank that simply exits while
+#  its peer still computes can end in gloo's threads being destroyed mid-flight -- "terminate called without an active exception" -- and torchrun
+#  then kills the peer before it has printed; seen once under the load of six pytest-xdist workers)
+import torch.distributed as dist
+dist.barrier()
+dist.destroy_process_group()
 ''' % ROOT
 
 
