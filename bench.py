@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=0, help="1: dojo_set_async(h, 2) -- the IFT kernel of a group's step runs next to the group's next step kernel "
                     "(two hand-off records in turn; the rollout's states and controls sit in per-step buffers, as the asynchronous contract wants); 0: plain asynchronous groups")
+    ap.add_argument("--dispatch-order", type=int, default=1, help="dojo_set_dispatch_order: 1 (the library's default) = joined steps of a batch of more workgroups than the "
+                    "GPU holds at once hand the previous step's longest solves out first (the sync_per_step and single_launch legs); 0 = batch order; 2 = always")
     ap.add_argument("--iter-cap", type=int, default=-1, help="dojo_set_iteration_cap: solves unfinished after this many Newton iterations go on in the continuation "
                     "kernel (line-search trials side by side; joined steps only: the sync_per_step leg); 0 / -1 = off (the library's default)")
     ap.add_argument("--timed-only", action="store_true", help="warmup + the timed region only (no joined-per-step leg, no roofline leg, no parity, no CPU baseline): "
@@ -119,6 +121,7 @@ def main():
     if args.chunks > 0:
         gm.set_groups(args.chunks)
     gm.set_iteration_cap(args.iter_cap)
+    gm.set_dispatch_order(args.dispatch_order)
     gm.set_async(2 if args.pipeline else True)
     NCH = args.chunks if args.chunks > 0 else min(16, max(1, B // 256))
     lib_gather, lib_stuck = False, False
@@ -324,6 +327,7 @@ def main():
                        "io_dtype": args.io_dtype, "arithmetic": "fp64 state/residual/factorization, %s buffers at the ABI" % args.io_dtype,
                        "solver_options": "reference defaults (rtol 1e-6, btol 1e-4, max_iter 50, max_ls 10)",
                        "parallelism": "batch-sharded x%d, no data-path collective; per GPU ONE handle, dojo_step_dev steps its batch as %d environment groups on internal HIP streams (asynchronous, one join per rollout%s)" % (world, NCH, "; pipelined: a group's IFT kernel of step k next to its step kernel of step k + 1" if args.pipeline else ""),
+                       "dispatch_order": {0: "batch order", 1: "library default: joined steps (the sync_per_step and single_launch legs) hand out the previous step's longest solves first; the asynchronous timed region runs in batch order", 2: "longest solves of the previous step first, in every leg"}[args.dispatch_order],
                        "iteration_cap": "off (library default; dojo_set_iteration_cap: measured gain only at per-GPU batches <= 2048, DESIGN.md section 6)" if args.iter_cap <= 0 else args.iter_cap,
                        "converged_fraction_last_step": ok_frac, "mean_newton_iters_last_step": mean_iters,
                        "sync_per_step_value": world * B * K / el_sync, "sync_per_step_ms": 1e3 * el_sync / K,

@@ -5116,6 +5116,8 @@ struct KernelArgs {
     int* cont_count = nullptr;     // [1] entries of cont_list (zeroed before the step kernel, atomically advanced by it)
     int wave_base = 0;             // index of this launch's first workgroup in the batch: cont_list holds batch-level workgroup indices (the
                                    // continuation kernels run once over the whole batch, behind the step kernels of all environment groups)
+    const int* dispatch = nullptr; // [workgroups of this launch] the step kernel's hardware workgroup -> workgroup of this launch it works for (a permutation:
+                                   // the longest solves of the previous step first, dojo_set_dispatch_order), or null: in order
 #ifdef DJ_DEBUG
     T* dbg = nullptr;            // [B][Nb][512] test hook
 #endif

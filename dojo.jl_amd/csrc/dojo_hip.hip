@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 #include <algorithm>
 #include <mutex>
@@ -109,6 +110,11 @@ struct DojoSim {
     int *d_cont_list = nullptr, *d_cont_count = nullptr;   // [workgroups of the batch] the continuation list (batch-level workgroup indices), [1] its length
     int *d_cstat = nullptr;             // [B] status buffer of launches whose caller passed none (the continuation kernel reads it)
     hipStream_t cstream = nullptr; hipEvent_t cont_event = nullptr, allmain_event = nullptr; std::vector<hipEvent_t> main_events;   // the continuation's stream; "step kernel done" per group
+    // dispatch order of the step kernel (dojo_set_dispatch_order): 0 off, 1 where a launch has more workgroups than the GPU holds at once and the step is
+    // joined into the caller's stream (the step then waits for its last wavefront), 2 always
+    int dispatch_mode = 1, sm_count = 0; size_t step_groups = 1; bool chained_now = false;      // step_groups: groups of the dojo_step_dev in progress;      // chained_now: launches of rollout_core (one group's steps back to back)
+    int *d_dispatch = nullptr, *d_liters = nullptr;        // [workgroups of the batch] the permutations, one segment per launch; [B] iteration counts when the caller passes no buffer
+    std::map<size_t, int> dispatch_have;                   // first workgroup of a segment -> environments of the launch whose permutation it holds
     int phase_slot = -1;                // timing slot of the phased launch in progress (PH_MAIN -> PH_GRAD of the same group)
     std::vector<int> group_slot;        // ... per environment group
     bool have_grad = false, have_solution = false, have_u = false;
@@ -347,6 +353,22 @@ template <class TIO> __global__ void fold_impulses_kernel(long long n, const TIO
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (TIO)((fext ? (double)fext[i] : 0.0) + (double)jf[i] * inv_dt);
 }
+// dojo_set_dispatch_order: the permutation the NEXT step kernel of these workgroups hands its hardware workgroups out by -- a counting sort of
+// the launch's workgroups by the Newton iterations their environments took in this step, longest first (a solve that was long stays long for
+// a while: the same contacts are closing).  One workgroup; the order inside a bucket is whatever the atomics give (results do not depend on it:
+// every environment is computed by the same program wherever it runs).  E = environments per workgroup.
+__global__ void __launch_bounds__(1024) dispatch_order_kernel(const int* iters, int nenv, int E, int nwg, int* order) {
+    __shared__ int cnt[64];
+    const int t = (int)threadIdx.x;
+    if (t < 64) cnt[t] = 0;
+    __syncthreads();
+    auto bucket = [&](int wg) { int k = 0; for (int e = 0; e < E; ++e) { const int env = wg * E + e; if (env < nenv) k = max(k, iters[env]); } return 63 - min(max(k, 0), 63); };
+    for (int wg = t; wg < nwg; wg += 1024) atomicAdd(&cnt[bucket(wg)], 1);
+    __syncthreads();
+    if (t == 0) { int a = 0; for (int b = 0; b < 64; ++b) { const int c = cnt[b]; cnt[b] = a; a += c; } }
+    __syncthreads();
+    for (int wg = t; wg < nwg; wg += 1024) order[atomicAdd(&cnt[bucket(wg)], 1)] = wg;
+}
 } // namespace ckern
 
 template <class T>
@@ -440,7 +462,13 @@ double refine_threshold(const DojoSim* s) {
 }
 // scalars per contact in the exported [s; gamma] block: 8 (NonlinearContact; ImpactContact uses the first of each four), 12 (LinearContact)
 size_t csg_per(const DojoSim* s) { return s->M.contact_model == 2 ? 12 : 8; }
-size_t group_count(const DojoSim* s, bool want) {
+// does the batch have more workgroups than the GPU holds at once (these kernels: one wavefront per SIMD, four SIMDs per compute unit)?
+bool several_rounds(const DojoSim* s) {
+    const int NW = mapping_waves(s->M);
+    const size_t E = (size_t)std::max(1, 64 * (NW > 0 ? NW : 1) / (s->M.S * (NW > 0 ? 4 : 1)));
+    return ((size_t)s->B + E - 1) / E * (size_t)std::max(NW, 1) > (size_t)4 * (size_t)(s->sm_count > 0 ? s->sm_count : 256);
+}
+size_t group_count(const DojoSim* s, bool want, bool joined_steps = false) {
     const size_t B = (size_t)s->B;
     size_t NG = (want && B >= 512) ? std::min<size_t>(16, B / 256) : 1;
     // An asynchronous handle (dojo_set_async) chains its groups' steps: a group that holds a long solve delays only itself, so below 4096 environments
@@ -455,6 +483,11 @@ size_t group_count(const DojoSim* s, bool want) {
         const size_t min_envs = 64 * per_wg;
         if (B >= 2 * min_envs) NG = std::max<size_t>(NG, std::min<size_t>(16, B / min_envs));
     }
+    // A handle that joins after every step and whose batch takes several rounds of workgroups: two groups.  Each launch then has the whole GPU for
+    // its rounds (with the dispatch order: its long solves first), and the IFT kernel of the first group runs under the tail of the second's step
+    // kernel.  profiles/r06_i_dispatch.txt, joined ms per step at 1 / 2 / 4 / 8 / 16 groups: Ant B = 4096 5.93 / 5.84 / 6.19 / 6.14 / 6.28
+    // (batch order: 6.45 / 6.22 / 6.47 / 6.48 / 6.49), Atlas B = 2048 6.57 / 6.35 / 6.70 / 6.89 / 6.85, Quadruped B = 8192 12.5 / 12.1 / 12.1 / 12.0 / 11.9.
+    if (joined_steps && !s->async && want && several_rounds(s)) NG = std::min<size_t>(NG, 2);
     if (s->groups > 0) NG = std::min<size_t>(std::min<size_t>((size_t)s->groups, 16), std::max<size_t>(1, B / 64));   // (more than 16 queues in flight collapse: 0.68 M against 1.00 M at 24, same session)
     const char* hq = getenv("GPU_MAX_HW_QUEUES");
     const int nq = hq ? atoi(hq) : 4;
@@ -631,6 +664,24 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
         }
         if (!status) A.status = s->d_cstat + env0;
     }
+    // Dispatch order (dojo_set_dispatch_order): this launch's step kernel hands its workgroups out by the permutation the previous launch over the same
+    // environments left behind; the permutation for the next one is made behind this launch's kernels, from this step's iteration counts.
+    bool reorder = false;
+    if (phase == PH_ALL && dc == nullptr && s->dispatch_mode != 0) {
+        // (mode 1: the order only matters when the GPU cannot hold the batch's workgroups at once)
+        // (... and its launches are not chained next to other groups' -- an asynchronous handle of several groups, a rollout: a single launch per step
+        //  waits for its last wavefront on an asynchronous handle too)
+        reorder = s->dispatch_mode == 2 || ((!s->async || s->step_groups <= 1) && !s->chained_now && several_rounds(s));
+    }
+    if (reorder) {
+        if (!s->d_dispatch) HIPCHK(hipMalloc((void**)&s->d_dispatch, (waves_total + 1) * sizeof(int)));
+        if (!A.iters) {
+            if (!s->d_liters) HIPCHK(hipMalloc((void**)&s->d_liters, (size_t)s->B * sizeof(int)));
+            A.iters = s->d_liters + env0;
+        }
+        auto it_ = s->dispatch_have.find(wave0);
+        if (it_ != s->dispatch_have.end() && it_->second == nenv) A.dispatch = s->d_dispatch + wave0;
+    }
     A.blk = nullptr; A.flag = nullptr;
     if (quad && A.G.refine_w < INFINITY) {                  // the refining kernels follow the plain ones (dojo_kernels.hip)
         if (!s->d_blk) HIPCHK(hipMalloc(&s->d_blk, waves_total * 90 * 64 * NW * sizeof(T)));
@@ -687,6 +738,16 @@ int launch(DojoSim* s, const void* z, const void* u, void* zn, int* status, int*
     HIPCHK(hipGetLastError());
     if (timed && (phase == PH_ALL || phase == PH_GRAD || (phase == PH_MAIN && !g))) {
         DojoSim::Ev3& e = s->ring[slot]; HIPCHK(hipEventRecord(e.b, st)); e.has_mid = g != 0; e.n = 1; e.used = true; s->last_slot = slot;
+    }
+    if (reorder) {
+        // (segments of another partition of the batch that overlap this one hold permutations of other ranges: forgotten before this one is written)
+        for (auto it_ = s->dispatch_have.begin(); it_ != s->dispatch_have.end();) {
+            const size_t a_ = it_->first, b_ = a_ + ((size_t)it_->second + E - 1) / E;
+            if (a_ < wave0 + grid.x && wave0 < b_) it_ = s->dispatch_have.erase(it_); else ++it_;
+        }
+        hipLaunchKernelGGL(ckern::dispatch_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)A.iters, nenv, E, (int)grid.x, s->d_dispatch + wave0);
+        HIPCHK(hipGetLastError());
+        s->dispatch_have[wave0] = nenv;
     }
     if (storage) {                         // record: the Storage rows of the environments of this launch
         const long long n = (long long)nenv * Nb; const int T_ = 128;
@@ -778,6 +839,7 @@ int dojo_create(const DojoTopology* topo, int32_t batch, int32_t dtype, int32_t 
     s->B = batch; s->dtype = dtype; s->device = device; s->w = dtype == DOJO_DTYPE_F32 ? 4 : 8;
     s->opts = dj::default_options();
     if (hipSetDevice(device) != hipSuccess) { g_err = "dojo_create: hipSetDevice failed"; delete s; return DOJO_ERR_DEVICE; }
+    if (hipDeviceGetAttribute(&s->sm_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) s->sm_count = 0;      // (several_rounds: 256 then)
     rc = upload_tables<double>(s);
     if (rc != DOJO_OK) { dojo_destroy(s); return rc; }          // frees whatever part of the tables was uploaded
     *out = s;
@@ -789,7 +851,7 @@ void dojo_destroy(DojoHandle s) {
     (void)hipSetDevice(s->device);
     void* ps[] = {s->d_tsd, s->d_mlim, s->d_cuts, s->d_cutws, s->d_sol2, s->d_fext, s->d_res, s->d_nodes, s->d_contacts, s->d_z, s->d_u, s->d_zn, s->d_vel, s->d_jimp, s->d_csg, s->d_dz, s->d_du, s->d_status, s->d_iters, s->d_sol, s->d_fac, s->d_lu, s->d_blk, s->d_ypark, s->d_msg, (void*)s->d_flag, s->d_cz, s->d_jf, (void*)s->d_mu, (void*)s->d_diag, s->d_order, s->d_x, s->d_xn, s->d_jm, s->d_jt, s->d_jb};
     for (void* p : ps) if (p) (void)hipFree(p);
-    void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat};
+    void* pc[] = {s->d_resume, (void*)s->d_cont_list, (void*)s->d_cont_count, (void*)s->d_cstat, (void*)s->d_dispatch, (void*)s->d_liters};
     for (void* p : pc) if (p) (void)hipFree(p);
     if (s->cstream) (void)hipStreamDestroy(s->cstream);
     if (s->cont_event) (void)hipEventDestroy(s->cont_event);
@@ -919,7 +981,8 @@ int dojo_step_dev(DojoHandle s, const void* z, const void* u, void* z_next, int3
     if ((rc = ensure(&s->d_csg, B * (csg_per(s) * s->M.Nc + 1) * w))) return rc;
     if ((rc = ensure((void**)&s->d_mu, B * sizeof(double)))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t NG = group_count(s, true);
+    const size_t NG = group_count(s, true, true);
+    s->step_groups = NG;
     // Iteration cap (dojo_set_iteration_cap): in force for steps that are joined into the caller's stream -- there the step waits for its longest
     // solve.  An asynchronous handle chains its groups' steps without a barrier and hides that tail behind the other groups' kernels.
     const bool capped = !s->async && effective_cap(s) > 0;
@@ -1038,6 +1101,15 @@ int dojo_set_async(DojoHandle s, int32_t on) {
     Enter enter_(s);
     if (!s) { g_err = "dojo_set_async: bad argument"; return DOJO_ERR_INVALID; }
     s->async = on == 2 ? 2 : (on != 0 ? 1 : 0); return DOJO_OK;
+}
+// Order in which the step kernel's workgroups are handed to the GPU (no counterpart in the reference): 0 = batch order; 1 (default) = the longest
+// solves of the previous step first, where that can matter -- steps joined into the caller's stream whose launch has more workgroups than the GPU
+// holds at once: the launch ends with its last wavefront, and a 50-iteration solve that starts in the last round is that wavefront; 2 = always.
+// Results do not depend on it.
+int dojo_set_dispatch_order(DojoHandle s, int32_t mode) {
+    Enter en_(s);
+    if (!s || mode < 0 || mode > 2) { g_err = "dojo_set_dispatch_order: bad argument"; return DOJO_ERR_INVALID; }
+    s->dispatch_mode = mode; return DOJO_OK;
 }
 int dojo_set_iteration_cap(DojoHandle s, int32_t cap) {
     Enter en_(s);
@@ -1224,7 +1296,9 @@ static int rollout_core(DojoHandle s, const void* z0, const void* U, int32_t H, 
             char* nxt = Z ? (char*)Z + (size_t)k * B * nz * w : (char*)((k & 1) ? s->d_z : s->d_zn);
             const char* uk = (U && nu) ? (const char*)U + (size_t)k * B * nu * w : nullptr;
             void* sk = storage ? (char*)storage + (size_t)k * B * 25 * s->M.Nb * w : nullptr;
+            s->chained_now = true;
             rc = launch_any(s, c, uk, nxt, status ? status + (size_t)k * B : nullptr, nullptr, s->d_vel, s->d_jimp, s->d_csg, nullptr, nullptr, gs, false, env0, nenv, nullptr, sk);
+            s->chained_now = false;
             if (rc != DOJO_OK) return rc;
             c = nxt;
         }

@@ -211,7 +211,8 @@ dojo_step_kernel(dj::KernelArgs<TIO, TS> A) {
     GpuWave<NW> w;
     w.lds_ = (void*)lds_buf; w.red_ = (double*)((char*)lds_buf + LY::red_off);
     DJ_P2_DECL(w)
-    dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, (int)blockIdx.x);
+    // (a launch lasts as long as its last wavefront: the workgroups whose solves were long in the previous step are handed out first)
+    dj::step_entry<TIO, TS, TL, MAXC, QUAD, GpuWave<NW>>(w, A, A.dispatch ? A.dispatch[blockIdx.x] : (int)blockIdx.x);
 }
 // Globals::iter_cap: the rest of the Newton loops the step kernel left unfinished, one listed workgroup of the step kernel per
 // pass of a workgroup here, the line-search trials side by side on R replicas (quad mapping, one wavefront per environment set)

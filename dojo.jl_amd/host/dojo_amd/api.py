@@ -35,7 +35,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.dojo_last_error.restype = C.c_char_p
         L.dojo_handle_error.restype = C.c_char_p; L.dojo_handle_error.argtypes = [C.c_void_p]
-        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_set_iteration_cap", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_step_impulses", "dojo_get_mu", "dojo_get_diagnostics", "dojo_next_state", "dojo_next_state_dev",
+        for f in ("dojo_device_count", "dojo_create", "dojo_get_dims", "dojo_set_options", "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_set_iteration_cap", "dojo_set_dispatch_order", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_step_impulses", "dojo_get_mu", "dojo_get_diagnostics", "dojo_next_state", "dojo_next_state_dev",
                   "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state", "dojo_step_dev", "dojo_rollout_dev",
                   "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                   "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
@@ -48,7 +48,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["dojo_device_count", "dojo_last_error", "dojo_handle_error", "dojo_step_impulses", "dojo_get_mu", "dojo_get_diagnostics", "dojo_next_state", "dojo_next_state_dev", "dojo_create", "dojo_destroy", "dojo_get_dims", "dojo_set_options",
-                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_set_iteration_cap", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
+                    "dojo_set_gradient_mode", "dojo_set_refinement", "dojo_set_async", "dojo_set_groups", "dojo_set_iteration_cap", "dojo_set_dispatch_order", "dojo_join", "dojo_comm_unique_id", "dojo_comm_init", "dojo_allgather_dev", "dojo_comm_info", "dojo_step", "dojo_get_solution", "dojo_gradients", "dojo_rollout", "dojo_get_state",
                     "dojo_step_dev", "dojo_rollout_dev", "dojo_last_kernel_ms", "dojo_last_kernel_times", "dojo_kernel_time_totals",
                     "dojo_minimal_to_maximal", "dojo_maximal_to_minimal", "dojo_step_minimal",
                     "dojo_minimal_to_maximal_dev", "dojo_maximal_to_minimal_dev", "dojo_step_minimal_dev",
@@ -124,6 +124,11 @@ class BatchedMechanism:
         """dojo_set_iteration_cap: solves unfinished after `cap` Newton iterations go on in the continuation kernel (line-search trials
         side by side) in steps that are joined into the caller's stream; 0 / < 0: off (the default).  Include/dojo_hip.h has the measurements."""
         _chk(lib().dojo_set_iteration_cap(self.h, int(cap)))
+
+    def set_dispatch_order(self, mode):
+        """dojo_set_dispatch_order: 0 batch order, 1 (default) the previous step's longest solves first where a joined step has more workgroups
+        than the GPU holds at once, 2 always.  Results do not depend on it."""
+        _chk(lib().dojo_set_dispatch_order(self.h, int(mode)))
 
     def join(self, stream=None):
         _chk(lib().dojo_join(self.h, C.c_void_p(stream or 0)))

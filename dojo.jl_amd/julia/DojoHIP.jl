@@ -250,6 +250,7 @@ end
 set_groups!(bm::BatchedMechanism, n::Integer) = check(@ccall $(fn(:dojo_set_groups))(bm.handle::Ptr{Cvoid}, n::Int32)::Cint)
 "iteration cap of the step kernel: solves unfinished after `cap` Newton iterations go on in the continuation kernel (line-search trials side by side) in joined steps; 0 / < 0: off (the default); include/dojo_hip.h has the measurements"
 set_iteration_cap!(bm::BatchedMechanism, cap::Integer) = check(@ccall $(fn(:dojo_set_iteration_cap))(bm.handle::Ptr{Cvoid}, cap::Int32)::Cint)
+set_dispatch_order!(bm::BatchedMechanism, mode::Integer) = check(@ccall $(fn(:dojo_set_dispatch_order))(bm.handle::Ptr{Cvoid}, mode::Int32)::Cint)
 "asynchronous environment groups: consecutive step_dev! calls chain per group; join!(bm; stream) orders `stream` behind everything in flight"
 set_async!(bm::BatchedMechanism, on::Bool) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, on::Int32)::Cint)
 set_async!(bm::BatchedMechanism, mode::Integer) = check(@ccall $(fn(:dojo_set_async))(bm.handle::Ptr{Cvoid}, Int32(mode)::Int32)::Cint)      # 2: pipelined groups (dojo_hip.h)

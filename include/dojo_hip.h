@@ -256,7 +256,8 @@ int  dojo_step_dev(DojoHandle h, const void* z, const void* u, void* z_next,
  * groups on internal HIP streams (of >= 256 environments each; an asynchronous handle, below, of a mechanism with one
  * wavefront per workgroup: of >= 64 workgroups, so that batches of 128 .. 2048 Ants are split further): a group that holds an environment running into max_iter (~5x the mean step time for
  * its wavefront) delays only itself.  By default the call forks from and joins into `stream`, i.e. it behaves like one
- * launch on `stream`.  dojo_set_async(h, 1) drops the join: consecutive dojo_step_dev calls then chain per group (group g
+ * launch on `stream` (such a joined handle steps a batch of more workgroups than the GPU holds at once as TWO groups: each launch has the whole GPU for its
+ * rounds of workgroups, the first group's IFT kernel runs under the tail of the second's step kernel; see dojo_set_dispatch_order).  dojo_set_async(h, 1) drops the join: consecutive dojo_step_dev calls then chain per group (group g
  * of call k+1 runs behind group g of call k and behind what `stream` held at call time), and dojo_join(h, stream)
  * -- or any host-pointer entry point -- orders `stream` behind everything in flight.  The caller must not touch the
  * outputs, nor overwrite the inputs, of un-joined calls.  dojo_set_groups(h, n): n groups, at most 16 (n <= 0: automatic; 1: a
@@ -285,6 +286,15 @@ int  dojo_set_groups(DojoHandle h, int32_t n);
  * environment variable DOJO_ITER_CAP=<cap> changes the default, not an explicit setting).  Asynchronous handles and rollouts never cap. */
 #define DOJO_DEFAULT_ITERATION_CAP 0
 int  dojo_set_iteration_cap(DojoHandle h, int32_t cap);
+/* Order in which the step kernel's workgroups are handed to the GPU (no counterpart in the reference: mehrotra!, src/solver/mehrotra.jl:9-73, runs
+ * one mechanism).  A launch ends with its last wavefront, and the Newton loops of a batch take 5 ... max_iter iterations: a 50-iteration solve that
+ * starts in the launch's last round of workgroups IS that wavefront.  A solve that was long in one step is long in the next (the same contacts are
+ * closing), so the library sorts the workgroups of a launch by the iteration counts of the previous step, longest first (a one-workgroup counting
+ * sort behind the step's kernels; the step kernel reads its workgroup index through the permutation).
+ * mode 0: batch order.  1 (default): sorted where it can matter -- steps joined into the caller's stream (or stepped as a single group) whose batch has
+ * more workgroups than the GPU holds at once (asynchronous handles of several groups hide the tail behind the other groups' kernels).  2: always.  Results do not depend on the order: every
+ * environment is computed by the same program wherever it runs.  Measurements: DESIGN.md section 6. */
+int  dojo_set_dispatch_order(DojoHandle h, int32_t mode);
 int  dojo_join(DojoHandle h, void* stream);
 
 /* Multi-GPU (nothing to cite in the reference, which has no multi-device code).  Environments are

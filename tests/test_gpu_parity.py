@@ -1566,3 +1566,47 @@ def test_pipelined_groups_equal_plain_groups():
         got = rollout(mode)
         for a, b, name in zip(ref, got, ("states", "dz", "du", "status", "iterations")):
             assert np.array_equal(a, b), (mode, name)
+
+
+def test_dispatch_order_leaves_results_alone():
+    """dojo_set_dispatch_order: the step kernel hands its workgroups out by the previous step's iteration counts, longest first.  Closed-loop rollouts of
+    640 Ants (mode 2 = sorted whatever the batch size) against batch order (mode 0): states, status, iteration counts and every Jacobian bit-identical --
+    as one launch, as three environment groups, with the partition changed in mid-rollout (the permutations of the old partition must not be used
+    for the new one), on an asynchronous handle, and without an iteration-count buffer from the caller"""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    spec = d.baseline_config(3)
+    B, K = 640, 6
+    Z0, _ = d.synthetic_inputs(spec, B)
+    rng = np.random.default_rng(9)
+    nz, nx, nu = 13 * spec.Nb, 12 * spec.Nb, spec.nu
+    dev = torch.device("cuda:0")
+    z0 = torch.tensor(Z0, dtype=torch.float64, device=dev)
+    U = torch.tensor(0.5 * rng.standard_normal((K, B, nu)), dtype=torch.float64, device=dev)
+
+    def rollout(mode, groups, asyn=0, with_iters=True):
+        gm = api.BatchedMechanism(spec, B, dtype="f64")
+        gm.set_dispatch_order(mode); gm.set_groups(groups[0]); gm.set_async(asyn)
+        traj = torch.zeros((K + 1, B, nz), dtype=torch.float64, device=dev); traj[0] = z0
+        dz = torch.zeros((K, B, nx, nx), dtype=torch.float64, device=dev); du = torch.zeros((K, B, nu, nx), dtype=torch.float64, device=dev)
+        st = torch.zeros((K, B), dtype=torch.int32, device=dev); it = torch.zeros((K, B), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for k in range(K):
+            if k == K // 2 and len(groups) > 1:
+                gm.set_groups(groups[1])
+            api._chk(api.lib().dojo_step_dev(gm.h, p(traj[k]), p(U[k]), p(traj[k + 1]), p(st[k]), p(it[k]) if with_iters else C.c_void_p(0), p(dz[k]), p(du[k]), stream))
+        gm.join(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy() for t in (traj, dz, du, st, it)]
+        gm.close()
+        return out
+    ref = rollout(0, (1,))
+    assert (ref[3] == 0).mean() > 0.99 and not np.isnan(ref[1]).any() and np.abs(ref[1]).max() > 1.0
+    assert ref[4][1:].max() > ref[4][1:].min() + 3            # (there is something to sort)
+    for groups, asyn, with_iters in (((1,), 0, True), ((3,), 0, True), ((3, 2), 0, True), ((2, 5), 1, True), ((1,), 0, False), ((4,), 0, False)):
+        got = rollout(2, groups, asyn, with_iters)
+        for a, b, name in zip(ref, got, ("states", "dz", "du", "status", "iterations")):
+            if name == "iterations" and not with_iters: continue
+            assert np.array_equal(a, b), (groups, asyn, with_iters, name)
