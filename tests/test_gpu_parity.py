@@ -1571,8 +1571,9 @@ def test_pipelined_groups_equal_plain_groups():
 def test_dispatch_order_leaves_results_alone():
     """dojo_set_dispatch_order: the step kernel hands its workgroups out by the previous step's iteration counts, longest first.  Closed-loop rollouts of
     640 Ants (mode 2 = sorted whatever the batch size) against batch order (mode 0): states, status, iteration counts and every Jacobian bit-identical --
-    as one launch, as three environment groups, with the partition changed in mid-rollout (the permutations of the old partition must not be used
-    for the new one), on an asynchronous handle, and without an iteration-count buffer from the caller"""
+    as one launch, as three environment groups (a permutation per launch), with the partition changed in mid-rollout (the permutations of the old
+    partition must not be used for the new one), on an asynchronous handle, switching between joined and asynchronous in mid-rollout, and without an
+    iteration-count buffer from the caller"""
     import ctypes as C
     torch = pytest.importorskip("torch")
     spec = d.baseline_config(3)
@@ -1586,7 +1587,7 @@ def test_dispatch_order_leaves_results_alone():
 
     def rollout(mode, groups, asyn=0, with_iters=True):
         gm = api.BatchedMechanism(spec, B, dtype="f64")
-        gm.set_dispatch_order(mode); gm.set_groups(groups[0]); gm.set_async(asyn)
+        gm.set_dispatch_order(mode); gm.set_groups(groups[0]); gm.set_async(1 if asyn in (1, 3) else 0)
         traj = torch.zeros((K + 1, B, nz), dtype=torch.float64, device=dev); traj[0] = z0
         dz = torch.zeros((K, B, nx, nx), dtype=torch.float64, device=dev); du = torch.zeros((K, B, nu, nx), dtype=torch.float64, device=dev)
         st = torch.zeros((K, B), dtype=torch.int32, device=dev); it = torch.zeros((K, B), dtype=torch.int32, device=dev)
@@ -1596,6 +1597,10 @@ def test_dispatch_order_leaves_results_alone():
         for k in range(K):
             if k == K // 2 and len(groups) > 1:
                 gm.set_groups(groups[1])
+            if k == K // 2 and asyn == 3:                      # (asynchronous first, joined from here on)
+                gm.join(torch.cuda.current_stream().cuda_stream); gm.set_async(0)
+            if k == K // 2 + 1 and asyn == 4:                  # (joined first, asynchronous from here on)
+                gm.set_async(1)
             api._chk(api.lib().dojo_step_dev(gm.h, p(traj[k]), p(U[k]), p(traj[k + 1]), p(st[k]), p(it[k]) if with_iters else C.c_void_p(0), p(dz[k]), p(du[k]), stream))
         gm.join(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -1605,7 +1610,7 @@ def test_dispatch_order_leaves_results_alone():
     ref = rollout(0, (1,))
     assert (ref[3] == 0).mean() > 0.99 and not np.isnan(ref[1]).any() and np.abs(ref[1]).max() > 1.0
     assert ref[4][1:].max() > ref[4][1:].min() + 3            # (there is something to sort)
-    for groups, asyn, with_iters in (((1,), 0, True), ((3,), 0, True), ((3, 2), 0, True), ((2, 5), 1, True), ((1,), 0, False), ((4,), 0, False)):
+    for groups, asyn, with_iters in (((1,), 0, True), ((3,), 0, True), ((3, 2), 0, True), ((2, 5), 1, True), ((1,), 0, False), ((4,), 0, False), ((3,), 3, True), ((4, 1), 4, True), ((1, 3), 0, False)):
         got = rollout(2, groups, asyn, with_iters)
         for a, b, name in zip(ref, got, ("states", "dz", "du", "status", "iterations")):
             if name == "iterations" and not with_iters: continue

@@ -34,15 +34,17 @@ def timed(n, label, sync=False):
         if sync: torch.cuda.synchronize()
     gm.join(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t) / n
-    print("%-58s %.3f ms/step  %8.0f env-steps/s   iters mean %.2f max %d" % (label, ms, B / ms * 1e3, it.float().mean().item(), it.max().item()), flush=True)
+    try: kt = gm.last_kernel_times()
+    except Exception: kt = (float("nan"), float("nan"))
+    print("%-58s %.3f ms/step  %8.0f env-steps/s   iters mean %.2f max %d   last launch: step %.3f ift %.3f ms" % (label, ms, B / ms * 1e3, it.float().mean().item(), it.max().item(), kt[0], kt[1]), flush=True)
 print("config %d, B = %d %s" % (cfg, B, kw))
 gm.set_async(True); timed(10, "warmup async"); zsave = z.clone()
 for rep in range(2):
-    for mode in (0, 2):
+    for mode in ((2,) if os.environ.get('ONLY_SORTED') else (0, 2)):
         gm.set_dispatch_order(mode)
         gm.set_async(True); gm.set_groups(0); timed(20, "async, default groups, order %d" % mode)
         gm.set_async(False)
-        for g in (0, 1, 2, 4, 8):
+        for g in (0, 1, 2, 3, 4, 8, 16):
             gm.set_groups(g); timed(20, "joined, set_groups(%d), order %d" % (g, mode))
         gm.set_groups(1); timed(20, "joined + host sync per step, groups 1, order %d" % mode, sync=True)
         gm.set_groups(4); timed(20, "joined + host sync per step, groups 4, order %d" % mode, sync=True)
