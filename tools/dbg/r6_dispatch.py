@@ -39,6 +39,7 @@ def timed(n, label, sync=False):
     print("%-58s %.3f ms/step  %8.0f env-steps/s   iters mean %.2f max %d   last launch: step %.3f ift %.3f ms" % (label, ms, B / ms * 1e3, it.float().mean().item(), it.max().item(), kt[0], kt[1]), flush=True)
 print("config %d, B = %d %s" % (cfg, B, kw))
 gm.set_async(True); timed(10, "warmup async"); zsave = z.clone()
+if os.environ.get('CAP'): gm.set_iteration_cap(int(os.environ['CAP'])); print('iteration cap', os.environ['CAP'])
 for rep in range(2):
     for mode in ((2,) if os.environ.get('ONLY_SORTED') else (0, 2)):
         gm.set_dispatch_order(mode)
